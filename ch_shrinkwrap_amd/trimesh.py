@@ -1,0 +1,244 @@
+"""
+Minimal half-edge triangle-mesh substrate for the NanoWrap hot path.
+
+The reference inherits all of this from ``PYME.experimental._triangle_mesh.TriangleMesh``
+(cimported at /root/reference/ch_shrinkwrap/_membrane_mesh.pyx:11-13,78-80), which is a third-party
+dependency that is NOT part of the reference tree.  The optimiser only consumes a handful of
+attributes of that object (/root/reference/ch_shrinkwrap/mesh_conj_grad.py:44-54, 777-788, 807,
+289-290):
+
+    mesh._vertices   structured array, fields position(3f4) normal(3f4) halfedge(i4) valence(i4)
+                     neighbors(20 i4, half-edge ids, -1 padded) component(i4) locally_manifold(i4)
+                     -- layout of vertex_t, /root/reference/ch_shrinkwrap/membrane_mesh_utils.h:57-65
+    mesh._halfedges  structured array, fields vertex face twin next prev length component
+                     -- halfedge_t, membrane_mesh_utils.h:31-39
+    mesh._faces      structured array, fields halfedge normal(3f4) area component
+                     -- face_t, membrane_mesh_utils.h:41-46
+    mesh.faces (F,3) i4, mesh.vertices, mesh.vertex_normals, mesh.vertex_neighbors,
+    mesh.face_normals, mesh._initialize_curvature_vectors()
+
+This module provides exactly that surface, with this build's OWN definitions of the things PYME
+leaves unpinned:
+
+  * half-edge ``3f+k`` runs faces[f,k] -> faces[f,(k+1)%3]; its ``vertex`` field is the vertex it
+    points TO (so ``_halfedges['vertex'][_vertices['neighbors']]`` are the 1-ring vertex ids, as the
+    reference expects at mesh_conj_grad.py:50);
+  * the 1-ring is ordered by rotating ``h -> twin[prev[h]]`` starting from the lowest-numbered
+    outgoing half-edge (for boundary vertices: from the outgoing half-edge whose ``prev`` has no twin);
+  * vertex normals are the normalised sum of the (area-weighted) cross products of incident faces.
+
+The same arrays are fed to the reference (golden generation), the oracle and the HIP path, so hot-loop
+parity does not depend on PYME's conventions.
+"""
+import numpy as np
+
+NEIGHBORSIZE = 20   # membrane_mesh_utils.h:29
+VECTORSIZE = 3      # membrane_mesh_utils.h:26
+
+VERTEX_DTYPE = np.dtype([('position', '3f4'), ('normal', '3f4'), ('halfedge', 'i4'), ('valence', 'i4'),
+                         ('neighbors', '%di4' % NEIGHBORSIZE), ('component', 'i4'),
+                         ('locally_manifold', 'i4')])
+HALFEDGE_DTYPE = np.dtype([('vertex', 'i4'), ('face', 'i4'), ('twin', 'i4'), ('next', 'i4'), ('prev', 'i4'),
+                           ('length', 'f4'), ('component', 'i4')])
+FACE_DTYPE = np.dtype([('halfedge', 'i4'), ('normal', '3f4'), ('area', 'f4'), ('component', 'i4')])
+
+assert VERTEX_DTYPE.itemsize == 120 and HALFEDGE_DTYPE.itemsize == 28 and FACE_DTYPE.itemsize == 24
+
+
+def icosahedron():
+    t = (1.0 + np.sqrt(5.0)) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0],
+                  [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype='f8')
+    v /= np.linalg.norm(v, axis=1)[:, None]
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11],
+                  [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+                  [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9],
+                  [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], dtype='i4')
+    return v, f
+
+
+def subdivide(v, f):
+    """One 1->4 subdivision; new vertices at edge midpoints (not re-projected)."""
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    es = np.sort(e, 1)
+    key = es[:, 0].astype('i8') * (v.shape[0] + 1) + es[:, 1]
+    uk, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    mid = 0.5 * (v[es[first, 0]] + v[es[first, 1]])
+    nv = np.concatenate([v, mid], 0)
+    F = f.shape[0]
+    m01 = v.shape[0] + inv[0:F]
+    m12 = v.shape[0] + inv[F:2 * F]
+    m20 = v.shape[0] + inv[2 * F:3 * F]
+    nf = np.concatenate([np.stack([f[:, 0], m01, m20], 1),
+                         np.stack([f[:, 1], m12, m01], 1),
+                         np.stack([f[:, 2], m20, m12], 1),
+                         np.stack([m01, m12, m20], 1)], 0).astype('i4')
+    return nv, nf
+
+
+def icosphere(nsub=4, radius=1.0, dtype='f4'):
+    """Unit icosahedron subdivided ``nsub`` times, vertices pushed to ``radius``.
+    nsub=4 -> 2562 vertices / 5120 faces (config C1)."""
+    v, f = icosahedron()
+    for _ in range(nsub):
+        v, f = subdivide(v, f)
+        v /= np.linalg.norm(v, axis=1)[:, None]
+    return (v * radius).astype(dtype), f
+
+
+def _build_halfedges(faces, n_vertices):
+    F = faces.shape[0]
+    he = np.zeros(3 * F, HALFEDGE_DTYPE)
+    idx = np.arange(3 * F, dtype='i4')
+    k = idx % 3
+    fi = idx // 3
+    origin = faces[fi, k]
+    dest = faces[fi, (k + 1) % 3]
+    he['vertex'] = dest
+    he['face'] = fi
+    he['next'] = 3 * fi + (k + 1) % 3
+    he['prev'] = 3 * fi + (k + 2) % 3
+    he['component'] = 0
+    # twins: match (origin,dest) with (dest,origin)
+    nv = np.int64(n_vertices)
+    key = origin.astype('i8') * nv + dest
+    rkey = dest.astype('i8') * nv + origin
+    order = np.argsort(key, kind='stable')
+    pos = np.searchsorted(key[order], rkey)
+    pos = np.minimum(pos, 3 * F - 1)
+    cand = order[pos]
+    twin = np.where(key[cand] == rkey, cand, -1).astype('i4')
+    he['twin'] = twin
+    return he, origin.astype('i4')
+
+
+class TriMesh(object):
+    """Duck-typed stand-in for the PYME mesh object the optimiser reads (see module docstring)."""
+
+    def __init__(self, vertices, faces, max_vertices=None):
+        vertices = np.ascontiguousarray(vertices, dtype='f4')
+        faces = np.ascontiguousarray(faces, dtype='i4')
+        M = vertices.shape[0] if max_vertices is None else int(max_vertices)
+        self._vertices = np.zeros(M, VERTEX_DTYPE)
+        self._vertices['halfedge'] = -1
+        self._vertices['neighbors'] = -1
+        self._vertices['position'][:vertices.shape[0]] = vertices
+        self._nv = vertices.shape[0]
+        self._faces_arr = faces
+        self._halfedges, self._origin = _build_halfedges(faces, M)
+        self._faces = np.zeros(faces.shape[0], FACE_DTYPE)
+        self._faces['halfedge'] = 3 * np.arange(faces.shape[0], dtype='i4')
+        self._build_rings()
+        self.update_geometry()
+        self.cg = None
+        self.vertex_properties = []
+        self.vertex_vector_properties = []
+
+    # -- topology ---------------------------------------------------------------------------
+    def _build_rings(self):
+        he = self._halfedges
+        M = self._vertices.shape[0]
+        nhe = he.shape[0]
+        origin = self._origin
+        twin, prev = he['twin'], he['prev']
+        # choose the start half-edge per vertex: lowest-numbered outgoing; boundary vertices start at
+        # the outgoing half-edge whose prev has no twin (so that the walk covers the whole fan)
+        start = np.full(M, -1, 'i4')
+        order = np.arange(nhe - 1, -1, -1, dtype='i4')
+        start[origin[order]] = order                      # lowest index wins (written last)
+        bnd = np.nonzero(twin[prev] == -1)[0]
+        if bnd.size:
+            start[origin[bnd]] = bnd.astype('i4')
+        self._vertices['halfedge'] = start
+        nb = np.full((M, NEIGHBORSIZE), -1, 'i4')
+        cur = start.copy()
+        alive = cur != -1
+        valence = np.zeros(M, 'i4')
+        for s in range(NEIGHBORSIZE):
+            if not alive.any():
+                break
+            nb[alive, s] = cur[alive]
+            valence[alive] += 1
+            p = prev[np.where(alive, cur, 0)]
+            nxt = np.where(alive, twin[p], -1)
+            alive = alive & (nxt != -1) & (nxt != start)
+            cur = np.where(alive, nxt, -1).astype('i4')
+        # boundary fans end with the incoming boundary edge's origin: add it as a last neighbour is
+        # NOT done -- open fans simply list their outgoing half-edges (documented convention).
+        self._vertices['neighbors'] = nb
+        self._vertices['valence'] = valence
+        self._vertices['locally_manifold'] = 1
+        self._vertices['component'] = 0
+
+    # -- geometry ---------------------------------------------------------------------------
+    def update_geometry(self):
+        """Face normals/areas, half-edge lengths and vertex normals from the current positions.
+        This is the block-boundary refresh the reference triggers at _membrane_mesh.pyx:1524-1527."""
+        pos = self._vertices['position']
+        f = self._faces_arr
+        v0, v1, v2 = pos[f[:, 0]], pos[f[:, 1]], pos[f[:, 2]]
+        cr = np.cross(v1 - v0, v2 - v0)                      # f32, |cr| = 2*area
+        nrm = np.sqrt((cr * cr).sum(1))
+        with np.errstate(invalid='ignore', divide='ignore'):
+            fn = cr / nrm[:, None]
+        fn[~np.isfinite(fn)] = 0
+        self._faces['normal'] = fn
+        self._faces['area'] = 0.5 * nrm
+        vn = np.zeros((pos.shape[0], 3), 'f8')
+        for k in range(3):
+            np.add.at(vn, f[:, k], cr)
+        l = np.sqrt((vn * vn).sum(1))
+        with np.errstate(invalid='ignore', divide='ignore'):
+            vn = vn / l[:, None]
+        vn[~np.isfinite(vn)] = 0
+        self._vertices['normal'] = vn.astype('f4')
+        he = self._halfedges
+        d = pos[he['vertex']] - pos[self._origin]
+        he['length'] = np.sqrt((d * d).sum(1))
+
+    # -- PYME-like attribute surface --------------------------------------------------------
+    @property
+    def faces(self):
+        return self._faces_arr
+
+    @property
+    def vertices(self):
+        return self._vertices['position']
+
+    @property
+    def vertex_normals(self):
+        return self._vertices['normal']
+
+    @property
+    def face_normals(self):
+        return self._faces['normal']
+
+    @property
+    def vertex_neighbors(self):
+        return self._vertices['neighbors']
+
+    @property
+    def _mean_edge_length(self):
+        l = self._halfedges['length']
+        return np.mean(l[l != -1])
+
+    def area(self):
+        return float(self._faces['area'].sum())
+
+    def neighbor_vertex_table(self):
+        """(M, NEIGHBORSIZE) i4 table of 1-ring VERTEX ids, -1 padded -- what the reference caches
+        at mesh_conj_grad.py:50-54."""
+        n = self._halfedges['vertex'][self._vertices['neighbors']]
+        n[self._vertices['neighbors'] == -1] = -1
+        return np.ascontiguousarray(n, dtype='i4')
+
+    @property
+    def point_influence(self):
+        # _membrane_mesh.pyx:1625-1634
+        s = self.cg.Ahfunc(np.ones_like(self.cg.res)).reshape(self.vertices.shape)
+        return np.sqrt((s * s).sum(1))
+
+    def _initialize_curvature_vectors(self):
+        # _membrane_mesh.pyx:188-214 zeroes the cached curvature arrays; nothing cached here.
+        pass

@@ -1,0 +1,206 @@
+"""
+Generates the committed golden fixtures (tests/golden/*.npz) by running the REFERENCE implementation in the
+build container (needs /root/reference and oracle/_ref, see oracle/ref_harness.py).  The fixtures are data only:
+inputs (mesh arrays, points, sigma) and the reference's outputs / intermediates.  Re-run with
+
+    python tests/golden/make_golden.py
+
+The reference exposes no hooks, so intermediates are captured by wrapping bound methods of the reference
+optimiser INSTANCE (`_compute_weight_matrix4`, `_ncc`, `subsearch`) with recorders; the reference code
+itself runs unmodified.
+"""
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness                                    # noqa: E402
+from ch_shrinkwrap_amd.trimesh import TriMesh, icosphere         # noqa: E402
+
+
+def sphere_cloud(n, radius, sigma, seed, background=0.0, dtype='f4'):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    pts = d * radius + rng.normal(scale=sigma, size=(n, 3))
+    nb = int(round(background * n))
+    if nb:
+        pts[:nb] = rng.uniform(-1.6 * radius, 1.6 * radius, size=(nb, 3))
+    return pts.astype(dtype)
+
+
+def mesh_inputs(mesh):
+    return dict(vertices=mesh.vertices.copy(), faces=mesh.faces.copy(), normals=mesh.vertex_normals.copy(),
+                nbr=mesh.neighbor_vertex_table(), valid=(mesh._vertices['halfedge'] != -1))
+
+
+def run_reference(mesh, pts, lams, num_iters, sigma_inv, weights=None, record=False, cg=None):
+    if cg is None:
+        cg = ref_harness.new_reference_optimiser(mesh, pts, search_k=200, search_rad=100,
+                                                 shield_sigma=float(mesh._mean_edge_length) / 2.0)
+    rec = []
+    if record:
+        cur = {}
+        o_w, o_ncc, o_sub = cg._compute_weight_matrix4, cg._ncc, cg.subsearch
+
+        def w4(f, *a, **k):
+            v_idx, w = o_w(f, *a, **k)
+            cur['v_idx'], cur['w'], cur['dmean'] = v_idx.copy(), w.copy(), cg.d[:, 0].copy()
+            return v_idx, w
+
+        def ncc():
+            vc = o_ncc()
+            cur['fdef'] = vc.copy()
+            cur['pi'] = np.asarray(mesh.point_influence).copy()
+            return vc
+
+        def sub(f0, res, fdefs, Afunc, Lfuncs, lams_, S):
+            cur['res_masked'] = res.copy()
+            cur['S'] = S.copy()
+            cur['f0'] = f0.copy()
+            fnew, cpred, wpreds = o_sub(f0, res, fdefs, Afunc, Lfuncs, lams_, S)
+            cur['fnew'] = np.asarray(fnew).copy()
+            cur['cpred'] = float(cpred)
+            cur['wpred'] = float(wpreds[0])
+            rec.append(dict(cur))
+            cur.clear()
+            return fnew, cpred, wpreds
+
+        cg._compute_weight_matrix4, cg._ncc, cg.subsearch = w4, ncc, sub
+    out = cg.search(pts, lams=lams, num_iters=num_iters, sigma_inv=sigma_inv, weights=weights)
+    if record:
+        cg._compute_weight_matrix4, cg._ncc, cg.subsearch = o_w, o_ncc, o_sub
+    return cg, np.array(out), rec
+
+
+def logs(cg):
+    return dict(tests=np.array(cg.tests, 'f8'), ress=np.array(cg.ress, 'f8'),
+                prefs=np.array([p[0] for p in cg.prefs], 'f8'), cpred=float(cg.cpred), wpred=float(cg.wpreds[0]),
+                loopcount=int(cg.loopcount))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('wrote %s (%.1f KiB)' % (path, os.path.getsize(path) / 1024.0))
+
+
+def golden_stages():
+    v, f = icosphere(3, 120.0)
+    mesh = TriMesh(v, f)
+    inp = mesh_inputs(mesh)
+    pts = sphere_cloud(2000, 100.0, 10.0, seed=1)
+    sigma = np.full((2000, 3), 10.0, 'f4')
+    s = 1.0 / sigma.ravel()
+    cg, out, rec = run_reference(mesh, pts, [10.0], 3, s, record=True)
+    arrays = dict(points=pts, sigma=sigma, lams=np.array([10.0]), positions=out, S_final=cg.S.copy(), res_final=cg.res.copy(), **inp)
+    for k, v_ in logs(cg).items():
+        arrays['log_' + k] = v_
+    for it, r in enumerate(rec):
+        for k, v_ in r.items():
+            arrays['it%d_%s' % (it, k)] = v_
+    save('stages_642', **arrays)
+
+
+def golden_c1():
+    v, f = icosphere(4, 120.0)
+    mesh = TriMesh(v, f)
+    inp = mesh_inputs(mesh)
+    pts = sphere_cloud(10000, 100.0, 10.0, seed=0)
+    sigma = np.full((10000, 3), 10.0, 'f4')
+    s = 1.0 / sigma.ravel()
+    cg, out, rec = run_reference(mesh, pts, [10.0], 20, s, record=True)
+    arrays = dict(points=pts, sigma=sigma, lams=np.array([10.0]), positions_20=out,
+                  positions_5=rec[4]['fnew'].reshape(-1, 3).astype('f4'),
+                  positions_1=rec[0]['fnew'].reshape(-1, 3).astype('f4'), **inp)
+    for k, v_ in logs(cg).items():
+        arrays['log_' + k] = v_
+    save('c1_sphere_10k', **arrays)
+
+
+def golden_variants():
+    v, f = icosphere(3, 120.0)
+    N = 3000
+    arrays = {}
+    # (i) scalar sigma: the driver passes s = float(sigma) un-inverted (_membrane_mesh.pyx:1460-1461)
+    mesh = TriMesh(v, f)
+    arrays.update({'mesh_' + k: a for k, a in mesh_inputs(mesh).items()})
+    pts = sphere_cloud(N, 100.0, 10.0, seed=2)
+    arrays['points'] = pts
+    cg, out, _ = run_reference(mesh, pts, [10.0], 5, 10.0)
+    arrays['scalar_positions'] = out
+    arrays.update({'scalar_log_' + k: a for k, a in logs(cg).items()})
+    # (ii) explicit weights with zeros (mask) and a non-uniform sigma
+    rng = np.random.default_rng(3)
+    sigma = rng.uniform(5.0, 20.0, size=(N, 3)).astype('f4')
+    wts = (1.0 / sigma.ravel()).astype('f4')
+    wts[rng.random(3 * N) < 0.1] = 0
+    mesh = TriMesh(v, f)
+    cg, out, _ = run_reference(mesh, pts, [10.0], 5, 1.0 / sigma.ravel(), weights=wts)
+    arrays['weights_sigma'] = sigma
+    arrays['weights_weights'] = wts
+    arrays['weights_positions'] = out
+    arrays.update({'weights_log_' + k: a for k, a in logs(cg).items()})
+    # (iii) two extra vertex slots that belong to no face (halfedge == -1), 10 % uniform background
+    mesh = TriMesh(v, f, max_vertices=v.shape[0] + 2)
+    mesh._vertices['position'][-2:] = [[500, 0, 0], [0, 500, 0]]
+    pts_bg = sphere_cloud(N, 100.0, 10.0, seed=4, background=0.1)
+    sig3 = np.full((N, 3), 10.0, 'f4')
+    arrays.update({'holes_mesh_' + k: a for k, a in mesh_inputs(mesh).items()})
+    arrays['holes_points'] = pts_bg
+    cg, out, _ = run_reference(mesh, pts_bg, [10.0, 0.5], 5, 1.0 / sig3.ravel())
+    arrays['holes_positions'] = out
+    arrays['holes_mesh_positions'] = mesh.vertices.copy()
+    arrays.update({'holes_log_' + k: a for k, a in logs(cg).items()})
+    # (iv) two consecutive search() calls on one optimiser object (history of `tests` carries over,
+    #      the second call restarts from the mesh's current positions)
+    mesh = TriMesh(v, f)
+    cg, out1, _ = run_reference(mesh, pts, [10.0], 3, 1.0 / sig3.ravel())
+    cg, out2, _ = run_reference(mesh, pts, [10.0], 3, 1.0 / sig3.ravel(), cg=cg)
+    arrays['twice_positions_a'] = out1
+    arrays['twice_positions_b'] = out2
+    arrays.update({'twice_log_' + k: a for k, a in logs(cg).items()})
+    save('variants_642', **arrays)
+
+
+def golden_lfuncs():
+    """Outputs of the reference's compiled C helpers (conj_grad_utils.c) on a small sphere."""
+    _, _, cgu = ref_harness.load()
+    v, f = icosphere(2, 50.0)
+    mesh = TriMesh(v, f, max_vertices=v.shape[0] + 1)
+    nbr = mesh.neighbor_vertex_table()
+    M, NB = nbr.shape
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=3 * M).astype('f4')
+    f0 = (mesh.vertices + rng.normal(scale=0.5, size=(M, 3))).astype('f4').ravel()
+    arrays = dict(nbr=nbr, x=x, f0=f0)
+    for name, fn, second in (('l', cgu.c_shrinkwrap_l_func, None), ('lh', cgu.c_shrinkwrap_lh_func, None),
+                             ('lw', cgu.c_shrinkwrap_lw_func, f0), ('lhw', cgu.c_shrinkwrap_lhw_func, f0)):
+        d = np.zeros_like(x)
+        w = d if second is None else second
+        fn(np.ascontiguousarray(x), nbr, w, d, 3, 0, M, NB)
+        arrays['out_' + name] = d
+    o = np.zeros(3 * M, 'f4')
+    cgu.vertex_area_weights(f0, nbr, o, M, NB)
+    arrays['out_vaw'] = o
+    # scatter helper
+    N = 500
+    v_idx = rng.integers(0, M - 1, size=(N, 3)).astype('i4')
+    w = rng.random((N, 3)).astype('f4')
+    r = rng.normal(size=(N, 3)).astype('f4')
+    out = np.zeros((M, 3), 'f4')
+    cgu.c_shrinkwrap_ah_helper(v_idx, w, r, out)
+    arrays.update(ah_v_idx=v_idx, ah_w=w, ah_r=r, ah_out=out)
+    save('native_helpers', **arrays)
+
+
+if __name__ == '__main__':
+    if not ref_harness.available():
+        raise SystemExit('reference not available here')
+    golden_stages()
+    golden_c1()
+    golden_variants()
+    golden_lfuncs()
