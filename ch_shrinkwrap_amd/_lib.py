@@ -1,0 +1,109 @@
+"""
+ctypes binding of include/nanowrap.h (libnanowrap_hip.so).  There is NO CPU fallback: if the HIP library is
+missing or no GPU is visible, construction of the optimiser raises.
+"""
+import os
+import ctypes
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libnanowrap_hip.so')
+
+NW_OK = 0
+NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+NW_WEIGHTS_FROM_SIGMA_INV, NW_WEIGHTS_SCALAR, NW_WEIGHTS_ARRAY = 0, 1, 2
+NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP = 1, 2
+(NW_ARR_S, NW_ARR_RES, NW_ARR_VIDX, NW_ARR_W, NW_ARR_DIST, NW_ARR_FACE, NW_ARR_POS, NW_ARR_FDEF, NW_ARR_PI,
+ NW_ARR_MESHPOS, NW_ARR_VACC, NW_ARR_SCALARS) = range(12)
+NW_N_SCALARS = 32
+
+# every symbol include/nanowrap.h declares (tests/test_abi.py checks the exports against the header)
+SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set_stream', 'nw_synchronize',
+           'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_search', 'nw_search_begin',
+           'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars',
+           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_device_ptr', 'nw_lfunc', 'nw_set_profiling', 'nw_stage_ms']
+
+
+class IterLog(ctypes.Structure):
+    _fields_ = [('test', ctypes.c_double), ('res_norm', ctypes.c_double), ('prefs_norm', ctypes.c_double),
+                ('cpred', ctypes.c_double), ('wpred', ctypes.c_double), ('c', ctypes.c_double * 3),
+                ('H', ctypes.c_double * 9), ('G', ctypes.c_double * 3), ('mean_dist', ctypes.c_double),
+                ('n_search', ctypes.c_int32), ('nn_max_ring', ctypes.c_int32), ('status', ctypes.c_int32),
+                ('executed', ctypes.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('%s not found: build it with `python -m ch_shrinkwrap_amd.build` (hipcc, gfx950). '
+                           'There is no CPU fallback for the NanoWrap hot path.' % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32, u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
+    L.nw_abi_version.argtypes = []
+    L.nw_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.nw_destroy.argtypes = [vp]
+    L.nw_destroy.restype = None
+    L.nw_last_error.argtypes = [vp]
+    L.nw_last_error.restype = ctypes.c_char_p
+    L.nw_set_stream.argtypes = [vp, vp]
+    L.nw_synchronize.argtypes = [vp]
+    L.nw_set_points.argtypes = [vp, vp, i64, vp, f32, i32, vp, f32]
+    L.nw_set_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32]
+    L.nw_set_normals.argtypes = [vp, vp]
+    L.nw_set_positions.argtypes = [vp, vp]
+    L.nw_search.argtypes = [vp, vp, i32, i32, u32, vp, ctypes.POINTER(IterLog), ctypes.POINTER(i32)]
+    L.nw_search_begin.argtypes = [vp, vp, i32, i32, u32]
+    L.nw_iter_attract.argtypes = [vp]
+    L.nw_iter_directions.argtypes = [vp]
+    L.nw_iter_update.argtypes = [vp]
+    L.nw_search_end.argtypes = [vp, vp, ctypes.POINTER(IterLog), ctypes.POINTER(i32)]
+    L.nw_n_point_scalars.argtypes = []
+    L.nw_apply_A.argtypes = [vp, vp, vp]
+    L.nw_apply_At.argtypes = [vp, vp, vp]
+    L.nw_get.argtypes = [vp, i32, vp, i64]
+    L.nw_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    L.nw_lfunc.argtypes = [vp, i32, vp, vp, vp]
+    L.nw_set_profiling.argtypes = [vp, i32]
+    L.nw_stage_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
+    for s in SYMBOLS:
+        if s not in ('nw_destroy', 'nw_last_error'):
+            getattr(L, s).restype = i32
+    if L.nw_abi_version() != 1:
+        raise RuntimeError('libnanowrap_hip.so ABI version mismatch')
+    _lib = L
+    return L
+
+
+def ptr(a):
+    """host ndarray (C-contiguous) or raw integer device pointer -> c_void_p"""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return ctypes.c_void_p(int(a))
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class NanoWrapError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, 'nanowrap status %d: %s' % (code, msg))
+        self.code = code
+
+
+def check(L, ctx, code):
+    """Map a status to the exception the reference would have raised at the same place."""
+    if code == NW_OK:
+        return
+    msg = L.nw_last_error(ctx)
+    msg = msg.decode() if msg else ''
+    if code == NW_ERR_NAN:
+        raise AssertionError(msg)                       # mesh_conj_grad.py:514,548,580 are `assert`s
+    if code == NW_ERR_SINGULAR:
+        raise np.linalg.LinAlgError(msg)                # numpy.linalg.solve, conj_grad.py:219
+    if code == NW_ERR_BADARG:
+        raise ValueError(msg)
+    raise NanoWrapError(code, msg)

@@ -1,0 +1,41 @@
+"""
+Builds the native pieces in-tree (no pip, no JIT cache):
+  * ch_shrinkwrap_amd/libnanowrap_hip.so  -- the HIP kernels + C-ABI (hipcc, --offload-arch=gfx950)
+The oracle (test infrastructure) is built by oracle/Makefile, see __graft_entry__.build().
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, 'libnanowrap_hip.so')
+SRC = os.path.join(HERE, 'csrc', 'nanowrap.hip')
+DEPS = [SRC, os.path.join(HERE, 'csrc', 'nw_kernels.h'), os.path.join(HERE, 'csrc', 'nw_device.h'),
+        os.path.join(os.path.dirname(HERE), 'include', 'nanowrap.h')]
+
+# -ffp-contract=off : the parity-critical float32 arithmetic must round products before adding, exactly like
+#                     the NumPy reference (explicit fma() is used where contraction is wanted);
+# -munsafe-fp-atomics: float/double atomicAdd -> global_atomic_add_f32/f64 (no CAS loop).
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-shared', '-ffp-contract=off', '-munsafe-fp-atomics',
+               '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_hip_library(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc] + HIPCC_FLAGS + ['-o', LIB, SRC]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build_hip_library(force=True, verbose=True)

@@ -1,0 +1,779 @@
+// libnanowrap_hip.so -- host side of the C-ABI declared in include/nanowrap.h.
+// MI355X (gfx950) only.  One nw_ctx = one device + one stream; all state stays resident in HBM between
+// nw_set_* and nw_get; a search() block is a fixed sequence of kernel launches with no host synchronisation
+// until the per-iteration logs are read back at the end.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/nanowrap.h"
+#include "nw_kernels.h"
+
+static_assert(sizeof(NwIterLogDev) == sizeof(nw_iter_log), "device/host log record mismatch");
+static_assert(SC_COUNT <= NW_N_SCALARS, "scalar slots");
+
+#define NW_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count)
+    {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+enum { ST_TOTAL = 0, ST_GRID = 1, ST_NN = 2, ST_ATTRACT = 3, ST_PRIOR = 4, ST_AS = 5, ST_UPDATE = 6, ST_COUNT = 7 };
+
+}  // namespace
+
+struct nw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // sizes
+    int64_t N = 0, M = 0, F = 0;
+    int NB = 0;
+    bool have_points = false, have_mesh = false;
+
+    // localizations as given (caller order) -- kept so the grid can be rebuilt when the cell size changes
+    DevBuf<float> pts_in, sinv_in, w_in;
+    bool sinv_array = false;
+    float sinv_scalar = 1.0f, w_scalar = 1.0f;
+    int w_mode = NW_WEIGHTS_FROM_SIGMA_INV;
+    bool w_array = false;             // effective weights are a (3N,) array
+    float pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
+    DevBuf<double> wsum;
+
+    // localizations in cell order
+    DevBuf<float4> pts;
+    DevBuf<int> perm, pt_cell;
+    DevBuf<float> sinv, wnorm;
+    DevBuf<unsigned char> mask;
+
+    // grid
+    NwGrid grid{};
+    bool grid_valid = false;
+    double last_mean_dist = -1.0, spacing = 0.0;
+    DevBuf<int> pcount, pstart, ccount, cstart, scan_tmp, item_count, item_start;
+    DevBuf<NwWorkItem> items;
+    int nitems = 0;
+
+    // mesh
+    DevBuf<float> pos, meshpos, nrm;
+    DevBuf<int> nbr, nbr_t, faces;
+    DevBuf<unsigned char> valid;
+    bool have_valid = false;
+    int maxdeg = 0;
+    DevBuf<int> d_small;              // small int scratch (maxdeg, flags)
+
+    // per-iteration work arrays
+    DevBuf<float4> cent_tmp, cent;
+    DevBuf<int> fcell, face, vidx;
+    DevBuf<float> dist, w, res, vacc, S, fdef, pi;
+    DevBuf<double> scalars;           // [2][NW_N_SCALARS]
+    DevBuf<NwDevState> state;
+    DevBuf<NwIterLogDev> logs;
+    DevBuf<float> mm;                 // min/max scratch
+    DevBuf<float> tmp_f;              // read-back / operator scratch
+    DevBuf<float> tmp_f2;
+
+    // search bookkeeping
+    int global_iter = 0;              // iteration counter across search() calls (stop condition indexing)
+    int search_iters = 0, search_done = 0;
+    uint32_t search_flags = 0;
+    float lam0 = 0.0f;
+    bool in_search = false;
+    bool searched = false;
+
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    size_t ev_used = 0;
+    double stage_ms[ST_COUNT] = {0};
+    int64_t stage_launches[ST_COUNT] = {0};
+};
+
+namespace {
+
+int fail(nw_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define NW_HIP(call)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, NW_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+#define NW_TRY(expr)                                                                                         \
+    do {                                                                                                     \
+        int r_ = (expr);                                                                                     \
+        if (r_ != NW_OK) return r_;                                                                          \
+    } while (0)
+
+inline int nblk(int64_t n, int b = NW_BLOCK) { return (int)((n + b - 1) / b); }
+
+int scan_exclusive(nw_ctx *ctx, const int *in, int n, int *out)
+{
+    const int nb = (n + NW_SCAN_TILE - 1) / NW_SCAN_TILE;
+    NW_HIP(ctx->scan_tmp.ensure((size_t)nb + 1));
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, in, n, ctx->scan_tmp.p);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, ctx->stream, ctx->scan_tmp.p, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, in, n, ctx->scan_tmp.p, out);
+    NW_HIP(hipGetLastError());
+    return NW_OK;
+}
+
+float dec_ord(int v)   // inverse of the monotone float->int map used by k_minmax3
+{
+    unsigned u = v >= 0 ? (unsigned)v : (0x80000000u - (unsigned)v);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int enc_ord(float f)
+{
+    f = f + 0.0f;
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return f >= 0 ? (int)u : (int)(0x80000000u - u);
+}
+
+int minmax3(nw_ctx *ctx, const float *xyz, int64_t n, float lo[3], float hi[3], bool *nonfinite)
+{
+    NW_HIP(ctx->mm.ensure(8));
+    int init[8];
+    for (int k = 0; k < 3; ++k) { init[k] = enc_ord(INFINITY); init[3 + k] = enc_ord(-INFINITY); }
+    init[6] = 0; init[7] = 0;
+    NW_HIP(hipMemcpyAsync(ctx->mm.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    const int blocks = (int)std::min<int64_t>(1024, (n + NW_BLOCK - 1) / NW_BLOCK);
+    hipLaunchKernelGGL(k_minmax3, dim3(blocks), dim3(NW_BLOCK), 0, ctx->stream, xyz, n, ctx->mm.p, (int *)(ctx->mm.p + 6));
+    NW_HIP(hipGetLastError());
+    int out[8];
+    NW_HIP(hipMemcpyAsync(out, ctx->mm.p, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; ++k) { lo[k] = dec_ord(out[k]); hi[k] = dec_ord(out[3 + k]); }
+    if (nonfinite) *nonfinite = out[6] != 0;
+    return NW_OK;
+}
+
+// ---- grid construction ---------------------------------------------------------------------------------
+// Cell size: ~1.5x the mean point->centroid distance (most points then finish in the first ring), but at
+// least two centroid spacings so that a cell holds a handful of candidates; dims capped at 2^25 cells.
+int build_grid(nw_ctx *ctx, double mean_dist)
+{
+    const int64_t N = ctx->N, F = ctx->F;
+    // mesh bbox + area
+    float mlo[3], mhi[3];
+    bool bad = false;
+    NW_TRY(minmax3(ctx, ctx->pos.p, ctx->M, mlo, mhi, &bad));
+    if (bad) return fail(ctx, NW_ERR_NONFINITE, "non-finite vertex coordinate");
+    NW_HIP(ctx->wsum.ensure(4));
+    NW_HIP(hipMemsetAsync(ctx->wsum.p + 1, 0, 2 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_mesh_area, dim3(std::min(1024, nblk(F))), dim3(NW_BLOCK), 0, ctx->stream, ctx->pos.p, ctx->faces.p, (int)F, ctx->wsum.p + 1);
+    const int nsample = (int)std::min<int64_t>(N, 256);
+    if (mean_dist <= 0.0)
+        hipLaunchKernelGGL(k_sample_nn, dim3(nsample), dim3(NW_BLOCK), 0, ctx->stream, ctx->pts_in.p, N, nsample, ctx->pos.p, ctx->faces.p, (int)F, ctx->wsum.p + 2);
+    NW_HIP(hipGetLastError());
+    double h2[2];
+    NW_HIP(hipMemcpyAsync(h2, ctx->wsum.p + 1, sizeof(h2), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    const double area = h2[0];
+    if (mean_dist <= 0.0) mean_dist = h2[1] / nsample;
+    double spacing = std::sqrt(std::max(area, 1e-30) / (double)F);
+    float lo[3], hi[3];
+    double ext = 0;
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = std::min(mlo[k], ctx->pmin[k]);
+        hi[k] = std::max(mhi[k], ctx->pmax[k]);
+        ext = std::max(ext, (double)hi[k] - lo[k]);
+    }
+    if (!(ext > 0)) ext = 1.0;
+    ctx->spacing = spacing;
+    double h = std::max(1.5 * mean_dist, 2.0 * spacing);
+    if (!(h > 0) || !std::isfinite(h)) h = ext / 16;
+    h = std::max(h, ext / 1024.0);                       // at most 1024 cells per axis
+    const char *env_h = getenv("NW_CELL_SIZE");
+    if (env_h && atof(env_h) > 0) h = atof(env_h);
+    NwGrid g;
+    for (;;) {
+        const double margin = 0.5 * h;
+        g.ox = (float)(lo[0] - margin); g.oy = (float)(lo[1] - margin); g.oz = (float)(lo[2] - margin);
+        g.gx = std::max(1, (int)std::ceil((hi[0] + margin - g.ox) / h));
+        g.gy = std::max(1, (int)std::ceil((hi[1] + margin - g.oy) / h));
+        g.gz = std::max(1, (int)std::ceil((hi[2] + margin - g.oz) / h));
+        if ((double)g.gx * g.gy * g.gz <= (double)(1 << 25)) break;
+        h *= 1.26;
+    }
+    g.h = (float)h;
+    g.inv_h = 1.0f / g.h;
+    g.ncell = g.gx * g.gy * g.gz;
+    const double maxc = std::max({std::fabs((double)g.ox), std::fabs((double)g.oy), std::fabs((double)g.oz),
+                                  std::fabs(g.ox + g.gx * h), std::fabs(g.oy + g.gy * h), std::fabs(g.oz + g.gz * h)});
+    g.eps = (float)(1e-3 * h + 2e-6 * maxc);
+    ctx->grid = g;
+
+    const size_t nc = (size_t)g.ncell;
+    NW_HIP(ctx->pcount.ensure(nc));
+    NW_HIP(ctx->pstart.ensure(nc + 1));
+    NW_HIP(ctx->ccount.ensure(nc));
+    NW_HIP(ctx->cstart.ensure(nc + 1));
+    NW_HIP(ctx->item_count.ensure(nc));
+    NW_HIP(ctx->item_start.ensure(nc + 1));
+    NW_HIP(hipMemsetAsync(ctx->pcount.p, 0, nc * sizeof(int), ctx->stream));
+    NW_HIP(hipMemsetAsync(ctx->ccount.p, 0, nc * sizeof(int), ctx->stream));
+
+    // sort the localizations into cell order, baking the residual weighting
+    NW_HIP(ctx->pts.ensure(N));
+    NW_HIP(ctx->perm.ensure(N));
+    NW_HIP(ctx->pt_cell.ensure(N));
+    NW_HIP(ctx->mask.ensure(N));
+    if (ctx->sinv_array) NW_HIP(ctx->sinv.ensure(3 * N));
+    if (ctx->w_array) NW_HIP(ctx->wnorm.ensure(3 * N));
+    hipLaunchKernelGGL(k_point_cells, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pts_in.p, (int)N, ctx->pt_cell.p, ctx->pcount.p);
+    NW_TRY(scan_exclusive(ctx, ctx->pcount.p, g.ncell, ctx->pstart.p));
+    const float *w_src = ctx->w_array ? (ctx->w_mode == NW_WEIGHTS_ARRAY ? ctx->w_in.p : ctx->sinv_in.p) : nullptr;
+    hipLaunchKernelGGL(k_point_scatter, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts_in.p, ctx->pt_cell.p, ctx->pstart.p, ctx->pcount.p,
+                       ctx->sinv_array ? ctx->sinv_in.p : nullptr, w_src, ctx->wsum.p, ctx->w_array ? 1 : 0,
+                       ctx->pts.p, ctx->perm.p, ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->mask.p);
+    // work list
+    hipLaunchKernelGGL(k_count_items, dim3(nblk(g.ncell)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pstart.p, g.ncell, ctx->item_count.p);
+    NW_TRY(scan_exclusive(ctx, ctx->item_count.p, g.ncell, ctx->item_start.p));
+    int nitems = 0;
+    NW_HIP(hipMemcpyAsync(&nitems, ctx->item_start.p + g.ncell, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->nitems = nitems;
+    NW_HIP(ctx->items.ensure((size_t)nitems));
+    hipLaunchKernelGGL(k_fill_items, dim3(nblk(g.ncell)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pstart.p, ctx->item_start.p, g.ncell, ctx->items.p);
+    NW_HIP(hipGetLastError());
+    ctx->grid_valid = true;
+    if (getenv("NW_VERBOSE"))
+        fprintf(stderr, "[nanowrap] grid %dx%dx%d h=%.3f (mean_dist %.3f, spacing %.3f) items=%d\n", g.gx, g.gy, g.gz, g.h, mean_dist, spacing, nitems);
+    return NW_OK;
+}
+
+// desired cell edge from the mean NN distance of the last iteration and the centroid spacing
+double desired_cell(double mean_dist, double spacing) { return std::max(1.5 * mean_dist, 2.0 * spacing); }
+
+int ensure_grid(nw_ctx *ctx)
+{
+    if (ctx->grid_valid && ctx->last_mean_dist > 0) {
+        // keep the grid (and the cell-sorted localizations) unless the cell size drifted far from what the last
+        // iteration suggests: re-sorting N points costs more than a slightly off cell size
+        const double want = desired_cell(ctx->last_mean_dist, ctx->spacing);
+        if (want < 1.6 * ctx->grid.h && want > 0.6 * ctx->grid.h) return NW_OK;
+        if (getenv("NW_CELL_SIZE")) return NW_OK;
+    } else if (ctx->grid_valid) {
+        return NW_OK;
+    }
+    return build_grid(ctx, ctx->last_mean_dist);
+}
+
+hipEvent_t next_event(nw_ctx *ctx)
+{
+    if (ctx->ev_used == ctx->events.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        ctx->events.push_back(e);
+    }
+    hipEvent_t e = ctx->events[ctx->ev_used++];
+    (void)hipEventRecord(e, ctx->stream);
+    return e;
+}
+
+struct StageMarks { std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans; };
+thread_local StageMarks g_marks;
+
+struct StageScope {
+    nw_ctx *c; int stage; hipEvent_t a;
+    StageScope(nw_ctx *ctx, int s) : c(ctx), stage(s), a(nullptr) { if (c->profiling) a = next_event(c); }
+    ~StageScope() { if (c->profiling) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
+};
+
+int alloc_work(nw_ctx *ctx)
+{
+    const int64_t N = ctx->N, M = ctx->M, F = ctx->F;
+    NW_HIP(ctx->cent_tmp.ensure(F));
+    NW_HIP(ctx->cent.ensure(F));
+    NW_HIP(ctx->fcell.ensure(F));
+    NW_HIP(ctx->face.ensure(N));
+    NW_HIP(ctx->dist.ensure(N));
+    NW_HIP(ctx->vidx.ensure(3 * N));
+    NW_HIP(ctx->w.ensure(3 * N));
+    NW_HIP(ctx->res.ensure(3 * N));
+    NW_HIP(ctx->vacc.ensure(4 * M));
+    NW_HIP(ctx->S.ensure(9 * M));
+    NW_HIP(ctx->fdef.ensure(3 * M));
+    NW_HIP(ctx->pi.ensure(M));
+    NW_HIP(ctx->scalars.ensure(2 * NW_N_SCALARS));
+    return NW_OK;
+}
+
+}  // namespace
+
+// =============================================================================================================
+NW_EXPORT int nw_abi_version(void) { return NW_ABI_VERSION; }
+NW_EXPORT int nw_n_point_scalars(void) { return SC_NPOINT; }
+
+NW_EXPORT int nw_create(int device, nw_ctx **out)
+{
+    if (!out) return NW_ERR_BADARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NW_ERR_HIP;
+    if (device < 0 || device >= ndev) return NW_ERR_BADARG;
+    if (hipSetDevice(device) != hipSuccess) return NW_ERR_HIP;
+    nw_ctx *ctx = new nw_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NW_ERR_HIP; }
+    ctx->own_stream = true;
+    if (ctx->state.ensure(1) != hipSuccess) { delete ctx; return NW_ERR_NOMEM; }
+    NwDevState st{};
+    st.stop_at = 0x7fffffff;
+    (void)hipMemcpy(ctx->state.p, &st, sizeof(st), hipMemcpyHostToDevice);
+    *out = ctx;
+    return NW_OK;
+}
+
+NW_EXPORT void nw_destroy(nw_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->pts_in.release(); ctx->sinv_in.release(); ctx->w_in.release(); ctx->wsum.release();
+    ctx->pts.release(); ctx->perm.release(); ctx->pt_cell.release(); ctx->sinv.release(); ctx->wnorm.release(); ctx->mask.release();
+    ctx->pcount.release(); ctx->pstart.release(); ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release();
+    ctx->item_count.release(); ctx->item_start.release(); ctx->items.release();
+    ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
+    ctx->valid.release(); ctx->d_small.release();
+    ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->face.release(); ctx->vidx.release();
+    ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
+    ctx->scalars.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
+    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+NW_EXPORT const char *nw_last_error(nw_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+NW_EXPORT int nw_set_stream(nw_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return NW_ERR_BADARG;
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
+    else { NW_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    return NW_OK;
+}
+
+NW_EXPORT int nw_synchronize(nw_ctx *ctx)
+{
+    if (!ctx) return NW_ERR_BADARG;
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, const float *sigma_inv, float sigma_inv_scalar,
+                            int weights_mode, const float *weights, float weights_scalar)
+{
+    if (!ctx) return NW_ERR_BADARG;
+    if (!xyz || n_points <= 0 || n_points > 0x7fffffff / 4) return fail(ctx, NW_ERR_BADARG, "nw_set_points: bad points array/size");
+    if (weights_mode < 0 || weights_mode > 2) return fail(ctx, NW_ERR_BADARG, "nw_set_points: bad weights_mode");
+    if (weights_mode == NW_WEIGHTS_ARRAY && !weights) return fail(ctx, NW_ERR_BADARG, "nw_set_points: weights array missing");
+    NW_HIP(hipSetDevice(ctx->device));
+    const int64_t N = n_points;
+    ctx->N = N;
+    NW_HIP(ctx->pts_in.ensure(3 * N));
+    NW_HIP(hipMemcpyAsync(ctx->pts_in.p, xyz, 3 * N * sizeof(float), hipMemcpyDefault, ctx->stream));
+    ctx->sinv_array = sigma_inv != nullptr;
+    ctx->sinv_scalar = sigma_inv_scalar;
+    if (sigma_inv) {
+        NW_HIP(ctx->sinv_in.ensure(3 * N));
+        NW_HIP(hipMemcpyAsync(ctx->sinv_in.p, sigma_inv, 3 * N * sizeof(float), hipMemcpyDefault, ctx->stream));
+    }
+    ctx->w_mode = weights_mode;
+    if (weights_mode == NW_WEIGHTS_ARRAY) {
+        NW_HIP(ctx->w_in.ensure(3 * N));
+        NW_HIP(hipMemcpyAsync(ctx->w_in.p, weights, 3 * N * sizeof(float), hipMemcpyDefault, ctx->stream));
+        ctx->w_array = true;
+    } else if (weights_mode == NW_WEIGHTS_SCALAR) {
+        ctx->w_array = false;
+        ctx->w_scalar = weights_scalar;
+    } else {
+        ctx->w_array = ctx->sinv_array;       // weights = sigma_inv
+        ctx->w_scalar = sigma_inv_scalar;
+    }
+    NW_HIP(ctx->wsum.ensure(4));
+    NW_HIP(hipMemsetAsync(ctx->wsum.p, 0, 4 * sizeof(double), ctx->stream));
+    if (ctx->w_array) {
+        const float *src = weights_mode == NW_WEIGHTS_ARRAY ? ctx->w_in.p : ctx->sinv_in.p;
+        hipLaunchKernelGGL(k_sum_f64, dim3(std::min(1024, nblk(3 * N))), dim3(NW_BLOCK), 0, ctx->stream, src, 3 * N, ctx->wsum.p);
+        NW_HIP(hipGetLastError());
+    }
+    bool bad = false;
+    NW_TRY(minmax3(ctx, ctx->pts_in.p, N, ctx->pmin, ctx->pmax, &bad));
+    if (bad) { ctx->have_points = false; return fail(ctx, NW_ERR_NONFINITE, "non-finite localization coordinate"); }
+    ctx->have_points = true;
+    ctx->grid_valid = false;
+    ctx->last_mean_dist = -1.0;
+    ctx->searched = false;
+    return NW_OK;
+}
+
+NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const int32_t *nbr, const uint8_t *valid, const int32_t *faces,
+                          int64_t n_vertices, int64_t n_faces, int n_nbr)
+{
+    if (!ctx) return NW_ERR_BADARG;
+    if (!pos || !nrm || !nbr || !faces || n_vertices <= 0 || n_faces <= 0 || n_nbr <= 0 || n_vertices > 0x7fffffff / 16 || n_faces > 0x7fffffff / 4)
+        return fail(ctx, NW_ERR_BADARG, "nw_set_mesh: bad array/size");
+    NW_HIP(hipSetDevice(ctx->device));
+    const int64_t M = n_vertices, F = n_faces;
+    const bool topo_change = (M != ctx->M) || (F != ctx->F);
+    ctx->M = M; ctx->F = F; ctx->NB = n_nbr;
+    NW_HIP(ctx->pos.ensure(3 * M));
+    NW_HIP(ctx->meshpos.ensure(3 * M));
+    NW_HIP(ctx->nrm.ensure(3 * M));
+    NW_HIP(ctx->nbr.ensure((size_t)M * n_nbr));
+    NW_HIP(ctx->nbr_t.ensure((size_t)M * n_nbr));
+    NW_HIP(ctx->faces.ensure(3 * F));
+    NW_HIP(ctx->d_small.ensure(8));
+    NW_HIP(hipMemcpyAsync(ctx->pos.p, pos, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipMemcpyAsync(ctx->meshpos.p, pos, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipMemcpyAsync(ctx->nrm.p, nrm, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipMemcpyAsync(ctx->nbr.p, nbr, (size_t)M * n_nbr * sizeof(int), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipMemcpyAsync(ctx->faces.p, faces, 3 * F * sizeof(int), hipMemcpyDefault, ctx->stream));
+    ctx->have_valid = valid != nullptr;
+    if (valid) {
+        NW_HIP(ctx->valid.ensure(M));
+        NW_HIP(hipMemcpyAsync(ctx->valid.p, valid, M, hipMemcpyDefault, ctx->stream));
+    }
+    NW_HIP(hipMemsetAsync(ctx->d_small.p, 0, 8 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_nbr_transpose, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, ctx->nbr.p, (int)M, n_nbr, ctx->nbr_t.p, ctx->d_small.p);
+    NW_HIP(hipGetLastError());
+    NW_HIP(hipMemcpyAsync(&ctx->maxdeg, ctx->d_small.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->have_mesh = true;
+    if (topo_change) { ctx->grid_valid = false; }
+    // a new mesh object = a new optimiser in the reference (_membrane_mesh.pyx:1510): history restarts
+    NwDevState st{};
+    st.stop_at = 0x7fffffff;
+    NW_HIP(hipMemcpyAsync(ctx->state.p, &st, sizeof(st), hipMemcpyHostToDevice, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->global_iter = 0;
+    ctx->searched = false;
+    return NW_OK;
+}
+
+NW_EXPORT int nw_set_normals(nw_ctx *ctx, const float *nrm)
+{
+    if (!ctx || !nrm || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_normals: mesh not set");
+    NW_HIP(hipMemcpyAsync(ctx->nrm.p, nrm, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_set_positions(nw_ctx *ctx, const float *pos)
+{
+    if (!ctx || !pos || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_positions: mesh not set");
+    NW_HIP(hipMemcpyAsync(ctx->pos.p, pos, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipMemcpyAsync(ctx->meshpos.p, pos, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    return NW_OK;
+}
+
+// ---- the iteration -------------------------------------------------------------------------------------------
+NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags)
+{
+    if (!ctx) return NW_ERR_BADARG;
+    if (!ctx->have_points || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_search: set points and mesh first");
+    if (!lams || n_lams < 1 || num_iters < 0) return fail(ctx, NW_ERR_BADARG, "nw_search: need at least one lambda and num_iters >= 0");
+    if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_search_begin: previous search not ended");
+    NW_HIP(hipSetDevice(ctx->device));
+    NW_TRY(alloc_work(ctx));
+    // start_guess: fs = vertices.copy() -> f restarts from the mesh positions (mesh_conj_grad.py:170, :1002-1007)
+    NW_HIP(hipMemcpyAsync(ctx->pos.p, ctx->meshpos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    NW_TRY(ensure_grid(ctx));
+    ctx->lam0 = lams[0];
+    ctx->search_flags = flags;
+    ctx->search_iters = num_iters;
+    ctx->search_done = 0;
+    NW_HIP(ctx->logs.ensure((size_t)std::max(num_iters, 1)));
+    NW_HIP(hipMemsetAsync(ctx->logs.p, 0, (size_t)std::max(num_iters, 1) * sizeof(NwIterLogDev), ctx->stream));
+    NW_HIP(hipMemsetAsync(ctx->S.p, 0, 9 * ctx->M * sizeof(float), ctx->stream));         // S = zeros (:207)
+    NW_HIP(hipMemsetAsync(ctx->res.p, 0, 3 * ctx->N * sizeof(float), ctx->stream));       // res = 0*data (:181)
+    NW_HIP(hipMemsetAsync(ctx->vacc.p, 0, 4 * ctx->M * sizeof(float), ctx->stream));
+    NW_HIP(hipMemsetAsync(ctx->scalars.p, 0, 2 * NW_N_SCALARS * sizeof(double), ctx->stream));
+    if (ctx->profiling) { ctx->ev_used = 0; g_marks.spans.clear(); for (int k = 0; k < ST_COUNT; ++k) { ctx->stage_ms[k] = 0; ctx->stage_launches[k] = 0; } }
+    ctx->in_search = true;
+    return NW_OK;
+}
+
+NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
+{
+    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_attract outside a search");
+    const int it = ctx->global_iter;
+    const int par = it & 1;
+    const int64_t N = ctx->N, F = ctx->F;
+    const NwGrid g = ctx->grid;
+    double *sc = ctx->scalars.p + par * NW_N_SCALARS;
+    {
+        StageScope s(ctx, ST_GRID);
+        hipLaunchKernelGGL(k_face_centroids, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pos.p, ctx->faces.p, (int)F,
+                           ctx->cent_tmp.p, ctx->fcell.p, ctx->ccount.p, ctx->state.p, it);
+        NW_TRY(scan_exclusive(ctx, ctx->ccount.p, g.ncell, ctx->cstart.p));
+        hipLaunchKernelGGL(k_centroid_scatter, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, (int)F, ctx->cent_tmp.p, ctx->fcell.p, ctx->cstart.p,
+                           ctx->ccount.p, ctx->cent.p, ctx->state.p, it);
+    }
+    {
+        StageScope s(ctx, ST_NN);
+        const int nb = 8 * ((ctx->nitems + 7) / 8);
+        hipLaunchKernelGGL(k_nearest_face, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                           ctx->face.p, ctx->dist.p, ctx->state.p, it);
+    }
+    {
+        StageScope s(ctx, ST_ATTRACT);
+        hipLaunchKernelGGL(k_attract, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts.p, ctx->face.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
+                           ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->sinv_scalar, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->w_scalar, ctx->mask.p,
+                           ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, sc, ctx->state.p, it);
+    }
+    NW_HIP(hipGetLastError());
+    return NW_OK;
+}
+
+NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
+{
+    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_directions outside a search");
+    const int it = ctx->global_iter;
+    const int par = it & 1;
+    const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
+    double *sc = ctx->scalars.p + par * NW_N_SCALARS;
+    {
+        StageScope s(ctx, ST_PRIOR);
+        hipLaunchKernelGGL(k_prior_directions, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->maxdeg, ctx->nbr_t.p, ctx->pos.p,
+                           ctx->meshpos.p, ctx->nrm.p, ctx->vacc.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, sc, ctx->state.p, it, n_search);
+    }
+    {
+        StageScope s(ctx, ST_AS);
+        hipLaunchKernelGGL(k_subspace_point_sums, dim3(nblk(ctx->N)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
+                           ctx->mask.p, ctx->S.p, sc, ctx->state.p, it, n_search);
+    }
+    NW_HIP(hipGetLastError());
+    return NW_OK;
+}
+
+NW_EXPORT int nw_iter_update(nw_ctx *ctx)
+{
+    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_update outside a search");
+    if (ctx->search_done >= ctx->search_iters) return fail(ctx, NW_ERR_BADARG, "nw_iter_update: more iterations than announced");
+    const int it = ctx->global_iter;
+    const int par = it & 1;
+    const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
+    double *sc = ctx->scalars.p + par * NW_N_SCALARS;
+    double *sc_next = ctx->scalars.p + (par ^ 1) * NW_N_SCALARS;
+    {
+        StageScope s(ctx, ST_UPDATE);
+        hipLaunchKernelGGL(k_solve_update, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->lam0, n_search, ctx->search_flags,
+                           ctx->have_valid ? ctx->valid.p : nullptr, ctx->pos.p, ctx->meshpos.p, ctx->S.p, ctx->vacc.p, sc, sc_next, ctx->state.p,
+                           ctx->logs.p + ctx->search_done, it);
+    }
+    NW_HIP(hipGetLastError());
+    ctx->global_iter += 1;
+    ctx->search_done += 1;
+    return NW_OK;
+}
+
+NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *loopcount)
+{
+    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_search_end outside a search");
+    ctx->in_search = false;
+    std::vector<nw_iter_log> host((size_t)std::max(ctx->search_done, 1));
+    if (ctx->search_done > 0)
+        NW_HIP(hipMemcpyAsync(host.data(), ctx->logs.p, (size_t)ctx->search_done * sizeof(nw_iter_log), hipMemcpyDeviceToHost, ctx->stream));
+    if (pos_out) NW_HIP(hipMemcpyAsync(pos_out, ctx->pos.p, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NwDevState st;
+    NW_HIP(hipMemcpyAsync(&st, ctx->state.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    int executed = 0;
+    for (int i = 0; i < ctx->search_done; ++i) executed += host[i].executed ? 1 : 0;
+    if (loopcount) *loopcount = executed;
+    if (log) for (int i = 0; i < ctx->search_done; ++i) log[i] = host[i];
+    if (executed > 0) ctx->last_mean_dist = host[executed - 1].mean_dist;
+    ctx->searched = ctx->searched || executed > 0;
+    if (ctx->profiling) {
+        for (auto &sp : g_marks.spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sp.second.first, sp.second.second) == hipSuccess) { ctx->stage_ms[sp.first] += ms; ctx->stage_ms[ST_TOTAL] += ms; }
+        }
+        g_marks.spans.clear();
+    }
+    if (st.status != 0) {
+        // clear the sticky device status so the ctx stays usable; report it once
+        const int code = st.status;
+        NwDevState st2 = st; st2.status = 0;
+        (void)hipMemcpy(ctx->state.p, &st2, sizeof(st2), hipMemcpyHostToDevice);
+        if (code == NW_ERR_NAN) return fail(ctx, NW_ERR_NAN, "NaN detected in weight matrix / A f / A^T r (reference asserts at mesh_conj_grad.py:514,548,580)");
+        if (code == NW_ERR_SINGULAR) return fail(ctx, NW_ERR_SINGULAR, "singular subspace normal equations (numpy.linalg.solve would raise LinAlgError)");
+        return fail(ctx, code, "device-side error");
+    }
+    return NW_OK;
+}
+
+NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags, float *pos_out, nw_iter_log *log, int *loopcount)
+{
+    NW_TRY(nw_search_begin(ctx, lams, n_lams, num_iters, flags));
+    for (int i = 0; i < num_iters; ++i) {
+        int r = nw_iter_attract(ctx);
+        if (r == NW_OK) r = nw_iter_directions(ctx);
+        if (r == NW_OK) r = nw_iter_update(ctx);
+        if (r != NW_OK) { ctx->in_search = false; return r; }
+    }
+    return nw_search_end(ctx, pos_out, log, loopcount);
+}
+
+// ---- operators & read-back -------------------------------------------------------------------------------------
+NW_EXPORT int nw_apply_A(nw_ctx *ctx, const float *x, float *y)
+{
+    if (!ctx || !x || !y) return NW_ERR_BADARG;
+    if (!ctx->searched) return fail(ctx, NW_ERR_BADARG, "nw_apply_A: no weight matrix yet (run a search iteration first)");
+    NW_HIP(ctx->tmp_f.ensure(3 * ctx->M));
+    NW_HIP(ctx->tmp_f2.ensure(3 * ctx->N));
+    NW_HIP(hipMemcpyAsync(ctx->tmp_f.p, x, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    hipLaunchKernelGGL(k_apply_A, dim3(nblk(ctx->N)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->perm.p, ctx->vidx.p, ctx->w.p, ctx->tmp_f.p, ctx->tmp_f2.p);
+    NW_HIP(hipGetLastError());
+    NW_HIP(hipMemcpyAsync(y, ctx->tmp_f2.p, 3 * ctx->N * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_apply_At(nw_ctx *ctx, const float *r, float *z)
+{
+    if (!ctx || !r || !z) return NW_ERR_BADARG;
+    if (!ctx->searched) return fail(ctx, NW_ERR_BADARG, "nw_apply_At: no weight matrix yet (run a search iteration first)");
+    NW_HIP(ctx->tmp_f.ensure(3 * ctx->M));
+    NW_HIP(ctx->tmp_f2.ensure(3 * ctx->N));
+    NW_HIP(hipMemcpyAsync(ctx->tmp_f2.p, r, 3 * ctx->N * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipMemsetAsync(ctx->tmp_f.p, 0, 3 * ctx->M * sizeof(float), ctx->stream));
+    hipLaunchKernelGGL(k_apply_At, dim3(nblk(ctx->N)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->perm.p, ctx->vidx.p, ctx->w.p, ctx->tmp_f2.p, ctx->tmp_f.p);
+    NW_HIP(hipGetLastError());
+    NW_HIP(hipMemcpyAsync(z, ctx->tmp_f.p, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes)
+{
+    if (!ctx || !ptr) return NW_ERR_BADARG;
+    void *p = nullptr;
+    int64_t nb = 0;
+    switch (what) {
+    case NW_ARR_S: p = ctx->S.p; nb = 9 * ctx->M * 4; break;
+    case NW_ARR_POS: p = ctx->pos.p; nb = 3 * ctx->M * 4; break;
+    case NW_ARR_MESHPOS: p = ctx->meshpos.p; nb = 3 * ctx->M * 4; break;
+    case NW_ARR_FDEF: p = ctx->fdef.p; nb = 3 * ctx->M * 4; break;
+    case NW_ARR_PI: p = ctx->pi.p; nb = ctx->M * 4; break;
+    case NW_ARR_VACC: p = ctx->vacc.p; nb = 4 * ctx->M * 4; break;
+    case NW_ARR_SCALARS: p = ctx->scalars.p ? ctx->scalars.p + (ctx->global_iter & 1) * NW_N_SCALARS : nullptr; nb = NW_N_SCALARS * 8; break;
+    default: return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array is not device-addressable in caller order");
+    }
+    if (!p) return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array not allocated yet");
+    *ptr = p;
+    if (nbytes) *nbytes = nb;
+    return NW_OK;
+}
+
+NW_EXPORT int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes)
+{
+    if (!ctx || !dst) return NW_ERR_BADARG;
+    const int64_t N = ctx->N;
+    const void *src = nullptr;
+    int64_t need = 0;
+    int width = 0;                       // >0: per-point array that must be un-permuted
+    switch (what) {
+    case NW_ARR_RES: src = ctx->res.p; width = 3; break;
+    case NW_ARR_VIDX: src = ctx->vidx.p; width = 3; break;
+    case NW_ARR_W: src = ctx->w.p; width = 3; break;
+    case NW_ARR_DIST: src = ctx->dist.p; width = 1; break;
+    case NW_ARR_FACE: src = ctx->face.p; width = 1; break;
+    default: {
+        void *p; int64_t nb;
+        NW_TRY(nw_device_ptr(ctx, what, &p, &nb));
+        src = p; need = nb;
+    }
+    }
+    if (width > 0) {
+        if (!src || !ctx->perm.p) return fail(ctx, NW_ERR_BADARG, "nw_get: array not available yet");
+        need = (int64_t)width * N * 4;
+        if (nbytes < need) return fail(ctx, NW_ERR_BADARG, "nw_get: destination too small");
+        NW_HIP(ctx->tmp_f2.ensure(3 * N));
+        hipLaunchKernelGGL(k_unpermute, dim3(nblk((int64_t)width * N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, width, ctx->perm.p, (const uint32_t *)src, (uint32_t *)ctx->tmp_f2.p);
+        NW_HIP(hipGetLastError());
+        NW_HIP(hipMemcpyAsync(dst, ctx->tmp_f2.p, need, hipMemcpyDefault, ctx->stream));
+    } else {
+        if (nbytes < need) return fail(ctx, NW_ERR_BADARG, "nw_get: destination too small");
+        NW_HIP(hipMemcpyAsync(dst, src, need, hipMemcpyDefault, ctx->stream));
+    }
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, float *out)
+{
+    if (!ctx || !x || !out || kind < 0 || kind > 4) return NW_ERR_BADARG;
+    if (!ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_lfunc: mesh not set");
+    if ((kind == 2 || kind == 3) && !f0) return fail(ctx, NW_ERR_BADARG, "nw_lfunc: f0 required");
+    const int64_t M = ctx->M;
+    DevBuf<float> dx, df, dout;
+    NW_HIP(dx.ensure(3 * M)); NW_HIP(df.ensure(3 * M)); NW_HIP(dout.ensure(3 * M));
+    int rc = NW_OK;
+    do {
+        if (hipMemcpyAsync(dx.p, x, 3 * M * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        if (f0 && hipMemcpyAsync(df.p, f0, 3 * M * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        // outputs accumulate into the caller's array, as in the reference (kind 4 overwrites the rows it visits)
+        if (hipMemcpyAsync(dout.p, out, 3 * M * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        if (kind == 1) hipLaunchKernelGGL(k_lfunc_lh_serial, dim3(1), dim3(64), 0, ctx->stream, (int)M, ctx->NB, ctx->nbr.p, dx.p, dout.p);
+        else if (kind == 3) hipLaunchKernelGGL(k_lfunc_lhw, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, (int)M, ctx->NB, ctx->nbr.p, dx.p, df.p, dout.p);
+        else hipLaunchKernelGGL(k_lfunc_gather, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, kind, (int)M, ctx->NB, ctx->nbr.p, dx.p, df.p, dout.p);
+        if (hipGetLastError() != hipSuccess) { rc = NW_ERR_HIP; break; }
+        if (hipMemcpyAsync(out, dout.p, 3 * M * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+    } while (0);
+    dx.release(); df.release(); dout.release();
+    if (rc != NW_OK) return fail(ctx, rc, "nw_lfunc: HIP failure");
+    return NW_OK;
+}
+
+NW_EXPORT int nw_set_profiling(nw_ctx *ctx, int enable)
+{
+    if (!ctx) return NW_ERR_BADARG;
+    ctx->profiling = enable != 0;
+    return NW_OK;
+}
+
+NW_EXPORT int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches)
+{
+    if (!ctx || stage < 0 || stage >= ST_COUNT) return NW_ERR_BADARG;
+    if (ms) *ms = ctx->stage_ms[stage];
+    if (launches) *launches = ctx->stage_launches[stage];
+    return NW_OK;
+}

@@ -1,0 +1,876 @@
+// NanoWrap inner-loop kernels for MI355X (gfx950).  HBM/latency-bound irregular work: no MFMA anywhere.
+// Reference arithmetic being reproduced is cited per kernel (paths relative to /root/reference/ch_shrinkwrap/).
+#pragma once
+#include "nw_device.h"
+
+// ---- scalar slots (double), double-buffered by iteration parity ------------------------------------------
+enum {
+    // point-side partial sums (all-reduced across ranks in multi-GPU runs)
+    SC_RES2 = 0,     // sum res^2            -> ress log          mesh_conj_grad.py:270
+    SC_C0 = 1,       // sum_mask res^2       -> c0                conj_grad.py:189
+    SC_SUMD = 2,     // sum of NN distances  -> grid cell-size control
+    SC_NPTS = 3,     // number of points contributing
+    SC_HC = 4,       // 6: AS^T AS (00,01,02,11,12,22)            conj_grad.py:202
+    SC_GC = 10,      // 3: AS^T res                               conj_grad.py:203
+    SC_NPOINT = 13,
+    // vertex-side sums (replicated on every rank)
+    SC_SS = 13,      // 6: S^T S = Hw                             conj_grad.py:211
+    SC_SP = 19,      // 3: S_k . prefs64 (Gw = -SP)               conj_grad.py:212
+    SC_PP64 = 22,    // sum prefs64^2 -> wpreds                   conj_grad.py:192
+    SC_PP32 = 23,    // sum prefs32^2 -> prefs log                mesh_conj_grad.py:271
+    SC_COUNT = 24
+};
+
+struct NwDevState {
+    int stop_at;          // first iteration index (global, per ctx) that must not execute (stop condition)
+    int ntests;           // number of test statistics recorded so far (history survives search() calls)
+    float tests[3];       // last three test statistics, oldest first
+    int status;           // sticky nw_status raised on the device
+    int nn_max_ring;
+    int pad;
+};
+
+struct NwWorkItem { int cell, p0, p1; };
+
+// ============================================================================================================
+// generic exclusive scan of int32 counts (3 launches): out[0..n] with out[n] = total
+// ============================================================================================================
+#define NW_SCAN_TILE 2048   // 256 threads x 8
+
+__global__ __launch_bounds__(NW_BLOCK) void k_scan_tile_sums(const int *__restrict__ in, int n, int *__restrict__ bsum)
+{
+    __shared__ int s_w[4];
+    const int base = blockIdx.x * NW_SCAN_TILE + threadIdx.x * 8;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += (base + k < n) ? in[base + k] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_bsums(int *__restrict__ bsum, int nb)
+{
+    // single workgroup: in-place exclusive scan of the tile sums
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? bsum[i] : 0;
+        int inc = nw_wave_incl_scan(v, lane);
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; ++w) woff += s_w[w];
+        const int carry = s_carry;
+        if (i < nb) bsum[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_scan_final(const int *__restrict__ in, int n, const int *__restrict__ bsum, int *__restrict__ out)
+{
+    __shared__ int s_w[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int base = blockIdx.x * NW_SCAN_TILE + threadIdx.x * 8;
+    int v[8];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    const int inc = nw_wave_incl_scan(s, lane);
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int off = bsum[blockIdx.x] + inc - s;
+    for (int w = 0; w < wv; ++w) off += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (base + k < n) out[base + k] = off;
+        off += v[k];
+        if (base + k == n - 1) out[n] = off;
+    }
+}
+
+// ============================================================================================================
+// set-up kernels (once per nw_set_points / grid change)
+// ============================================================================================================
+__global__ void k_minmax3(const float *__restrict__ xyz, int64_t n, float *__restrict__ mm /* [6]: min xyz, max xyz */, int *__restrict__ nonfinite)
+{
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int bad = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        for (int k = 0; k < 3; ++k) {
+            const float v = xyz[3 * i + k];
+            if (!isfinite(v)) bad = 1;
+            lo[k] = fminf(lo[k], v);
+            hi[k] = fmaxf(hi[k], v);
+        }
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // float atomic min/max through the monotone int mapping
+        for (int k = 0; k < 3; ++k) {
+            atomicMin((int *)&mm[k], lo[k] >= 0 ? __float_as_int(lo[k]) : (int)(0x80000000u - (unsigned)__float_as_int(lo[k])));
+            atomicMax((int *)&mm[3 + k], hi[k] >= 0 ? __float_as_int(hi[k]) : (int)(0x80000000u - (unsigned)__float_as_int(hi[k])));
+        }
+    }
+    if (bad) atomicOr(nonfinite, 1);
+}
+
+// sum of a float array in float64 (weights.mean(), mesh_conj_grad.py:162)
+__global__ __launch_bounds__(NW_BLOCK) void k_sum_f64(const float *__restrict__ x, int64_t n, double *__restrict__ out)
+{
+    __shared__ double s_part[4];
+    double s[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s[0] += (double)x[i];
+    nw_block_reduce_atomic<1>(s, out, s_part);
+}
+
+// total mesh area (sum over faces of |cross|/2) in float64: sets the centroid spacing for the grid cell size
+__global__ __launch_bounds__(NW_BLOCK) void k_mesh_area(const float *__restrict__ pos, const int *__restrict__ faces, int F, double *__restrict__ out)
+{
+    __shared__ double s_part[4];
+    double s[1] = {0.0};
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < F; f += gridDim.x * blockDim.x) {
+        const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+        const float ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
+        const float ux = pos[3 * b] - ax, uy = pos[3 * b + 1] - ay, uz = pos[3 * b + 2] - az;
+        const float vx = pos[3 * c] - ax, vy = pos[3 * c + 1] - ay, vz = pos[3 * c + 2] - az;
+        const float cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+        s[0] += 0.5 * sqrt((double)cx * cx + (double)cy * cy + (double)cz * cz);
+    }
+    nw_block_reduce_atomic<1>(s, out, s_part);
+}
+
+// brute-force NN distance of a strided sample of the points against ALL face centroids (calibration of the
+// grid cell size before the first query): one workgroup per sample point.
+__global__ __launch_bounds__(NW_BLOCK) void k_sample_nn(const float *__restrict__ pts_xyz, int64_t N, int nsample, const float *__restrict__ pos,
+                                                       const int *__restrict__ faces, int F, double *__restrict__ out_sum)
+{
+    __shared__ float s_min[4];
+    const int64_t i = (int64_t)blockIdx.x * (N / nsample);
+    const float px = pts_xyz[3 * i], py = pts_xyz[3 * i + 1], pz = pts_xyz[3 * i + 2];
+    float best = INFINITY;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+        const float cx = (pos[3 * a] + pos[3 * b] + pos[3 * c]) * (1.0f / 3.0f) - px;
+        const float cy = (pos[3 * a + 1] + pos[3 * b + 1] + pos[3 * c + 1]) * (1.0f / 3.0f) - py;
+        const float cz = (pos[3 * a + 2] + pos[3 * b + 2] + pos[3 * c + 2]) * (1.0f / 3.0f) - pz;
+        best = fminf(best, cx * cx + cy * cy + cz * cz);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = fminf(best, __shfl_xor(best, off, 64));
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out_sum, (double)sqrtf(fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]))));
+}
+
+__global__ void k_point_cells(NwGrid g, const float *__restrict__ xyz, int N, int *__restrict__ pt_cell, int *__restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int ix, iy, iz;
+    nw_cell_coords(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], ix, iy, iz);
+    const int c = nw_cell_index(g, ix, iy, iz);
+    pt_cell[i] = c;
+    atomicAdd(&count[c], 1);
+}
+
+// counting-sort scatter of the localizations into cell order.  Also bakes the residual weighting of
+// search() (mesh_conj_grad.py:156-164): weights = weights/weights.mean(), mask = weights > 0 (array) or
+// isfinite(data) (scalar).  `count` holds the per-cell counts and is decremented back to zero.
+__global__ void k_point_scatter(int N, const float *__restrict__ xyz, const int *__restrict__ pt_cell, const int *__restrict__ start, int *__restrict__ count,
+                                const float *__restrict__ sinv_in, const float *__restrict__ w_in, const double *__restrict__ wsum, int w_is_array,
+                                float4 *__restrict__ pts, int *__restrict__ perm, float *__restrict__ sinv, float *__restrict__ wnorm, unsigned char *__restrict__ mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int c = pt_cell[i];
+    const int slot = start[c] + atomicSub(&count[c], 1) - 1;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    pts[slot] = make_float4(x, y, z, __int_as_float(i));
+    perm[slot] = i;
+    if (sinv_in)
+        for (int k = 0; k < 3; ++k) sinv[3 * slot + k] = sinv_in[3 * i + k];
+    unsigned m = 0;
+    if (w_is_array) {
+        const float mean = (float)(wsum[0] / (3.0 * (double)N));
+        for (int k = 0; k < 3; ++k) {
+            const float w = w_in[3 * i + k];
+            wnorm[3 * slot + k] = w / mean;
+            m |= (w > 0.0f) ? (1u << k) : 0u;
+        }
+    } else {
+        m = (isfinite(x) ? 1u : 0u) | (isfinite(y) ? 2u : 0u) | (isfinite(z) ? 4u : 0u);
+    }
+    mask[slot] = (unsigned char)m;
+}
+
+// work list for the NN kernel: one item per (non-empty cell, chunk of <= 256 of its points)
+__global__ void k_count_items(const int *__restrict__ pstart, int ncell, int *__restrict__ nitems)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const int np = pstart[c + 1] - pstart[c];
+    nitems[c] = (np + NW_BLOCK - 1) / NW_BLOCK;
+}
+
+__global__ void k_fill_items(const int *__restrict__ pstart, const int *__restrict__ istart, int ncell, NwWorkItem *__restrict__ items)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const int p0 = pstart[c], p1 = pstart[c + 1];
+    int o = istart[c];
+    for (int p = p0; p < p1; p += NW_BLOCK) {
+        NwWorkItem w;
+        w.cell = c; w.p0 = p; w.p1 = min(p + NW_BLOCK, p1);
+        items[o++] = w;
+    }
+}
+
+// neighbour table (M, NB) row-major -> slot-major ELL nbr_t[s*M + v] (coalesced over vertices) + max degree
+__global__ void k_nbr_transpose(const int *__restrict__ nbr, int M, int NB, int *__restrict__ nbr_t, int *__restrict__ maxdeg)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M) return;
+    int last = 0;
+    for (int s = 0; s < NB; ++s) {
+        const int n = nbr[(int64_t)v * NB + s];
+        nbr_t[(int64_t)s * M + v] = n;
+        if (n >= 0) last = s + 1;
+    }
+    atomicMax(maxdeg, last);
+}
+
+// ============================================================================================================
+// per-iteration kernels
+// ============================================================================================================
+
+// K1: face centroids + cell histogram.  centroid = ((v0+v1)+v2)/3 in float32 = numpy's fv[faces].mean(1)
+// (mesh_conj_grad.py:443).
+__global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const float *__restrict__ pos, const int *__restrict__ faces, int F,
+                                                            float4 *__restrict__ cent_tmp, int *__restrict__ fcell, int *__restrict__ count,
+                                                            const NwDevState *__restrict__ st, int it)
+{
+    if (it >= st->stop_at) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+    const float x = ((pos[3 * a] + pos[3 * b]) + pos[3 * c]) / 3.0f;
+    const float y = ((pos[3 * a + 1] + pos[3 * b + 1]) + pos[3 * c + 1]) / 3.0f;
+    const float z = ((pos[3 * a + 2] + pos[3 * b + 2]) + pos[3 * c + 2]) / 3.0f;
+    int ix, iy, iz;
+    nw_cell_coords(g, x, y, z, ix, iy, iz);
+    const int cell = nw_cell_index(g, ix, iy, iz);
+    cent_tmp[f] = make_float4(x, y, z, __int_as_float(f));
+    fcell[f] = cell;
+    atomicAdd(&count[cell], 1);
+}
+
+// K3: scatter centroids into cell order (count is decremented back to zero for the next iteration)
+__global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const float4 *__restrict__ cent_tmp, const int *__restrict__ fcell,
+                                                              const int *__restrict__ start, int *__restrict__ count, float4 *__restrict__ cent,
+                                                              const NwDevState *__restrict__ st, int it)
+{
+    if (it >= st->stop_at) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int c = fcell[f];
+    const int slot = start[c] + atomicSub(&count[c], 1) - 1;
+    cent[slot] = cent_tmp[f];
+}
+
+// K4a: exact nearest face centroid of every localization (replaces cKDTree build + query,
+// mesh_conj_grad.py:451-454: exact Euclidean 1-NN in float64).
+//
+// One workgroup per work item = the (<=256) localizations of one grid cell.  The candidate centroids of the
+// surrounding cells are walked ring by ring; each (dz,dy) row of a ring is ONE contiguous range of the
+// cell-sorted centroid array (x is the fastest cell index), so the walk is a handful of coalesced float4
+// range copies into LDS, shared by all points of the cell.  The 256 threads are split into groups of G lanes
+// per point (G = largest power of two with np*G <= 256): each lane scans every G-th staged candidate from
+// LDS (ds_read_b128, broadcast across groups), then the group reduces (distance, face) with wave shuffles.
+// Ring R is final for a point once best <= R*h + (distance to its own cell wall) - eps, which proves no
+// unexplored cell can hold a closer centroid; the workgroup stops when all its points are final.
+#define NW_NN_CAP 1024   // staged candidates per pass (16 KiB of LDS)
+
+__device__ __forceinline__ void nw_ring_row(int R, int q, int cx, int cy, int cz, const NwGrid &g, int &cell_lo, int &ncells)
+{
+    // row slots of ring R: q = 2*((dz+R)*(2R+1) + (dy+R)) + e.  R == 1 also covers the centre cell.
+    const int w = 2 * R + 1;
+    const int e = q & 1, r = q >> 1;
+    const int dz = r / w - R, dy = r % w - R;
+    const int y = cy + dy, z = cz + dz;
+    ncells = 0; cell_lo = 0;
+    if (y < 0 || y >= g.gy || z < 0 || z >= g.gz) return;
+    int x0, x1;
+    const int ady = dy < 0 ? -dy : dy, adz = dz < 0 ? -dz : dz;
+    if (R == 1 || (ady > adz ? ady : adz) == R) {      // full row of the shell
+        if (e) return;
+        x0 = cx - R; x1 = cx + R;
+    } else {                                            // interior row: only the two end cells belong to ring R
+        x0 = x1 = e ? cx + R : cx - R;
+    }
+    x0 = x0 < 0 ? 0 : x0;
+    x1 = x1 >= g.gx ? g.gx - 1 : x1;
+    if (x1 < x0) return;
+    cell_lo = nw_cell_index(g, x0, y, z);
+    ncells = x1 - x0 + 1;
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_nearest_face(NwGrid g, const NwWorkItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
+                                                          const int *__restrict__ cstart, const float4 *__restrict__ cent,
+                                                          int *__restrict__ face_out, float *__restrict__ dist_out, NwDevState *__restrict__ st, int it)
+{
+    if (it >= st->stop_at) return;
+    const int wi = nw_xcd_remap(blockIdx.x, nitems);
+    if (wi < 0) return;
+    __shared__ float4 s_cand[NW_NN_CAP];
+    __shared__ int s_rs[64];
+    __shared__ int s_ro[65];
+
+    const NwWorkItem item = items[wi];
+    const int tid = threadIdx.x;
+    const int np = item.p1 - item.p0;
+    const int cz = item.cell / (g.gx * g.gy), cy = (item.cell / g.gx) % g.gy, cx = item.cell % g.gx;
+    int G = 1;
+    while (((G << 1) * np <= NW_BLOCK) && G < 64) G <<= 1;
+    const int slot = tid / G, sub = tid & (G - 1);
+    const bool has = slot < np;
+    const float4 P = has ? pts[item.p0 + slot] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const double px = P.x, py = P.y, pz = P.z;
+    // distance from the point to the walls of its own cell (>= 0)
+    float m;
+    {
+        const float lx = g.ox + cx * g.h, ly = g.oy + cy * g.h, lz = g.oz + cz * g.h;
+        m = fminf(fminf(fminf(P.x - lx, lx + g.h - P.x), fminf(P.y - ly, ly + g.h - P.y)), fminf(P.z - lz, lz + g.h - P.z));
+        m = fmaxf(m, 0.0f);
+    }
+    double best = INFINITY;
+    int bestf = 0x7fffffff;
+    int maxR = max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz));
+    if (maxR < 1) maxR = 1;
+    bool done = !has;
+    int R = 1;
+    for (;; ++R) {
+        const int w = 2 * R + 1;
+        const int nq = 2 * w * w;
+        for (int qb = 0; qb < nq; qb += 64) {
+            if (tid < 64) {
+                int start = 0, len = 0;
+                const int q = qb + tid;
+                if (q < nq) {
+                    int lo, nc;
+                    nw_ring_row(R, q, cx, cy, cz, g, lo, nc);
+                    if (nc > 0) { start = cstart[lo]; len = cstart[lo + nc] - start; }
+                }
+                s_rs[tid] = start;
+                const int inc = nw_wave_incl_scan(len, tid);
+                s_ro[tid + 1] = inc;
+                if (tid == 0) s_ro[0] = 0;
+            }
+            __syncthreads();
+            const int total = s_ro[64];
+            for (int base = 0; base < total; base += NW_NN_CAP) {
+                const int n = min(NW_NN_CAP, total - base);
+                for (int e = tid; e < n; e += NW_BLOCK) {
+                    const int ge = base + e;
+                    int lo = 0, hi = 64;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ro[mid] <= ge) lo = mid; else hi = mid; }
+                    s_cand[e] = cent[s_rs[lo] + (ge - s_ro[lo])];
+                }
+                __syncthreads();
+                if (!done) {
+                    for (int c = sub; c < n; c += G) {
+                        const float4 C = s_cand[c];
+                        const double dx = px - (double)C.x, dy = py - (double)C.y, dz = pz - (double)C.z;
+                        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                        const int fid = __float_as_int(C.w);
+                        if (d2 < best || (d2 == best && fid < bestf)) { best = d2; bestf = fid; }
+                    }
+                }
+                __syncthreads();
+            }
+            if (total == 0) __syncthreads();
+        }
+        // group reduction: (distance, lowest face id on exact ties)
+        for (int off = G >> 1; off > 0; off >>= 1) {
+            const double od = __shfl_xor(best, off, 64);
+            const int of = __shfl_xor(bestf, off, 64);
+            if (od < best || (od == best && of < bestf)) { best = od; bestf = of; }
+        }
+        if (!done) {
+            const double bound = (double)R * (double)g.h + (double)m - (double)g.eps;
+            done = (bound > 0.0) && (best <= bound * bound);
+        }
+        if (R >= maxR) break;
+        if (__syncthreads_and(done ? 1 : 0)) break;
+    }
+    if (has && sub == 0) {
+        face_out[item.p0 + slot] = bestf;
+        dist_out[item.p0 + slot] = (float)sqrt(best);
+    }
+    if (tid == 0 && R > 1) atomicMax(&st->nn_max_ring, R);
+}
+
+// K4b: weight matrix row, A f, weighted + de-weighted residual, and the A^T scatter -- one thread per
+// localization (cell-sorted order, so the three vertices of neighbouring threads sit in the same L2 lines).
+//   v_idx = faces[face]; d_j = |f[v_j] - p| (f32); w_j = 1/max(d_j,1e-6), row-normalised    mesh_conj_grad.py:488-510
+//   Af = sum_j f[v_j] w_j (f32, corner order)                                                :544-545
+//   res = weights*(p - Af); res *= 1/(d*sigma_inv/2 + 1) (float64 factor, float32 store)      :222,231,248
+//   vacc[v_j] += {w_j*res, w_j}  -> S0 = A^T res and A^T 1 in ONE pass                        :253, conj_grad_utils.c:153-162,
+//                                                                                            _membrane_mesh.pyx:1633
+// float atomics (global_atomic_add_f32, memory-side): the 4 floats of one vertex are contiguous (float4).
+__global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__restrict__ pts, const int *__restrict__ face, const float *__restrict__ dist,
+                                                     const int *__restrict__ faces, const float *__restrict__ pos,
+                                                     const float *__restrict__ sinv, float sinv_scalar, const float *__restrict__ wnorm, float w_scalar,
+                                                     const unsigned char *__restrict__ mask,
+                                                     int *__restrict__ vidx, float *__restrict__ wout, float *__restrict__ res, float *__restrict__ vacc,
+                                                     double *__restrict__ sc, NwDevState *__restrict__ st, int it)
+{
+    if (it >= st->stop_at) return;
+    __shared__ double s_part[4 * 4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double red[4] = {0.0, 0.0, 0.0, 0.0};
+    if (i < N) {
+        const float4 P = pts[i];
+        const int f = face[i];
+        const float p[3] = {P.x, P.y, P.z};
+        int v[3];
+        float w[3], fv[3][3];
+        float wsum;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            v[j] = faces[3 * f + j];
+            float dd = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                fv[j][k] = pos[3 * v[j] + k];
+                const float d = fv[j][k] - p[k];
+                const float sq = d * d;
+                dd = (k == 0) ? sq : dd + sq;
+            }
+            w[j] = 1.0f / fmaxf(sqrtf(dd), 1e-6f);
+        }
+        wsum = (w[0] + w[1]) + w[2];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { w[j] = w[j] / wsum; bad |= isnan(w[j]); }
+        const float d = dist[i];
+        const unsigned m = mask[i];
+        float r[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float af = 0.0f + fv[0][k] * w[0];
+            af = af + fv[1][k] * w[1];
+            af = af + fv[2][k] * w[2];
+            bad |= isnan(af);
+            const float wt = wnorm ? wnorm[3 * i + k] : w_scalar;
+            const float r0 = wt * (p[k] - af);
+            const double si = sinv ? (double)sinv[3 * i + k] : (double)sinv_scalar;
+            const double wd = 1.0 / ((double)d * si / 2.0 + 1.0);
+            r[k] = (float)((double)r0 * wd);
+            res[3 * i + k] = r[k];
+            const double r2 = (double)r[k] * (double)r[k];
+            red[0] += r2;
+            if (m & (1u << k)) red[1] += r2;
+        }
+        red[2] = (double)d;
+        red[3] = 1.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            vidx[3 * i + j] = v[j];
+            wout[3 * i + j] = w[j];
+            float *a = vacc + 4 * (int64_t)v[j];
+            atomicAdd(a + 0, w[j] * r[0]);
+            atomicAdd(a + 1, w[j] * r[1]);
+            atomicAdd(a + 2, w[j] * r[2]);
+            atomicAdd(a + 3, w[j]);
+        }
+        if (bad) atomicCAS(&st->status, 0, -3 /* NW_ERR_NAN */);
+    }
+    nw_block_reduce_atomic<4>(red, sc + SC_RES2, s_part);
+}
+
+// K5: curvature prior + search directions S0, S1 + all vertex-side dot products.  One thread per vertex;
+// the 1-ring comes from the slot-major neighbour table (coalesced over vertices).
+//   S0 = vacc.xyz (A^T res)                                                            mesh_conj_grad.py:253
+//   pi = sqrt(3 (sum w)^2) in f32, gate min(pi^2,1)                                    _membrane_mesh.pyx:1633-1634, :807-814
+//   fdef = _ncc(): 1-ring centroid (f32 slot-ordered sum -> /ms in f64), alpha from neighbour normals (block-stale)
+//          and current mesh positions; isolated vertices keep their position           :770-820
+//   prefs = f - fdef (f64), stored f32; S1 = -prefs                                    :257-258
+__global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg, const int *__restrict__ nbr_t, const float *__restrict__ pos,
+                                                              const float *__restrict__ meshpos, const float *__restrict__ nrm,
+                                                              const float *__restrict__ vacc, float *__restrict__ S, float *__restrict__ fdef_out,
+                                                              float *__restrict__ pi_out, double *__restrict__ sc, NwDevState *__restrict__ st, int it, int n_search)
+{
+    if (it >= st->stop_at) return;
+    __shared__ double s_part[11 * 4];
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    double red[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) red[k] = 0.0;
+    if (v < M) {
+        const float4 acc = *reinterpret_cast<const float4 *>(vacc + 4 * (int64_t)v);
+        const float sw = acc.w;
+        const float pi = sqrtf((sw * sw + sw * sw) + sw * sw);
+        const float gate = fminf(pi * pi, 1.0f);
+        pi_out[v] = pi;
+        if (isnan(acc.x) || isnan(acc.y) || isnan(acc.z) || isnan(sw)) atomicCAS(&st->status, 0, -3);
+        // pass 1: centroid
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        int ms = 0;
+        for (int s = 0; s < maxdeg; ++s) {
+            const int n = nbr_t[(int64_t)s * M + v];
+            if (n >= 0) {
+                sx += meshpos[3 * n]; sy += meshpos[3 * n + 1]; sz += meshpos[3 * n + 2];
+                ++ms;
+            }
+        }
+        double fd[3];
+        if (ms > 0) {
+            const double vcx = (double)sx / ms, vcy = (double)sy / ms, vcz = (double)sz / ms;
+            const float Nx = nrm[3 * v], Ny = nrm[3 * v + 1], Nz = nrm[3 * v + 2];
+            double asum = 0.0;
+            for (int s = 0; s < maxdeg; ++s) {
+                const int n = nbr_t[(int64_t)s * M + v];
+                if (n >= 0) {
+                    const double cnx = (double)meshpos[3 * n] - vcx, cny = (double)meshpos[3 * n + 1] - vcy, cnz = (double)meshpos[3 * n + 2] - vcz;
+                    const float nx = nrm[3 * n], ny = nrm[3 * n + 1], nz = nrm[3 * n + 2];
+                    const double cdot = (cnx * (double)nx + cny * (double)ny) + cnz * (double)nz;
+                    const float ndn = (nx * Nx + ny * Ny) + nz * Nz;
+                    const float den = sqrtf(2.0f * (fmaxf(ndn, 0.0f) + 1.0f));
+                    asum += cdot / (double)den;
+                }
+            }
+            const double alpha = (asum / ms) * (double)gate;
+            fd[0] = vcx + alpha * (double)Nx; fd[1] = vcy + alpha * (double)Ny; fd[2] = vcz + alpha * (double)Nz;
+        } else {
+            fd[0] = meshpos[3 * v]; fd[1] = meshpos[3 * v + 1]; fd[2] = meshpos[3 * v + 2];
+        }
+        const float s0[3] = {acc.x, acc.y, acc.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double p64 = (double)pos[3 * v + c] - fd[c];
+            const float p32 = (float)p64;
+            const float s1 = -1.0f * p32;
+            float *row = S + (int64_t)(3 * v + c) * 3;
+            const float s2 = (n_search > 2) ? row[2] : 0.0f;
+            row[0] = s0[c];
+            row[1] = s1;
+            fdef_out[3 * v + c] = (float)fd[c];
+            red[0] += (double)s0[c] * s0[c];
+            red[1] += (double)s0[c] * s1;
+            red[2] += (double)s0[c] * s2;
+            red[3] += (double)s1 * s1;
+            red[4] += (double)s1 * s2;
+            red[5] += (double)s2 * s2;
+            red[6] += (double)s0[c] * p64;
+            red[7] += (double)s1 * p64;
+            red[8] += (double)s2 * p64;
+            red[9] += p64 * p64;
+            red[10] += (double)p32 * (double)p32;
+        }
+    }
+    nw_block_reduce_atomic<11>(red, sc + SC_SS, s_part);
+}
+
+// K6: A.S_k for the n_search directions and the point-side normal-equation sums, never materialising AS:
+//   AS_k[i] = sum_j w_ij S_k[v_ij] (f32, corner order, mesh_conj_grad.py:544-545 via conj_grad.py:198)
+//   Hc = AS^T AS, Gc = AS^T res over the masked entries (conj_grad.py:198-203)
+// S is stored (3M,3) row-major exactly as the reference's `cg.S`, so the 9 floats of one vertex are contiguous.
+__global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const int *__restrict__ vidx, const float *__restrict__ w, const float *__restrict__ res,
+                                                                 const unsigned char *__restrict__ mask, const float *__restrict__ S, double *__restrict__ sc,
+                                                                 const NwDevState *__restrict__ st, int it, int n_search)
+{
+    if (it >= st->stop_at) return;
+    __shared__ double s_part[9 * 4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double red[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[k] = 0.0;
+    if (i < N) {
+        const unsigned m = mask[i];
+        float as[3][3];   // [direction][component]
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) as[k][c] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int v = vidx[3 * i + j];
+            const float wj = w[3 * i + j];
+            const float *row = S + (int64_t)v * 9;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                as[0][c] = as[0][c] + row[3 * c + 0] * wj;
+                as[1][c] = as[1][c] + row[3 * c + 1] * wj;
+                if (n_search > 2) as[2][c] = as[2][c] + row[3 * c + 2] * wj;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (m & (1u << c)) {
+                const double a0 = as[0][c], a1 = as[1][c], a2 = as[2][c], r = res[3 * i + c];
+                red[0] += a0 * a0; red[1] += a0 * a1; red[2] += a0 * a2;
+                red[3] += a1 * a1; red[4] += a1 * a2; red[5] += a2 * a2;
+                red[6] += a0 * r;  red[7] += a1 * r;  red[8] += a2 * r;
+            }
+        }
+    }
+    nw_block_reduce_atomic<9>(red, sc + SC_HC, s_part);
+}
+
+// K7: <=3x3 regularised normal equations (every workgroup solves them redundantly from the reduced sums),
+// f += S c, last step -> S2, write-back, per-iteration log, stop condition.
+//   H = Hc + lam^2 Hw accumulated in place in float32, G likewise (conj_grad.py:208-215); float32 LU with
+//   partial pivoting (LAPACK sgesv through numpy.linalg.solve, :219); fnew = f0 + S.c in float32 (:227);
+//   S[:,2] = fnew - f; f = fnew; mesh positions updated at valid vertices only (mesh_conj_grad.py:281-289).
+struct NwSolve { float c[3]; float H[9]; float G[3]; int singular; };
+
+__device__ inline void nw_solve_small(const double *__restrict__ sc, float lam, int n, NwSolve &o)
+{
+    static const int idx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    const double l2 = (double)lam * (double)lam;
+    float A[3][4];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            const float hc = (float)sc[SC_HC + idx[r][c]];
+            const float hw = (float)sc[SC_SS + idx[r][c]];
+            const float h = (float)((double)hc + l2 * (double)hw);
+            o.H[3 * r + c] = h;
+            A[r][c] = h;
+        }
+    for (int r = 0; r < 3; ++r) {
+        const float gc = (float)sc[SC_GC + r];
+        const double gw = -sc[SC_SP + r];
+        const float gg = (float)((double)gc + l2 * gw);
+        o.G[r] = gg;
+        A[r][3] = gg;
+    }
+    o.singular = 0;
+    // Gaussian elimination with partial pivoting, float32
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        float mx = fabsf(A[k][k]);
+        for (int r = k + 1; r < n; ++r)
+            if (fabsf(A[r][k]) > mx) { mx = fabsf(A[r][k]); p = r; }
+        if (!(mx > 0.0f)) { o.singular = 1; break; }
+        if (p != k)
+            for (int c = 0; c < 4; ++c) { const float t = A[k][c]; A[k][c] = A[p][c]; A[p][c] = t; }
+        for (int r = k + 1; r < n; ++r) {
+            const float l = A[r][k] / A[k][k];
+            for (int c = k; c < 4; ++c) A[r][c] = A[r][c] - l * A[k][c];
+        }
+    }
+    o.c[0] = o.c[1] = o.c[2] = 0.0f;
+    if (!o.singular)
+        for (int k = n - 1; k >= 0; --k) {
+            float s = A[k][3];
+            for (int c = k + 1; c < n; ++c) s = s - A[k][c] * o.c[c];
+            o.c[k] = s / A[k][k];
+        }
+}
+
+struct NwIterLogDev {   // mirrors nw_iter_log in include/nanowrap.h
+    double test, res_norm, prefs_norm, cpred, wpred, c[3], H[9], G[3], mean_dist;
+    int n_search, nn_max_ring, status, executed;
+};
+
+__global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int n_search, unsigned flags, const unsigned char *__restrict__ valid,
+                                                          float *__restrict__ pos, float *__restrict__ meshpos, float *__restrict__ S, float *__restrict__ vacc,
+                                                          double *__restrict__ sc, double *__restrict__ sc_next, NwDevState *__restrict__ st,
+                                                          NwIterLogDev *__restrict__ logrec, int it)
+{
+    if (it >= st->stop_at) return;
+    __shared__ NwSolve s_sol;
+    if (threadIdx.x == 0) nw_solve_small(sc, lam, n_search, s_sol);
+    __syncthreads();
+    const NwSolve sol = s_sol;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < M && !sol.singular) {
+        const bool ok = valid ? valid[v] != 0 : true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float *row = S + (int64_t)(3 * v + c) * 3;
+            float step = row[0] * sol.c[0];
+            step = step + row[1] * sol.c[1];
+            if (n_search > 2) step = step + row[2] * sol.c[2];
+            const float f0 = pos[3 * v + c];
+            float fn = f0 + step;
+            if ((flags & 1u) && !(fn > 0.0f)) fn = fn * 0.0f;       // fnew*(fnew > 0), mesh_conj_grad.py:277-278
+            if (!(flags & 2u)) row[2] = fn - f0;
+            pos[3 * v + c] = fn;
+            if (ok) meshpos[3 * v + c] = fn;
+        }
+    }
+    if (v < M) *reinterpret_cast<float4 *>(vacc + 4 * (int64_t)v) = make_float4(0.f, 0.f, 0.f, 0.f);   // ready for the next scatter
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // logs (mesh_conj_grad.py:262-274)
+        const double s00 = sc[SC_SS + 0], s01 = sc[SC_SS + 1], s11 = sc[SC_SS + 3];
+        const float test = 1.0f - (float)(fabs(s01) / (sqrt(s00) * sqrt(s11)));
+        NwIterLogDev L;
+        L.test = test;
+        L.res_norm = sqrt(sc[SC_RES2]);
+        L.prefs_norm = sqrt(sc[SC_PP32]);
+        double cHc = 0, cG = 0, cHwc = 0, cGw = 0;
+        static const int idx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+        for (int r = 0; r < n_search; ++r) {
+            cG += (double)sol.c[r] * sol.G[r];
+            cGw += (double)sol.c[r] * (-sc[SC_SP + r]);
+            for (int c = 0; c < n_search; ++c) {
+                cHc += (double)sol.c[r] * sol.H[3 * r + c] * sol.c[c];
+                cHwc += (double)sol.c[r] * (double)(float)sc[SC_SS + idx[r][c]] * sol.c[c];
+            }
+        }
+        L.cpred = sc[SC_C0] + cHc - cG;          // Hc/Gc alias the regularised H/G in the reference (conj_grad.py:208,223)
+        L.wpred = sc[SC_PP64] + cHwc - cGw;      // conj_grad.py:225
+        for (int k = 0; k < 3; ++k) { L.c[k] = sol.c[k]; L.G[k] = sol.G[k]; }
+        for (int k = 0; k < 9; ++k) L.H[k] = sol.H[k];
+        L.mean_dist = sc[SC_NPTS] > 0 ? sc[SC_SUMD] / sc[SC_NPTS] : 0.0;
+        L.n_search = n_search;
+        L.nn_max_ring = st->nn_max_ring;
+        if (sol.singular) atomicCAS(&st->status, 0, -4 /* NW_ERR_SINGULAR */);
+        L.status = st->status;
+        L.executed = 1;
+        *logrec = L;
+        // history + stop condition for the NEXT iteration (mesh_conj_grad.py:1009-1016)
+        float a = st->tests[1], b = st->tests[2];
+        st->tests[0] = a; st->tests[1] = b; st->tests[2] = test;
+        st->ntests += 1;
+        if (st->ntests >= 3 && (test < b) && (b < a) && (a < 1e-6f)) st->stop_at = it + 1;
+        if (st->status != 0) st->stop_at = it + 1;
+        for (int k = 0; k < SC_COUNT; ++k) sc_next[k] = 0.0;
+    }
+}
+
+// ============================================================================================================
+// operators / read-back helpers
+// ============================================================================================================
+// y[perm[i]] = A x   (Afunc with the cached weight matrix)
+__global__ void k_apply_A(int N, const int *__restrict__ perm, const int *__restrict__ vidx, const float *__restrict__ w, const float *__restrict__ x, float *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int o = perm[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a = a + x[3 * vidx[3 * i + j] + c] * w[3 * i + j];
+        y[3 * o + c] = a;
+    }
+}
+
+// z += A^T r, r given in the caller's point order
+__global__ void k_apply_At(int N, const int *__restrict__ perm, const int *__restrict__ vidx, const float *__restrict__ w, const float *__restrict__ r, float *__restrict__ z)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int o = perm[i];
+    const float r0 = r[3 * o], r1 = r[3 * o + 1], r2 = r[3 * o + 2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float *a = z + 3 * (int64_t)vidx[3 * i + j];
+        const float wj = w[3 * i + j];
+        atomicAdd(a + 0, wj * r0);
+        atomicAdd(a + 1, wj * r1);
+        atomicAdd(a + 2, wj * r2);
+    }
+}
+
+// un-permute per-point arrays (width floats or ints per point) back to the caller's point order
+__global__ void k_unpermute(int N, int width, const int *__restrict__ perm, const uint32_t *__restrict__ in, uint32_t *__restrict__ out)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= (int64_t)N * width) return;
+    const int i = (int)(t / width), k = (int)(t % width);
+    out[(int64_t)perm[i] * width + k] = in[t];
+}
+
+// alternate regularisers (gather forms are one thread per vertex; the scatter forms use float atomics except
+// kind 1, whose in-place division makes it order dependent and is run by a single thread to keep the
+// reference's serial semantics).
+__global__ void k_lfunc_gather(int kind, int M, int NB, const int *__restrict__ nbr, const float *__restrict__ x, const float *__restrict__ f0, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int *row = nbr + (int64_t)i * NB;
+    if (row[0] == -1) return;
+    if (kind == 0) {           // conj_grad_utils.c:286-302
+        for (int j = 0; j < 3; ++j) {
+            float d = out[3 * i + j];
+            int n_ = 0;
+            for (int k = 0; k < NB; ++k) { const int n = row[k]; if (n == -1) break; d += (x[3 * n + j] - x[3 * i + j]); ++n_; }
+            out[3 * i + j] = d / n_;
+        }
+    } else if (kind == 2) {    // conj_grad_utils.c:412-491
+        float w = 0; int n_ = 0;
+        for (int k = 0; k < NB; ++k) {
+            const int n = row[k]; if (n == -1) break;
+            float d2 = 0;
+            for (int j = 0; j < 3; ++j) { const float dd = f0[3 * n + j] - f0[3 * i + j]; d2 += dd * dd; }
+            w += d2; ++n_;
+        }
+        if (w > 0) {
+            const float sw = sqrtf(w);
+            for (int k = 0; k < n_; ++k) { const int n = row[k]; for (int j = 0; j < 3; ++j) out[3 * i + j] += (x[3 * n + j] - x[3 * i + j]) / sw; }
+        }
+    } else if (kind == 4) {    // conj_grad_utils.c:500-548
+        float w = 0;
+        for (int k = 0; k < NB; ++k) {
+            const int n = row[k]; if (n == -1) break;
+            float d2 = 0;
+            for (int j = 0; j < 3; ++j) { const float dd = x[3 * n + j] - x[3 * i + j]; d2 += dd * dd; }
+            w += d2;
+        }
+        w = (w > 0) ? (float)(1.0 / (double)sqrtf(w + 1)) : 0.0f;
+        out[3 * i] = w; out[3 * i + 1] = w; out[3 * i + 2] = w;
+    }
+}
+
+__global__ void k_lfunc_lhw(int M, int NB, const int *__restrict__ nbr, const float *__restrict__ x, const float *__restrict__ f0, float *__restrict__ out)
+{
+    // conj_grad_utils.c:628-697, scatter form
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int *row = nbr + (int64_t)i * NB;
+    if (row[0] == -1) return;
+    float w = 0; int n_ = 0;
+    for (int k = 0; k < NB; ++k) {
+        const int n = row[k]; if (n == -1) break;
+        float d2 = 0;
+        for (int j = 0; j < 3; ++j) { const float dd = f0[3 * i + j] - f0[3 * n + j]; d2 += dd * dd; }
+        w += d2; ++n_;
+    }
+    if (w > 0) {
+        const float sw = sqrtf(w);
+        for (int k = 0; k < n_; ++k) { const int n = row[k]; for (int j = 0; j < 3; ++j) atomicAdd(&out[3 * n + j], (x[3 * i + j] - x[3 * n + j]) / sw); }
+    }
+}
+
+__global__ void k_lfunc_lh_serial(int M, int NB, const int *__restrict__ nbr, const float *__restrict__ x, float *__restrict__ out)
+{
+    // conj_grad_utils.c:344-364: the per-vertex in-place "/= N" on the neighbours makes the result depend on the
+    // vertex visiting order, so the reference's serial order is kept (not on the default path; M-sized, one lane).
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int i = 0; i < M; ++i) {
+        const int *row = nbr + (int64_t)i * NB;
+        if (row[0] == -1) continue;
+        for (int j = 0; j < 3; ++j) {
+            int n_ = 0;
+            for (int k = 0; k < NB; ++k) { const int n = row[k]; if (n == -1) break; out[3 * n + j] += (x[3 * i + j] - x[3 * n + j]); ++n_; }
+            for (int k = 0; k < n_; ++k) { const int n = row[k]; out[3 * n + j] /= n_; }
+        }
+    }
+}

@@ -1,0 +1,319 @@
+"""
+Host-side mirror of the reference optimiser class for the NanoWrap inner loop, backed by the HIP library.
+
+Drop-in seam: the reference's outer loop imports the optimiser by name,
+
+    from ch_shrinkwrap.mesh_conj_grad import ShrinkwrapMeshConjGrad          (_membrane_mesh.pyx:1428)
+    cg = ShrinkwrapMeshConjGrad(mesh, points, search_k=, search_rad=, shield_sigma=)      (:1510-1512)
+    vp = cg.search(points, lams=lams, num_iters=n_it, sigma_inv=s, weights=weights)       (:1516-1517)
+
+and later reads cg.S, cg.res, cg.points, cg.Ahfunc(...), cg.w (:1563-1634).  This class keeps that constructor,
+`search` signature, attribute surface, log lists (tests / ress / prefs / cpred / wpreds / loopcount) and error
+behaviour (AssertionError on NaN, numpy.linalg.LinAlgError on a singular subspace system), while every array
+of the iteration lives in HBM inside one `nw_ctx` (include/nanowrap.h) for the whole block.
+
+Differences that are deliberate and documented:
+  * float32 only: points/sigma/weights are cast to float32 on upload (the reference follows the dtype of `points`);
+  * `data` passed to search() must be the localizations the optimiser was constructed with (the only way the
+    reference ever calls it, _membrane_mesh.pyx:1516);
+  * `mesh._vertices['position']` is written back (and `mesh._initialize_curvature_vectors()` called) once at the
+    end of search() instead of after every iteration (mesh_conj_grad.py:289-290) -- same final state;
+  * `defaults` is accepted and ignored, exactly as the reference overwrites it at mesh_conj_grad.py:224;
+  * the unused point kd-tree of the reference constructor (mesh_conj_grad.py:127-130) is not built.
+There is no CPU fallback: without libnanowrap_hip.so and a GPU the constructor raises.
+"""
+import ctypes
+import numpy as np
+
+from . import _lib as nw
+
+
+class NativeContext(object):
+    """Owns one nw_ctx.  Shared between consecutive optimiser objects of one fit so that the localizations stay
+    resident in HBM across remesh blocks (the reference builds a new optimiser per block, _membrane_mesh.pyx:1510)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = nw.load()
+        self.h = ctypes.c_void_p()
+        code = self.L.nw_create(int(device), ctypes.byref(self.h))
+        if code != nw.NW_OK:
+            raise nw.NanoWrapError(code, 'nw_create failed (is a MI355X visible? HIP extension present?)')
+        if stream is not None:
+            self.check(self.L.nw_set_stream(self.h, ctypes.c_void_p(int(stream))))
+        self.device = int(device)
+        self.points_key = None
+        self._keep = []
+
+    def check(self, code):
+        nw.check(self.L, self.h, code)
+
+    def close(self):
+        if self.h:
+            self.L.nw_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class ShrinkwrapMeshConjGrad(object):
+    """MI355X-native counterpart of ch_shrinkwrap.mesh_conj_grad.ShrinkwrapMeshConjGrad (mesh_conj_grad.py:20)."""
+
+    def __init__(self, mesh, points, sigma=None, search_k=200, search_rad=100, shield_sigma=None, use_octree=False,
+                 device=0, native=None, stream=None):
+        # TikhonovConjugateGradient.__init__ (conj_grad.py:35-43)
+        self.tests, self.ress, self.prefs = [], [], []
+        self.Lfuncs, self.Lhfuncs = ["I"], ["I"]            # mesh_conj_grad.py:38
+        self.cpred, self.wpreds = None, None
+        self.loopcount = 0
+        self.mesh = mesh
+        self.sigma = sigma
+        self.search_k = min(search_k, points.shape[0])      # kept for API compatibility; unused on the live path
+        self.search_rad = max(search_rad, 1.0)
+        self._use_octreee = use_octree
+        self.nn_max_ring = 0
+        self.mean_dist = 0.0
+        self.iter_logs = []
+
+        self._mesh_vertex_mask = mesh._vertices['halfedge'] != -1                      # :44
+        self._vertices = mesh._vertices['position']                                    # :46 (view)
+        self.M = self._vertices.shape[0]
+        self.dims = self._vertices.shape[1]
+        self.shape = self._vertices.shape
+        self.faces = mesh.faces                                                        # :47
+        n = mesh._halfedges['vertex'][mesh._vertices['neighbors']]                     # :50-54
+        n[mesh._vertices['neighbors'] == -1] = -1
+        self.vertex_neighbors = np.ascontiguousarray(n, dtype=np.int32)
+        self.N = self.vertex_neighbors.shape[1]
+
+        self._native = native if native is not None else NativeContext(device, stream)
+        self._L = self._native.L
+        self._h = self._native.h
+        self.points = points
+        self._upload_mesh()
+        self._weights_key = None
+        self._cache = {}
+        self.fs = None
+        self.f = None
+        self.mask = None
+
+    # -- uploads ------------------------------------------------------------------------------
+    def _upload_mesh(self):
+        pos = _as_f32(self.mesh._vertices['position'])
+        nrm = _as_f32(self.mesh.vertex_normals)
+        faces = np.ascontiguousarray(self.faces, dtype=np.int32)
+        valid = np.ascontiguousarray(self._mesh_vertex_mask, dtype=np.uint8)
+        self._native.check(self._L.nw_set_mesh(self._h, nw.ptr(pos), nw.ptr(nrm), nw.ptr(self.vertex_neighbors), nw.ptr(valid),
+                                               nw.ptr(faces), pos.shape[0], faces.shape[0], self.vertex_neighbors.shape[1]))
+
+    @property
+    def points(self):
+        return self._points
+
+    @points.setter
+    def points(self, pts):
+        self._points = pts
+        self._points_f32 = _as_f32(pts)
+        if self._points_f32.ndim != 2 or self._points_f32.shape[1] != 3:
+            raise ValueError('points must be (N, 3)')
+
+    @property
+    def vertices(self):
+        return self._vertices
+
+    def _upload_points(self, sigma_inv, weights):
+        """search() weight handling, mesh_conj_grad.py:156-164, done on the device at upload."""
+        N3 = self._points_f32.size
+        key = (id(self._points), id(sigma_inv) if not np.isscalar(sigma_inv) else float(sigma_inv),
+               None if weights is None else (id(weights) if not np.isscalar(weights) else float(weights)))
+        if self._native.points_key == key:
+            return
+        s_arr, s_sc = None, 1.0
+        if np.isscalar(sigma_inv):
+            s_sc = float(sigma_inv)
+        else:
+            s_arr = _as_f32(np.asarray(sigma_inv).ravel())
+            if s_arr.size != N3:
+                raise ValueError('sigma_inv must be a scalar or have 3N entries')
+        w_arr, w_sc, mode = None, 1.0, nw.NW_WEIGHTS_FROM_SIGMA_INV
+        if weights is not None:
+            if np.isscalar(weights):
+                mode, w_sc = nw.NW_WEIGHTS_SCALAR, float(weights)
+            else:
+                mode = nw.NW_WEIGHTS_ARRAY
+                w_arr = _as_f32(np.asarray(weights).ravel())
+                if w_arr.size != N3:
+                    raise ValueError('weights must be a scalar or have 3N entries')
+        self._native.check(self._L.nw_set_points(self._h, nw.ptr(self._points_f32), self._points_f32.shape[0], nw.ptr(s_arr), s_sc,
+                                                 mode, nw.ptr(w_arr), w_sc))
+        self._native.points_key = key
+        self._native._keep = [self._points, sigma_inv, weights]      # keep ids alive while they key the cache
+        # host view of the mask for API parity (`cg.mask`)
+        if mode == nw.NW_WEIGHTS_ARRAY:
+            self.mask = w_arr > 0
+        elif mode == nw.NW_WEIGHTS_FROM_SIGMA_INV and s_arr is not None:
+            self.mask = s_arr > 0
+        else:
+            self.mask = np.isfinite(self._points_f32.ravel())
+
+    # -- the hot path ---------------------------------------------------------------------------
+    def search(self, data, lams, defaults=None, num_iters=10, weights=None, sigma_inv=1.0, pos=False, last_step=True):
+        """mesh_conj_grad.py:150-292.  Returns the (M,3) float32 vertex estimate."""
+        if data is not self._points:
+            d = np.asarray(data)
+            if d.shape != np.asarray(self._points).shape or not np.array_equal(d, self._points):
+                raise NotImplementedError('search(data=...) must be the localizations the optimiser was built with')
+        if type(lams) is float or np.isscalar(lams):
+            lams = [float(lams)]
+        lams_a = np.ascontiguousarray(lams, dtype=np.float32)
+        self._upload_points(sigma_inv, weights)
+        num_iters = int(num_iters)
+        flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP)
+        out = np.empty((self.M, 3), np.float32)
+        logs = (nw.IterLog * max(num_iters, 1))()
+        lc = ctypes.c_int(0)
+        self._cache = {}
+        code = self._L.nw_search(self._h, nw.ptr(lams_a), lams_a.size, num_iters, flags, nw.ptr(out), logs, ctypes.byref(lc))
+        self._native.check(code)
+        self._consume_logs(logs, lc.value)
+        self._finish(out)
+        return np.real(self.fs)
+
+    def _consume_logs(self, logs, executed):
+        self.loopcount = executed
+        for i in range(executed):
+            L = logs[i]
+            self.tests.append(np.float32(L.test))
+            self.ress.append(np.float32(L.res_norm))
+            self.prefs.append(np.array([L.prefs_norm], np.float32))
+            self.cpred = np.float32(L.cpred)
+            self.wpreds = [np.float64(L.wpred)]
+            self.nn_max_ring = max(self.nn_max_ring, int(L.nn_max_ring))
+            self.mean_dist = float(L.mean_dist)
+            self.iter_logs.append(dict(test=L.test, res_norm=L.res_norm, prefs_norm=L.prefs_norm, cpred=L.cpred, wpred=L.wpred,
+                                       c=np.array(L.c[:]), H=np.array(L.H[:]).reshape(3, 3), G=np.array(L.G[:]),
+                                       mean_dist=L.mean_dist, n_search=int(L.n_search), nn_max_ring=int(L.nn_max_ring)))
+
+    def _finish(self, out):
+        self.fs = out
+        self.f = self.fs.ravel()
+        # write-back (mesh_conj_grad.py:289-290)
+        m = self._mesh_vertex_mask
+        self.mesh._vertices['position'][m] = out[m]
+        self.mesh._initialize_curvature_vectors()
+
+    # -- state the mesh reads back (_membrane_mesh.pyx:1563-1634) ----------------------------------
+    def _get(self, what, shape, dtype):
+        if what in self._cache:
+            return self._cache[what]
+        a = np.empty(shape, dtype)
+        self._native.check(self._L.nw_get(self._h, what, nw.ptr(a), a.nbytes))
+        self._cache[what] = a
+        return a
+
+    @property
+    def S(self):
+        return self._get(nw.NW_ARR_S, (3 * self.M, 3), np.float32)
+
+    @property
+    def res(self):
+        return self._get(nw.NW_ARR_RES, (self._points_f32.size,), np.float32)
+
+    @property
+    def w(self):
+        n = self._points_f32.shape[0]
+        return (self._get(nw.NW_ARR_VIDX, (n, 3), np.int32), self._get(nw.NW_ARR_W, (n, 3), np.float32))
+
+    @property
+    def d(self):
+        dm = self._get(nw.NW_ARR_DIST, (self._points_f32.shape[0],), np.float32).astype(np.float64)
+        return np.vstack([dm, dm, dm]).T                                           # mesh_conj_grad.py:483
+
+    @property
+    def nearest_face(self):
+        return self._get(nw.NW_ARR_FACE, (self._points_f32.shape[0],), np.int32)
+
+    @property
+    def fdef(self):
+        return self._get(nw.NW_ARR_FDEF, (self.M, 3), np.float32)
+
+    @property
+    def point_influence(self):
+        return self._get(nw.NW_ARR_PI, (self.M,), np.float32)
+
+    def Afunc(self, f):
+        """mesh_conj_grad.py:518-551 with the cached weight matrix."""
+        x = _as_f32(np.asarray(f).ravel())
+        if x.size != 3 * self.M:
+            raise ValueError('Afunc expects 3M values')
+        y = np.empty(self._points_f32.size, np.float32)
+        self._native.check(self._L.nw_apply_A(self._h, nw.ptr(x), nw.ptr(y)))
+        return y
+
+    def Ahfunc(self, f):
+        """mesh_conj_grad.py:553-588."""
+        r = _as_f32(np.asarray(f).ravel())
+        if r.size != self._points_f32.size:
+            raise ValueError('Ahfunc expects 3N values')
+        z = np.empty(3 * self.M, np.float32)
+        self._native.check(self._L.nw_apply_At(self._h, nw.ptr(r), nw.ptr(z)))
+        if np.any(np.isnan(z)):
+            raise AssertionError('NaN in A^T r')                                    # :580
+        return z
+
+    def I(self, f):
+        return f                                                                    # :912-914
+
+    # alternate regularisers (default off; mesh_conj_grad.py:590-736 -> conj_grad_utils.c)
+    def _lfunc(self, kind, f, f0=None):
+        x = _as_f32(np.asarray(f).ravel())
+        d = np.zeros_like(x)
+        f0a = None if f0 is None else _as_f32(np.asarray(f0).ravel())
+        self._native.check(self._L.nw_lfunc(self._h, kind, nw.ptr(x), nw.ptr(f0a), nw.ptr(d)))
+        if np.any(np.isnan(d)):
+            raise AssertionError('NaN in regulariser output')
+        return d
+
+    def Lfunc(self, f):
+        return self._lfunc(0, f)
+
+    def Lhfunc(self, f):
+        return self._lfunc(1, f)
+
+    def Lfunc3(self, f):
+        return self._lfunc(2, f, self.f if self.f is not None else self._vertices)
+
+    def Lhfunc3(self, f):
+        return self._lfunc(3, f, self.f if self.f is not None else self._vertices)
+
+    def vertex_area_weights(self, f=None):
+        return self._lfunc(4, self._vertices if f is None else f)
+
+    def start_guess(self, data):
+        return self._vertices.copy()                                                # :1002-1007
+
+    def _stop_cond(self):
+        if len(self.tests) < 3:                                                     # :1009-1016
+            return False
+        a, b, c = self.tests[-3:]
+        return (c < b) and (b < a) and (a < 1e-6)
+
+    # -- timing hooks for bench.py ------------------------------------------------------------------
+    def set_profiling(self, on=True):
+        self._native.check(self._L.nw_set_profiling(self._h, 1 if on else 0))
+
+    def stage_ms(self):
+        names = ['total', 'grid', 'nn', 'attract', 'prior', 'as', 'update']
+        out = {}
+        for i, nme in enumerate(names):
+            ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+            self._native.check(self._L.nw_stage_ms(self._h, i, ctypes.byref(ms), ctypes.byref(n)))
+            out[nme] = (ms.value, n.value)
+        return out

@@ -1,0 +1,162 @@
+/*
+ * nanowrap.h -- C-ABI of libnanowrap_hip.so: the MI355X (gfx950) implementation of the NanoWrap inner loop.
+ *
+ * Plain C, plain pointers and sizes, no Python.h / torch types: loadable with ctypes/cffi/dlopen.
+ * Every entry point names the reference interface it replaces (paths relative to /root/reference/).
+ *
+ * Conventions
+ *   - every call returns an int status: NW_OK (0) or a negative nw_status; nw_last_error(ctx) gives text;
+ *     nothing is thrown across the ABI;
+ *   - the caller owns all host buffers, the library owns all device buffers and copies on nw_set_xxx and nw_get;
+ *     input pointers may be host OR device pointers (copied with hipMemcpyDefault);
+ *   - one nw_ctx = one device + one HIP stream; a ctx is not thread-safe, distinct ctxs are independent;
+ *   - all floating-point data is float32, indices are int32, row-major, C-contiguous (the reference's
+ *     contract is "contiguous ndarray, dtypes unchecked": ch_shrinkwrap/conj_grad_utils.c:130-149).
+ */
+#ifndef NANOWRAP_H_
+#define NANOWRAP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NW_ABI_VERSION 1
+
+typedef struct nw_ctx nw_ctx;
+
+typedef enum nw_status {
+    NW_OK = 0,
+    NW_ERR_BADARG = -1,      /* NULL pointer, non-positive size, call order (mesh/points not set) */
+    NW_ERR_HIP = -2,         /* a HIP runtime call failed; text in nw_last_error */
+    NW_ERR_NAN = -3,         /* NaN detected where the reference asserts: mesh_conj_grad.py:514,548,580 */
+    NW_ERR_SINGULAR = -4,    /* subspace normal equations singular: numpy.linalg.solve raises LinAlgError, conj_grad.py:219 */
+    NW_ERR_NONFINITE = -5,   /* non-finite localization or vertex coordinate (cKDTree cannot index it) */
+    NW_ERR_NOMEM = -6
+} nw_status;
+
+/* how the residual weights are given -- mirrors `search(..., weights=None, sigma_inv=1.0)`,
+ * ch_shrinkwrap/mesh_conj_grad.py:150-164 */
+typedef enum nw_weights_mode {
+    NW_WEIGHTS_FROM_SIGMA_INV = 0,   /* weights=None  -> weights = sigma_inv (array or scalar)            */
+    NW_WEIGHTS_SCALAR = 1,           /* scalar weights: mask = isfinite(data), no normalisation          */
+    NW_WEIGHTS_ARRAY = 2             /* (3N,) weights: mask = weights > 0, weights /= weights.mean()      */
+} nw_weights_mode;
+
+/* nw_search flags -- keyword arguments of search(), mesh_conj_grad.py:150 */
+#define NW_FLAG_POSITIVITY   1u      /* pos=True        (mesh_conj_grad.py:277-278) */
+#define NW_FLAG_NO_LAST_STEP 2u      /* last_step=False (mesh_conj_grad.py:281-283) */
+
+/* per-iteration record; the reference keeps these as Python lists / attributes:
+ * tests, ress, prefs (mesh_conj_grad.py:269-271), cpred, wpreds (:274, conj_grad.py:223-225) */
+typedef struct nw_iter_log {
+    double test;            /* 1 - |S0.S1| / (|S0||S1|)                                                */
+    double res_norm;        /* || res ||_2 after distance de-weighting                                  */
+    double prefs_norm;      /* || f - fdef ||_2                                                         */
+    double cpred;           /* predicted data misfit (with the reference's aliasing quirk)              */
+    double wpred;           /* predicted regulariser misfit                                             */
+    double c[3];            /* subspace coefficients                                                    */
+    double H[9];            /* regularised normal matrix actually solved (float32 values), row-major 3x3 */
+    double G[3];
+    double mean_dist;       /* mean point -> nearest-centroid distance (drives the grid cell size)      */
+    int32_t n_search;       /* 2 in the first iteration of a search() call, 3 afterwards               */
+    int32_t nn_max_ring;    /* largest ring any point needed in the exact NN query                      */
+    int32_t status;         /* NW_OK or the nw_status raised in this iteration                          */
+    int32_t executed;       /* 0 if the stop condition (mesh_conj_grad.py:1009-1016) cancelled it        */
+} nw_iter_log;
+
+/* what nw_get / nw_device_ptr can return */
+typedef enum nw_array {
+    NW_ARR_S = 0,           /* (3M, 3) f32  search directions            -- `cg.S`,  _membrane_mesh.pyx:1569-1599 */
+    NW_ARR_RES = 1,         /* (3N,)   f32  weighted residual, point order of nw_set_points -- `cg.res`, :1621  */
+    NW_ARR_VIDX = 2,        /* (N, 3)  i32  vertices of the nearest face -- `cg.w[0]`, mesh_conj_grad.py:488       */
+    NW_ARR_W = 3,           /* (N, 3)  f32  normalised inverse-distance weights -- `cg.w[1]`, :503-510            */
+    NW_ARR_DIST = 4,        /* (N,)    f32  distance to the nearest face centroid -- `cg.d[:,0]`, :483            */
+    NW_ARR_FACE = 5,        /* (N,)    i32  nearest face id                                                       */
+    NW_ARR_POS = 6,         /* (M, 3)  f32  current estimate `cg.f`                                              */
+    NW_ARR_FDEF = 7,        /* (M, 3)  f32  curvature prior of the last iteration (float32 copy), :770-820        */
+    NW_ARR_PI = 8,          /* (M,)    f32  point influence ||A^T 1||, _membrane_mesh.pyx:1625-1634              */
+    NW_ARR_MESHPOS = 9,     /* (M, 3)  f32  mesh._vertices['position'] as written back at :289                   */
+    NW_ARR_VACC = 10,       /* (M, 4)  f32  device-only: per-vertex accumulator {A^T res, sum w} (multi-GPU all-reduce) */
+    NW_ARR_SCALARS = 11     /* (NW_N_SCALARS,) f64 device-only: normal-equation partial sums (multi-GPU all-reduce)    */
+} nw_array;
+
+#define NW_N_SCALARS 32
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+int nw_abi_version(void);
+int nw_create(int device, nw_ctx **out);          /* replaces ShrinkwrapMeshConjGrad.__init__, mesh_conj_grad.py:33-65 */
+void nw_destroy(nw_ctx *ctx);
+const char *nw_last_error(nw_ctx *ctx);
+/* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int nw_set_stream(nw_ctx *ctx, void *hip_stream);
+int nw_synchronize(nw_ctx *ctx);
+
+/* ---- inputs -------------------------------------------------------------------------------------------- */
+/* localizations + residual weighting; replaces the `points` setter (mesh_conj_grad.py:127-130, without the
+ * unused point kd-tree) and the weight handling at :156-164.  sigma_inv: (3N,) or NULL (then sigma_inv_scalar);
+ * weights: (3N,) for NW_WEIGHTS_ARRAY else NULL. */
+int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points,
+                  const float *sigma_inv, float sigma_inv_scalar,
+                  int weights_mode, const float *weights, float weights_scalar);
+
+/* mesh arrays the optimiser reads: positions `mesh._vertices['position']` (M,3), block-stale vertex normals
+ * `mesh.vertex_normals` (M,3), 1-ring VERTEX ids (M,NB), -1 padded (= mesh._halfedges['vertex'][mesh._vertices
+ * ['neighbors']], mesh_conj_grad.py:50-54), valid = (mesh._vertices['halfedge'] != -1) (M bytes or NULL = all
+ * valid, :44), faces (F,3) (:47). */
+int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const int32_t *nbr, const uint8_t *valid,
+                const int32_t *faces, int64_t n_vertices, int64_t n_faces, int n_nbr);
+/* cheap refresh between blocks with unchanged topology (_membrane_mesh.pyx:1524-1527) */
+int nw_set_normals(nw_ctx *ctx, const float *nrm);
+int nw_set_positions(nw_ctx *ctx, const float *pos);
+
+/* ---- the hot path -------------------------------------------------------------------------------------- */
+/* `num_iters` iterations of ShrinkwrapMeshConjGrad.search (mesh_conj_grad.py:150-292), device resident.
+ * lams: regularisation weights (only lams[0] is live with Lfuncs=['I'], :38,184); pos_out (M,3) or NULL;
+ * log: num_iters records or NULL; loopcount: iterations actually executed (stop condition) or NULL. */
+int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags,
+              float *pos_out, nw_iter_log *log, int *loopcount);
+
+/* split-phase form of ONE iteration for multi-GPU runs (points sharded across ranks, mesh replicated):
+ *   nw_iter_attract  : grid build, exact NN, weights, residual, A^T scatter -> NW_ARR_VACC partial sums
+ *   -- all-reduce(sum) NW_ARR_VACC over ranks --
+ *   nw_iter_directions: curvature prior, S0/S1, vertex dot products, A.S_k and point dot products -> NW_ARR_SCALARS
+ *   -- all-reduce(sum) the first nw_n_point_scalars() entries of NW_ARR_SCALARS over ranks --
+ *   nw_iter_update   : <=3x3 solve, f += S c, write-back, log record
+ * nw_search_begin/_end bracket the iterations of one search() call. */
+int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags);
+int nw_iter_attract(nw_ctx *ctx);
+int nw_iter_directions(nw_ctx *ctx);
+int nw_iter_update(nw_ctx *ctx);
+int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *loopcount);
+int nw_n_point_scalars(void);
+
+/* ---- operators & state read-back ------------------------------------------------------------------------- */
+/* y = A x   (Afunc, mesh_conj_grad.py:518-551)  x: (3M,) -> y: (3N,), with the cached weight matrix */
+int nw_apply_A(nw_ctx *ctx, const float *x, float *y);
+/* z = A^T r (Ahfunc, mesh_conj_grad.py:553-588 + c_shrinkwrap_ah_helper, conj_grad_utils.c:123-167) */
+int nw_apply_At(nw_ctx *ctx, const float *r, float *z);
+int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes);
+/* raw device pointer + byte size of a device-resident array (NW_ARR_VACC, NW_ARR_SCALARS, NW_ARR_POS, ...) */
+int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes);
+
+/* alternate regularisers (default off in the reference; selectable through Lfuncs, mesh_conj_grad.py:36-39):
+ * kind 0: c_shrinkwrap_l_func   conj_grad_utils.c:249-306      d = L x        (umbrella / N)
+ *      1: c_shrinkwrap_lh_func  :308-368                        d = L^H x      (order-dependent in-place /N)
+ *      2: c_shrinkwrap_lw_func  :370-497                        area-normalised, metric from f0
+ *      3: c_shrinkwrap_lhw_func :585-710                        transpose of 2
+ *      4: vertex_area_weights   :551-582                        1/sqrt(sum|e|^2+1) replicated x3 (x = positions)
+ * x, f0, out: (3M,) float32 host or device; f0 may be NULL for kinds 0,1,4. Uses the neighbour table of nw_set_mesh. */
+int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, float *out);
+
+/* device timing of the last nw_search (ms), split by stage; for bench.py's roofline object.
+ * stage: 0 total, 1 grid build, 2 NN query, 3 attraction (weights/residual/scatter), 4 prior+directions,
+ * 5 A.S + dots, 6 solve+update.  Only valid if nw_set_profiling(ctx, 1) was called before the search. */
+int nw_set_profiling(nw_ctx *ctx, int enable);
+int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANOWRAP_H_ */

@@ -1,0 +1,55 @@
+"""CPU test: libnanowrap_hip.so loads and exports every function include/nanowrap.h declares (no GPU calls)."""
+import os
+import re
+import ctypes
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'nanowrap.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(nw_[a-zA-Z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_header_symbols():
+    from ch_shrinkwrap_amd import build, _lib
+    build.build_hip_library()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), 'libnanowrap_hip.so does not export %s' % n
+    assert sorted(_lib.SYMBOLS) == names
+    assert _lib.load().nw_abi_version() == 1
+    assert _lib.load().nw_n_point_scalars() == 13
+
+
+def test_log_struct_layout_matches_header():
+    from ch_shrinkwrap_amd import _lib
+    # 5 + 3 + 9 + 3 + 1 doubles, 4 int32
+    assert ctypes.sizeof(_lib.IterLog) == 21 * 8 + 4 * 4
+
+
+def test_product_path_never_imports_the_oracle():
+    """The shipped package must not reference oracle/ (it is test infrastructure)."""
+    pkg = os.path.join(ROOT, 'ch_shrinkwrap_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert 'nanowrap_oracle' not in src and 'from oracle' not in src and 'import oracle' not in src, fn
+
+
+def test_no_gpu_means_loud_failure():
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from ch_shrinkwrap_amd.trimesh import TriMesh, icosphere
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    v, f = icosphere(1, 10.0)
+    with pytest.raises(RuntimeError):
+        ShrinkwrapMeshConjGrad(TriMesh(v, f), np.zeros((10, 3), 'f4'))

@@ -1,0 +1,231 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI (ctypes), against
+  * the committed golden vectors produced by the reference (tests/golden/), and
+  * the CPU oracle on fresh seeded inputs at sizes the oracle finishes in seconds.
+Tolerances (fp32 path): integer arrays exact apart from a counted handful of fp ties; single-stage float arrays
+rtol 2e-5; vertex RMS <= 1e-4 of the bounding-box diagonal after the full run (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _imports():
+    from ch_shrinkwrap_amd.trimesh import TriMesh
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    return TriMesh, ShrinkwrapMeshConjGrad
+
+
+def _mesh_from_golden(g, prefix=''):
+    TriMesh, _ = _imports()
+    v, f = g[prefix + 'vertices'], g[prefix + 'faces']
+    used = int(f.max()) + 1
+    m = TriMesh(v[:used], f, max_vertices=v.shape[0])
+    m._vertices['position'][:] = v
+    # the fixtures carry the exact arrays the reference saw; make sure the substrate reproduces them
+    assert np.array_equal(m.neighbor_vertex_table(), g[prefix + 'nbr'])
+    assert np.array_equal(m.vertex_normals[:used], g[prefix + 'normals'][:used])
+    return m
+
+
+def _close(a, b, rtol=2e-5, atol=1e-6, what=''):
+    a = np.asarray(a, 'f8')
+    b = np.asarray(b, 'f8')
+    scale = np.abs(b).max() if b.size else 1.0
+    err = np.abs(a - b).max() if b.size else 0.0
+    assert err <= atol + rtol * scale, '%s: max err %.3e vs scale %.3e' % (what, err, scale)
+
+
+def test_stage_parity_against_golden():
+    _, CG = _imports()
+    g = load_golden('stages_642')
+    s = 1.0 / g['sigma'].ravel()
+    pts = g['points']
+    for n_it in (1, 2, 3):
+        mesh = _mesh_from_golden(g)
+        cg = CG(mesh, pts, search_k=200, search_rad=100, shield_sigma=5.0)
+        out = cg.search(pts, lams=[10.0], num_iters=n_it, sigma_inv=s)
+        k = 'it%d_' % (n_it - 1)
+        v_idx, w = cg.w
+        # nearest face: exact (vertex triple of the nearest face)
+        mism = int((v_idx != g[k + 'v_idx']).any(1).sum())
+        assert mism == 0, '%d points picked a different nearest face in iteration %d' % (mism, n_it)
+        _close(w, g[k + 'w'], what='w')
+        _close(cg.d[:, 0], g[k + 'dmean'], what='dmean')
+        _close(cg.point_influence, g[k + 'pi'], what='pi')
+        _close(cg.fdef, g[k + 'fdef'], what='fdef')
+        _close(cg.res, g[k + 'res_masked'], what='res')
+        S = cg.S
+        ns = g[k + 'S'].shape[1]
+        _close(S[:, :ns], g[k + 'S'], what='S')
+        _close(out.ravel(), g[k + 'fnew'], rtol=2e-6, what='fnew')
+        assert abs(cg.cpred - g[k + 'cpred']) <= 2e-4 * abs(g[k + 'cpred'])
+        assert abs(cg.wpreds[0] - g[k + 'wpred']) <= 2e-4 * abs(g[k + 'wpred'])
+        if n_it == 3:
+            assert cg.loopcount == 3
+            assert rel_rms(out, g['positions']) <= 1e-5
+            _close(np.array(cg.tests), g['log_tests'], rtol=1e-4, atol=1e-5, what='tests')
+            _close(np.array(cg.ress), g['log_ress'], rtol=1e-5, what='ress')
+            _close(np.array([p[0] for p in cg.prefs]), g['log_prefs'], rtol=1e-5, what='prefs')
+            _close(S, g['S_final'], rtol=2e-4, what='S_final')       # S2 = fnew - f: cancellation amplifies 1-ulp differences
+
+
+def test_c1_golden_20_iterations():
+    """BASELINE.json configs[0]: sphere, 10k localizations, 2562-vertex icosphere, 20 iterations."""
+    _, CG = _imports()
+    g = load_golden('c1_sphere_10k')
+    s = 1.0 / g['sigma'].ravel()
+    pts = g['points']
+    for n_it, key in ((1, 'positions_1'), (5, 'positions_5'), (20, 'positions_20')):
+        mesh = _mesh_from_golden(g)
+        cg = CG(mesh, pts, search_k=200, search_rad=100, shield_sigma=5.0)
+        out = cg.search(pts, lams=[10.0], num_iters=n_it, sigma_inv=s)
+        rms = rel_rms(out, g[key])
+        print('C1 after %d iterations: vertex RMS vs reference = %.3e of bbox diagonal' % (n_it, rms))
+        assert rms <= 1e-4
+        assert np.array_equal(mesh.vertices, out)                    # write-back into the mesh
+    _close(np.array(cg.tests), g['log_tests'], rtol=1e-3, atol=1e-5, what='tests')
+    _close(np.array(cg.ress), g['log_ress'], rtol=1e-4, what='ress')
+    assert cg.loopcount == int(g['log_loopcount'])
+
+
+def test_variants_against_golden():
+    TriMesh, CG = _imports()
+    g = load_golden('variants_642')
+    pts = g['points']
+    # scalar sigma
+    mesh = _mesh_from_golden(g, 'mesh_')
+    cg = CG(mesh, pts)
+    out = cg.search(pts, lams=[10.0], num_iters=5, sigma_inv=10.0)
+    assert rel_rms(out, g['scalar_positions']) <= 1e-5
+    _close(np.array(cg.tests), g['scalar_log_tests'], rtol=1e-4, atol=1e-5, what='tests')
+    # explicit weights with zeros -> mask
+    mesh = _mesh_from_golden(g, 'mesh_')
+    cg = CG(mesh, pts)
+    out = cg.search(pts, lams=[10.0], num_iters=5, sigma_inv=1.0 / g['weights_sigma'].ravel(), weights=g['weights_weights'])
+    assert rel_rms(out, g['weights_positions']) <= 1e-5
+    assert abs(cg.cpred - g['weights_log_cpred']) <= 1e-3 * abs(g['weights_log_cpred'])
+    assert np.array_equal(cg.mask, g['weights_weights'] > 0)
+    # unused vertex slots + background points + ignored second lambda
+    mesh = _mesh_from_golden(g, 'holes_mesh_')
+    hp = g['holes_points']
+    cg = CG(mesh, hp)
+    out = cg.search(hp, lams=[10.0, 0.5], num_iters=5, sigma_inv=1.0 / np.full(3 * hp.shape[0], 10.0, 'f4'))
+    assert rel_rms(out, g['holes_positions']) <= 1e-5
+    assert rel_rms(mesh.vertices, g['holes_mesh_positions']) <= 1e-5
+    assert np.array_equal(out[-2:], g['holes_positions'][-2:])       # the two unused slots never move
+    assert cg.nn_max_ring >= 2                                        # background points exercised ring expansion
+    # two consecutive calls on one optimiser
+    mesh = _mesh_from_golden(g, 'mesh_')
+    s = 1.0 / np.full(3 * pts.shape[0], 10.0, 'f4')
+    cg = CG(mesh, pts)
+    a = cg.search(pts, lams=[10.0], num_iters=3, sigma_inv=s).copy()
+    b = cg.search(pts, lams=[10.0], num_iters=3, sigma_inv=s).copy()
+    assert rel_rms(a, g['twice_positions_a']) <= 1e-5
+    assert rel_rms(b, g['twice_positions_b']) <= 1e-5
+    _close(np.array(cg.tests), g['twice_log_tests'], rtol=1e-4, atol=1e-5, what='tests')
+    assert len(cg.tests) == 6
+
+
+def test_operators_and_diagnostics():
+    """A / A^T with the cached weight matrix (Afunc/Ahfunc) and the mesh-side diagnostics built on them
+    (_membrane_mesh.pyx:1563-1634)."""
+    _, CG = _imports()
+    from oracle import nanowrap_oracle as O
+    g = load_golden('stages_642')
+    mesh = _mesh_from_golden(g)
+    pts = g['points']
+    cg = CG(mesh, pts)
+    cg.search(pts, lams=[10.0], num_iters=2, sigma_inv=1.0 / g['sigma'].ravel())
+    v_idx, w = cg.w
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=3 * cg.M).astype('f4')
+    r = rng.normal(size=pts.size).astype('f4')
+    _close(cg.Afunc(x), O.apply_A(x, v_idx, w, pts), what='Afunc')
+    _close(cg.Ahfunc(r), O.apply_At(r, v_idx, w, cg.M), rtol=1e-5, what='Ahfunc')
+    # <A x, r> == <x, A^T r>
+    lhs = float(np.dot(cg.Afunc(x).astype('f8'), r))
+    rhs = float(np.dot(x.astype('f8'), cg.Ahfunc(r)))
+    assert abs(lhs - rhs) <= 1e-4 * (abs(lhs) + 1)
+    pi = np.sqrt((cg.Ahfunc(np.ones_like(cg.res)).reshape(-1, 3) ** 2).sum(1))
+    _close(pi, cg.point_influence, rtol=1e-5, what='point_influence')
+
+
+def test_alternate_regularisers_against_reference_c():
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd.trimesh import icosphere
+    g = load_golden('native_helpers')
+    v, f = icosphere(2, 50.0)
+    mesh = TriMesh(v, f, max_vertices=v.shape[0] + 1)
+    assert np.array_equal(mesh.neighbor_vertex_table(), g['nbr'])
+    pts = (v[:50] * 0.9).astype('f4')
+    cg = CG(mesh, pts)
+    x, f0 = g['x'], g['f0']
+    assert np.array_equal(cg._lfunc(0, x), g['out_l'])               # same order, no contraction: bit exact
+    assert np.array_equal(cg._lfunc(1, x), g['out_lh'])
+    assert np.array_equal(cg._lfunc(2, x, f0), g['out_lw'])
+    _close(cg._lfunc(3, x, f0), g['out_lhw'], rtol=1e-6, what='lhw (atomic scatter order)')
+    assert np.array_equal(cg._lfunc(4, f0), g['out_vaw'])
+
+
+@pytest.mark.parametrize('name,scale', [('c2', 0.1), ('c3', 0.05)])
+def test_against_oracle_fresh_inputs(name, scale):
+    """Seeded capsule / two-lobe clouds (BASELINE.json configs[1], configs[2] shapes at reduced size)."""
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    from oracle import nanowrap_oracle as O
+    c = synth.make_config(name, scale=scale, seed=11)
+    pts, sig = c['points'], c['sigma']
+    s = 1.0 / sig.ravel()
+    mesh = TriMesh(c['vertices'], c['faces'])
+    trace = []
+    ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, c['lams'], 5, s, trace=trace)
+    cg = CG(mesh, pts)
+    out = cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+    rms = rel_rms(out, ref.positions)
+    mism = int((cg.nearest_face != trace[-1]['face']).sum())
+    print('%s x%.2f: N=%d M=%d  vertex RMS vs oracle %.3e, NN mismatches in last iteration %d, max ring %d'
+          % (name, scale, pts.shape[0], mesh.vertices.shape[0], rms, mism, cg.nn_max_ring))
+    assert rms <= 1e-4
+    assert mism <= max(2, pts.shape[0] // 20000)        # only fp near-ties after 5 iterations of drift
+    _close(np.array(cg.ress), np.array(ref.ress), rtol=1e-4, what='ress')
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[2] at full size (1M localizations, 163 842 vertices): size-independent properties."""
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    from oracle import nanowrap_oracle as O
+    c = synth.make_config('c3', scale=1.0, seed=3)
+    pts, sig = c['points'], c['sigma']
+    s = 1.0 / sig.ravel()
+    mesh = TriMesh(c['vertices'], c['faces'])
+    pos0 = mesh.vertices.copy()
+    cg = CG(mesh, pts)
+    cg.search(pts, lams=c['lams'], num_iters=1, sigma_inv=s)
+    v_idx, w = cg.w
+    # (1) exactness of the NN query on a random sample, against the float64 brute force
+    rng = np.random.default_rng(0)
+    sel = rng.choice(pts.shape[0], 3000, replace=False)
+    cent = O.face_centroids(pos0, mesh.faces)
+    d_ref, f_ref = O.nearest_faces(cent, pts[sel], brute=True)
+    assert np.array_equal(cg.nearest_face[sel], f_ref)
+    assert np.allclose(cg.d[sel, 0], d_ref, rtol=1e-6)
+    assert np.array_equal(v_idx[sel], mesh.faces[f_ref])
+    # (2) rows of A sum to one; A^T conserves the total: sum_v (A^T r)_v == sum_i r_i
+    assert np.allclose(w.sum(1), 1.0, atol=1e-6)
+    S0 = cg.S[:, 0].reshape(-1, 3).astype('f8')
+    tot = cg.res.reshape(-1, 3).astype('f8').sum(0)
+    assert np.allclose(S0.sum(0), tot, rtol=1e-4, atol=1e-3 * np.abs(tot).max())
+    # (3) linearity of the operators
+    x = rng.normal(size=3 * cg.M).astype('f4')
+    y = rng.normal(size=3 * cg.M).astype('f4')
+    assert np.allclose(cg.Afunc(x + 2 * y), cg.Afunc(x) + 2 * cg.Afunc(y), atol=1e-4)
+    # (4) the step is the stated combination of the search directions
+    L = cg.iter_logs[-1]
+    step = (cg.S[:, :2].astype('f8') @ L['c'][:2]).reshape(-1, 3)
+    assert np.allclose(cg.fs - pos0, step, atol=1e-3)
+    assert np.allclose(cg.S[:, 2].reshape(-1, 3), cg.fs - pos0, atol=1e-6)
