@@ -183,6 +183,7 @@ class ShrinkwrapMeshConjGrad(object):
         code = self._L.nw_search(self._h, nw.ptr(lams_a), lams_a.size, num_iters, flags, nw.ptr(out), logs, ctypes.byref(lc))
         self._native.check(code)
         self._consume_logs(logs, lc.value)
+        self._accumulate_stage_ms()
         self._finish(out)
         return np.real(self.fs)
 
@@ -308,6 +309,16 @@ class ShrinkwrapMeshConjGrad(object):
     # -- timing hooks for bench.py ------------------------------------------------------------------
     def set_profiling(self, on=True):
         self._native.check(self._L.nw_set_profiling(self._h, 1 if on else 0))
+        self._profiling = bool(on)
+        self.stage_ms_total = {k: (0.0, 0) for k in ('total', 'grid', 'nn', 'attract', 'prior', 'as', 'update')}
+
+    def _accumulate_stage_ms(self):
+        # HIP-event timings of the last search() (per stage: summed ms, number of timed spans), accumulated over calls
+        if not getattr(self, '_profiling', False):
+            return
+        for k, (ms, n) in self.stage_ms().items():
+            a, b = self.stage_ms_total[k]
+            self.stage_ms_total[k] = (a + ms, b + n)
 
     def stage_ms(self):
         names = ['total', 'grid', 'nn', 'attract', 'prior', 'as', 'update']

@@ -1,0 +1,143 @@
+"""
+Multi-GPU form of the NanoWrap iteration: one process per GPU, `torch.distributed` over RCCL (xGMI).
+
+The reference is single-process (no collective anywhere); what shards naturally is the
+localization cloud, because A is row-separable -- each localization touches the three vertices of ONE face
+(SURVEY.md section 8e).  Two exact decompositions are provided, both driving the SAME split-phase C-ABI
+(nw_iter_attract / nw_iter_directions / nw_iter_update, include/nanowrap.h):
+
+  mode 'tiles'       every rank owns a spatial tile of the scene = its localizations AND the mesh component(s) inside
+                     it; tiles share no vertices (BASELINE.json configs[4]: independent vesicles).  The boundary set is
+                     empty, so no vertex data is exchanged; but the reference solves ONE <=3x3 subspace system for the
+                     whole mesh (conj_grad.py:202-219), so the 24 normal-equation partial sums are all-reduced once per
+                     iteration and every rank solves the same system.
+  mode 'replicated'  the mesh is replicated, only the localizations are sharded.  Per iteration: all-reduce(sum) of the
+                     per-vertex accumulator {A^T res, A^T 1} (M x 4 float32) and of the 13 point-side scalars.
+
+Collectives are issued on the stream the kernels run on (the optimiser is constructed with torch's current stream), so
+an iteration is kernels -> all-reduce -> kernels with no host synchronisation.  Messages are KB..MB sized: the per-link
+xGMI bandwidth is irrelevant for the scalar exchange (latency-bound), and the vertex accumulator is one bucket.
+
+The orchestration below is backend-agnostic: it talks to an "executor" (HipExecutor for the product; tests drive the
+same code over gloo with a CPU executor built from the oracle) so that the N > 1 protocol is covered on CPU.
+"""
+import ctypes
+import numpy as np
+
+from . import _lib as nw
+
+
+class _DevArray(object):
+    """Minimal __cuda_array_interface__ carrier so torch can view library-owned device memory without a copy."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
+
+
+class HipExecutor(object):
+    """Phases of one iteration on this rank's nw_ctx + torch views of the buffers that get all-reduced."""
+
+    def __init__(self, cg):
+        self.cg = cg
+        self.L, self.h, self.native = cg._L, cg._h, cg._native
+        self.n_point_scalars = self.L.nw_n_point_scalars()
+        self.n_scalars = 24
+        self._views = {}
+
+    def begin(self, data, lams, num_iters, sigma_inv, weights, pos, last_step):
+        cg = self.cg
+        cg._upload_points(sigma_inv, weights)
+        lams_a = np.ascontiguousarray(lams, dtype=np.float32)
+        flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP)
+        cg._cache = {}
+        self.native.check(self.L.nw_search_begin(self.h, nw.ptr(lams_a), lams_a.size, int(num_iters), flags))
+        self._num_iters = int(num_iters)
+
+    def attract(self):
+        self.native.check(self.L.nw_iter_attract(self.h))
+
+    def directions(self):
+        self.native.check(self.L.nw_iter_directions(self.h))
+
+    def update(self):
+        self.native.check(self.L.nw_iter_update(self.h))
+
+    def _view(self, what, count, typestr):
+        import torch
+        p, nb = ctypes.c_void_p(), ctypes.c_int64()
+        self.native.check(self.L.nw_device_ptr(self.h, what, ctypes.byref(p), ctypes.byref(nb)))
+        key = (p.value, count, typestr)
+        if key not in self._views:
+            self._views[key] = torch.as_tensor(_DevArray(p.value, (count,), typestr), device='cuda')
+        return self._views[key]
+
+    def scalars(self, count):
+        # the scalar block of the CURRENT iteration's parity (double-buffered on the device)
+        return self._view(nw.NW_ARR_SCALARS, count, '<f8')
+
+    def vertex_accumulator(self):
+        return self._view(nw.NW_ARR_VACC, 4 * self.cg.M, '<f4')
+
+    def end(self):
+        cg = self.cg
+        out = np.empty((cg.M, 3), np.float32)
+        logs = (nw.IterLog * max(self._num_iters, 1))()
+        lc = ctypes.c_int(0)
+        code = self.L.nw_search_end(self.h, nw.ptr(out), logs, ctypes.byref(lc))
+        self.native.check(code)
+        cg._consume_logs(logs, lc.value)
+        cg._accumulate_stage_ms()
+        cg._finish(out)
+        return out
+
+
+def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
+    """One search() call of `num_iters` iterations over all ranks of `dist` (a torch.distributed-like module with an
+    initialised default group).  Every rank calls this collectively with its own executor."""
+    if mode not in ('tiles', 'replicated'):
+        raise ValueError(mode)
+    ex.begin(data, lams, num_iters, sigma_inv, weights, pos, last_step)
+    n_red = ex.n_scalars if mode == 'tiles' else ex.n_point_scalars
+    for _ in range(int(num_iters)):
+        ex.attract()
+        if mode == 'replicated':
+            dist.all_reduce(ex.vertex_accumulator())
+        ex.directions()
+        dist.all_reduce(ex.scalars(n_red))
+        ex.update()
+    return ex.end()
+
+
+class TiledScene(object):
+    """Convenience front end used by bench.py: single-GPU -> plain cg.search; multi-GPU -> run_search in 'tiles' mode."""
+
+    def __init__(self, cg, dist=None, mode='tiles'):
+        self.cg = cg
+        self.dist = dist
+        self.mode = mode
+        self.ex = HipExecutor(cg) if dist is not None else None
+
+    def search(self, data, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
+        if self.dist is None:
+            return self.cg.search(data, lams=lams, num_iters=num_iters, sigma_inv=sigma_inv, weights=weights, pos=pos, last_step=last_step)
+        if type(lams) is float or np.isscalar(lams):
+            lams = [float(lams)]
+        return run_search(self.ex, self.dist, self.mode, data, lams, num_iters, sigma_inv, weights, pos, last_step)
+
+
+def partition_by_tiles(points, n_ranks):
+    """Spatial tiling of a localization cloud for mode 'replicated': recursive median splits along the longest axis
+    (balanced counts, compact tiles -> each rank's scatter touches a compact set of vertices).
+    Returns a list of index arrays, one per rank."""
+    idx = [np.arange(points.shape[0])]
+    while len(idx) < n_ranks:
+        # split the largest part
+        k = max(range(len(idx)), key=lambda i: idx[i].size)
+        part = idx.pop(k)
+        p = points[part]
+        ax = int(np.argmax(p.max(0) - p.min(0))) if part.size else 0
+        order = np.argsort(p[:, ax], kind='stable')
+        half = part.size // 2
+        idx.append(part[order[:half]])
+        idx.append(part[order[half:]])
+    return idx

@@ -9,7 +9,7 @@ with isotropic Gaussian localization error.  All float32, all seeded.
 """
 import numpy as np
 
-from .trimesh import icosphere, TriMesh
+from .trimesh import icosphere, geodesic_sphere, TriMesh
 
 
 def sphere_cloud(n, radius, sigma, seed, background=0.0, dtype='f4'):
@@ -68,11 +68,11 @@ def project_to_level(sdf, p, level=0.0, iters=8):
     return p
 
 
-def star_mesh(sdf, nsub, level=0.0, rmax=None, relax=10):
+def star_mesh(sdf, freq, level=0.0, rmax=None, relax=10):
     """Closed genus-0 mesh of the level set `sdf == level` for a shape that is star-shaped about the origin:
-    icosphere directions are ray-marched to the level set (bisection), then tangentially relaxed (umbrella
+    geodesic-sphere directions (frequency `freq`, 10 freq^2 + 2 vertices) are ray-marched to the level set (bisection), then tangentially relaxed (umbrella
     smoothing + re-projection) so that triangle sizes even out on elongated shapes."""
-    v, f = icosphere(nsub, 1.0, dtype='f8')
+    v, f = geodesic_sphere(freq, 1.0, dtype='f8')
     if rmax is None:
         rmax = 1.0
         while (sdf(v * rmax) - level).min() < 0:
@@ -119,20 +119,20 @@ def make_config(name, scale=1.0, seed=0):
         v, f = icosphere(4, 120.0)
         pts = sphere_cloud(10000, 100.0, 10.0, seed)
         return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=20, block=20)
-    if name == 'c2':      # capped tube r=50, L=1000 along y: 200k localizations, ~40k vertices, 50 iterations in blocks of 5
+    if name == 'c2':      # capped tube r=50, L=1000 along y: 200k localizations, 39 692 vertices, 50 iterations in blocks of 5
         sdf = lambda p: sdf_capsule(p, (0, -500, 0), (0, 500, 0), 50.0)
-        nsub = 6 if scale >= 1 else 4
+        freq = max(4, int(round(63 * np.sqrt(scale))))
         n = int(200000 * scale)
-        v0, f = star_mesh(sdf, nsub, level=0.0)
+        v0, f = star_mesh(sdf, freq, level=0.0)
         pts = sample_surface(sdf, v0, f, n, 10.0, seed)
-        v, _ = star_mesh(sdf, nsub, level=20.0)
+        v, _ = star_mesh(sdf, freq, level=20.0)
         return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=50, block=5)
-    if name == 'c3':      # two-lobe vesicle: 1M localizations, 163 842 (nsub 7) vertices, blocks of 5
+    if name == 'c3':      # two-lobe vesicle (headline): 1M localizations, 198 812 vertices, remesh_frequency=5 -> blocks of 5
         sdf = sdf_two_lobe
-        nsub = 7 if scale >= 1 else (6 if scale >= 0.2 else 5)
+        freq = max(4, int(round(141 * np.sqrt(scale))))
         n = int(1000000 * scale)
-        v0, f = star_mesh(sdf, nsub, level=0.0, relax=4)
+        v0, f = star_mesh(sdf, freq, level=0.0, relax=4)
         pts = sample_surface(sdf, v0, f, n, 10.0, seed)
-        v, _ = star_mesh(sdf, nsub, level=20.0, relax=4)
+        v, _ = star_mesh(sdf, freq, level=20.0, relax=4)
         return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5)
     raise ValueError(name)

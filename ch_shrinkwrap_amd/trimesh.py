@@ -87,6 +87,44 @@ def icosphere(nsub=4, radius=1.0, dtype='f4'):
     return (v * radius).astype(dtype), f
 
 
+def geodesic_sphere(n, radius=1.0, dtype='f4'):
+    """Class-I geodesic sphere of frequency n: every icosahedron face is split into n^2 triangles, giving
+    10 n^2 + 2 vertices and 20 n^2 faces (n=141 -> 198 812 vertices, the '200k' of BASELINE.json's headline config;
+    n=63 -> 39 692; n=283 -> 800 892).  Vertices are pushed to `radius`."""
+    v0, f0 = icosahedron()
+    n = int(n)
+    # integer barycentric lattice of one face
+    ij = [(i, j) for i in range(n + 1) for j in range(n + 1 - i)]
+    ij = np.array(ij, 'i8')
+    i, j = ij[:, 0], ij[:, 1]
+    k = n - i - j
+    lut = -np.ones((n + 1, n + 1), 'i8')
+    lut[i, j] = np.arange(ij.shape[0])
+    # small triangles of the lattice: "up" (i,j),(i+1,j),(i,j+1) and "down" (i+1,j),(i+1,j+1),(i,j+1)
+    up = ij[(i + j) < n]
+    dn = ij[(i + j) < n - 1]
+    tri = np.concatenate([np.stack([lut[up[:, 0], up[:, 1]], lut[up[:, 0] + 1, up[:, 1]], lut[up[:, 0], up[:, 1] + 1]], 1),
+                          np.stack([lut[dn[:, 0] + 1, dn[:, 1]], lut[dn[:, 0] + 1, dn[:, 1] + 1], lut[dn[:, 0], dn[:, 1] + 1]], 1)], 0)
+    P = []
+    T = []
+    nl = ij.shape[0]
+    for fi, (a, b, c) in enumerate(f0):
+        # weights (k, i, j) on corners (a, b, c): orientation-preserving
+        p = (k[:, None] * v0[a][None, :] + i[:, None] * v0[b][None, :] + j[:, None] * v0[c][None, :]) / float(n)
+        P.append(p)
+        T.append(tri + fi * nl)
+    P = np.concatenate(P, 0)
+    T = np.concatenate(T, 0)
+    # merge the lattice points shared along icosahedron edges / corners
+    key = np.round(P * (4.0 * n)).astype('i8')
+    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    V = P[first]
+    V /= np.linalg.norm(V, axis=1)[:, None]
+    F = inv[T].astype('i4')
+    return (V * radius).astype(dtype), F
+
+
 def _build_halfedges(faces, n_vertices):
     F = faces.shape[0]
     he = np.zeros(3 * F, HALFEDGE_DTYPE)
