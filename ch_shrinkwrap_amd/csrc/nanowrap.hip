@@ -74,6 +74,7 @@ struct nw_ctx {
     DevBuf<int> pcount, pstart, ccount, cstart, scan_tmp, item_count, item_start;
     DevBuf<NwWorkItem> items;
     int nitems = 0;
+    int nn_block = 256;               // threads per NN workgroup (64 = one wave per work item)
 
     // mesh
     DevBuf<float> pos, meshpos, nrm;
@@ -85,7 +86,7 @@ struct nw_ctx {
 
     // per-iteration work arrays
     DevBuf<float4> cent_tmp, cent;
-    DevBuf<int> fcell, face, vidx;
+    DevBuf<int> fcell, face, vidx, ambig_list, ambig_count;
     DevBuf<float> dist, w, res, vacc, S, fdef, pi;
     DevBuf<double> scalars;           // [2][NW_N_SCALARS]
     DevBuf<NwDevState> state;
@@ -178,6 +179,16 @@ int minmax3(nw_ctx *ctx, const float *xyz, int64_t n, float lo[3], float hi[3], 
     return NW_OK;
 }
 
+// desired fine-cell edge from the mean NN distance of the last iteration and the centroid spacing: a fraction of the
+// typical search radius (several thin stages instead of one fat neighbourhood), but at least two centroid spacings so
+// that a cell holds a handful of candidates
+double desired_cell(double mean_dist, double spacing)
+{
+    const char *e = getenv("NW_CELL_FACTOR");
+    const double f = (e && atof(e) > 0) ? atof(e) : 0.6;
+    return std::max(f * mean_dist, 2.0 * spacing);
+}
+
 // ---- grid construction ---------------------------------------------------------------------------------
 // Cell size: ~1.5x the mean point->centroid distance (most points then finish in the first ring), but at
 // least two centroid spacings so that a cell holds a handful of candidates; dims capped at 2^25 cells.
@@ -211,21 +222,27 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     }
     if (!(ext > 0)) ext = 1.0;
     ctx->spacing = spacing;
-    double h = std::max(1.5 * mean_dist, 2.0 * spacing);
+    double h = desired_cell(mean_dist, spacing);
     if (!(h > 0) || !std::isfinite(h)) h = ext / 16;
-    h = std::max(h, ext / 1024.0);                       // at most 1024 cells per axis
+    h = std::max(h, ext / 1024.0);                       // at most ~1024 fine cells per axis
     const char *env_h = getenv("NW_CELL_SIZE");
     if (env_h && atof(env_h) > 0) h = atof(env_h);
+    const char *env_b = getenv("NW_BRICK");
+    const int B = (env_b && atoi(env_b) > 0) ? std::min(atoi(env_b), 8) : 2;
     NwGrid g;
     for (;;) {
         const double margin = 0.5 * h;
         g.ox = (float)(lo[0] - margin); g.oy = (float)(lo[1] - margin); g.oz = (float)(lo[2] - margin);
-        g.gx = std::max(1, (int)std::ceil((hi[0] + margin - g.ox) / h));
-        g.gy = std::max(1, (int)std::ceil((hi[1] + margin - g.oy) / h));
-        g.gz = std::max(1, (int)std::ceil((hi[2] + margin - g.oz) / h));
+        g.bx = std::max(1, (int)std::ceil((hi[0] + margin - g.ox) / (h * B)));
+        g.by = std::max(1, (int)std::ceil((hi[1] + margin - g.oy) / (h * B)));
+        g.bz = std::max(1, (int)std::ceil((hi[2] + margin - g.oz) / (h * B)));
+        g.gx = g.bx * B; g.gy = g.by * B; g.gz = g.bz * B;
         if ((double)g.gx * g.gy * g.gz <= (double)(1 << 25)) break;
         h *= 1.26;
     }
+    g.B = B;
+    { const char *e0 = getenv("NW_STAGE0"); g.s0 = (e0 && atoi(e0) > 0) ? std::min(atoi(e0), 8) : 1; }
+    g.nbrick = g.bx * g.by * g.bz;
     g.h = (float)h;
     g.inv_h = 1.0f / g.h;
     g.ncell = g.gx * g.gy * g.gz;
@@ -234,14 +251,15 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     g.eps = (float)(1e-3 * h + 2e-6 * maxc);
     ctx->grid = g;
 
-    const size_t nc = (size_t)g.ncell;
-    NW_HIP(ctx->pcount.ensure(nc));
-    NW_HIP(ctx->pstart.ensure(nc + 1));
+    { const char *et = getenv("NW_NN_BLOCK"); ctx->nn_block = (et && atoi(et) == 64) ? 64 : 256; }
+    const size_t nc = (size_t)g.ncell, nbk = (size_t)g.nbrick;
+    NW_HIP(ctx->pcount.ensure(nbk));
+    NW_HIP(ctx->pstart.ensure(nbk + 1));
     NW_HIP(ctx->ccount.ensure(nc));
     NW_HIP(ctx->cstart.ensure(nc + 1));
-    NW_HIP(ctx->item_count.ensure(nc));
-    NW_HIP(ctx->item_start.ensure(nc + 1));
-    NW_HIP(hipMemsetAsync(ctx->pcount.p, 0, nc * sizeof(int), ctx->stream));
+    NW_HIP(ctx->item_count.ensure(nbk));
+    NW_HIP(ctx->item_start.ensure(nbk + 1));
+    NW_HIP(hipMemsetAsync(ctx->pcount.p, 0, nbk * sizeof(int), ctx->stream));
     NW_HIP(hipMemsetAsync(ctx->ccount.p, 0, nc * sizeof(int), ctx->stream));
 
     // sort the localizations into cell order, baking the residual weighting
@@ -252,29 +270,26 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     if (ctx->sinv_array) NW_HIP(ctx->sinv.ensure(3 * N));
     if (ctx->w_array) NW_HIP(ctx->wnorm.ensure(3 * N));
     hipLaunchKernelGGL(k_point_cells, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pts_in.p, (int)N, ctx->pt_cell.p, ctx->pcount.p);
-    NW_TRY(scan_exclusive(ctx, ctx->pcount.p, g.ncell, ctx->pstart.p));
-    const float *w_src = ctx->w_array ? (ctx->w_mode == NW_WEIGHTS_ARRAY ? ctx->w_in.p : ctx->sinv_in.p) : nullptr;
+    NW_TRY(scan_exclusive(ctx, ctx->pcount.p, g.nbrick, ctx->pstart.p));
+    const float *w_src = ctx->w_array ? ((ctx->w_mode == NW_WEIGHTS_ARRAY || ctx->w_mode == NW_WEIGHTS_PRENORMALIZED) ? ctx->w_in.p : ctx->sinv_in.p) : nullptr;
     hipLaunchKernelGGL(k_point_scatter, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts_in.p, ctx->pt_cell.p, ctx->pstart.p, ctx->pcount.p,
-                       ctx->sinv_array ? ctx->sinv_in.p : nullptr, w_src, ctx->wsum.p, ctx->w_array ? 1 : 0,
+                       ctx->sinv_array ? ctx->sinv_in.p : nullptr, w_src, ctx->wsum.p, ctx->w_array ? (ctx->w_mode == NW_WEIGHTS_PRENORMALIZED ? 2 : 1) : 0,
                        ctx->pts.p, ctx->perm.p, ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->mask.p);
     // work list
-    hipLaunchKernelGGL(k_count_items, dim3(nblk(g.ncell)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pstart.p, g.ncell, ctx->item_count.p);
-    NW_TRY(scan_exclusive(ctx, ctx->item_count.p, g.ncell, ctx->item_start.p));
+    hipLaunchKernelGGL(k_count_items, dim3(nblk(g.nbrick)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pstart.p, g.nbrick, ctx->nn_block, ctx->item_count.p);
+    NW_TRY(scan_exclusive(ctx, ctx->item_count.p, g.nbrick, ctx->item_start.p));
     int nitems = 0;
-    NW_HIP(hipMemcpyAsync(&nitems, ctx->item_start.p + g.ncell, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipMemcpyAsync(&nitems, ctx->item_start.p + g.nbrick, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     NW_HIP(hipStreamSynchronize(ctx->stream));
     ctx->nitems = nitems;
     NW_HIP(ctx->items.ensure((size_t)nitems));
-    hipLaunchKernelGGL(k_fill_items, dim3(nblk(g.ncell)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pstart.p, ctx->item_start.p, g.ncell, ctx->items.p);
+    hipLaunchKernelGGL(k_fill_items, dim3(nblk(g.nbrick)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pstart.p, ctx->item_start.p, g.nbrick, ctx->nn_block, ctx->items.p);
     NW_HIP(hipGetLastError());
     ctx->grid_valid = true;
     if (getenv("NW_VERBOSE"))
-        fprintf(stderr, "[nanowrap] grid %dx%dx%d h=%.3f (mean_dist %.3f, spacing %.3f) items=%d\n", g.gx, g.gy, g.gz, g.h, mean_dist, spacing, nitems);
+        fprintf(stderr, "[nanowrap] grid %dx%dx%d h=%.3f brick=%d s0=%d tb=%d (mean_dist %.3f, spacing %.3f) items=%d\n", g.gx, g.gy, g.gz, g.h, g.B, g.s0, ctx->nn_block, mean_dist, spacing, nitems);
     return NW_OK;
 }
-
-// desired cell edge from the mean NN distance of the last iteration and the centroid spacing
-double desired_cell(double mean_dist, double spacing) { return std::max(1.5 * mean_dist, 2.0 * spacing); }
 
 int ensure_grid(nw_ctx *ctx)
 {
@@ -318,6 +333,8 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->cent.ensure(F));
     NW_HIP(ctx->fcell.ensure(F));
     NW_HIP(ctx->face.ensure(N));
+    NW_HIP(ctx->ambig_list.ensure(N));
+    NW_HIP(ctx->ambig_count.ensure(4));
     NW_HIP(ctx->dist.ensure(N));
     NW_HIP(ctx->vidx.ensure(3 * N));
     NW_HIP(ctx->w.ensure(3 * N));
@@ -367,7 +384,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->item_count.release(); ctx->item_start.release(); ctx->items.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->d_small.release();
-    ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->face.release(); ctx->vidx.release();
+    ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
@@ -399,8 +416,8 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
 {
     if (!ctx) return NW_ERR_BADARG;
     if (!xyz || n_points <= 0 || n_points > 0x7fffffff / 4) return fail(ctx, NW_ERR_BADARG, "nw_set_points: bad points array/size");
-    if (weights_mode < 0 || weights_mode > 2) return fail(ctx, NW_ERR_BADARG, "nw_set_points: bad weights_mode");
-    if (weights_mode == NW_WEIGHTS_ARRAY && !weights) return fail(ctx, NW_ERR_BADARG, "nw_set_points: weights array missing");
+    if (weights_mode < 0 || weights_mode > 3) return fail(ctx, NW_ERR_BADARG, "nw_set_points: bad weights_mode");
+    if ((weights_mode == NW_WEIGHTS_ARRAY || weights_mode == NW_WEIGHTS_PRENORMALIZED) && !weights) return fail(ctx, NW_ERR_BADARG, "nw_set_points: weights array missing");
     NW_HIP(hipSetDevice(ctx->device));
     const int64_t N = n_points;
     ctx->N = N;
@@ -413,7 +430,7 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
         NW_HIP(hipMemcpyAsync(ctx->sinv_in.p, sigma_inv, 3 * N * sizeof(float), hipMemcpyDefault, ctx->stream));
     }
     ctx->w_mode = weights_mode;
-    if (weights_mode == NW_WEIGHTS_ARRAY) {
+    if (weights_mode == NW_WEIGHTS_ARRAY || weights_mode == NW_WEIGHTS_PRENORMALIZED) {
         NW_HIP(ctx->w_in.ensure(3 * N));
         NW_HIP(hipMemcpyAsync(ctx->w_in.p, weights, 3 * N * sizeof(float), hipMemcpyDefault, ctx->stream));
         ctx->w_array = true;
@@ -427,7 +444,7 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
     NW_HIP(ctx->wsum.ensure(4));
     NW_HIP(hipMemsetAsync(ctx->wsum.p, 0, 4 * sizeof(double), ctx->stream));
     if (ctx->w_array) {
-        const float *src = weights_mode == NW_WEIGHTS_ARRAY ? ctx->w_in.p : ctx->sinv_in.p;
+        const float *src = (weights_mode == NW_WEIGHTS_ARRAY || weights_mode == NW_WEIGHTS_PRENORMALIZED) ? ctx->w_in.p : ctx->sinv_in.p;
         hipLaunchKernelGGL(k_sum_f64, dim3(std::min(1024, nblk(3 * N))), dim3(NW_BLOCK), 0, ctx->stream, src, 3 * N, ctx->wsum.p);
         NW_HIP(hipGetLastError());
     }
@@ -540,7 +557,7 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
     {
         StageScope s(ctx, ST_GRID);
         hipLaunchKernelGGL(k_face_centroids, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pos.p, ctx->faces.p, (int)F,
-                           ctx->cent_tmp.p, ctx->fcell.p, ctx->ccount.p, ctx->state.p, it);
+                           ctx->cent_tmp.p, ctx->fcell.p, ctx->ccount.p, ctx->ambig_count.p, ctx->state.p, it);
         NW_TRY(scan_exclusive(ctx, ctx->ccount.p, g.ncell, ctx->cstart.p));
         hipLaunchKernelGGL(k_centroid_scatter, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, (int)F, ctx->cent_tmp.p, ctx->fcell.p, ctx->cstart.p,
                            ctx->ccount.p, ctx->cent.p, ctx->state.p, it);
@@ -548,7 +565,13 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
     {
         StageScope s(ctx, ST_NN);
         const int nb = 8 * ((ctx->nitems + 7) / 8);
-        hipLaunchKernelGGL(k_nearest_face, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+        if (ctx->nn_block == 64)
+            hipLaunchKernelGGL((k_nearest_face<64, 256>), dim3(nb), dim3(64), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                               ctx->cent_tmp.p, ctx->face.p, ctx->dist.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
+        else
+            hipLaunchKernelGGL((k_nearest_face<256, 1024>), dim3(nb), dim3(256), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                               ctx->cent_tmp.p, ctx->face.p, ctx->dist.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
+        hipLaunchKernelGGL(k_nn_fixup, dim3(64), dim3(64), 0, ctx->stream, g, ctx->ambig_list.p, ctx->ambig_count.p, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->face.p, ctx->dist.p, ctx->state.p, it);
     }
     {

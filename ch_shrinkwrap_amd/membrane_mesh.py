@@ -1,0 +1,272 @@
+"""
+Outer-loop driver for the NanoWrap hot path: the host-side mirror of
+
+    MembraneMesh.__init__                 /root/reference/ch_shrinkwrap/_membrane_mesh.pyx:79-120
+    MembraneMesh.opt_conjugate_gradient   :1427-1560   (block scheduler around ShrinkwrapMeshConjGrad.search)
+    MembraneMesh.shrink_wrap              :1641-1669
+    diagnostics S0..S3, _S0, point_dis, rms_point_sc, point_influence            :1563-1634
+
+built on this package's own half-edge substrate (trimesh.TriMesh) because the reference's base class is PYME's
+TriangleMesh (third party, absent).  What is in scope is the DRIVER: sigma handling, lambda, block sizes, one
+optimiser per block, the post-block normal refresh, the remesh target-length schedule and `truncate_at`.  What is
+out of scope this round is the topology surgery PYME performs at block boundaries --
+`remesh`, `remove_necks`, `punch_holes`, `remove_extra_short_edges`: they are exposed as hooks (`remesher`,
+`neck_remover`, `hole_puncher` callables) and, when no hook is installed, the topology is held fixed and that is
+logged once.  The numerical path of every block is the HIP library; there is no CPU fallback.
+"""
+import math
+import numpy as np
+
+from .trimesh import TriMesh
+from .mesh_conj_grad import ShrinkwrapMeshConjGrad, NativeContext
+
+KBT = 0.0257                                             # _membrane_mesh.pyx:22
+DESCENT_METHODS = ['conjugate_gradient', 'skeleton']     # :19
+DEFAULT_DESCENT_METHOD = 'conjugate_gradient'            # :20
+
+
+class MembraneMesh(TriMesh):
+    def __init__(self, vertices=None, faces=None, mesh=None, device=0, **kwargs):
+        if mesh is not None:
+            vertices, faces = np.asarray(mesh.vertices), np.asarray(mesh.faces)
+        TriMesh.__init__(self, vertices, faces)
+        # defaults: _membrane_mesh.pyx:82-117
+        self.kc = 20.0 * KBT
+        self.kg = -20.0 * KBT
+        self.a = 1.0
+        self.c = 1.0
+        self.c0 = 0.0
+        self.step_size = 1
+        self.beta_1 = 0.8
+        self.beta_2 = 0.7
+        self.eps = 1e-8
+        self.max_iter = 250
+        self.remesh_frequency = 100
+        self.delaunay_remesh_frequency = 150
+        self.delaunay_eps = 0.0
+        self.search_k = 200
+        self.search_rad = 100
+        self.skip_prob = 0.0
+        self.shrink_weight = 0.0
+        self.smooth_curvature = False
+        self.vertex_properties.extend(['E', 'curvature_principal0', 'curvature_principal1', 'point_dis', 'rms_point_sc', 'point_influence'])
+        self.vertex_vector_properties.extend(['S0', 'S1', 'S2', 'S3'])
+        self._points = None
+        self._sigma = None
+        self.cg = None
+        # block-boundary topology hooks (PYME's job in the reference; see module docstring)
+        self.remesher = None          # callable(mesh, n, target_edge_length, l, n_relax)
+        self.neck_remover = None      # callable(mesh, threshold_low, threshold_high)
+        self.hole_puncher = None      # callable(mesh, points, eps)
+        self.edge_cleaner = None      # callable(mesh)  (remove_extra_short_edges)
+        self._device = device
+        self._native = None
+        self._warned_fixed_topology = False
+        self.block_log = []
+        for key, value in kwargs.items():                # :119-120
+            setattr(self, key, value)
+
+    # -- topology hooks ---------------------------------------------------------------------------------------
+    def _topology_changed(self, vertices, faces):
+        TriMesh.__init__(self, vertices, faces)
+
+    def remesh(self, n=5, target_edge_length=-1, l=0.5, n_relax=10):
+        if self.remesher is None:
+            if not self._warned_fixed_topology:
+                print('MembraneMesh: no remesher installed (PYME TriangleMesh.remesh is out of scope this round) -- topology held fixed')
+                self._warned_fixed_topology = True
+            return False
+        self.remesher(self, n, target_edge_length, l, n_relax)
+        return True
+
+    # -- the driver -------------------------------------------------------------------------------------------
+    def opt_conjugate_gradient(self, points, sigma, max_iter=10, step_size=1.0, weights=None, **kwargs):
+        """_membrane_mesh.pyx:1427-1560."""
+        r = (self.remesh_frequency != 0) and (self.remesh_frequency <= max_iter)
+        dr = (self.delaunay_remesh_frequency != 0) and (self.delaunay_remesh_frequency <= max_iter)
+        if r and dr:
+            rf = math.gcd(self.remesh_frequency, self.delaunay_remesh_frequency)
+        elif r:
+            rf = self.remesh_frequency
+        elif dr:
+            rf = self.delaunay_remesh_frequency
+        else:
+            rf = max_iter
+
+        if r:
+            initial_length = self._mean_edge_length
+            if kwargs.get('minimum_edge_length', -1) < 0:
+                final_length = np.clip(np.min(sigma) / 2.5, 1.0, 50.0)
+            else:
+                final_length = kwargs.get('minimum_edge_length')
+            m = (final_length - initial_length) / (rf * np.ceil(max_iter / rf))          # :1455 (linear in edge length)
+
+        neck_first_iter = getattr(self, 'neck_first_iter', -1)
+
+        # sigma -> s (:1460-1473).  NB the scalar branch passes sigma through UN-inverted, as the reference does.
+        if np.isscalar(sigma):
+            s = float(sigma)
+        elif (len(sigma.shape) == 1) and (sigma.shape[0] == points.shape[0]):
+            s = 1.0 / np.repeat(sigma, points.shape[1])
+        elif (len(sigma.shape) == 2) and (sigma.shape[0] == points.shape[0]) and (sigma.shape[1] == points.shape[1]):
+            s = (1.0 / sigma.ravel())
+        else:
+            raise ValueError('Sigma must be of shape (%d,) or (%d,%d).' % (points.shape[0], points.shape[0], points.shape[1]))
+
+        last_area = self.area()
+        self.cg = None
+        j = 0
+        if self.shrink_weight > 0:                                                       # :1483-1486
+            lams = [step_size * self.kc / 2.0, self.shrink_weight]
+        else:
+            lams = [step_size * self.kc / 2.0, ]
+
+        n_iter = min(max_iter, getattr(self, 'truncate_at', max_iter))                   # :1490
+        if self._native is None:
+            self._native = NativeContext(self._device)      # localizations stay in HBM across blocks
+
+        while j < n_iter:
+            # a new optimiser per block (:1510-1512); it re-uploads the mesh, the localizations are already resident
+            self.cg = ShrinkwrapMeshConjGrad(self, points, search_k=self.search_k, search_rad=self.search_rad,
+                                             shield_sigma=self._mean_edge_length / 2.0, native=self._native)
+            n_it = min(n_iter - j, rf)
+            self.cg.search(points, lams=lams, num_iters=n_it, sigma_inv=s, weights=weights)   # :1516-1517
+            j += n_it
+
+            # :1524-1527 -- face normals / vertex normals / neighbours refreshed from the new positions
+            self.update_geometry()
+
+            if dr and ((j % self.delaunay_remesh_frequency) == 0) and self.hole_puncher is not None:   # :1530-1532
+                self.hole_puncher(self, points, self.delaunay_eps)
+
+            if r and ((j % self.remesh_frequency) == 0):                                 # :1537-1549
+                if (neck_first_iter > 0) and (j > neck_first_iter) and self.neck_remover is not None:
+                    self.neck_remover(self, getattr(self, 'neck_threshold_low', -1e-4), getattr(self, 'neck_threshold_high', 1e-2))
+                if self.edge_cleaner is not None:
+                    self.edge_cleaner(self)
+                target_length = (initial_length + m * (j + 1))                           # :1544
+                if self.remesh(5, target_length, 0.5, n_relax=0):
+                    self.cg = None
+                self.block_log.append(dict(iteration=j, target_length=float(target_length), mean_length=float(self._mean_edge_length)))
+
+            area = self.area()                                                           # :1552-1558 (convergence break disabled upstream)
+            last_area = area
+        return j
+
+    def shrink_wrap(self, points=None, sigma=None, method='conjugate_gradient', max_iter=None, **kwargs):
+        """_membrane_mesh.pyx:1641-1669."""
+        if method not in DESCENT_METHODS:
+            print('Unknown gradient descent method. Using {}.'.format(DEFAULT_DESCENT_METHOD))
+            method = DEFAULT_DESCENT_METHOD
+        if method != 'conjugate_gradient':
+            raise NotImplementedError("only method='conjugate_gradient' is on the NanoWrap hot path")
+        if max_iter is None:
+            max_iter = self.max_iter
+        if points is None:
+            points = self._points
+        if sigma is None:
+            sigma = self._sigma
+        self._points = points
+        self._sigma = sigma
+        opts = dict(points=points, sigma=sigma, max_iter=max_iter, step_size=self.step_size, beta_1=self.beta_1, beta_2=self.beta_2,
+                    eps=self.eps, **kwargs)
+        return self.opt_conjugate_gradient(**opts)
+
+    # -- diagnostics that re-enter the optimiser (:1563-1634) -------------------------------------------------
+    @property
+    def _S0(self):
+        return self.cg.Ahfunc(self.cg.res).reshape(self.vertices.shape)
+
+    @property
+    def S0(self):
+        return self.cg.S[:, 0].reshape(self.vertices.shape)
+
+    @property
+    def S1(self):
+        return self.cg.S[:, 1].reshape(self.vertices.shape)
+
+    @property
+    def S2(self):
+        return self.cg.S[:, 2].reshape(self.vertices.shape)
+
+    @property
+    def S3(self):
+        return self.cg.S[:, 3].reshape(self.vertices.shape)      # IndexError with 3 columns, exactly as upstream
+
+    @property
+    def point_dis(self):
+        s0 = self._S0
+        return np.sqrt((s0 * s0).sum(1))
+
+    @property
+    def rms_point_sc(self):
+        rn = (np.sqrt((self.cg.res * self.cg.res).reshape(self.cg.points.shape).sum(1))[:, None] * np.ones(3)[None, :]).ravel()
+        rme = self.cg.Ahfunc(rn).reshape(self.vertices.shape)
+        return np.sqrt((rme * rme).sum(1))
+
+    @property
+    def point_influence(self):
+        s = self.cg.Ahfunc(np.ones_like(self.cg.res)).reshape(self.vertices.shape)
+        return np.sqrt((s * s).sum(1))
+
+
+class ShrinkwrapMembrane(object):
+    """Parameter surface of the PYME recipe module `ShrinkwrapMembrane`
+    (/root/reference/ch_shrinkwrap/recipe_modules/surface_fitting.py:11-115) without the PYME/traits machinery: same trait
+    names and defaults, `execute(namespace)` with the same namespace protocol (input mesh under `input`, a table-like
+    with 'x','y','z' and the sigma columns under `points`, result stored under `output`).  INTEGRATION.md shows the
+    two-line change that makes the real PYME module use this package."""
+
+    def __init__(self, **kw):
+        self.input, self.output, self.points = 'surf', 'membrane', 'filtered_localizations'
+        self.max_iters = 39
+        self.curvature_weight = 20.0
+        self.finishing_iters = 0
+        self.finishing_curvature_weight = 20.0
+        self.shrink_weight = 0.0
+        self.kc = 1.0
+        self.remesh_frequency = 5
+        self.punch_frequency = 0
+        self.min_hole_radius = 100.0
+        self.sigma_x, self.sigma_y, self.sigma_z = 'error_x', 'error_y', 'error_z'
+        self.neck_threshold_low = -1e-3
+        self.neck_threshold_high = 1e-2
+        self.neck_first_iter = 9
+        self.truncate_at = 1000
+        self.minimum_edge_length = 5.0
+        self.smooth_curvature = True
+        self.device = 0
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError('unknown parameter %s' % k)
+            setattr(self, k, v)
+
+    def execute(self, namespace):
+        import time
+        inp = namespace[self.input]
+        n_faces = len(inp.faces)
+        if not n_faces > 4:                                                                # surface_fitting.py:51-53
+            raise RuntimeError('Input mesh only has %d faces, a valid surface needs at least 4 faces' % n_faces)
+        mesh = MembraneMesh(mesh=inp, device=self.device, kc=self.kc, max_iter=self.max_iters, step_size=self.curvature_weight,
+                            remesh_frequency=self.remesh_frequency, delaunay_remesh_frequency=self.punch_frequency,
+                            delaunay_eps=self.min_hole_radius, neck_threshold_low=self.neck_threshold_low,
+                            neck_threshold_high=self.neck_threshold_high, neck_first_iter=self.neck_first_iter,
+                            shrink_weight=self.shrink_weight, truncate_at=self.truncate_at)
+        namespace[self.output] = mesh
+        src = namespace[self.points]
+        pts = np.ascontiguousarray(np.vstack([src['x'], src['y'], src['z']]).T)
+        try:
+            sigma = np.vstack([src[self.sigma_x], src[self.sigma_y], src[self.sigma_z]]).T
+        except Exception:
+            try:
+                sigma = src[self.sigma_x]
+            except KeyError:
+                print('%s not found in data source, defaulting to 10 nm precision.' % self.sigma_x)
+                sigma = 10 * np.ones_like(src['x'])
+        start = time.time()
+        mesh.shrink_wrap(pts, sigma, method='conjugate_gradient', minimum_edge_length=self.minimum_edge_length)
+        if self.finishing_iters > 0:
+            mesh.step_size = self.finishing_curvature_weight
+            mesh.shrink_wrap(pts, sigma, method='conjugate_gradient', minimum_edge_length=self.minimum_edge_length, max_iter=self.finishing_iters)
+        mesh.runtime = time.time() - start          # the reference stores this under md['Processing.ShrinkwrapMembrane.Runtime']
+        return mesh

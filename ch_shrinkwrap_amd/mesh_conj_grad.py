@@ -83,6 +83,7 @@ class ShrinkwrapMeshConjGrad(object):
         self.iter_logs = []
 
         self._mesh_vertex_mask = mesh._vertices['halfedge'] != -1                      # :44
+        self._all_valid = bool(self._mesh_vertex_mask.all())
         self._vertices = mesh._vertices['position']                                    # :46 (view)
         self.M = self._vertices.shape[0]
         self.dims = self._vertices.shape[1]
@@ -128,11 +129,13 @@ class ShrinkwrapMeshConjGrad(object):
     def vertices(self):
         return self._vertices
 
-    def _upload_points(self, sigma_inv, weights):
-        """search() weight handling, mesh_conj_grad.py:156-164, done on the device at upload."""
+    def _upload_points(self, sigma_inv, weights, prenormalized=None):
+        """search() weight handling, mesh_conj_grad.py:156-164, done on the device at upload.
+        `prenormalized`: (3N,) weights already divided by the mean over ALL ranks (parallel.run_search)."""
         N3 = self._points_f32.size
         key = (id(self._points), id(sigma_inv) if not np.isscalar(sigma_inv) else float(sigma_inv),
-               None if weights is None else (id(weights) if not np.isscalar(weights) else float(weights)))
+               None if weights is None else (id(weights) if not np.isscalar(weights) else float(weights)),
+               None if prenormalized is None else 'pre')
         if self._native.points_key == key:
             return
         s_arr, s_sc = None, 1.0
@@ -151,12 +154,15 @@ class ShrinkwrapMeshConjGrad(object):
                 w_arr = _as_f32(np.asarray(weights).ravel())
                 if w_arr.size != N3:
                     raise ValueError('weights must be a scalar or have 3N entries')
+        if prenormalized is not None:
+            mode = nw.NW_WEIGHTS_PRENORMALIZED
+            w_arr = _as_f32(np.asarray(prenormalized).ravel())
         self._native.check(self._L.nw_set_points(self._h, nw.ptr(self._points_f32), self._points_f32.shape[0], nw.ptr(s_arr), s_sc,
                                                  mode, nw.ptr(w_arr), w_sc))
         self._native.points_key = key
         self._native._keep = [self._points, sigma_inv, weights]      # keep ids alive while they key the cache
         # host view of the mask for API parity (`cg.mask`)
-        if mode == nw.NW_WEIGHTS_ARRAY:
+        if mode in (nw.NW_WEIGHTS_ARRAY, nw.NW_WEIGHTS_PRENORMALIZED):
             self.mask = w_arr > 0
         elif mode == nw.NW_WEIGHTS_FROM_SIGMA_INV and s_arr is not None:
             self.mask = s_arr > 0
@@ -207,7 +213,10 @@ class ShrinkwrapMeshConjGrad(object):
         self.f = self.fs.ravel()
         # write-back (mesh_conj_grad.py:289-290)
         m = self._mesh_vertex_mask
-        self.mesh._vertices['position'][m] = out[m]
+        if self._all_valid:
+            self.mesh._vertices['position'][:] = out
+        else:
+            np.copyto(self.mesh._vertices['position'], out, where=m[:, None])
         self.mesh._initialize_curvature_vectors()
 
     # -- state the mesh reads back (_membrane_mesh.pyx:1563-1634) ----------------------------------

@@ -44,9 +44,13 @@ class HipExecutor(object):
         self.n_scalars = 24
         self._views = {}
 
-    def begin(self, data, lams, num_iters, sigma_inv, weights, pos, last_step):
+    def new_tensor(self, values):
+        import torch
+        return torch.tensor(values, dtype=torch.float64, device='cuda')
+
+    def begin(self, data, lams, num_iters, sigma_inv, weights, prenormalized, pos, last_step):
         cg = self.cg
-        cg._upload_points(sigma_inv, weights)
+        cg._upload_points(sigma_inv, weights, prenormalized)
         lams_a = np.ascontiguousarray(lams, dtype=np.float32)
         flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP)
         cg._cache = {}
@@ -96,7 +100,15 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
     initialised default group).  Every rank calls this collectively with its own executor."""
     if mode not in ('tiles', 'replicated'):
         raise ValueError(mode)
-    ex.begin(data, lams, num_iters, sigma_inv, weights, pos, last_step)
+    # weights = weights / weights.mean() (mesh_conj_grad.py:160-162): the mean runs over the WHOLE scene, i.e. all ranks
+    w_eff = weights if weights is not None else sigma_inv
+    prenorm = None
+    if not np.isscalar(w_eff):
+        w_eff = np.asarray(w_eff, dtype=np.float32).ravel()
+        t = ex.new_tensor([float(w_eff.astype(np.float64).sum()), float(w_eff.size)])
+        dist.all_reduce(t)
+        prenorm = (w_eff / np.float32(float(t[0]) / float(t[1]))).astype(np.float32)
+    ex.begin(data, lams, num_iters, sigma_inv, weights, prenorm, pos, last_step)
     n_red = ex.n_scalars if mode == 'tiles' else ex.n_point_scalars
     for _ in range(int(num_iters)):
         ex.attract()
@@ -126,18 +138,16 @@ class TiledScene(object):
 
 
 def partition_by_tiles(points, n_ranks):
-    """Spatial tiling of a localization cloud for mode 'replicated': recursive median splits along the longest axis
-    (balanced counts, compact tiles -> each rank's scatter touches a compact set of vertices).
-    Returns a list of index arrays, one per rank."""
-    idx = [np.arange(points.shape[0])]
-    while len(idx) < n_ranks:
-        # split the largest part
-        k = max(range(len(idx)), key=lambda i: idx[i].size)
-        part = idx.pop(k)
+    """Spatial tiling of a localization cloud for mode 'replicated': recursive splits along the longest axis, each split
+    dividing the counts in proportion to the ranks on either side (balanced counts for any n_ranks, compact tiles ->
+    each rank's scatter touches a compact set of vertices).  Returns a list of index arrays, one per rank."""
+    def split(part, k):
+        if k == 1:
+            return [part]
         p = points[part]
         ax = int(np.argmax(p.max(0) - p.min(0))) if part.size else 0
         order = np.argsort(p[:, ax], kind='stable')
-        half = part.size // 2
-        idx.append(part[order[:half]])
-        idx.append(part[order[half:]])
-    return idx
+        kl = k // 2
+        cut = (part.size * kl) // k
+        return split(part[order[:cut]], kl) + split(part[order[cut:]], k - kl)
+    return split(np.arange(points.shape[0]), int(n_ranks))

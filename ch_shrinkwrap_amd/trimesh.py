@@ -224,8 +224,9 @@ class TriMesh(object):
         self._faces['normal'] = fn
         self._faces['area'] = 0.5 * nrm
         vn = np.zeros((pos.shape[0], 3), 'f8')
-        for k in range(3):
-            np.add.at(vn, f[:, k], cr)
+        fi = f.T.ravel()                                     # corner-major: all corner-0 ids, then corner-1, corner-2
+        for c in range(3):
+            vn[:, c] = np.bincount(fi, weights=np.tile(cr[:, c].astype('f8'), 3), minlength=pos.shape[0])
         l = np.sqrt((vn * vn).sum(1))
         with np.errstate(invalid='ignore', divide='ignore'):
             vn = vn / l[:, None]

@@ -41,7 +41,8 @@ typedef enum nw_status {
 typedef enum nw_weights_mode {
     NW_WEIGHTS_FROM_SIGMA_INV = 0,   /* weights=None  -> weights = sigma_inv (array or scalar)            */
     NW_WEIGHTS_SCALAR = 1,           /* scalar weights: mask = isfinite(data), no normalisation          */
-    NW_WEIGHTS_ARRAY = 2             /* (3N,) weights: mask = weights > 0, weights /= weights.mean()      */
+    NW_WEIGHTS_ARRAY = 2,            /* (3N,) weights: mask = weights > 0, weights /= weights.mean()      */
+    NW_WEIGHTS_PRENORMALIZED = 3     /* (3N,) weights already divided by the GLOBAL mean (multi-GPU: the mean runs over all ranks) */
 } nw_weights_mode;
 
 /* nw_search flags -- keyword arguments of search(), mesh_conj_grad.py:150 */
@@ -96,7 +97,7 @@ int nw_synchronize(nw_ctx *ctx);
 /* ---- inputs -------------------------------------------------------------------------------------------- */
 /* localizations + residual weighting; replaces the `points` setter (mesh_conj_grad.py:127-130, without the
  * unused point kd-tree) and the weight handling at :156-164.  sigma_inv: (3N,) or NULL (then sigma_inv_scalar);
- * weights: (3N,) for NW_WEIGHTS_ARRAY else NULL. */
+ * weights: (3N,) for NW_WEIGHTS_ARRAY / NW_WEIGHTS_PRENORMALIZED else NULL. */
 int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points,
                   const float *sigma_inv, float sigma_inv_scalar,
                   int weights_mode, const float *weights, float weights_scalar);

@@ -1,0 +1,121 @@
+"""
+Host logic of the outer-loop driver (ch_shrinkwrap_amd.membrane_mesh.MembraneMesh.opt_conjugate_gradient), which mirrors
+/root/reference/ch_shrinkwrap/_membrane_mesh.pyx:1427-1560.  CPU tests replace the optimiser class with a recorder;
+the GPU test runs two real blocks against the oracle driven with the same block structure.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+from ch_shrinkwrap_amd import membrane_mesh as mm
+from ch_shrinkwrap_amd.trimesh import icosphere, geodesic_sphere, TriMesh
+
+
+class _Recorder(object):
+    calls = []
+
+    def __init__(self, mesh, points, **kw):
+        self.mesh, self.kw = mesh, kw
+
+    def search(self, points, lams=None, num_iters=None, sigma_inv=None, weights=None):
+        _Recorder.calls.append(dict(lams=list(lams), num_iters=num_iters, sigma_inv=sigma_inv, weights=weights, kw=self.kw))
+        return self.mesh.vertices
+
+
+@pytest.fixture
+def recorder(monkeypatch):
+    _Recorder.calls = []
+    monkeypatch.setattr(mm, 'ShrinkwrapMeshConjGrad', _Recorder)
+    monkeypatch.setattr(mm, 'NativeContext', lambda device=0: object())
+    return _Recorder
+
+
+def _mesh(**kw):
+    v, f = icosphere(2, 50.0)
+    return mm.MembraneMesh(v, f, **kw)
+
+
+def test_block_schedule_and_lambda(recorder):
+    m = _mesh(kc=1.0, step_size=20.0, max_iter=39, remesh_frequency=5, delaunay_remesh_frequency=0, truncate_at=1000)
+    pts = np.zeros((7, 3), 'f4')
+    sigma = np.full((7, 3), 10.0, 'f4')
+    n = m.shrink_wrap(pts, sigma, method='conjugate_gradient', minimum_edge_length=5.0)
+    assert n == 39
+    its = [c['num_iters'] for c in recorder.calls]
+    assert its == [5] * 7 + [4]                                     # blocks of remesh_frequency, last one truncated
+    assert all(c['lams'] == [10.0] for c in recorder.calls)         # step_size*kc/2  (_membrane_mesh.pyx:1486)
+    assert np.allclose(recorder.calls[0]['sigma_inv'], 0.1) and recorder.calls[0]['sigma_inv'].shape == (21,)
+    assert recorder.calls[0]['kw']['shield_sigma'] == pytest.approx(m._mean_edge_length / 2.0)
+    # remesh target-length schedule (:1443-1455, :1544): linear from the initial mean edge length to minimum_edge_length
+    assert len(m.block_log) == 7
+    L0 = m._mean_edge_length
+    slope = (5.0 - L0) / (5 * np.ceil(39 / 5))
+    assert m.block_log[0]['target_length'] == pytest.approx(L0 + slope * 6)
+
+
+def test_sigma_forms_truncate_and_shrink_weight(recorder):
+    pts = np.zeros((4, 3), 'f4')
+    m = _mesh(kc=2.0, step_size=3.0, max_iter=10, remesh_frequency=0, delaunay_remesh_frequency=0, shrink_weight=0.5, truncate_at=6)
+    m.shrink_wrap(pts, 12.5)                                        # scalar sigma is passed through UN-inverted (:1460-1461)
+    assert recorder.calls[-1]['sigma_inv'] == 12.5 and recorder.calls[-1]['num_iters'] == 6
+    assert recorder.calls[-1]['lams'] == [3.0, 0.5]
+    m.shrink_wrap(pts, np.array([1.0, 2.0, 4.0, 8.0]))              # (N,) -> 1/repeat(sigma, 3)  (:1462-1466)
+    assert np.allclose(recorder.calls[-1]['sigma_inv'], np.repeat([1.0, 0.5, 0.25, 0.125], 3))
+    with pytest.raises(ValueError):
+        m.shrink_wrap(pts, np.ones((3, 3)))
+    # gcd of remesh and punch frequencies (:1433-1435)
+    recorder.calls.clear()
+    m2 = _mesh(max_iter=12, remesh_frequency=6, delaunay_remesh_frequency=4)
+    m2.shrink_wrap(pts, 10.0)
+    assert [c['num_iters'] for c in recorder.calls] == [2] * 6
+    # continuing a fit re-uses the cached points/sigma (:1650-1667)
+    recorder.calls.clear()
+    m2.shrink_wrap(max_iter=2)
+    assert len(recorder.calls) == 1 and recorder.calls[0]['sigma_inv'] == 10.0
+
+
+def test_recipe_module_parameter_surface():
+    r = mm.ShrinkwrapMembrane()
+    # defaults of recipe_modules/surface_fitting.py:17-42
+    assert (r.max_iters, r.curvature_weight, r.remesh_frequency, r.punch_frequency, r.kc) == (39, 20.0, 5, 0, 1.0)
+    assert (r.neck_threshold_low, r.neck_threshold_high, r.neck_first_iter, r.truncate_at, r.minimum_edge_length) == (-1e-3, 1e-2, 9, 1000, 5.0)
+    with pytest.raises(AttributeError):
+        mm.ShrinkwrapMembrane(not_a_trait=1)
+
+    class Few(object):
+        faces = np.zeros((4, 3), 'i4')
+        vertices = np.zeros((4, 3), 'f4')
+    with pytest.raises(RuntimeError):
+        r.execute({'surf': Few(), 'filtered_localizations': {}})
+
+
+def test_geometry_refresh_matches_definition():
+    v, f = geodesic_sphere(6, 30.0)
+    m = TriMesh(v, f)
+    n = m.vertex_normals
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-5)
+    assert np.allclose(n, v / 30.0, atol=2e-2)                       # sphere: normals are radial
+    assert m.area() == pytest.approx(4 * np.pi * 900.0, rel=2e-2)
+
+
+@pytest.mark.gpu
+def test_two_blocks_against_oracle():
+    from oracle import nanowrap_oracle as O
+    from ch_shrinkwrap_amd import synth
+    v, f = icosphere(4, 120.0)
+    pts = synth.sphere_cloud(20000, 100.0, 10.0, seed=5)
+    sigma = np.full(pts.shape, 10.0, 'f4')
+    m = mm.MembraneMesh(v, f, kc=1.0, step_size=20.0, max_iter=8, remesh_frequency=4, delaunay_remesh_frequency=0)
+    m.shrink_wrap(pts, sigma, minimum_edge_length=5.0)
+    # oracle: same two blocks, normals refreshed between them with the same substrate
+    ref = TriMesh(v, f)
+    s = 1.0 / sigma.ravel()
+    for _ in range(2):
+        r = O.search(ref.vertices.copy(), ref.vertex_normals.copy(), ref.neighbor_vertex_table(), ref.faces, pts, [10.0], 4, s)
+        ref._vertices['position'][:] = r.positions
+        ref.update_geometry()
+    assert rel_rms(m.vertices, ref.vertices) <= 1e-5
+    assert np.allclose(m.vertex_normals, ref.vertex_normals, atol=1e-4)
+    assert m.S0.shape == m.vertices.shape and np.isfinite(m.point_dis).all() and np.isfinite(m.rms_point_sc).all()
+    pi = m.point_influence
+    assert np.allclose(pi, m.cg.point_influence, rtol=1e-4, atol=1e-6)

@@ -1,0 +1,254 @@
+"""
+Multi-rank protocol of ch_shrinkwrap_amd.parallel.run_search.
+
+CPU (world_size 2, gloo): the orchestration code that the GPU path uses is driven with an executor built from the ORACLE's
+stage functions (test infrastructure), and the sharded result is compared with the single-process oracle run:
+  * mode 'replicated': localizations split by spatial tiles, mesh replicated -> all-reduce of the vertex accumulator + 13 scalars
+  * mode 'tiles'     : two disjoint vesicles, one per rank -> all-reduce of all 24 scalars; must equal the single-process run
+                       on the union scene (ONE global subspace solve, conj_grad.py:202-219).
+GPU (world_size 1, nccl = RCCL): the split-phase C-ABI path must reproduce nw_search.
+"""
+import os
+import socket
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import rel_rms
+from ch_shrinkwrap_amd import parallel
+from ch_shrinkwrap_amd.trimesh import TriMesh, icosphere
+from ch_shrinkwrap_amd.synth import sphere_cloud
+
+N_SC = 24
+
+
+class OracleExecutor(object):
+    """CPU stand-in for HipExecutor: same phases, same reduction buffers, arithmetic from oracle/nanowrap_oracle.py."""
+
+    n_point_scalars = 13
+    n_scalars = N_SC
+
+    def __init__(self, pos, nrm, nbr, faces, points):
+        self.pos0, self.nrm, self.nbr, self.faces, self.points = pos, nrm, nbr, faces, points
+        self.M = pos.shape[0]
+
+    def new_tensor(self, values):
+        return torch.tensor(values, dtype=torch.float64)
+
+    def begin(self, data, lams, num_iters, sigma_inv, weights, prenormalized, pos, last_step):
+        self.lam = float(lams[0])
+        self.f = self.pos0.copy().ravel()
+        self.S = np.zeros((3 * self.M, 3), 'f4')
+        self.it = 0
+        self.sigma_inv = sigma_inv
+        self.wn = prenormalized if prenormalized is not None else (weights if weights is not None else sigma_inv)
+        self.sc = torch.zeros(N_SC, dtype=torch.float64)
+        self.vacc = torch.zeros(4 * self.M, dtype=torch.float32)
+
+    def attract(self):
+        from oracle import nanowrap_oracle as O
+        p = self.points
+        self.sc.zero_()
+        self.vacc.zero_()
+        if p.shape[0] == 0:
+            self.wm = None
+            return
+        v_idx, w, dmean, _ = O.weight_matrix(self.f.reshape(-1, 3), self.faces, p)
+        Af = O.apply_A(self.f, v_idx, w, p)
+        res = (self.wn * (p.ravel() - Af)).astype('f4')
+        d3 = np.repeat(dmean, 3)
+        res = (res * (1.0 / (d3 * self.sigma_inv / 2.0 + 1))).astype('f4')
+        self.wm, self.res = (v_idx, w), res
+        va = np.zeros((self.M, 4), 'f4')
+        va[:, :3] = O.apply_At(res, v_idx, w, self.M).reshape(-1, 3)
+        va[:, 3] = O.apply_At(np.ones_like(res), v_idx, w, self.M).reshape(-1, 3)[:, 0]
+        self.vacc += torch.from_numpy(va.ravel())
+        r2 = float((res.astype('f8') ** 2).sum())
+        self.sc[0], self.sc[1], self.sc[2], self.sc[3] = r2, r2, float(dmean.sum()), float(p.shape[0])
+
+    def vertex_accumulator(self):
+        return self.vacc
+
+    def directions(self):
+        from oracle import nanowrap_oracle as O
+        va = self.vacc.numpy().reshape(self.M, 4)
+        sw = va[:, 3]
+        pi = np.sqrt((sw * sw + sw * sw) + sw * sw)
+        fdef = O.ncc_prior(self.f.reshape(-1, 3).astype('f4'), self.nrm, self.nbr, pi).ravel()
+        p64 = self.f.astype('f8') - fdef
+        self.S[:, 0] = va[:, :3].ravel()
+        self.S[:, 1] = -1.0 * p64.astype('f4')
+        ns = 2 if self.it == 0 else 3
+        self.ns = ns
+        S = self.S.astype('f8')
+        idx = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+        for k, (a, b) in enumerate(idx):
+            self.sc[13 + k] = float((S[:, a] * S[:, b]).sum()) if max(a, b) < ns else 0.0
+        for k in range(3):
+            self.sc[19 + k] = float((S[:, k] * p64).sum()) if k < ns else 0.0
+        self.sc[22] = float((p64 * p64).sum())
+        self.sc[23] = float((p64.astype('f4').astype('f8') ** 2).sum())
+        if self.wm is not None:
+            v_idx, w = self.wm
+            AS = np.stack([O.apply_A(self.S[:, k].copy(), v_idx, w, self.points).astype('f8') if k < ns else np.zeros(self.points.size)
+                           for k in range(3)], 1)
+            for k, (a, b) in enumerate(idx):
+                self.sc[4 + k] = float((AS[:, a] * AS[:, b]).sum())
+            for k in range(3):
+                self.sc[10 + k] = float((AS[:, k] * self.res.astype('f8')).sum())
+
+    def scalars(self, count):
+        return self.sc[:count]
+
+    def update(self):
+        sc = self.sc.numpy()
+        ns = self.ns
+        l2 = self.lam * self.lam
+        tri = {(0, 0): 0, (0, 1): 1, (0, 2): 2, (1, 1): 3, (1, 2): 4, (2, 2): 5}
+        H = np.zeros((ns, ns), 'f4')
+        G = np.zeros(ns, 'f4')
+        for a in range(ns):
+            G[a] = np.float32(np.float64(np.float32(sc[10 + a])) + l2 * (-sc[19 + a]))
+            for b in range(ns):
+                k = tri[(min(a, b), max(a, b))]
+                H[a, b] = np.float32(np.float64(np.float32(sc[4 + k])) + l2 * np.float64(np.float32(sc[13 + k])))
+        c = np.linalg.solve(H, G)
+        fnew = (self.f + np.dot(self.S[:, :ns], c)).astype('f4')
+        self.S[:, 2] = fnew - self.f
+        self.f = fnew
+        self.it += 1
+
+    def end(self):
+        return self.f.reshape(-1, 3).copy()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(two_vesicles):
+    v, f = icosphere(3, 60.0)
+    pts = sphere_cloud(6000, 50.0, 5.0, seed=21)
+    rng = np.random.default_rng(3)
+    sigma = rng.uniform(3.0, 8.0, size=pts.shape).astype('f4')
+    if two_vesicles:
+        off = np.array([200.0, 0, 0], 'f4')
+        v2 = (v * 1.1 + off).astype('f4')
+        pts2 = (sphere_cloud(4000, 52.0, 5.0, seed=22) + off).astype('f4')
+        sig2 = rng.uniform(4.0, 12.0, size=pts2.shape).astype('f4')
+        return [(v, f, pts, sigma), (v2, f, pts2, sig2)]
+    return [(v, f, pts, sigma)]
+
+
+def _worker(rank, world, port, mode, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        if mode == 'replicated':
+            (v, f, pts, sigma), = _scene(False)
+            mesh = TriMesh(v, f)
+            parts = parallel.partition_by_tiles(pts, world)
+            mine = parts[rank]
+            ex = OracleExecutor(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts[mine])
+            out = parallel.run_search(ex, dist, 'replicated', pts[mine], [7.0], 4, 1.0 / sigma[mine].ravel())
+        else:
+            v, f, pts, sigma = _scene(True)[rank]
+            mesh = TriMesh(v, f)
+            ex = OracleExecutor(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts)
+            out = parallel.run_search(ex, dist, 'tiles', pts, [7.0], 4, 1.0 / sigma.ravel())
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(mode):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(300)
+def test_replicated_mesh_sharded_points_gloo():
+    from oracle import nanowrap_oracle as O
+    res = _run('replicated')
+    (v, f, pts, sigma), = _scene(False)
+    mesh = TriMesh(v, f)
+    ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, [7.0], 4, 1.0 / sigma.ravel())
+    assert np.array_equal(res[0], res[1])                       # replicated state stays bitwise in sync
+    assert rel_rms(res[0], ref.positions) <= 1e-5
+
+
+@pytest.mark.timeout(300)
+def test_tiles_two_vesicles_gloo():
+    from oracle import nanowrap_oracle as O
+    res = _run('tiles')
+    (v1, f1, p1, s1), (v2, f2, p2, s2) = _scene(True)
+    # single-process run on the union scene: one mesh with two components, one global subspace solve
+    V = np.concatenate([v1, v2], 0)
+    F = np.concatenate([f1, f2 + v1.shape[0]], 0).astype('i4')
+    mesh = TriMesh(V, F)
+    P = np.concatenate([p1, p2], 0)
+    S = np.concatenate([s1, s2], 0)
+    ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, P, [7.0], 4, 1.0 / S.ravel())
+    got = np.concatenate([res[0], res[1]], 0)
+    assert rel_rms(got, ref.positions) <= 1e-5
+    # and it is NOT what two independent fits would give (the coefficient vector c is shared)
+    m1 = TriMesh(v1, f1)
+    ind = O.search(m1.vertices.copy(), m1.vertex_normals.copy(), m1.neighbor_vertex_table(), m1.faces, p1, [7.0], 4, 1.0 / s1.ravel())
+    assert rel_rms(res[0], ind.positions) > 1e-5
+
+
+def test_partition_by_tiles_is_a_partition():
+    pts = sphere_cloud(5000, 50.0, 5.0, seed=2)
+    for n in (1, 2, 3, 4, 8):
+        parts = parallel.partition_by_tiles(pts, n)
+        allidx = np.sort(np.concatenate(parts))
+        assert len(parts) == n and np.array_equal(allidx, np.arange(5000))
+        assert max(p.size for p in parts) - min(p.size for p in parts) <= 5000 // n // 2 + 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['tiles', 'replicated'])
+def test_split_phase_equals_search_on_one_gpu(mode):
+    """world_size 1 over nccl (= RCCL): kernels -> all-reduce -> kernels on one stream, torch viewing library memory."""
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    v, f = icosphere(4, 120.0)
+    pts = sphere_cloud(20000, 100.0, 10.0, seed=9)
+    rng = np.random.default_rng(1)
+    sigma = rng.uniform(5.0, 15.0, size=pts.shape).astype('f4')
+    s = 1.0 / sigma.ravel()
+    m1 = TriMesh(v, f)
+    a = ShrinkwrapMeshConjGrad(m1, pts).search(pts, lams=[10.0], num_iters=5, sigma_inv=s).copy()
+    own = not dist.is_initialized()
+    if own:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(_free_port())
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        m2 = TriMesh(v, f)
+        cg = ShrinkwrapMeshConjGrad(m2, pts, stream=torch.cuda.current_stream().cuda_stream)
+        scene = parallel.TiledScene(cg, dist, mode=mode)
+        b = scene.search(pts, [10.0], 5, s).copy()
+        c = scene.search(pts, [10.0], 3, s).copy()          # second call continues from the mesh
+    finally:
+        if own:
+            dist.destroy_process_group()
+    assert rel_rms(b, a) <= 1e-6
+    assert cg.loopcount == 3 and len(cg.tests) == 8
+    assert np.array_equal(m2.vertices, c)
