@@ -185,7 +185,7 @@ int minmax3(nw_ctx *ctx, const float *xyz, int64_t n, float lo[3], float hi[3], 
 double desired_cell(double mean_dist, double spacing)
 {
     const char *e = getenv("NW_CELL_FACTOR");
-    const double f = (e && atof(e) > 0) ? atof(e) : 0.6;
+    const double f = (e && atof(e) > 0) ? atof(e) : 0.8;
     return std::max(f * mean_dist, 2.0 * spacing);
 }
 

@@ -318,7 +318,8 @@ __device__ __forceinline__ void nw_stage_segment(int s, int q, int x0, int y0, i
     const int B = g.B;
     const int W = B + 2 * s;
     const int e = q & 1, r = q >> 1;
-    const int iz = r / W, iy = r % W;
+    const int iz = (int)(((float)r + 0.5f) * (1.0f / (float)W));     // exact r / W for the small ints involved, no integer division
+    const int iy = r - iz * W;
     const int y = y0 - s + iy, z = z0 - s + iz;
     ncells = 0; cell_lo = 0;
     if (y < 0 || y >= g.gy || z < 0 || z >= g.gz) return;
@@ -347,8 +348,9 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
     const int wi = nw_xcd_remap(blockIdx.x, nitems);
     if (wi < 0) return;
     __shared__ float4 s_cand[CAP];
-    __shared__ int s_rs[64];
-    __shared__ int s_ro[65];
+    __shared__ int s_rs[TB];
+    __shared__ int s_ro[TB + 1];
+    __shared__ int s_wtot[TB / 64];
     // per-point state of the unfinished points (compacted after every stage)
     __shared__ int s_idx[TB];
     __shared__ float s_b1[TB], s_b2[TB];
@@ -387,8 +389,8 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
         __syncthreads();                                   // everyone has read the compacted state
         const int W = g.B + 2 * stage;
         const int nq = 2 * W * W;
-        for (int qb = 0; qb < nq; qb += 64) {
-            if (tid < 64) {
+        for (int qb = 0; qb < nq; qb += TB) {
+            {
                 int start = 0, len = 0;
                 const int q = qb + tid;
                 if (q < nq) {
@@ -397,29 +399,56 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
                     if (nc > 0) { start = cstart[lo]; len = cstart[lo + nc] - start; }
                 }
                 s_rs[tid] = start;
-                const int inc = nw_wave_incl_scan(len, tid);
-                s_ro[tid + 1] = inc;
+                const int inc = nw_wave_incl_scan(len, tid & 63);
+                if (TB > 64) {
+                    if ((tid & 63) == 63) s_wtot[tid >> 6] = inc;
+                    __syncthreads();
+                    int woff = 0;
+                    for (int w = 0; w < (tid >> 6); ++w) woff += s_wtot[w];
+                    s_ro[tid + 1] = woff + inc;
+                } else {
+                    s_ro[tid + 1] = inc;
+                }
                 if (tid == 0) s_ro[0] = 0;
             }
             __syncthreads();
-            const int total = s_ro[64];
+            const int total = s_ro[TB];
             for (int base = 0; base < total; base += CAP) {
                 const int nc = min(CAP, total - base);
                 for (int e = tid; e < nc; e += TB) {
                     const int ge = base + e;
-                    int lo = 0, hi = 64;
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ro[mid] <= ge) lo = mid; else hi = mid; }
+                    int lo = 0, hi = TB;
+#pragma unroll
+                    for (int stp = 0; stp < (TB == 64 ? 6 : 8); ++stp) { const int mid = (lo + hi) >> 1; if (s_ro[mid] <= ge) lo = mid; else hi = mid; }
                     s_cand[e] = cent[s_rs[lo] + (ge - s_ro[lo])];
                 }
                 __syncthreads();
                 if (has) {
-                    for (int c = sub; c < nc; c += G) {
-                        const float4 C = s_cand[c];
-                        const float dx = px - C.x, dy = py - C.y, dz = pz - C.z;
-                        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                        const int fid = __float_as_int(C.w);
-                        if (d2 < b1) { b2 = b1; b1 = d2; bf = fid; }
-                        else if (d2 < b2) { b2 = d2; }
+                    int c = sub;
+                    for (; c + G < nc; c += 2 * G) {
+                        const float4 C0 = s_cand[c];
+                        const float4 C1 = s_cand[c + G];
+                        const float ax = px - C0.x, ay = py - C0.y, az = pz - C0.z;
+                        const float bx = px - C1.x, by = py - C1.y, bz = pz - C1.z;
+                        const float d0 = fmaf(az, az, fmaf(ay, ay, ax * ax));
+                        const float d1 = fmaf(bz, bz, fmaf(by, by, bx * bx));
+                        const bool l0 = d0 < b1;
+                        b2 = l0 ? b1 : fminf(b2, d0);
+                        bf = l0 ? __float_as_int(C0.w) : bf;
+                        b1 = l0 ? d0 : b1;
+                        const bool l1 = d1 < b1;
+                        b2 = l1 ? b1 : fminf(b2, d1);
+                        bf = l1 ? __float_as_int(C1.w) : bf;
+                        b1 = l1 ? d1 : b1;
+                    }
+                    if (c < nc) {
+                        const float4 C0 = s_cand[c];
+                        const float ax = px - C0.x, ay = py - C0.y, az = pz - C0.z;
+                        const float d0 = fmaf(az, az, fmaf(ay, ay, ax * ax));
+                        const bool l0 = d0 < b1;
+                        b2 = l0 ? b1 : fminf(b2, d0);
+                        bf = l0 ? __float_as_int(C0.w) : bf;
+                        b1 = l0 ? d0 : b1;
                     }
                 }
                 __syncthreads();
