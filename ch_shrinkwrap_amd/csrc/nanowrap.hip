@@ -786,6 +786,47 @@ NW_EXPORT int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, f
     return NW_OK;
 }
 
+NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, const double *jitter, float kc, float kg, float c0, float dN,
+                           float *k0, float *k1, float *e0, float *e1, float *H, float *K, float *dH, float *dK, float *E, float *pE,
+                           float *dE_neighbors, float *dEdN)
+{
+    if (!ctx || !nbr_next || !nbr_area) return NW_ERR_BADARG;
+    if (!ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_curvature: mesh not set");
+    NW_HIP(hipSetDevice(ctx->device));
+    const int64_t M = ctx->M;
+    const int NB = ctx->NB;
+    DevBuf<int> d_next;
+    DevBuf<float> d_area, d_out;
+    DevBuf<double> d_jit;
+    int rc = NW_OK;
+    std::string msg;
+    do {
+        if (d_next.ensure((size_t)M * NB) != hipSuccess || d_area.ensure((size_t)M * NB) != hipSuccess || d_out.ensure((size_t)18 * M) != hipSuccess) { rc = NW_ERR_NOMEM; break; }
+        if (hipMemcpyAsync(d_next.p, nbr_next, (size_t)M * NB * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        if (hipMemcpyAsync(d_area.p, nbr_area, (size_t)M * NB * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        if (jitter) {
+            if (d_jit.ensure((size_t)3 * M) != hipSuccess) { rc = NW_ERR_NOMEM; break; }
+            if (hipMemcpyAsync(d_jit.p, jitter, (size_t)3 * M * 8, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        }
+        float *o = d_out.p;
+        float *p_k0 = o, *p_k1 = o + M, *p_H = o + 2 * M, *p_K = o + 3 * M, *p_dH = o + 4 * M, *p_dK = o + 5 * M, *p_E = o + 6 * M, *p_pE = o + 7 * M,
+              *p_dEn = o + 8 * M, *p_e0 = o + 9 * M, *p_e1 = o + 12 * M, *p_dEdN = o + 15 * M;
+        hipLaunchKernelGGL(k_curvature, dim3(nblk(M, 128)), dim3(128), 0, ctx->stream, (int)M, NB, ctx->meshpos.p, ctx->nrm.p,
+                           ctx->have_valid ? ctx->valid.p : nullptr, ctx->nbr.p, d_next.p, d_area.p, jitter ? d_jit.p : nullptr, dN, kc, kg, c0,
+                           p_k0, p_k1, p_e0, p_e1, p_H, p_K, p_dH, p_dK, p_E, p_pE, p_dEn, p_dEdN);
+        if (hipGetLastError() != hipSuccess) { rc = NW_ERR_HIP; break; }
+        struct { float *dst; float *src; int64_t n; } outs[12] = {{k0, p_k0, M}, {k1, p_k1, M}, {H, p_H, M}, {K, p_K, M}, {dH, p_dH, M}, {dK, p_dK, M},
+                                                                   {E, p_E, M}, {pE, p_pE, M}, {dE_neighbors, p_dEn, M}, {e0, p_e0, 3 * M}, {e1, p_e1, 3 * M}, {dEdN, p_dEdN, 3 * M}};
+        for (auto &t : outs)
+            if (t.dst && hipMemcpyAsync(t.dst, t.src, (size_t)t.n * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        if (rc != NW_OK) break;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+    } while (0);
+    d_next.release(); d_area.release(); d_out.release(); d_jit.release();
+    if (rc != NW_OK) return fail(ctx, rc, "nw_curvature: HIP failure");
+    return NW_OK;
+}
+
 NW_EXPORT int nw_set_profiling(nw_ctx *ctx, int enable)
 {
     if (!ctx) return NW_ERR_BADARG;

@@ -1006,3 +1006,208 @@ __global__ void k_lfunc_lh_serial(int M, int NB, const int *__restrict__ nbr, co
         }
     }
 }
+
+// ============================================================================================================
+// Block-boundary kernel: per-vertex curvature tensor / Canham-Helfrich energy (c_curvature_grad,
+// membrane_mesh_utils.c:915-1250; Householder+Givens eigen-solve :618-720; 2x2 pseudo-inverse :841-890).
+// One thread per vertex, three passes over the <= 20 1-ring neighbours, float64 internals / float32 outputs exactly
+// where the reference has them.  Deviations from the reference's arithmetic (all at the 1e-15 level): the least-squares
+// system A^T A, A^T b is accumulated on the fly instead of materialising A (no 2x20 scratch arrays), and the random
+// jitter (rand(), :1017) is either supplied by the caller or replaced by a counter-based hash of (vertex, axis).
+// ============================================================================================================
+__device__ __forceinline__ double nw_jitter_unit(unsigned v, unsigned k)
+{
+    unsigned x = v * 0x9E3779B1u + k * 0x85EBCA77u + 0x165667B1u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (double)(x >> 8) / 16777216.0;
+}
+
+__device__ __forceinline__ double nw_norm3d(double a, double b, double c) { return sqrt((a * a + b * b) + c * c); }
+__device__ __forceinline__ double nw_safe_div(double x, double y) { return (fabs(y) < 1e-15) ? 0.0 : x / y; }
+
+__device__ __forceinline__ void nw_proj_matrix(float vx, float vy, float vz, double coef, double *m)
+{
+    const double v0 = vx, v1 = vy, v2 = vz;
+    const float xy = (float)(-1.0 * coef * v0 * v1), xz = (float)(-1.0 * coef * v0 * v2), yz = (float)(-1.0 * coef * v1 * v2);   // float in the reference (:233)
+    m[0] = 1.0 - coef * v0 * v0; m[1] = xy; m[2] = xz;
+    m[3] = xy; m[4] = 1.0 - coef * v1 * v1; m[5] = yz;
+    m[6] = xz; m[7] = yz; m[8] = 1.0 - coef * v2 * v2;
+}
+
+__device__ __forceinline__ double nw_normal_diff(double q)
+{
+    q = q * q;
+    return (q > 1.0) ? sqrt(2.0) : sqrt(2.0 - 2.0 * sqrt(1.0 - q));
+}
+
+__global__ __launch_bounds__(128) void k_curvature(int M, int NB, const float *__restrict__ pos, const float *__restrict__ nrm, const unsigned char *__restrict__ valid,
+                                                  const int *__restrict__ nbr, const int *__restrict__ nbr_next, const float *__restrict__ nbr_area,
+                                                  const double *__restrict__ jitter, float dN, float kc, float kg, float c0,
+                                                  float *__restrict__ k_0, float *__restrict__ k_1, float *__restrict__ e_0, float *__restrict__ e_1,
+                                                  float *__restrict__ H, float *__restrict__ K, float *__restrict__ dH, float *__restrict__ dK,
+                                                  float *__restrict__ E, float *__restrict__ pE, float *__restrict__ dE_nb, float *__restrict__ dEdN)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (valid && !valid[i]) {
+        H[i] = K[i] = dH[i] = dK[i] = dE_nb[i] = E[i] = pE[i] = 0.0f;
+        dEdN[3 * i] = dEdN[3 * i + 1] = dEdN[3 * i + 2] = 0.0f;
+        return;
+    }
+    const float vix = pos[3 * i], viy = pos[3 * i + 1], viz = pos[3 * i + 2];
+    const float Nx = nrm[3 * i], Ny = nrm[3 * i + 1], Nz = nrm[3 * i + 2];
+    const int *row = nbr + (int64_t)i * NB;
+    // pass 1: radial weights, neighbour centroid, jitter width
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    double r_sum = 0.0, jw = 10000000000000000.0;
+    int n = 0;
+    while (n < NB && row[n] != -1) {
+        const int v = row[n];
+        const float x = pos[3 * v], y = pos[3 * v + 1], z = pos[3 * v + 2];
+        cx += x; cy += y; cz += z;
+        const double dn = nw_norm3d((double)x - (double)vix, (double)y - (double)viy, (double)z - (double)viz);
+        if (dn > 1e-15) r_sum += 1.0 / dn;
+        if (dn < jw) jw = dn;
+        ++n;
+    }
+    cx /= n; cy /= n; cz /= n;
+    {
+        const double j0 = jitter ? jitter[3 * i] : nw_jitter_unit((unsigned)i, 0u);
+        const double j1 = jitter ? jitter[3 * i + 1] : nw_jitter_unit((unsigned)i, 1u);
+        const double j2 = jitter ? jitter[3 * i + 2] : nw_jitter_unit((unsigned)i, 2u);
+        cx = (float)((double)cx + jw * (j0 - 0.5));
+        cy = (float)((double)cy + jw * (j1 - 0.5));
+        cz = (float)((double)cz + jw * (j2 - 0.5));
+    }
+    float ux = cx - vix, uy = cy - viy, uz = cz - viz;                  // vivj
+    float un = 0.0f;
+    un += ux * ux; un += uy * uy; un += uz * uz;
+    const float vivj_norm = (float)sqrt((double)un);
+    if (vivj_norm > 0.0f) { ux /= vivj_norm; uy /= vivj_norm; uz /= vivj_norm; } else { ux = uy = uz = 0.0f; }
+    const double sx = (double)ux * (double)dN, sy = (double)uy * (double)dN, sz = (double)uz * (double)dN;   // NvidN
+    const double wx = (double)vix - sx, wy = (double)viy - sy, wz = (double)viz - sz;                       // viNvidN
+    double p[9];
+    nw_proj_matrix(Nx, Ny, Nz, 1.0, p);
+    double M00 = 0, M01 = 0, M02 = 0, M10 = 0, M11 = 0, M12 = 0, M20 = 0, M21 = 0, M22 = 0;
+    double dareas = 0.0, areas = 0.0;
+    double hx = 0, hy = 0, hz = 0, gx = 0, gy = 0, gz = 0;            // dv_hat, dv_1_hat persist across neighbours (:1059-1062)
+    float den = 0.0f;
+    // pass 2: curvature tensor
+    for (int j = 0; j < n; ++j) {
+        const int v = row[j];
+        const double dx = (double)pos[3 * v] - (double)vix, dy = (double)pos[3 * v + 1] - (double)viy, dz = (double)pos[3 * v + 2] - (double)viz;
+        const double d1x = dx - sx, d1y = dy - sy, d1z = dz - sz;
+        const double dn = nw_norm3d(dx, dy, dz), dn1 = nw_norm3d(d1x, d1y, d1z);
+        if (dn > 1e-15) { hx = dx / dn; hy = dy / dn; hz = dz / dn; }
+        if (dn1 > 1e-15) { gx = d1x / dn1; gy = d1y / dn1; gz = d1z / dn1; }
+        const double nx_ = dx * -1.0, ny_ = dy * -1.0, nz_ = dz * -1.0;
+        const double Tx = (p[0] * nx_ + p[1] * ny_) + p[2] * nz_, Ty = (p[3] * nx_ + p[4] * ny_) + p[5] * nz_, Tz = (p[6] * nx_ + p[7] * ny_) + p[8] * nz_;
+        const double Tn = nw_norm3d(Tx, Ty, Tz);
+        double tx = 0, ty = 0, tz = 0;
+        if (Tn > 1e-15) { tx = Tx / Tn; ty = Ty / Tn; tz = Tz / Tn; }
+        const float jx = nrm[3 * v], jy = nrm[3 * v + 1], jz = nrm[3 * v + 2];
+        const double Ni_diff = nw_normal_diff(((double)Nx * hx + (double)Ny * hy) + (double)Nz * hz);
+        const double Nj_diff = nw_normal_diff(((double)jx * hx + (double)jy * hy) + (double)jz * hz);
+        const double Nj1_diff = nw_normal_diff(((double)jx * gx + (double)jy * gy) + (double)jz * gz);
+        const double kj = nw_safe_div(2.0 * Nj_diff, dn), kj1 = nw_safe_div(2.0 * Nj1_diff, dn1);
+        const double w = nw_safe_div(nw_safe_div(1.0, dn), r_sum);
+        const double sgn = ((((double)Nx * nx_ + (double)Ny * ny_) + (double)Nz * nz_) < 0) ? -1.0 : 1.0;
+        const double k = nw_safe_div(2.0 * sgn * Ni_diff, dn);
+        const double Aj = nbr_area[(int64_t)i * NB + j];
+        const int vn = nbr_next[(int64_t)i * NB + j];
+        const double ex = (double)pos[3 * vn] - wx, ey = (double)pos[3 * vn + 1] - wy, ez = (double)pos[3 * vn + 2] - wz;
+        const double crx = d1y * ez - d1z * ey, cry = d1z * ex - d1x * ez, crz = d1x * ey - d1y * ex;
+        const double dAj = 0.5 * nw_norm3d(crx, cry, crz);
+        dareas += dAj;
+        areas += Aj;
+        const double a0 = 2.0 * kj - (double)c0, a1 = 2.0 * kj1 - (double)c0;
+        den += ((float)((Aj * w * 0.5 * (double)kc * (a0 * a0) - dAj * w * 0.5 * (double)kc * (a1 * a1)))) / dN;
+        const double wk = w * k;
+        M00 += (tx * tx) * wk; M01 += (tx * ty) * wk; M02 += (tx * tz) * wk;
+        M10 += (ty * tx) * wk; M11 += (ty * ty) * wk; M12 += (ty * tz) * wk;
+        M20 += (tz * tx) * wk; M21 += (tz * ty) * wk; M22 += (tz * tz) * wk;
+    }
+    dE_nb[i] = den;
+    // eigen-solve: Householder reflection taking the normal to +-e1, then one Givens rotation on the 2x2 minor
+    double l1, l2, v1x, v1y, v1z, v2x, v2y, v2z;
+    {
+        const float sxf = 1.0f - Nx, syf = 0.0f - Ny, szf = 0.0f - Nz, axf = 1.0f + Nx, ayf = 0.0f + Ny, azf = 0.0f + Nz;
+        float ns = 0.0f, na = 0.0f;
+        ns += sxf * sxf; ns += syf * syf; ns += szf * szf;
+        na += axf * axf; na += ayf * ayf; na += azf * azf;
+        const float nsf = (float)sqrt((double)ns), naf = (float)sqrt((double)na);
+        float Wx, Wy, Wz;
+        if (nsf > naf) { Wx = sxf / nsf; Wy = syf / nsf; Wz = szf / nsf; } else { Wx = axf / naf; Wy = ayf / naf; Wz = azf / naf; }
+        double Q[9];
+        nw_proj_matrix(Wx, Wy, Wz, 2.0, Q);
+        const double Mv[9] = {M00, M01, M02, M10, M11, M12, M20, M21, M22};
+        double QM[9], R[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) { double a = 0.0; for (int kk = 0; kk < 3; ++kk) a += Q[3 * r + kk] * Mv[3 * kk + c]; QM[3 * r + c] = a; }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) { double a = 0.0; for (int kk = 0; kk < 3; ++kk) a += QM[3 * r + kk] * Q[3 * c + kk]; R[3 * r + c] = a; }   // * Q^T
+        const double tau = nw_safe_div(R[8] - R[4], 2.0 * R[5]);
+        const double t = ((tau < 0) ? -1.0 : 1.0) / (fabs(tau) + sqrt(1 + tau * tau));
+        l1 = R[4] - t * R[5];
+        l2 = R[8] + t * R[5];
+        const double cs = 1.0 / sqrt(1 + t * t), sn = t * cs;
+        // QviT[3i+1] = Q[3+i], QviT[3i+2] = Q[6+i]
+        const double ax = cs * Q[3] - sn * Q[6], ay = cs * Q[4] - sn * Q[7], az = cs * Q[5] - sn * Q[8];
+        const double bx = sn * Q[3] + cs * Q[6], by = sn * Q[4] + cs * Q[7], bz = sn * Q[5] + cs * Q[8];
+        if (l1 > l2) { v1x = ax; v1y = ay; v1z = az; v2x = bx; v2y = by; v2z = bz; }
+        else { const double tmp = l1; l1 = l2; l2 = tmp; v2x = ax; v2y = ay; v2z = az; v1x = bx; v1y = by; v1z = bz; }
+    }
+    float k0f, k1f;
+    if (isnan(l1)) { k0f = 0.0f; k1f = 0.0f; v1x = v1y = v1z = v2x = v2y = v2z = 0.0; }
+    else { k0f = (float)(3.0 * l1 - l2); k1f = (float)(3.0 * l2 - l1); }
+    k_0[i] = k0f; k_1[i] = k1f;
+    e_0[3 * i] = (float)v1x; e_0[3 * i + 1] = (float)v1y; e_0[3 * i + 2] = (float)v1z;
+    e_1[3 * i] = (float)v2x; e_1[3 * i + 1] = (float)v2y; e_1[3 * i + 2] = (float)v2z;
+    const float Hf = (float)(0.5 * (double)(k0f + k1f));
+    const float Kf = (float)(k0f * k1f);
+    H[i] = Hf; K[i] = Kf;
+    // pass 3: quadric fit in the (e0,e1) plane displaced by dN -> principal curvatures after the shift
+    double S00 = 0, S01 = 0, S11 = 0, r0 = 0, r1 = 0;
+    for (int j = 0; j < n; ++j) {
+        const int v = row[j];
+        const double dx = (double)pos[3 * v] - (double)vix, dy = (double)pos[3 * v + 1] - (double)viy, dz = (double)pos[3 * v + 2] - (double)viz;
+        const double t0 = (dx * v1x + dy * v1y) + dz * v1z, t1 = (dx * v2x + dy * v2y) + dz * v2z;
+        const double A0 = t0 * t0, A1 = t1 * t1;
+        const double b = A0 * (double)k0f + A1 * (double)k1f - (double)dN;
+        S00 += A0 * A0; S01 += A0 * A1; S11 += A1 * A1;
+        r0 += A0 * b; r1 += A1 * b;
+    }
+    double kp0, kp1;
+    {
+        const double a = S00, b = S01, c = S01, d = S11;
+        const double a2 = a * a, b2 = b * b, c2 = c * c, d2 = d * d;
+        const double a2b2 = a2 + b2, c2d2 = c2 + d2, dif = a2b2 - c2d2, tacbd = 2 * (a * c + b * d);
+        const double theta = 0.5 * atan2(2 * (a * b + c * d), a2 + c2 - b2 - d2), phi = 0.5 * atan2(tacbd, dif);
+        const double ct = cos(theta), cp = cos(phi), st = sin(theta), sp = sin(phi);
+        const double ctcp = ct * cp, ctsp = ct * sp, stcp = st * cp, stsp = st * sp;
+        const double sign0 = ((ctcp * a + ctsp * c + stcp * b + stsp * d) < 0) ? -1.0 : 1.0;
+        const double sign1 = ((stsp * a - stcp * c - ctsp * b + ctcp * d) < 0) ? -1.0 : 1.0;
+        const double ss = a2b2 + c2d2, sd = sqrt(dif * dif + tacbd * tacbd);
+        const double sig0 = sqrt((ss + sd) / 2.0), sssd = ss - sd;
+        const double sig1 = (sssd > 0) ? sqrt(sssd / 2.0) : 0.0;
+        const double thresh = (1e-8) * 0.5 * sqrt(5.0) * sig0;
+        const double si0 = (sig0 < thresh) ? 0.0 : (1.0 / sig0), si1 = (sig1 < thresh) ? 0.0 : (1.0 / sig1);
+        const double s0 = sign0 * si0, s1 = sign1 * si1;
+        const double i00 = ctcp * s0 + stsp * s1, i01 = ctsp * s0 - stcp * s1, i10 = stcp * s0 - ctsp * s1, i11 = stsp * s0 + ctcp * s1;
+        kp0 = i00 * r0 + i01 * r1;
+        kp1 = i10 * r0 + i11 * r1;
+    }
+    const float dHf = (float)(0.5 * (kp0 + kp1)), dKf = (float)(kp0 * kp1);
+    dH[i] = dHf; dK[i] = dKf;
+    const double hh = 2.0 * (double)Hf - (double)c0;
+    const float Ef = (float)(areas * ((0.5 * (double)kc * (hh * hh) + (double)kg * (double)Kf)));
+    E[i] = Ef;
+    const float pEf = (float)exp(-(1.0 / 0.0257) * (double)Ef);
+    pE[i] = pEf;
+    const double dh = 2.0 * (double)dHf - (double)c0;
+    const double dEdN_H = dareas * ((0.5 * (double)kc * (dh * dh) + (double)kg * (double)dKf));
+    const double dsum = ((double)Ef - dEdN_H) / (double)dN + (double)den;
+    const double lo = -0.5 * (double)vivj_norm, hi = 0.5 * (double)vivj_norm;
+    const float dEdNs = (float)(-1.0 * (double)((float)((dsum > hi) ? hi : ((dsum < lo) ? lo : dsum))) * (1.0 - (double)pEf));
+    dEdN[3 * i] = dEdNs * ux; dEdN[3 * i + 1] = dEdNs * uy; dEdN[3 * i + 2] = dEdNs * uz;
+}

@@ -63,6 +63,7 @@ class MembraneMesh(TriMesh):
         self._native = None
         self._warned_fixed_topology = False
         self.block_log = []
+        self._initialize_curvature_vectors()
         for key, value in kwargs.items():                # :119-120
             setattr(self, key, value)
 
@@ -78,6 +79,84 @@ class MembraneMesh(TriMesh):
             return False
         self.remesher(self, n, target_edge_length, l, n_relax)
         return True
+
+    # -- curvature (block-boundary kernel) --------------------------------------------------------------------
+    def _neighbor_tables(self):
+        """Flat per-slot tables the curvature kernel needs besides the 1-ring vertex ids: the vertex the NEXT half-edge
+        points to and the area of the half-edge's face (membrane_mesh_utils.c:1099-1104)."""
+        he = self._halfedges
+        nb = self._vertices['neighbors']
+        ok = nb != -1
+        safe = np.where(ok, nb, 0)
+        nxt = he['vertex'][he['next'][safe]]
+        nxt[~ok] = -1
+        area = self._faces['area'][he['face'][safe]]
+        area[~ok] = 0
+        return np.ascontiguousarray(nxt, 'i4'), np.ascontiguousarray(area, 'f4')
+
+    def curvature_grad_c(self, dN=0.1, skip_prob=0.0, jitter=None):
+        """_membrane_mesh.pyx:323-347 -> c_curvature_grad (membrane_mesh_utils.c:915-1250) on the GPU.  Fills the
+        per-vertex curvature arrays and returns dEdN (M,3).  `jitter`: optional (M,3) float64 array in [0,1) replacing the
+        reference's rand() stream; None = deterministic hash."""
+        import ctypes
+        from . import _lib as nw
+        if skip_prob != 0.0:
+            raise NotImplementedError('skip_prob != 0 is never used on the live path (_membrane_mesh.pyx:323)')
+        if self._native is None:
+            self._native = NativeContext(self._device)
+        nat = self._native
+        M = self._vertices.shape[0]
+        pos = np.ascontiguousarray(self._vertices['position'], 'f4')
+        nrm = np.ascontiguousarray(self.vertex_normals, 'f4')
+        nbr = self.neighbor_vertex_table()
+        valid = np.ascontiguousarray(self._vertices['halfedge'] != -1, 'u1')
+        faces = np.ascontiguousarray(self.faces, 'i4')
+        nat.check(nat.L.nw_set_mesh(nat.h, nw.ptr(pos), nw.ptr(nrm), nw.ptr(nbr), nw.ptr(valid), nw.ptr(faces), M, faces.shape[0], nbr.shape[1]))
+        nxt, area = self._neighbor_tables()
+        jit = None if jitter is None else np.ascontiguousarray(jitter, 'f8')
+        self._initialize_curvature_vectors()
+        dEdN = np.zeros((M, 3), 'f4')
+        nat.check(nat.L.nw_curvature(nat.h, nw.ptr(nxt), nw.ptr(area), nw.ptr(jit), float(self.kc), float(self.kg), float(self.c0), float(dN),
+                                     nw.ptr(self._k_0), nw.ptr(self._k_1), nw.ptr(self._e_0), nw.ptr(self._e_1), nw.ptr(self._H), nw.ptr(self._K),
+                                     nw.ptr(self._dH), nw.ptr(self._dK), nw.ptr(self._E), nw.ptr(self._pE), nw.ptr(self._dE_neighbors), nw.ptr(dEdN)))
+        return dEdN
+
+    def _initialize_curvature_vectors(self):
+        sz = self._vertices.shape[0]                                   # _membrane_mesh.pyx:188-200
+        for name in ('_H', '_K', '_E', '_k_0', '_k_1', '_pE', '_dH', '_dK', '_dE_neighbors'):
+            setattr(self, name, np.zeros(sz, np.float32))
+        self._e_0 = np.zeros((sz, 3), np.float32)
+        self._e_1 = np.zeros((sz, 3), np.float32)
+
+    def smooth_per_vertex_data(self, data):
+        """PYME's TriangleMesh.smooth_per_vertex_data is not in the reference tree; this build's definition: mean over
+        the vertex and its 1-ring."""
+        nbr = self.neighbor_vertex_table()
+        ok = nbr >= 0
+        s = np.asarray(data, 'f8') + (np.asarray(data, 'f8')[np.where(ok, nbr, 0)] * ok).sum(1)
+        return (s / (1 + ok.sum(1))).astype(np.float32)
+
+    def _populate_curvature_grad(self):
+        self.curvature_grad_c()                                        # :176-186
+        if self.smooth_curvature:
+            self._H = self.smooth_per_vertex_data(self._H)
+            self._K = self.smooth_per_vertex_data(self._K)
+            self._k_0 = self.smooth_per_vertex_data(self._k_0)
+            self._k_1 = self.smooth_per_vertex_data(self._k_1)
+
+    def _curv(self, name):
+        if not np.any(getattr(self, name)):
+            self._populate_curvature_grad()
+        return getattr(self, name)
+
+    E = property(lambda self: np.nan_to_num(self._curv('_E'), nan=0.0))                       # :122-127
+    pE = property(lambda self: np.nan_to_num(self._curv('_pE'), nan=0.0))                     # :129-134
+    curvature_principal0 = property(lambda self: self._curv('_k_0'))                          # :140-144
+    curvature_principal1 = property(lambda self: self._curv('_k_1'))
+    eigenvector_principal0 = property(lambda self: self._curv('_e_0'))
+    eigenvector_principal1 = property(lambda self: self._curv('_e_1'))
+    curvature_mean = property(lambda self: self._curv('_H'))                                  # :164-168
+    curvature_gaussian = property(lambda self: self._curv('_K'))                              # :170-174
 
     # -- the driver -------------------------------------------------------------------------------------------
     def opt_conjugate_gradient(self, points, sigma, max_iter=10, step_size=1.0, weights=None, **kwargs):

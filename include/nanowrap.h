@@ -151,6 +151,19 @@ int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes);
  * x, f0, out: (3M,) float32 host or device; f0 may be NULL for kinds 0,1,4. Uses the neighbour table of nw_set_mesh. */
 int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, float *out);
 
+/* Block-boundary kernel: per-vertex curvature tensor and Canham-Helfrich energy, replaces c_curvature_grad
+ * (membrane_mesh_utils.c:915-1250, reached through MembraneMesh.curvature_grad_c, _membrane_mesh.pyx:323-347), with
+ * skip_prob = 0 (the only value the live path uses).  Works on the ctx's CURRENT device-resident mesh positions, the
+ * normals of nw_set_mesh / nw_set_normals and the neighbour table of nw_set_mesh (walk stops at the first -1, as the
+ * reference's does).  nbr_next (M,NB) i32 = halfedges[halfedges[neighbors[j]].next].vertex, nbr_area (M,NB) f32 =
+ * faces[halfedges[neighbors[j]].face].area.  jitter: (M,3) float64 in [0,1) standing for the reference's rand() stream
+ * (:1017), or NULL for a deterministic hash of (vertex, axis).  Outputs (host or device): k0,k1,H,K,dH,dK,E,pE,
+ * dE_neighbors (M) f32; e0,e1,dEdN (M,3) f32; any output pointer may be NULL. */
+int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, const double *jitter,
+                 float kc, float kg, float c0, float dN,
+                 float *k0, float *k1, float *e0, float *e1, float *H, float *K, float *dH, float *dK,
+                 float *E, float *pE, float *dE_neighbors, float *dEdN);
+
 /* device timing of the last nw_search (ms), split by stage; for bench.py's roofline object.
  * stage: 0 total, 1 grid build, 2 NN query, 3 attraction (weights/residual/scatter), 4 prior+directions,
  * 5 A.S + dots, 6 solve+update.  Only valid if nw_set_profiling(ctx, 1) was called before the search. */

@@ -197,6 +197,39 @@ def golden_lfuncs():
     save('native_helpers', **arrays)
 
 
+def golden_curvature():
+    """c_curvature_grad (membrane_mesh_utils.c:915-1250) through oracle/_ref/libref_curvature.so on a noisy geodesic sphere
+    with one unused vertex slot; the rand() stream of the run (srand(seed)) is recorded so it can be replayed."""
+    import ctypes
+    from ch_shrinkwrap_amd.trimesh import geodesic_sphere
+    ref = ctypes.CDLL(os.path.join(ROOT, 'oracle', '_ref', 'libref_curvature.so'))
+    libc = ctypes.CDLL('libc.so.6')
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    v, f = geodesic_sphere(9, 40.0)
+    rng = np.random.default_rng(8)
+    v = (v * np.array([1.0, 0.7, 1.3]) + rng.normal(scale=0.25, size=v.shape)).astype('f4')     # ellipsoid + noise
+    m = TriMesh(v, f, max_vertices=v.shape[0] + 1)
+    M = m._vertices.shape[0]
+    names = ['k0', 'k1', 'e0', 'e1', 'H', 'K', 'dH', 'dK', 'E', 'pE', 'dEn', 'dEdN']
+    shp = {'e0': (M, 3), 'e1': (M, 3), 'dEdN': (M, 3)}
+    r = {n: np.zeros(shp.get(n, (M,)), 'f4') for n in names}
+    f32 = ctypes.c_float
+    seed, dN, kc, kg, c0 = 77, 0.1, 0.514, -0.514, 0.01
+    ref.ref_c_curvature_grad.argtypes = [ctypes.c_void_p] * 3 + [f32, f32, ctypes.c_int] + [ctypes.c_void_p] * 11 + [f32, f32, f32, ctypes.c_void_p, ctypes.c_uint]
+    ref.ref_c_curvature_grad(P(m._vertices), P(m._faces), P(m._halfedges), dN, 0.0, M, P(r['k0']), P(r['k1']), P(r['e0']), P(r['e1']), P(r['H']), P(r['K']),
+                             P(r['dH']), P(r['dK']), P(r['E']), P(r['pE']), P(r['dEn']), kc, kg, c0, P(r['dEdN']), seed)
+    libc.srand(seed)
+    libc.rand.restype = ctypes.c_int
+    valid = m._vertices['halfedge'] != -1
+    jit = np.zeros((M, 3))
+    for i in range(M):
+        if valid[i]:
+            for k in range(3):
+                jit[i, k] = libc.rand() / 2147483648.0
+    save('curvature_geo9', vertices=m.vertices.copy(), faces=m.faces.copy(), normals=m.vertex_normals.copy(), face_area=m._faces['area'].copy(),
+         params=np.array([dN, kc, kg, c0]), jitter=jit, **{'out_' + n: a for n, a in r.items()})
+
+
 if __name__ == '__main__':
     if not ref_harness.available():
         raise SystemExit('reference not available here')
@@ -204,3 +237,4 @@ if __name__ == '__main__':
     golden_c1()
     golden_variants()
     golden_lfuncs()
+    golden_curvature()
