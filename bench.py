@@ -113,9 +113,10 @@ def main():
     mesh = TriMesh(cfg['vertices'], cfg['faces'])
     N, M, F = pts.shape[0], int((mesh._vertices['halfedge'] != -1).sum()), mesh.faces.shape[0]
 
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
-    cg = ShrinkwrapMeshConjGrad(mesh, pts, device=local_rank, stream=stream)
-    runner = parallel.TiledScene(cg, dist if world > 1 else None)
+    # N > 1: kernels and RCCL collectives share one dedicated (non-default) torch stream
+    tstream = torch.cuda.Stream() if world > 1 else None
+    cg = ShrinkwrapMeshConjGrad(mesh, pts, device=local_rank, stream=tstream.cuda_stream if tstream is not None else None)
+    runner = parallel.TiledScene(cg, dist if world > 1 else None, torch_stream=tstream)
 
     def run_steps(k):
         done = 0

@@ -20,8 +20,8 @@ NW_N_SCALARS = 32
 # every symbol include/nanowrap.h declares (tests/test_abi.py checks the exports against the header)
 SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set_stream', 'nw_synchronize',
            'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_search', 'nw_search_begin',
-           'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars',
-           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms']
+           'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
+           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms']
 
 
 class IterLog(ctypes.Structure):
@@ -63,9 +63,12 @@ def load():
     L.nw_iter_update.argtypes = [vp]
     L.nw_search_end.argtypes = [vp, vp, ctypes.POINTER(IterLog), ctypes.POINTER(i32)]
     L.nw_n_point_scalars.argtypes = []
+    L.nw_n_scalars.argtypes = []
+    L.nw_scalar_stride.argtypes = []
     L.nw_apply_A.argtypes = [vp, vp, vp]
     L.nw_apply_At.argtypes = [vp, vp, vp]
     L.nw_get.argtypes = [vp, i32, vp, i64]
+    L.nw_write_back.argtypes = [vp, vp, vp, i64]
     L.nw_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     L.nw_lfunc.argtypes = [vp, i32, vp, vp, vp]
     L.nw_curvature.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32] + [vp] * 12

@@ -10,12 +10,15 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <chrono>
 
 #include "../../include/nanowrap.h"
 #include "nw_kernels.h"
 
 static_assert(sizeof(NwIterLogDev) == sizeof(nw_iter_log), "device/host log record mismatch");
 static_assert(SC_COUNT <= NW_N_SCALARS, "scalar slots");
+static_assert(NW_REPL == 32 && SC_COUNT * 8 <= NW_BLOCK, "nw_gather_scalars layout");
+#define NW_SC_BLOCK (NW_N_SCALARS * NW_REPL * NW_RSTRIDE)   // doubles per parity: replicated, line-padded slots
 
 #define NW_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -86,7 +89,7 @@ struct nw_ctx {
 
     // per-iteration work arrays
     DevBuf<float4> cent_tmp, cent;
-    DevBuf<int> fcell, face, vidx, ambig_list, ambig_count;
+    DevBuf<int> fcell, frank, face, vidx, ambig_list, ambig_count;
     DevBuf<float> dist, w, res, vacc, S, fdef, pi;
     DevBuf<double> scalars;           // [2][NW_N_SCALARS]
     DevBuf<NwDevState> state;
@@ -102,6 +105,9 @@ struct nw_ctx {
     float lam0 = 0.0f;
     bool in_search = false;
     bool searched = false;
+
+    void *pin = nullptr;              // pinned staging for the write-back
+    size_t pin_bytes = 0;
 
     // profiling
     bool profiling = false;
@@ -332,6 +338,7 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->cent_tmp.ensure(F));
     NW_HIP(ctx->cent.ensure(F));
     NW_HIP(ctx->fcell.ensure(F));
+    NW_HIP(ctx->frank.ensure(F));
     NW_HIP(ctx->face.ensure(N));
     NW_HIP(ctx->ambig_list.ensure(N));
     NW_HIP(ctx->ambig_count.ensure(4));
@@ -343,7 +350,7 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->S.ensure(9 * M));
     NW_HIP(ctx->fdef.ensure(3 * M));
     NW_HIP(ctx->pi.ensure(M));
-    NW_HIP(ctx->scalars.ensure(2 * NW_N_SCALARS));
+    NW_HIP(ctx->scalars.ensure(2 * NW_SC_BLOCK));
     return NW_OK;
 }
 
@@ -352,6 +359,8 @@ int alloc_work(nw_ctx *ctx)
 // =============================================================================================================
 NW_EXPORT int nw_abi_version(void) { return NW_ABI_VERSION; }
 NW_EXPORT int nw_n_point_scalars(void) { return SC_NPOINT; }
+NW_EXPORT int nw_n_scalars(void) { return SC_COUNT; }
+NW_EXPORT int nw_scalar_stride(void) { return NW_REPL * NW_RSTRIDE; }
 
 NW_EXPORT int nw_create(int device, nw_ctx **out)
 {
@@ -384,9 +393,10 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->item_count.release(); ctx->item_start.release(); ctx->items.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->d_small.release();
-    ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->face.release(); ctx->vidx.release();
+    ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -540,7 +550,7 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     NW_HIP(hipMemsetAsync(ctx->S.p, 0, 9 * ctx->M * sizeof(float), ctx->stream));         // S = zeros (:207)
     NW_HIP(hipMemsetAsync(ctx->res.p, 0, 3 * ctx->N * sizeof(float), ctx->stream));       // res = 0*data (:181)
     NW_HIP(hipMemsetAsync(ctx->vacc.p, 0, 4 * ctx->M * sizeof(float), ctx->stream));
-    NW_HIP(hipMemsetAsync(ctx->scalars.p, 0, 2 * NW_N_SCALARS * sizeof(double), ctx->stream));
+    NW_HIP(hipMemsetAsync(ctx->scalars.p, 0, 2 * NW_SC_BLOCK * sizeof(double), ctx->stream));
     if (ctx->profiling) { ctx->ev_used = 0; g_marks.spans.clear(); for (int k = 0; k < ST_COUNT; ++k) { ctx->stage_ms[k] = 0; ctx->stage_launches[k] = 0; } }
     ctx->in_search = true;
     return NW_OK;
@@ -553,14 +563,15 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
     const int par = it & 1;
     const int64_t N = ctx->N, F = ctx->F;
     const NwGrid g = ctx->grid;
-    double *sc = ctx->scalars.p + par * NW_N_SCALARS;
+    double *sc = ctx->scalars.p + par * NW_SC_BLOCK;
     {
         StageScope s(ctx, ST_GRID);
         hipLaunchKernelGGL(k_face_centroids, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pos.p, ctx->faces.p, (int)F,
-                           ctx->cent_tmp.p, ctx->fcell.p, ctx->ccount.p, ctx->ambig_count.p, ctx->state.p, it);
+                           ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->ccount.p, ctx->ambig_count.p, ctx->state.p, it);
         NW_TRY(scan_exclusive(ctx, ctx->ccount.p, g.ncell, ctx->cstart.p));
-        hipLaunchKernelGGL(k_centroid_scatter, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, (int)F, ctx->cent_tmp.p, ctx->fcell.p, ctx->cstart.p,
-                           ctx->ccount.p, ctx->cent.p, ctx->state.p, it);
+        hipLaunchKernelGGL(k_centroid_scatter, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, (int)F, ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->cstart.p,
+                           ctx->cent.p, ctx->state.p, it);
+        NW_HIP(hipMemsetAsync(ctx->ccount.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));   // histogram ready for the next iteration
     }
     {
         StageScope s(ctx, ST_NN);
@@ -590,10 +601,10 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
     const int it = ctx->global_iter;
     const int par = it & 1;
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
-    double *sc = ctx->scalars.p + par * NW_N_SCALARS;
+    double *sc = ctx->scalars.p + par * NW_SC_BLOCK;
     {
         StageScope s(ctx, ST_PRIOR);
-        hipLaunchKernelGGL(k_prior_directions, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->maxdeg, ctx->nbr_t.p, ctx->pos.p,
+        hipLaunchKernelGGL(k_prior_directions, dim3(std::min(nblk(ctx->M), 512)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->maxdeg, ctx->nbr_t.p, ctx->pos.p,
                            ctx->meshpos.p, ctx->nrm.p, ctx->vacc.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, sc, ctx->state.p, it, n_search);
     }
     {
@@ -612,11 +623,11 @@ NW_EXPORT int nw_iter_update(nw_ctx *ctx)
     const int it = ctx->global_iter;
     const int par = it & 1;
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
-    double *sc = ctx->scalars.p + par * NW_N_SCALARS;
-    double *sc_next = ctx->scalars.p + (par ^ 1) * NW_N_SCALARS;
+    double *sc = ctx->scalars.p + par * NW_SC_BLOCK;
+    double *sc_next = ctx->scalars.p + (par ^ 1) * NW_SC_BLOCK;
     {
         StageScope s(ctx, ST_UPDATE);
-        hipLaunchKernelGGL(k_solve_update, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->lam0, n_search, ctx->search_flags,
+        hipLaunchKernelGGL(k_solve_update, dim3(std::min(nblk(ctx->M), 512)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->lam0, n_search, ctx->search_flags,
                            ctx->have_valid ? ctx->valid.p : nullptr, ctx->pos.p, ctx->meshpos.p, ctx->S.p, ctx->vacc.p, sc, sc_next, ctx->state.p,
                            ctx->logs.p + ctx->search_done, it);
     }
@@ -664,14 +675,24 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
 
 NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags, float *pos_out, nw_iter_log *log, int *loopcount)
 {
+    const bool verbose = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 2;
+    const auto t0 = std::chrono::steady_clock::now();
     NW_TRY(nw_search_begin(ctx, lams, n_lams, num_iters, flags));
+    const auto t1 = std::chrono::steady_clock::now();
     for (int i = 0; i < num_iters; ++i) {
         int r = nw_iter_attract(ctx);
         if (r == NW_OK) r = nw_iter_directions(ctx);
         if (r == NW_OK) r = nw_iter_update(ctx);
         if (r != NW_OK) { ctx->in_search = false; return r; }
     }
-    return nw_search_end(ctx, pos_out, log, loopcount);
+    const auto t2 = std::chrono::steady_clock::now();
+    const int rc = nw_search_end(ctx, pos_out, log, loopcount);
+    if (verbose) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "[nanowrap] search(%d): begin %ld us, enqueue %ld us, end(sync+D2H) %ld us\n", num_iters, us(t0, t1), us(t1, t2), us(t2, t3));
+    }
+    return rc;
 }
 
 // ---- operators & read-back -------------------------------------------------------------------------------------
@@ -716,7 +737,7 @@ NW_EXPORT int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes)
     case NW_ARR_FDEF: p = ctx->fdef.p; nb = 3 * ctx->M * 4; break;
     case NW_ARR_PI: p = ctx->pi.p; nb = ctx->M * 4; break;
     case NW_ARR_VACC: p = ctx->vacc.p; nb = 4 * ctx->M * 4; break;
-    case NW_ARR_SCALARS: p = ctx->scalars.p ? ctx->scalars.p + (ctx->global_iter & 1) * NW_N_SCALARS : nullptr; nb = NW_N_SCALARS * 8; break;
+    case NW_ARR_SCALARS: p = ctx->scalars.p ? ctx->scalars.p + (ctx->global_iter & 1) * NW_SC_BLOCK : nullptr; nb = (int64_t)NW_SC_BLOCK * 8; break;
     default: return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array is not device-addressable in caller order");
     }
     if (!p) return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array not allocated yet");
@@ -757,6 +778,32 @@ NW_EXPORT int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes)
         NW_HIP(hipMemcpyAsync(dst, src, need, hipMemcpyDefault, ctx->stream));
     }
     NW_HIP(hipStreamSynchronize(ctx->stream));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes)
+{
+    if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_write_back: mesh not set");
+    if (rows && row_stride_bytes < 12) return fail(ctx, NW_ERR_BADARG, "nw_write_back: bad stride");
+    const int64_t M = ctx->M;
+    const size_t bytes = (size_t)3 * M * sizeof(float);
+    if (ctx->pin_bytes < bytes + (size_t)M) {
+        if (ctx->pin) (void)hipHostFree(ctx->pin);
+        ctx->pin = nullptr; ctx->pin_bytes = 0;
+        NW_HIP(hipHostMalloc(&ctx->pin, bytes + (size_t)M, hipHostMallocDefault));
+        ctx->pin_bytes = bytes + (size_t)M;
+    }
+    float *stage = (float *)ctx->pin;
+    unsigned char *vstage = (unsigned char *)ctx->pin + bytes;
+    NW_HIP(hipMemcpyAsync(stage, ctx->pos.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (rows && ctx->have_valid) NW_HIP(hipMemcpyAsync(vstage, ctx->valid.p, (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    if (contiguous) memcpy(contiguous, stage, bytes);
+    if (rows) {
+        char *dst = (char *)rows;
+        for (int64_t v = 0; v < M; ++v)
+            if (!ctx->have_valid || vstage[v]) memcpy(dst + v * row_stride_bytes, stage + 3 * v, 12);
+    }
     return NW_OK;
 }
 

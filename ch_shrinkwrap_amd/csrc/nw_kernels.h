@@ -134,7 +134,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_sum_f64(const float *__restrict__ 
     __shared__ double s_part[4];
     double s[1] = {0.0};
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s[0] += (double)x[i];
-    nw_block_reduce_atomic<1>(s, out, s_part);
+    nw_block_reduce_atomic<1, false>(s, out, s_part);
 }
 
 // total mesh area (sum over faces of |cross|/2) in float64: sets the centroid spacing for the grid cell size
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_mesh_area(const float *__restrict_
         const float cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
         s[0] += 0.5 * sqrt((double)cx * cx + (double)cy * cy + (double)cz * cz);
     }
-    nw_block_reduce_atomic<1>(s, out, s_part);
+    nw_block_reduce_atomic<1, false>(s, out, s_part);
 }
 
 // brute-force NN distance of a strided sample of the points against ALL face centroids (calibration of the
@@ -260,7 +260,7 @@ __global__ void k_nbr_transpose(const int *__restrict__ nbr, int M, int NB, int 
 // K1: face centroids + cell histogram.  centroid = ((v0+v1)+v2)/3 in float32 = numpy's fv[faces].mean(1)
 // (mesh_conj_grad.py:443).
 __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const float *__restrict__ pos, const int *__restrict__ faces, int F,
-                                                            float4 *__restrict__ cent_tmp, int *__restrict__ fcell, int *__restrict__ count,
+                                                            float4 *__restrict__ cent_tmp, int *__restrict__ fcell, int *__restrict__ frank, int *__restrict__ count,
                                                             int *__restrict__ ambig_count, const NwDevState *__restrict__ st, int it)
 {
     if (it >= st->stop_at) return;
@@ -276,20 +276,18 @@ __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const flo
     const int cell = nw_cell_index(g, ix, iy, iz);
     cent_tmp[f] = make_float4(x, y, z, __int_as_float(f));
     fcell[f] = cell;
-    atomicAdd(&count[cell], 1);
+    frank[f] = atomicAdd(&count[cell], 1);        // rank inside the cell: the scatter needs no second atomic
 }
 
-// K3: scatter centroids into cell order (count is decremented back to zero for the next iteration)
-__global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const float4 *__restrict__ cent_tmp, const int *__restrict__ fcell,
-                                                              const int *__restrict__ start, int *__restrict__ count, float4 *__restrict__ cent,
+// K3: scatter centroids into cell order
+__global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const float4 *__restrict__ cent_tmp, const int *__restrict__ fcell, const int *__restrict__ frank,
+                                                              const int *__restrict__ start, float4 *__restrict__ cent,
                                                               const NwDevState *__restrict__ st, int it)
 {
     if (it >= st->stop_at) return;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
-    const int c = fcell[f];
-    const int slot = start[c] + atomicSub(&count[c], 1) - 1;
-    cent[slot] = cent_tmp[f];
+    cent[start[fcell[f]] + frank[f]] = cent_tmp[f];
 }
 
 // K4a: exact nearest face centroid of every localization (replaces cKDTree build + query,
@@ -310,11 +308,11 @@ __global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const floa
 // float64 by k_nn_fixup (a handful of points per million), so the result is the float64 argmin for every point.
 #define NW_NN_AMBIG 2e-6f
 
-// segment q of stage s: rows r = q>>1 over the (W x W) (z,y) extent of the cube, e = q&1 selects the second
-// single-cell segment of interior shell rows
-__device__ __forceinline__ void nw_stage_segment(int s, int q, int x0, int y0, int z0, const NwGrid &g, int &cell_lo, int &ncells)
+// segment q of the stage that grows the covered cube from "brick +- sp" to "brick +- s" (sp < 0: nothing covered yet):
+// rows r = q>>1 over the (W x W) (z,y) extent of the new cube; rows inside the old cube's (z,y) extent contribute the two
+// x-runs left and right of it (e = q&1), all other rows one full run.  Every run is a contiguous range of fine cells.
+__device__ __forceinline__ void nw_stage_segment(int sp, int s, int q, int x0, int y0, int z0, const NwGrid &g, int &cell_lo, int &ncells)
 {
-    // the first stage (s == g.s0) covers the whole cube "brick +- s0"; later stages only the 1-cell shell they add
     const int B = g.B;
     const int W = B + 2 * s;
     const int e = q & 1, r = q >> 1;
@@ -324,12 +322,15 @@ __device__ __forceinline__ void nw_stage_segment(int s, int q, int x0, int y0, i
     ncells = 0; cell_lo = 0;
     if (y < 0 || y >= g.gy || z < 0 || z >= g.gz) return;
     int xa, xb;
-    const bool interior = (s > g.s0) && iz >= 1 && iz <= W - 2 && iy >= 1 && iy <= W - 2;
+    const int t = s - sp;                                            // shell thickness in cells
+    const bool interior = (sp >= 0) && iz >= t && iz <= W - 1 - t && iy >= t && iy <= W - 1 - t;
     if (!interior) {
         if (e) return;
         xa = x0 - s; xb = x0 + B - 1 + s;
+    } else if (e == 0) {
+        xa = x0 - s; xb = x0 - sp - 1;
     } else {
-        xa = xb = e ? (x0 + B - 1 + s) : (x0 - s);
+        xa = x0 + B + sp; xb = x0 + B - 1 + s;
     }
     xa = xa < 0 ? 0 : xa;
     xb = xb >= g.gx ? g.gx - 1 : xb;
@@ -337,6 +338,8 @@ __device__ __forceinline__ void nw_stage_segment(int s, int q, int x0, int y0, i
     cell_lo = nw_cell_index(g, xa, y, z);
     ncells = xb - xa + 1;
 }
+
+#define NW_STAGE_DOUBLE 4      // stages grow by one cell up to this margin, then double (far / background localizations)
 
 template <int TB, int CAP>
 __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
@@ -369,9 +372,9 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
     int maxS = max(max(max(x0, g.gx - (x0 + g.B)), max(y0, g.gy - (y0 + g.B))), max(z0, g.gz - (z0 + g.B)));
     if (maxS < 1) maxS = 1;
     if (maxS < g.s0) maxS = g.s0;
-    int stage = g.s0;
+    int stage = g.s0, prev = -1;
     __syncthreads();
-    for (;; ++stage) {
+    for (;;) {
         int G = 1;
         while (((G << 1) * n <= TB) && G < 64) G <<= 1;
         const int slot = tid / G, sub = tid & (G - 1);
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
                 const int q = qb + tid;
                 if (q < nq) {
                     int lo, nc;
-                    nw_stage_segment(stage, q, x0, y0, z0, g, lo, nc);
+                    nw_stage_segment(prev, stage, q, x0, y0, z0, g, lo, nc);
                     if (nc > 0) { start = cstart[lo]; len = cstart[lo + nc] - start; }
                 }
                 s_rs[tid] = start;
@@ -488,6 +491,8 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
         __syncthreads();
         n = s_n[stage & 1];
         if (n == 0) break;
+        prev = stage;
+        stage = stage < NW_STAGE_DOUBLE ? stage + 1 : min(2 * stage, maxS);
     }
     if (tid == 0 && stage > g.s0) atomicMax(&st->nn_max_ring, stage);
 }
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__res
         const int key = s_key[t >> 2];
         if (key >= 0) atomicAdd(vacc + 4 * (int64_t)key + (t & 3), s_val[t]);
     }
-    nw_block_reduce_atomic<4>(red, sc + SC_RES2, s_part);
+    nw_block_reduce_atomic<4, true>(red, sc + (int64_t)SC_RES2 * NW_REPL * NW_RSTRIDE, s_part);
 }
 
 // K5: curvature prior + search directions S0, S1 + all vertex-side dot products.  One thread per vertex;
@@ -648,21 +653,34 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
 {
     if (it >= st->stop_at) return;
     __shared__ double s_part[11 * 4];
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
     double red[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) red[k] = 0.0;
-    if (v < M) {
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < M; v += gridDim.x * blockDim.x) {
         const float4 acc = *reinterpret_cast<const float4 *>(vacc + 4 * (int64_t)v);
         const float sw = acc.w;
         const float pi = sqrtf((sw * sw + sw * sw) + sw * sw);
         const float gate = fminf(pi * pi, 1.0f);
         pi_out[v] = pi;
         if (isnan(acc.x) || isnan(acc.y) || isnan(acc.z) || isnan(sw)) atomicCAS(&st->status, 0, -3);
-        // pass 1: centroid
+        // the first 8 ring slots are fetched with independent (unrolled, predicated) loads so that their latencies
+        // overlap; valence > 8 falls through to the generic tail loops
+        int nb[8];
+        float qx[8], qy[8], qz[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) nb[s] = (s < maxdeg) ? nbr_t[(int64_t)s * M + v] : -1;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int n = nb[s] >= 0 ? nb[s] : v;
+            qx[s] = meshpos[3 * n]; qy[s] = meshpos[3 * n + 1]; qz[s] = meshpos[3 * n + 2];
+        }
+        // pass 1: centroid (float32 sum in slot order)
         float sx = 0.f, sy = 0.f, sz = 0.f;
         int ms = 0;
-        for (int s = 0; s < maxdeg; ++s) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (nb[s] >= 0) { sx += qx[s]; sy += qy[s]; sz += qz[s]; ++ms; }
+        for (int s = 8; s < maxdeg; ++s) {
             const int n = nbr_t[(int64_t)s * M + v];
             if (n >= 0) {
                 sx += meshpos[3 * n]; sy += meshpos[3 * n + 1]; sz += meshpos[3 * n + 2];
@@ -674,7 +692,23 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
             const double vcx = (double)sx / ms, vcy = (double)sy / ms, vcz = (double)sz / ms;
             const float Nx = nrm[3 * v], Ny = nrm[3 * v + 1], Nz = nrm[3 * v + 2];
             double asum = 0.0;
-            for (int s = 0; s < maxdeg; ++s) {
+            float ux[8], uy[8], uz[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int n = nb[s] >= 0 ? nb[s] : v;
+                ux[s] = nrm[3 * n]; uy[s] = nrm[3 * n + 1]; uz[s] = nrm[3 * n + 2];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (nb[s] >= 0) {
+                    const double cnx = (double)qx[s] - vcx, cny = (double)qy[s] - vcy, cnz = (double)qz[s] - vcz;
+                    const double cdot = (cnx * (double)ux[s] + cny * (double)uy[s]) + cnz * (double)uz[s];
+                    const float ndn = (ux[s] * Nx + uy[s] * Ny) + uz[s] * Nz;
+                    const float den = sqrtf(2.0f * (fmaxf(ndn, 0.0f) + 1.0f));
+                    asum += cdot / (double)den;
+                }
+            }
+            for (int s = 8; s < maxdeg; ++s) {
                 const int n = nbr_t[(int64_t)s * M + v];
                 if (n >= 0) {
                     const double cnx = (double)meshpos[3 * n] - vcx, cny = (double)meshpos[3 * n + 1] - vcy, cnz = (double)meshpos[3 * n + 2] - vcz;
@@ -714,7 +748,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
             red[10] += (double)p32 * (double)p32;
         }
     }
-    nw_block_reduce_atomic<11>(red, sc + SC_SS, s_part);
+    nw_block_reduce_atomic<11, true>(red, sc + (int64_t)SC_SS * NW_REPL * NW_RSTRIDE, s_part);
 }
 
 // K6: A.S_k for the n_search directions and the point-side normal-equation sums, never materialising AS:
@@ -760,7 +794,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
             }
         }
     }
-    nw_block_reduce_atomic<9>(red, sc + SC_HC, s_part);
+    nw_block_reduce_atomic<9, true>(red, sc + (int64_t)SC_HC * NW_REPL * NW_RSTRIDE, s_part);
 }
 
 // K7: <=3x3 regularised normal equations (every workgroup solves them redundantly from the reduced sums),
@@ -770,48 +804,62 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
 //   S[:,2] = fnew - f; f = fnew; mesh positions updated at valid vertices only (mesh_conj_grad.py:281-289).
 struct NwSolve { float c[3]; float H[9]; float G[3]; int singular; };
 
-__device__ inline void nw_solve_small(const double *__restrict__ sc, float lam, int n, NwSolve &o)
+// index of (r,c) in the packed upper triangle {00,01,02,11,12,22}
+__device__ __forceinline__ constexpr int nw_tri(int r, int c) { return r <= c ? (r == 0 ? c : (r == 1 ? 2 + c : 5)) : (c == 0 ? r : (c == 1 ? 2 + r : 5)); }
+
+// Fully unrolled (compile-time indices only -> registers, no scratch): the regularised system and its float32 LU solve.
+template <int N>
+__device__ __forceinline__ void nw_solve_small(const double *__restrict__ sc, float lam, NwSolve &o)
 {
-    static const int idx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
     const double l2 = (double)lam * (double)lam;
     float A[3][4];
-    for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float hc = (float)sc[SC_HC + idx[r][c]];
-            const float hw = (float)sc[SC_SS + idx[r][c]];
+            const float hc = (float)sc[SC_HC + nw_tri(r, c)];
+            const float hw = (float)sc[SC_SS + nw_tri(r, c)];
             const float h = (float)((double)hc + l2 * (double)hw);
             o.H[3 * r + c] = h;
             A[r][c] = h;
         }
-    for (int r = 0; r < 3; ++r) {
         const float gc = (float)sc[SC_GC + r];
         const double gw = -sc[SC_SP + r];
         const float gg = (float)((double)gc + l2 * gw);
         o.G[r] = gg;
         A[r][3] = gg;
     }
-    o.singular = 0;
-    // Gaussian elimination with partial pivoting, float32
-    for (int k = 0; k < n; ++k) {
-        int p = k;
+    bool singular = false;
+    // Gaussian elimination with partial pivoting, float32; row swaps as selects so every index stays a constant
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
         float mx = fabsf(A[k][k]);
-        for (int r = k + 1; r < n; ++r)
-            if (fabsf(A[r][k]) > mx) { mx = fabsf(A[r][k]); p = r; }
-        if (!(mx > 0.0f)) { o.singular = 1; break; }
-        if (p != k)
-            for (int c = 0; c < 4; ++c) { const float t = A[k][c]; A[k][c] = A[p][c]; A[p][c] = t; }
-        for (int r = k + 1; r < n; ++r) {
+#pragma unroll
+        for (int r = k + 1; r < N; ++r) {
+            const bool sw = fabsf(A[r][k]) > mx;
+            mx = sw ? fabsf(A[r][k]) : mx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float t = A[k][c]; A[k][c] = sw ? A[r][c] : t; A[r][c] = sw ? t : A[r][c]; }
+        }
+        singular = singular || !(mx > 0.0f);
+#pragma unroll
+        for (int r = k + 1; r < N; ++r) {
             const float l = A[r][k] / A[k][k];
+#pragma unroll
             for (int c = k; c < 4; ++c) A[r][c] = A[r][c] - l * A[k][c];
         }
     }
-    o.c[0] = o.c[1] = o.c[2] = 0.0f;
-    if (!o.singular)
-        for (int k = n - 1; k >= 0; --k) {
-            float s = A[k][3];
-            for (int c = k + 1; c < n; ++c) s = s - A[k][c] * o.c[c];
-            o.c[k] = s / A[k][k];
-        }
+    float x[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+        float sacc = A[k][3];
+#pragma unroll
+        for (int c = k + 1; c < N; ++c) sacc = sacc - A[k][c] * x[c];
+        x[k] = sacc / A[k][k];
+    }
+    o.singular = singular ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o.c[k] = singular ? 0.0f : x[k];
 }
 
 struct NwIterLogDev {   // mirrors nw_iter_log in include/nanowrap.h
@@ -821,16 +869,20 @@ struct NwIterLogDev {   // mirrors nw_iter_log in include/nanowrap.h
 
 __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int n_search, unsigned flags, const unsigned char *__restrict__ valid,
                                                           float *__restrict__ pos, float *__restrict__ meshpos, float *__restrict__ S, float *__restrict__ vacc,
-                                                          double *__restrict__ sc, double *__restrict__ sc_next, NwDevState *__restrict__ st,
+                                                          const double *__restrict__ sc_repl, double *__restrict__ sc_next, NwDevState *__restrict__ st,
                                                           NwIterLogDev *__restrict__ logrec, int it)
 {
     if (it >= st->stop_at) return;
     __shared__ NwSolve s_sol;
-    if (threadIdx.x == 0) nw_solve_small(sc, lam, n_search, s_sol);
+    __shared__ double s_sc[SC_COUNT];
+    nw_gather_scalars(sc_repl, SC_COUNT, s_sc);
+    __syncthreads();
+    const double *sc = s_sc;
+    if (threadIdx.x == 0) { if (n_search > 2) nw_solve_small<3>(sc, lam, s_sol); else nw_solve_small<2>(sc, lam, s_sol); }
     __syncthreads();
     const NwSolve sol = s_sol;
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < M && !sol.singular) {
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < M; v += gridDim.x * blockDim.x) {
+      if (!sol.singular) {
         const bool ok = valid ? valid[v] != 0 : true;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -845,8 +897,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
             pos[3 * v + c] = fn;
             if (ok) meshpos[3 * v + c] = fn;
         }
+      }
+      *reinterpret_cast<float4 *>(vacc + 4 * (int64_t)v) = make_float4(0.f, 0.f, 0.f, 0.f);   // ready for the next scatter
     }
-    if (v < M) *reinterpret_cast<float4 *>(vacc + 4 * (int64_t)v) = make_float4(0.f, 0.f, 0.f, 0.f);   // ready for the next scatter
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // logs (mesh_conj_grad.py:262-274)
         const double s00 = sc[SC_SS + 0], s01 = sc[SC_SS + 1], s11 = sc[SC_SS + 3];
@@ -856,13 +909,17 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
         L.res_norm = sqrt(sc[SC_RES2]);
         L.prefs_norm = sqrt(sc[SC_PP32]);
         double cHc = 0, cG = 0, cHwc = 0, cGw = 0;
-        static const int idx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-        for (int r = 0; r < n_search; ++r) {
-            cG += (double)sol.c[r] * sol.G[r];
-            cGw += (double)sol.c[r] * (-sc[SC_SP + r]);
-            for (int c = 0; c < n_search; ++c) {
-                cHc += (double)sol.c[r] * sol.H[3 * r + c] * sol.c[c];
-                cHwc += (double)sol.c[r] * (double)(float)sc[SC_SS + idx[r][c]] * sol.c[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (r < n_search) {
+                cG += (double)sol.c[r] * sol.G[r];
+                cGw += (double)sol.c[r] * (-sc[SC_SP + r]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < n_search) {
+                        cHc += (double)sol.c[r] * sol.H[3 * r + c] * sol.c[c];
+                        cHwc += (double)sol.c[r] * (double)(float)sc[SC_SS + nw_tri(r, c)] * sol.c[c];
+                    }
             }
         }
         L.cpred = sc[SC_C0] + cHc - cG;          // Hc/Gc alias the regularised H/G in the reference (conj_grad.py:208,223)
@@ -882,8 +939,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
         st->ntests += 1;
         if (st->ntests >= 3 && (test < b) && (b < a) && (a < 1e-6f)) st->stop_at = it + 1;
         if (st->status != 0) st->stop_at = it + 1;
-        for (int k = 0; k < SC_COUNT; ++k) sc_next[k] = 0.0;
     }
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < SC_COUNT * NW_REPL; k += blockDim.x) sc_next[(int64_t)k * NW_RSTRIDE] = 0.0;
 }
 
 // ============================================================================================================

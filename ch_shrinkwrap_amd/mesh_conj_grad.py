@@ -182,15 +182,14 @@ class ShrinkwrapMeshConjGrad(object):
         self._upload_points(sigma_inv, weights)
         num_iters = int(num_iters)
         flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP)
-        out = np.empty((self.M, 3), np.float32)
         logs = (nw.IterLog * max(num_iters, 1))()
         lc = ctypes.c_int(0)
         self._cache = {}
-        code = self._L.nw_search(self._h, nw.ptr(lams_a), lams_a.size, num_iters, flags, nw.ptr(out), logs, ctypes.byref(lc))
+        code = self._L.nw_search(self._h, nw.ptr(lams_a), lams_a.size, num_iters, flags, None, logs, ctypes.byref(lc))
         self._native.check(code)
         self._consume_logs(logs, lc.value)
         self._accumulate_stage_ms()
-        self._finish(out)
+        self._finish()
         return np.real(self.fs)
 
     def _consume_logs(self, logs, executed):
@@ -208,15 +207,19 @@ class ShrinkwrapMeshConjGrad(object):
                                        c=np.array(L.c[:]), H=np.array(L.H[:]).reshape(3, 3), G=np.array(L.G[:]),
                                        mean_dist=L.mean_dist, n_search=int(L.n_search), nn_max_ring=int(L.nn_max_ring)))
 
-    def _finish(self, out):
+    def _finish(self):
+        """write-back (mesh_conj_grad.py:288-290): one D2H into pinned memory, then the (M,3) result array and the strided
+        mesh._vertices['position'] rows (valid vertices only) are filled by the library."""
+        out = np.empty((self.M, 3), np.float32)
+        posv = self.mesh._vertices['position']
+        stride = posv.strides[0]
+        if posv.dtype == np.float32 and posv.strides[1] == 4 and stride >= 12:
+            self._native.check(self._L.nw_write_back(self._h, nw.ptr(out), ctypes.c_void_p(posv.ctypes.data), stride))
+        else:                                   # exotic vertex layout: let NumPy do the strided copy
+            self._native.check(self._L.nw_write_back(self._h, nw.ptr(out), None, 0))
+            np.copyto(posv, out, where=self._mesh_vertex_mask[:, None])
         self.fs = out
         self.f = self.fs.ravel()
-        # write-back (mesh_conj_grad.py:289-290)
-        m = self._mesh_vertex_mask
-        if self._all_valid:
-            self.mesh._vertices['position'][:] = out
-        else:
-            np.copyto(self.mesh._vertices['position'], out, where=m[:, None])
         self.mesh._initialize_curvature_vectors()
 
     # -- state the mesh reads back (_membrane_mesh.pyx:1563-1634) ----------------------------------

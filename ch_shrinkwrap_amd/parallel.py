@@ -40,8 +40,9 @@ class HipExecutor(object):
     def __init__(self, cg):
         self.cg = cg
         self.L, self.h, self.native = cg._L, cg._h, cg._native
-        self.n_point_scalars = self.L.nw_n_point_scalars()
-        self.n_scalars = 24
+        stride = self.L.nw_scalar_stride()          # doubles per slot (replicated, line-padded partial sums)
+        self.n_point_scalars = self.L.nw_n_point_scalars() * stride
+        self.n_scalars = self.L.nw_n_scalars() * stride
         self._views = {}
 
     def new_tensor(self, values):
@@ -84,15 +85,14 @@ class HipExecutor(object):
 
     def end(self):
         cg = self.cg
-        out = np.empty((cg.M, 3), np.float32)
         logs = (nw.IterLog * max(self._num_iters, 1))()
         lc = ctypes.c_int(0)
-        code = self.L.nw_search_end(self.h, nw.ptr(out), logs, ctypes.byref(lc))
+        code = self.L.nw_search_end(self.h, None, logs, ctypes.byref(lc))
         self.native.check(code)
         cg._consume_logs(logs, lc.value)
         cg._accumulate_stage_ms()
-        cg._finish(out)
-        return out
+        cg._finish()
+        return cg.fs
 
 
 def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
@@ -121,20 +121,29 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
 
 
 class TiledScene(object):
-    """Convenience front end used by bench.py: single-GPU -> plain cg.search; multi-GPU -> run_search in 'tiles' mode."""
+    """Convenience front end used by bench.py: single-GPU -> plain cg.search; multi-GPU -> run_search.
 
-    def __init__(self, cg, dist=None, mode='tiles'):
+    Stream discipline for N > 1: kernels and collectives must share ONE stream.  torch's default stream has the handle 0,
+    which the C-ABI reads as "use your own stream", so the optimiser must be constructed on a dedicated `torch.cuda.Stream`
+    (`stream=s.cuda_stream`) and that same torch stream is made current around every collective here."""
+
+    def __init__(self, cg, dist=None, mode='tiles', torch_stream=None):
         self.cg = cg
         self.dist = dist
         self.mode = mode
+        self.torch_stream = torch_stream
+        if dist is not None and torch_stream is None:
+            raise ValueError('multi-GPU runs need the torch stream the optimiser was constructed on (see class docstring)')
         self.ex = HipExecutor(cg) if dist is not None else None
 
     def search(self, data, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
         if self.dist is None:
             return self.cg.search(data, lams=lams, num_iters=num_iters, sigma_inv=sigma_inv, weights=weights, pos=pos, last_step=last_step)
+        import torch
         if type(lams) is float or np.isscalar(lams):
             lams = [float(lams)]
-        return run_search(self.ex, self.dist, self.mode, data, lams, num_iters, sigma_inv, weights, pos, last_step)
+        with torch.cuda.stream(self.torch_stream):
+            return run_search(self.ex, self.dist, self.mode, data, lams, num_iters, sigma_inv, weights, pos, last_step)
 
 
 def partition_by_tiles(points, n_ranks):

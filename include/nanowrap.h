@@ -80,7 +80,7 @@ typedef enum nw_array {
     NW_ARR_PI = 8,          /* (M,)    f32  point influence ||A^T 1||, _membrane_mesh.pyx:1625-1634              */
     NW_ARR_MESHPOS = 9,     /* (M, 3)  f32  mesh._vertices['position'] as written back at :289                   */
     NW_ARR_VACC = 10,       /* (M, 4)  f32  device-only: per-vertex accumulator {A^T res, sum w} (multi-GPU all-reduce) */
-    NW_ARR_SCALARS = 11     /* (NW_N_SCALARS,) f64 device-only: normal-equation partial sums (multi-GPU all-reduce)    */
+    NW_ARR_SCALARS = 11     /* f64 device-only: normal-equation partial sums of the current iteration (multi-GPU all-reduce), see nw_scalar_stride */
 } nw_array;
 
 #define NW_N_SCALARS 32
@@ -132,6 +132,11 @@ int nw_iter_directions(nw_ctx *ctx);
 int nw_iter_update(nw_ctx *ctx);
 int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *loopcount);
 int nw_n_point_scalars(void);
+/* NW_ARR_SCALARS layout: slot k occupies nw_scalar_stride() consecutive doubles (replicated, line-padded partial sums);
+ * all-reduce the first nw_n_point_scalars()*nw_scalar_stride() doubles ('replicated' mode) or nw_n_scalars()*nw_scalar_stride()
+ * ('tiles' mode). */
+int nw_n_scalars(void);
+int nw_scalar_stride(void);
 
 /* ---- operators & state read-back ------------------------------------------------------------------------- */
 /* y = A x   (Afunc, mesh_conj_grad.py:518-551)  x: (3M,) -> y: (3N,), with the cached weight matrix */
@@ -139,6 +144,10 @@ int nw_apply_A(nw_ctx *ctx, const float *x, float *y);
 /* z = A^T r (Ahfunc, mesh_conj_grad.py:553-588 + c_shrinkwrap_ah_helper, conj_grad_utils.c:123-167) */
 int nw_apply_At(nw_ctx *ctx, const float *r, float *z);
 int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes);
+/* The write-back of search(), mesh_conj_grad.py:288-289: copies the current estimate to `contiguous` ((M,3) float32, may be
+ * NULL) and/or into a strided host array of vertex records -- `rows` points at the first record's position field, consecutive
+ * records are `row_stride_bytes` apart (120 for PYME's vertex_t) -- touching only the valid vertices (halfedge != -1). */
+int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes);
 /* raw device pointer + byte size of a device-resident array (NW_ARR_VACC, NW_ARR_SCALARS, NW_ARR_POS, ...) */
 int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes);
 

@@ -230,3 +230,31 @@ def test_full_size_properties():
     step = (cg.S[:, :2].astype('f8') @ L['c'][:2]).reshape(-1, 3)
     assert np.allclose(cg.fs - pos0, step, atol=1e-3)
     assert np.allclose(cg.S[:, 2].reshape(-1, 3), cg.fs - pos0, atol=1e-6)
+
+
+def test_uniform_background_is_exact_and_terminates():
+    """10 % of the localizations are uniform background far from the surface (the robustness variant of SURVEY.md
+    section 8d): the staged NN walk must stay exact (geometric stage growth for far points) and finish quickly."""
+    import time
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    from oracle import nanowrap_oracle as O
+    c = synth.make_config('c3', scale=0.05, seed=5)
+    pts = c['points'].copy()
+    rng = np.random.default_rng(6)
+    nb = pts.shape[0] // 10
+    lo, hi = pts.min(0), pts.max(0)
+    pts[:nb] = rng.uniform(lo - 0.6 * (hi - lo), hi + 0.6 * (hi - lo), size=(nb, 3)).astype('f4')
+    s = 1.0 / c['sigma'].ravel()
+    mesh = TriMesh(c['vertices'], c['faces'])
+    pos0 = mesh.vertices.copy()
+    cg = CG(mesh, pts)
+    t0 = time.perf_counter()
+    cg.search(pts, lams=c['lams'], num_iters=1, sigma_inv=s)
+    dt = time.perf_counter() - t0
+    cent = O.face_centroids(pos0, mesh.faces)
+    d_ref, f_ref = O.nearest_faces(cent, pts)
+    assert np.array_equal(cg.nearest_face, f_ref)
+    assert np.allclose(cg.d[:, 0], d_ref, rtol=1e-6)
+    print('background case: N=%d (10%% background), one iteration incl. set-up %.1f ms, max stage %d' % (pts.shape[0], dt * 1e3, cg.nn_max_ring))
+    assert dt < 5.0

@@ -242,8 +242,10 @@ def test_split_phase_equals_search_on_one_gpu(mode):
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         m2 = TriMesh(v, f)
-        cg = ShrinkwrapMeshConjGrad(m2, pts, stream=torch.cuda.current_stream().cuda_stream)
-        scene = parallel.TiledScene(cg, dist, mode=mode)
+        ts = torch.cuda.Stream()
+        assert ts.cuda_stream != 0
+        cg = ShrinkwrapMeshConjGrad(m2, pts, stream=ts.cuda_stream)
+        scene = parallel.TiledScene(cg, dist, mode=mode, torch_stream=ts)
         b = scene.search(pts, [10.0], 5, s).copy()
         c = scene.search(pts, [10.0], 3, s).copy()          # second call continues from the mesh
     finally:
