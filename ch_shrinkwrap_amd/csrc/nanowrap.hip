@@ -578,16 +578,16 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
         const int nb = 8 * ((ctx->nitems + 7) / 8);
         if (ctx->nn_block == 64)
             hipLaunchKernelGGL((k_nearest_face<64, 256>), dim3(nb), dim3(64), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                               ctx->cent_tmp.p, ctx->face.p, ctx->dist.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
+                               ctx->cent_tmp.p, ctx->face.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
         else
             hipLaunchKernelGGL((k_nearest_face<256, 1024>), dim3(nb), dim3(256), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                               ctx->cent_tmp.p, ctx->face.p, ctx->dist.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
-        hipLaunchKernelGGL(k_nn_fixup, dim3(64), dim3(64), 0, ctx->stream, g, ctx->ambig_list.p, ctx->ambig_count.p, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                           ctx->face.p, ctx->dist.p, ctx->state.p, it);
+                               ctx->cent_tmp.p, ctx->face.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
+        hipLaunchKernelGGL(k_nn_fixup, dim3(512), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->ambig_list.p, ctx->ambig_count.p, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                           ctx->cent_tmp.p, ctx->face.p, ctx->state.p, it);
     }
     {
         StageScope s(ctx, ST_ATTRACT);
-        hipLaunchKernelGGL(k_attract, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts.p, ctx->face.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
+        hipLaunchKernelGGL(k_attract, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
                            ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->sinv_scalar, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->w_scalar, ctx->mask.p,
                            ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, sc, ctx->state.p, it);
     }
@@ -668,6 +668,7 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
         (void)hipMemcpy(ctx->state.p, &st2, sizeof(st2), hipMemcpyHostToDevice);
         if (code == NW_ERR_NAN) return fail(ctx, NW_ERR_NAN, "NaN detected in weight matrix / A f / A^T r (reference asserts at mesh_conj_grad.py:514,548,580)");
         if (code == NW_ERR_SINGULAR) return fail(ctx, NW_ERR_SINGULAR, "singular subspace normal equations (numpy.linalg.solve would raise LinAlgError)");
+        if (code == NW_ERR_INTERNAL) return fail(ctx, NW_ERR_INTERNAL, "internal error: the nearest-face query produced an invalid face id");
         return fail(ctx, code, "device-side error");
     }
     return NW_OK;

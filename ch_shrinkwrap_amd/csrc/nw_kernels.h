@@ -344,13 +344,16 @@ __device__ __forceinline__ void nw_stage_segment(int sp, int s, int q, int x0, i
 template <int TB, int CAP>
 __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
                                                           const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face,
-                                                          int *__restrict__ face_out, float *__restrict__ dist_out, int *__restrict__ ambig_list,
+                                                          int *__restrict__ face_out, int *__restrict__ ambig_list,
                                                           int *__restrict__ ambig_count, NwDevState *__restrict__ st, int it)
 {
     if (it >= st->stop_at) return;
     const int wi = nw_xcd_remap(blockIdx.x, nitems);
     if (wi < 0) return;
+    // staged candidates in BRICK-LOCAL coordinates, expanded form: {-2x', -2y', -2z', |c'|^2} so that
+    // |p' - c'|^2 - |p'|^2 = fma(px', X, fma(py', Y, fma(pz', Z, W))) -- three FMAs per candidate
     __shared__ float4 s_cand[CAP];
+    __shared__ int s_fid[CAP];
     __shared__ int s_rs[TB];
     __shared__ int s_ro[TB + 1];
     __shared__ int s_wtot[TB / 64];
@@ -365,7 +368,9 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
     const int brick = item.cell;
     const int Bz = brick / (g.bx * g.by), By = (brick / g.bx) % g.by, Bx = brick % g.bx;
     const int x0 = Bx * g.B, y0 = By * g.B, z0 = Bz * g.B;
-    const float blx = g.ox + x0 * g.h, bly = g.oy + y0 * g.h, blz = g.oz + z0 * g.h, bw = g.B * g.h;
+    const float bw = g.B * g.h;
+    const float blx = g.ox + x0 * g.h, bly = g.oy + y0 * g.h, blz = g.oz + z0 * g.h;
+    const float ccx = blx + 0.5f * bw, ccy = bly + 0.5f * bw, ccz = blz + 0.5f * bw;     // local origin = brick centre
     int n = item.p1 - item.p0;            // unfinished points
     if (tid < n) { s_idx[tid] = tid; s_b1[tid] = INFINITY; s_b2[tid] = INFINITY; s_bf[tid] = 0x7fffffff; }
     // the stage after which the cube covers the whole grid
@@ -376,17 +381,18 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
     __syncthreads();
     for (;;) {
         int G = 1;
-        while (((G << 1) * n <= TB) && G < 64) G <<= 1;
+        while (((G << 1) * n <= TB) && G < 64) G <<= 1;      // lanes per unfinished point
         const int slot = tid / G, sub = tid & (G - 1);
         const bool has = slot < n;
         int lidx = 0;
+        // b1/b2 hold (distance^2 - |p'|^2): the point-constant term is added back only where absolute values matter
         float b1 = INFINITY, b2 = INFINITY;
         int bf = 0x7fffffff;
         float px = 0.f, py = 0.f, pz = 0.f;
         if (has) {
             lidx = s_idx[slot];
             const float4 P = pts[item.p0 + lidx];
-            px = P.x; py = P.y; pz = P.z;
+            px = P.x - ccx; py = P.y - ccy; pz = P.z - ccz;
             if (sub == 0) { b1 = s_b1[slot]; b2 = s_b2[slot]; bf = s_bf[slot]; }
         }
         __syncthreads();                                   // everyone has read the compacted state
@@ -423,36 +429,35 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
                     int lo = 0, hi = TB;
 #pragma unroll
                     for (int stp = 0; stp < (TB == 64 ? 6 : 8); ++stp) { const int mid = (lo + hi) >> 1; if (s_ro[mid] <= ge) lo = mid; else hi = mid; }
-                    s_cand[e] = cent[s_rs[lo] + (ge - s_ro[lo])];
+                    const float4 C = cent[s_rs[lo] + (ge - s_ro[lo])];
+                    const float x = C.x - ccx, y = C.y - ccy, z = C.z - ccz;
+                    s_cand[e] = make_float4(-2.0f * x, -2.0f * y, -2.0f * z, fmaf(z, z, fmaf(y, y, x * x)));
+                    s_fid[e] = __float_as_int(C.w);
                 }
                 __syncthreads();
                 if (has) {
+                    int bi = -1;                           // LDS slot of the best candidate seen in THIS chunk
                     int c = sub;
                     for (; c + G < nc; c += 2 * G) {
                         const float4 C0 = s_cand[c];
                         const float4 C1 = s_cand[c + G];
-                        const float ax = px - C0.x, ay = py - C0.y, az = pz - C0.z;
-                        const float bx = px - C1.x, by = py - C1.y, bz = pz - C1.z;
-                        const float d0 = fmaf(az, az, fmaf(ay, ay, ax * ax));
-                        const float d1 = fmaf(bz, bz, fmaf(by, by, bx * bx));
-                        const bool l0 = d0 < b1;
-                        b2 = l0 ? b1 : fminf(b2, d0);
-                        bf = l0 ? __float_as_int(C0.w) : bf;
-                        b1 = l0 ? d0 : b1;
-                        const bool l1 = d1 < b1;
-                        b2 = l1 ? b1 : fminf(b2, d1);
-                        bf = l1 ? __float_as_int(C1.w) : bf;
-                        b1 = l1 ? d1 : b1;
+                        const float d0 = fmaf(px, C0.x, fmaf(py, C0.y, fmaf(pz, C0.z, C0.w)));
+                        const float d1 = fmaf(px, C1.x, fmaf(py, C1.y, fmaf(pz, C1.z, C1.w)));
+                        bi = d0 < b1 ? c : bi;
+                        b2 = __builtin_amdgcn_fmed3f(b1, b2, d0);      // b1 <= b2: the runner-up is the median of {b1, b2, d}
+                        b1 = fminf(b1, d0);
+                        bi = d1 < b1 ? c + G : bi;
+                        b2 = __builtin_amdgcn_fmed3f(b1, b2, d1);
+                        b1 = fminf(b1, d1);
                     }
                     if (c < nc) {
                         const float4 C0 = s_cand[c];
-                        const float ax = px - C0.x, ay = py - C0.y, az = pz - C0.z;
-                        const float d0 = fmaf(az, az, fmaf(ay, ay, ax * ax));
-                        const bool l0 = d0 < b1;
-                        b2 = l0 ? b1 : fminf(b2, d0);
-                        bf = l0 ? __float_as_int(C0.w) : bf;
-                        b1 = l0 ? d0 : b1;
+                        const float d0 = fmaf(px, C0.x, fmaf(py, C0.y, fmaf(pz, C0.z, C0.w)));
+                        bi = d0 < b1 ? c : bi;
+                        b2 = __builtin_amdgcn_fmed3f(b1, b2, d0);
+                        b1 = fminf(b1, d0);
                     }
+                    if (bi >= 0) bf = s_fid[bi];
                 }
                 __syncthreads();
             }
@@ -471,17 +476,19 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
         __syncthreads();
         bool fin = false;
         if (has && sub == 0) {
-            const float m = fmaxf(fminf(fminf(fminf(px - blx, blx + bw - px), fminf(py - bly, bly + bw - py)), fminf(pz - blz, blz + bw - pz)), 0.0f);
+            const float hb = 0.5f * bw;
+            const float m = fmaxf(fminf(fminf(hb - fabsf(px), hb - fabsf(py)), hb - fabsf(pz)), 0.0f);     // distance to the brick wall
             const float bound = (float)stage * g.h + m - g.eps;
-            fin = (stage >= maxS) || (bound > 0.0f && b1 <= bound * bound * 0.999999f);
+            const float pn = fmaf(pz, pz, fmaf(py, py, px * px));
+            // float32 error of the expanded form: < 4 ulp of the largest intermediate, |coordinates| <= Rc
+            const float Rc = hb + (float)stage * g.h + g.eps;
+            const float tol = 6e-6f * Rc * Rc;
+            fin = (stage >= maxS) || (bound > 0.0f && (b1 + pn) + tol <= bound * bound);
             if (fin) {
                 const int gi = item.p0 + lidx;
-                face_out[gi] = bf;
-                // distance to the winner in float64 (the reference's dmean is the float64 Euclidean distance)
-                const float4 C = cent_by_face[bf];
-                const double ddx = (double)px - (double)C.x, ddy = (double)py - (double)C.y, ddz = (double)pz - (double)C.z;
-                dist_out[gi] = (float)sqrt(fma(ddz, ddz, fma(ddy, ddy, ddx * ddx)));
-                if (b2 <= b1 * (1.0f + NW_NN_AMBIG)) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
+                face_out[gi] = bf;          // the float64 distance to the winner is taken by k_attract
+                // runner-up within the float32 error band -> exact float64 re-resolution (k_nn_fixup)
+                if (b2 - b1 <= 2.0f * tol + NW_NN_AMBIG * (b1 + pn)) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
             } else {
                 const int k = atomicAdd(&s_n[stage & 1], 1);
                 // safe: all threads loaded their slot state before the stage's first barrier
@@ -497,36 +504,63 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
     if (tid == 0 && stage > g.s0) atomicMax(&st->nn_max_ring, stage);
 }
 
-// exact float64 re-resolution of the ambiguous points (runner-up within 2e-6 of the best in float32): one wave per
-// point scans every fine cell that intersects the ball of radius dist*(1+1e-5)+eps around it, lowest face id on ties.
-__global__ __launch_bounds__(64) void k_nn_fixup(NwGrid g, const int *__restrict__ ambig_list, const int *__restrict__ ambig_count, const float4 *__restrict__ pts,
-                                                const int *__restrict__ cstart, const float4 *__restrict__ cent, int *__restrict__ face_out,
-                                                float *__restrict__ dist_out, const NwDevState *__restrict__ st, int it)
+// exact float64 re-resolution of the ambiguous points (runner-up inside the float32 error band of the best): one
+// workgroup per point.  Phase 1: every fine cell of the box around the ball of radius dist*(1+1e-4)+eps gets a thread that
+// fetches its candidate range; a block scan lays the ranges end to end.  Phase 2: the candidates are spread over the
+// threads (binary search in the scanned offsets), evaluated in float64, and reduced (lowest face id on exact ties).
+__global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__restrict__ ambig_list, const int *__restrict__ ambig_count, const float4 *__restrict__ pts,
+                                                      const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face,
+                                                      int *__restrict__ face_out, const NwDevState *__restrict__ st, int it)
 {
     if (it >= st->stop_at) return;
+    __shared__ int s_rs[NW_BLOCK];
+    __shared__ int s_ro[NW_BLOCK + 1];
+    __shared__ int s_wtot[4];
+    __shared__ double s_bd[4];
+    __shared__ int s_bfid[4];
     const int na = *ambig_count;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int a = blockIdx.x; a < na; a += gridDim.x) {
         const int gi = ambig_list[a];
         const float4 P = pts[gi];
-        const float r = dist_out[gi] * (1.0f + 1e-5f) + g.eps;
+        const float4 C0 = cent_by_face[face_out[gi]];
+        const float r = sqrtf((P.x - C0.x) * (P.x - C0.x) + (P.y - C0.y) * (P.y - C0.y) + (P.z - C0.z) * (P.z - C0.z)) * (1.0f + 1e-4f) + g.eps;
         int lx, ly, lz, hx, hy, hz;
         nw_cell_coords(g, P.x - r, P.y - r, P.z - r, lx, ly, lz);
         nw_cell_coords(g, P.x + r, P.y + r, P.z + r, hx, hy, hz);
-        const int nrow = (hy - ly + 1) * (hz - lz + 1);
+        const int ny = hy - ly + 1, nrow = ny * (hz - lz + 1);
         double best = INFINITY;
         int bf = 0x7fffffff;
-        for (int rr = lane; rr < nrow; rr += 64) {
-            const int y = ly + rr % (hy - ly + 1), z = lz + rr / (hy - ly + 1);
-            const int c0 = nw_cell_index(g, lx, y, z);
-            const int s = cstart[c0], e = cstart[c0 + (hx - lx) + 1];
-            for (int k = s; k < e; ++k) {
-                const float4 C = cent[k];
+        for (int rb = 0; rb < nrow; rb += NW_BLOCK) {
+            int start = 0, len = 0;
+            const int rr = rb + tid;
+            if (rr < nrow) {
+                const int z = lz + rr / ny, y = ly + rr % ny;
+                const int c0 = nw_cell_index(g, lx, y, z);
+                start = cstart[c0];
+                len = cstart[c0 + (hx - lx) + 1] - start;
+            }
+            s_rs[tid] = start;
+            const int inc = nw_wave_incl_scan(len, lane);
+            if (lane == 63) s_wtot[wv] = inc;
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wv; ++w) woff += s_wtot[w];
+            s_ro[tid + 1] = woff + inc;
+            if (tid == 0) s_ro[0] = 0;
+            __syncthreads();
+            const int total = s_ro[NW_BLOCK];
+            for (int e = tid; e < total; e += NW_BLOCK) {
+                int lo = 0, hi = NW_BLOCK;
+#pragma unroll
+                for (int stp = 0; stp < 8; ++stp) { const int mid = (lo + hi) >> 1; if (s_ro[mid] <= e) lo = mid; else hi = mid; }
+                const float4 C = cent[s_rs[lo] + (e - s_ro[lo])];
                 const double dx = (double)P.x - (double)C.x, dy = (double)P.y - (double)C.y, dz = (double)P.z - (double)C.z;
                 const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
                 const int fid = __float_as_int(C.w);
                 if (d2 < best || (d2 == best && fid < bf)) { best = d2; bf = fid; }
             }
+            __syncthreads();
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -534,7 +568,14 @@ __global__ __launch_bounds__(64) void k_nn_fixup(NwGrid g, const int *__restrict
             const int of = __shfl_xor(bf, off, 64);
             if (od < best || (od == best && of < bf)) { best = od; bf = of; }
         }
-        if (lane == 0) { face_out[gi] = bf; dist_out[gi] = (float)sqrt(best); }
+        if (lane == 0) { s_bd[wv] = best; s_bfid[wv] = bf; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (s_bd[w] < best || (s_bd[w] == best && s_bfid[w] < bf)) { best = s_bd[w]; bf = s_bfid[w]; }
+            face_out[gi] = bf;
+        }
+        __syncthreads();
     }
 }
 
@@ -552,7 +593,7 @@ __global__ __launch_bounds__(64) void k_nn_fixup(NwGrid g, const int *__restrict
 // scattered single-dword atomics run ~17x below the contiguous rate).
 #define NW_HT 1024
 
-__global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__restrict__ pts, const int *__restrict__ face, const float *__restrict__ dist,
+__global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4 *__restrict__ pts, const int *__restrict__ face, const float4 *__restrict__ cent_by_face, float *__restrict__ dist,
                                                      const int *__restrict__ faces, const float *__restrict__ pos,
                                                      const float *__restrict__ sinv, float sinv_scalar, const float *__restrict__ wnorm, float w_scalar,
                                                      const unsigned char *__restrict__ mask,
@@ -568,9 +609,13 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__res
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double red[4] = {0.0, 0.0, 0.0, 0.0};
-    if (i < N) {
+    const int f_raw = i < N ? face[i] : 0;
+    // a face id outside [0, F) can only come from a bug in the NN query: never dereference it (a faulting kernel can
+    // take the whole node down), raise the internal-error status instead
+    if (i < N && (unsigned)f_raw >= (unsigned)F) atomicCAS(&st->status, 0, -7 /* NW_ERR_INTERNAL */);
+    if (i < N && (unsigned)f_raw < (unsigned)F) {
         const float4 P = pts[i];
-        const int f = face[i];
+        const int f = f_raw;
         const float p[3] = {P.x, P.y, P.z};
         int v[3];
         float w[3], fv[3][3];
@@ -592,7 +637,14 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__res
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < 3; ++j) { w[j] = w[j] / wsum; bad |= isnan(w[j]); }
-        const float d = dist[i];
+        // dmean: float64 Euclidean distance to the nearest centroid (what cKDTree returns), rounded once to float32
+        float d;
+        {
+            const float4 C = cent_by_face[f];
+            const double ddx = (double)P.x - (double)C.x, ddy = (double)P.y - (double)C.y, ddz = (double)P.z - (double)C.z;
+            d = (float)sqrt(fma(ddz, ddz, fma(ddy, ddy, ddx * ddx)));
+            dist[i] = d;
+        }
         const unsigned m = mask[i];
         float r[3];
 #pragma unroll

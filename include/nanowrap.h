@@ -33,7 +33,8 @@ typedef enum nw_status {
     NW_ERR_NAN = -3,         /* NaN detected where the reference asserts: mesh_conj_grad.py:514,548,580 */
     NW_ERR_SINGULAR = -4,    /* subspace normal equations singular: numpy.linalg.solve raises LinAlgError, conj_grad.py:219 */
     NW_ERR_NONFINITE = -5,   /* non-finite localization or vertex coordinate (cKDTree cannot index it) */
-    NW_ERR_NOMEM = -6
+    NW_ERR_NOMEM = -6,
+    NW_ERR_INTERNAL = -7     /* invariant violated inside the library (reported instead of risking a GPU fault) */
 } nw_status;
 
 /* how the residual weights are given -- mirrors `search(..., weights=None, sigma_inv=1.0)`,
