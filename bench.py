@@ -93,9 +93,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the NanoWrap hot path has no CPU fallback')
+    # rehearsal hook: NW_BENCH_BACKEND=gloo lets several ranks share the one GPU of a development box (RCCL refuses duplicate
+    # devices); the driver's multi-GPU runs use the default, nccl (= RCCL) with one GPU per rank
+    backend = os.environ.get('NW_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = min(local_rank, torch.cuda.device_count() - 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from ch_shrinkwrap_amd import synth
     from ch_shrinkwrap_amd.trimesh import TriMesh

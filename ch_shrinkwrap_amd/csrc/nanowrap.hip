@@ -140,13 +140,13 @@ int fail(nw_ctx *c, int code, const std::string &msg)
 
 inline int nblk(int64_t n, int b = NW_BLOCK) { return (int)((n + b - 1) / b); }
 
-int scan_exclusive(nw_ctx *ctx, const int *in, int n, int *out)
+int scan_exclusive(nw_ctx *ctx, int *in, int n, int *out, bool zero_input = false)
 {
     const int nb = (n + NW_SCAN_TILE - 1) / NW_SCAN_TILE;
     NW_HIP(ctx->scan_tmp.ensure((size_t)nb + 1));
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, in, n, ctx->scan_tmp.p);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, ctx->stream, ctx->scan_tmp.p, nb);
-    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, in, n, ctx->scan_tmp.p, out);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, in, n, ctx->scan_tmp.p, out, zero_input ? 1 : 0);
     NW_HIP(hipGetLastError());
     return NW_OK;
 }
@@ -568,10 +568,9 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
         StageScope s(ctx, ST_GRID);
         hipLaunchKernelGGL(k_face_centroids, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pos.p, ctx->faces.p, (int)F,
                            ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->ccount.p, ctx->ambig_count.p, ctx->state.p, it);
-        NW_TRY(scan_exclusive(ctx, ctx->ccount.p, g.ncell, ctx->cstart.p));
+        NW_TRY(scan_exclusive(ctx, ctx->ccount.p, g.ncell, ctx->cstart.p, true));      // also re-zeroes the histogram
         hipLaunchKernelGGL(k_centroid_scatter, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, (int)F, ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->cstart.p,
                            ctx->cent.p, ctx->state.p, it);
-        NW_HIP(hipMemsetAsync(ctx->ccount.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));   // histogram ready for the next iteration
     }
     {
         StageScope s(ctx, ST_NN);

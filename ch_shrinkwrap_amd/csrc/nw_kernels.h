@@ -75,7 +75,7 @@ __global__ __launch_bounds__(1024) void k_scan_bsums(int *__restrict__ bsum, int
     }
 }
 
-__global__ __launch_bounds__(NW_BLOCK) void k_scan_final(const int *__restrict__ in, int n, const int *__restrict__ bsum, int *__restrict__ out)
+__global__ __launch_bounds__(NW_BLOCK) void k_scan_final(int *__restrict__ in, int n, const int *__restrict__ bsum, int *__restrict__ out, int zero_input)
 {
     __shared__ int s_w[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -84,6 +84,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_scan_final(const int *__restrict__
     int s = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    if (zero_input)          // the histogram is consumed: leave it zeroed for the next iteration (saves a memset launch)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (base + k < n) in[base + k] = 0;
     const int inc = nw_wave_incl_scan(s, lane);
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
