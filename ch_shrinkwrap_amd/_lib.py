@@ -19,7 +19,7 @@ NW_N_SCALARS = 32
 
 # every symbol include/nanowrap.h declares (tests/test_abi.py checks the exports against the header)
 SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set_stream', 'nw_synchronize',
-           'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_search', 'nw_search_begin',
+           'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_refresh_normals', 'nw_reset_history', 'nw_search', 'nw_search_begin',
            'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
            'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms']
 
@@ -56,6 +56,8 @@ def load():
     L.nw_set_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32]
     L.nw_set_normals.argtypes = [vp, vp]
     L.nw_set_positions.argtypes = [vp, vp]
+    L.nw_refresh_normals.argtypes = [vp, vp]
+    L.nw_reset_history.argtypes = [vp]
     L.nw_search.argtypes = [vp, vp, i32, i32, u32, vp, ctypes.POINTER(IterLog), ctypes.POINTER(i32)]
     L.nw_search_begin.argtypes = [vp, vp, i32, i32, u32]
     L.nw_iter_attract.argtypes = [vp]

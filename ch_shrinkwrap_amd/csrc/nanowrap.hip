@@ -520,6 +520,32 @@ NW_EXPORT int nw_set_normals(nw_ctx *ctx, const float *nrm)
     return NW_OK;
 }
 
+NW_EXPORT int nw_refresh_normals(nw_ctx *ctx, float *nrm_out)
+{
+    if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_refresh_normals: mesh not set");
+    NW_HIP(hipSetDevice(ctx->device));
+    NW_HIP(ctx->tmp_f.ensure(3 * ctx->M));
+    NW_HIP(hipMemsetAsync(ctx->tmp_f.p, 0, 3 * ctx->M * sizeof(float), ctx->stream));
+    hipLaunchKernelGGL(k_normals_scatter, dim3(nblk(ctx->F)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->F, ctx->faces.p, ctx->meshpos.p, ctx->tmp_f.p);
+    hipLaunchKernelGGL(k_normals_finish, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->tmp_f.p, ctx->nrm.p);
+    NW_HIP(hipGetLastError());
+    if (nrm_out) NW_HIP(hipMemcpyAsync(nrm_out, ctx->nrm.p, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_reset_history(nw_ctx *ctx)
+{
+    if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_reset_history: mesh not set");
+    if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_reset_history inside a search");
+    NwDevState st{};
+    st.stop_at = 0x7fffffff;
+    NW_HIP(hipMemcpyAsync(ctx->state.p, &st, sizeof(st), hipMemcpyHostToDevice, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->global_iter = 0;
+    return NW_OK;
+}
+
 NW_EXPORT int nw_set_positions(nw_ctx *ctx, const float *pos)
 {
     if (!ctx || !pos || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_positions: mesh not set");

@@ -1043,6 +1043,40 @@ __global__ void k_unpermute(int N, int width, const int *__restrict__ perm, cons
     out[(int64_t)perm[i] * width + k] = in[t];
 }
 
+// ---- block-boundary geometry refresh (the reference's `self.face_normals; self.vertex_neighbors` after a block,
+// _membrane_mesh.pyx:1524-1527, for an unchanged topology): area-weighted vertex normals from the CURRENT device positions.
+// Definition (this build's, PYME's is unpinned -- trimesh.py): n_v = normalise( sum over incident faces of
+// (v1-v0) x (v2-v0) ), zero for vertices without faces.  Faces scatter with float atomics, vertices normalise.
+__global__ __launch_bounds__(NW_BLOCK) void k_normals_scatter(int F, const int *__restrict__ faces, const float *__restrict__ pos, float *__restrict__ acc)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+    const float ax = pos[3 * a], ay = pos[3 * a + 1], az = pos[3 * a + 2];
+    const float ux = pos[3 * b] - ax, uy = pos[3 * b + 1] - ay, uz = pos[3 * b + 2] - az;
+    const float vx = pos[3 * c] - ax, vy = pos[3 * c + 1] - ay, vz = pos[3 * c + 2] - az;
+    const float cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+    const int vv[3] = {a, b, c};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        atomicAdd(&acc[3 * vv[k]], cx);
+        atomicAdd(&acc[3 * vv[k] + 1], cy);
+        atomicAdd(&acc[3 * vv[k] + 2], cz);
+    }
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_normals_finish(int M, const float *__restrict__ acc, float *__restrict__ nrm)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M) return;
+    const double x = acc[3 * v], y = acc[3 * v + 1], z = acc[3 * v + 2];
+    const double l = sqrt(x * x + y * y + z * z);
+    const bool ok = l > 0.0 && isfinite(l);
+    nrm[3 * v] = ok ? (float)(x / l) : 0.0f;
+    nrm[3 * v + 1] = ok ? (float)(y / l) : 0.0f;
+    nrm[3 * v + 2] = ok ? (float)(z / l) : 0.0f;
+}
+
 // alternate regularisers (gather forms are one thread per vertex; the scatter forms use float atomics except
 // kind 1, whose in-place division makes it order dependent and is run by a single thread to keep the
 // reference's serial semantics).

@@ -112,6 +112,7 @@ class MembraneMesh(TriMesh):
         valid = np.ascontiguousarray(self._vertices['halfedge'] != -1, 'u1')
         faces = np.ascontiguousarray(self.faces, 'i4')
         nat.check(nat.L.nw_set_mesh(nat.h, nw.ptr(pos), nw.ptr(nrm), nw.ptr(nbr), nw.ptr(valid), nw.ptr(faces), M, faces.shape[0], nbr.shape[1]))
+        nat.mesh_key = None                                 # uploaded outside an optimiser: do not assume it is reusable
         nxt, area = self._neighbor_tables()
         jit = None if jitter is None else np.ascontiguousarray(jitter, 'f8')
         self._initialize_curvature_vectors()
@@ -205,15 +206,19 @@ class MembraneMesh(TriMesh):
             self._native = NativeContext(self._device)      # localizations stay in HBM across blocks
 
         while j < n_iter:
-            # a new optimiser per block (:1510-1512); it re-uploads the mesh, the localizations are already resident
+            # a new optimiser per block (:1510-1512).  The localizations stay resident in HBM; while the topology is unchanged
+            # the mesh does too (positions and device-refreshed normals are already current) and only the history restarts
             self.cg = ShrinkwrapMeshConjGrad(self, points, search_k=self.search_k, search_rad=self.search_rad,
-                                             shield_sigma=self._mean_edge_length / 2.0, native=self._native)
+                                             shield_sigma=self._mean_edge_length / 2.0, native=self._native,
+                                             reuse_device_mesh=True)
             n_it = min(n_iter - j, rf)
             self.cg.search(points, lams=lams, num_iters=n_it, sigma_inv=s, weights=weights)   # :1516-1517
             j += n_it
 
-            # :1524-1527 -- face normals / vertex normals / neighbours refreshed from the new positions
-            self.update_geometry()
+            # :1524-1527 -- face normals / vertex normals / neighbours refreshed from the new positions: vertex normals on
+            # the device (they feed the next block's curvature prior), face areas / edge lengths on the host
+            self.cg.refresh_normals()
+            self.update_geometry(vertex_normals=False)
 
             if dr and ((j % self.delaunay_remesh_frequency) == 0) and self.hole_puncher is not None:   # :1530-1532
                 self.hole_puncher(self, points, self.delaunay_eps)
@@ -226,6 +231,7 @@ class MembraneMesh(TriMesh):
                 target_length = (initial_length + m * (j + 1))                           # :1544
                 if self.remesh(5, target_length, 0.5, n_relax=0):
                     self.cg = None
+                    self._native.mesh_key = None            # topology changed: the next optimiser uploads the new mesh
                 self.block_log.append(dict(iteration=j, target_length=float(target_length), mean_length=float(self._mean_edge_length)))
 
             area = self.area()                                                           # :1552-1558 (convergence break disabled upstream)

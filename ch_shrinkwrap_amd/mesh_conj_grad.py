@@ -67,7 +67,7 @@ class ShrinkwrapMeshConjGrad(object):
     """MI355X-native counterpart of ch_shrinkwrap.mesh_conj_grad.ShrinkwrapMeshConjGrad (mesh_conj_grad.py:20)."""
 
     def __init__(self, mesh, points, sigma=None, search_k=200, search_rad=100, shield_sigma=None, use_octree=False,
-                 device=0, native=None, stream=None):
+                 device=0, native=None, stream=None, reuse_device_mesh=False):
         # TikhonovConjugateGradient.__init__ (conj_grad.py:35-43)
         self.tests, self.ress, self.prefs = [], [], []
         self.Lfuncs, self.Lhfuncs = ["I"], ["I"]            # mesh_conj_grad.py:38
@@ -98,7 +98,14 @@ class ShrinkwrapMeshConjGrad(object):
         self._L = self._native.L
         self._h = self._native.h
         self.points = points
-        self._upload_mesh()
+        topo = (id(mesh), self.M, int(np.asarray(self.faces).shape[0]), self.vertex_neighbors.shape[1])
+        if reuse_device_mesh and getattr(self._native, 'mesh_key', None) == topo:
+            # same mesh object, same topology, positions/normals already current on the device (refresh_normals()):
+            # a new optimiser only restarts the logs and the stop-condition history
+            self._native.check(self._L.nw_reset_history(self._h))
+        else:
+            self._upload_mesh()
+            self._native.mesh_key = topo
         self._weights_key = None
         self._cache = {}
         self.fs = None
@@ -317,6 +324,14 @@ class ShrinkwrapMeshConjGrad(object):
             return False
         a, b, c = self.tests[-3:]
         return (c < b) and (b < a) and (a < 1e-6)
+
+    def refresh_normals(self):
+        """Block-boundary refresh for an unchanged topology (_membrane_mesh.pyx:1524-1527) on the device: vertex normals are
+        recomputed from the device-resident positions, kept in HBM for the next block and written to mesh.vertex_normals."""
+        nrm = np.empty((self.M, 3), np.float32)
+        self._native.check(self._L.nw_refresh_normals(self._h, nw.ptr(nrm)))
+        self.mesh._vertices['normal'][:] = nrm
+        return nrm
 
     # -- timing hooks for bench.py ------------------------------------------------------------------
     def set_profiling(self, on=True):

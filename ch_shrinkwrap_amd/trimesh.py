@@ -210,9 +210,9 @@ class TriMesh(object):
         self._vertices['component'] = 0
 
     # -- geometry ---------------------------------------------------------------------------
-    def update_geometry(self):
-        """Face normals/areas, half-edge lengths and vertex normals from the current positions.
-        This is the block-boundary refresh the reference triggers at _membrane_mesh.pyx:1524-1527."""
+    def update_geometry(self, vertex_normals=True):
+        """Face normals/areas, half-edge lengths and (unless they were refreshed on the device) vertex normals from the
+        current positions.  This is the block-boundary refresh the reference triggers at _membrane_mesh.pyx:1524-1527."""
         pos = self._vertices['position']
         f = self._faces_arr
         v0, v1, v2 = pos[f[:, 0]], pos[f[:, 1]], pos[f[:, 2]]
@@ -223,6 +223,11 @@ class TriMesh(object):
         fn[~np.isfinite(fn)] = 0
         self._faces['normal'] = fn
         self._faces['area'] = 0.5 * nrm
+        he = self._halfedges
+        d = pos[he['vertex']] - pos[self._origin]
+        he['length'] = np.sqrt((d * d).sum(1))
+        if not vertex_normals:
+            return
         vn = np.zeros((pos.shape[0], 3), 'f8')
         fi = f.T.ravel()                                     # corner-major: all corner-0 ids, then corner-1, corner-2
         for c in range(3):
@@ -232,9 +237,6 @@ class TriMesh(object):
             vn = vn / l[:, None]
         vn[~np.isfinite(vn)] = 0
         self._vertices['normal'] = vn.astype('f4')
-        he = self._halfedges
-        d = pos[he['vertex']] - pos[self._origin]
-        he['length'] = np.sqrt((d * d).sum(1))
 
     # -- PYME-like attribute surface --------------------------------------------------------
     @property

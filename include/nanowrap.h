@@ -112,6 +112,12 @@ int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const int32_t *
 /* cheap refresh between blocks with unchanged topology (_membrane_mesh.pyx:1524-1527) */
 int nw_set_normals(nw_ctx *ctx, const float *nrm);
 int nw_set_positions(nw_ctx *ctx, const float *pos);
+/* The same refresh done ON the device for an unchanged topology: area-weighted vertex normals recomputed from the current
+ * device-resident positions (no upload); nrm_out (M,3) receives a copy unless NULL. */
+int nw_refresh_normals(nw_ctx *ctx, float *nrm_out);
+/* Start a new optimiser on the resident mesh + localizations: what constructing a new ShrinkwrapMeshConjGrad per block does
+ * to the logs and the stop-condition history (_membrane_mesh.pyx:1510, conj_grad.py:35-39), without re-uploading anything. */
+int nw_reset_history(nw_ctx *ctx);
 
 /* ---- the hot path -------------------------------------------------------------------------------------- */
 /* `num_iters` iterations of ShrinkwrapMeshConjGrad.search (mesh_conj_grad.py:150-292), device resident.

@@ -13,6 +13,7 @@ from ch_shrinkwrap_amd.trimesh import icosphere, geodesic_sphere, TriMesh
 
 class _Recorder(object):
     calls = []
+    refreshes = 0
 
     def __init__(self, mesh, points, **kw):
         self.mesh, self.kw = mesh, kw
@@ -21,12 +22,19 @@ class _Recorder(object):
         _Recorder.calls.append(dict(lams=list(lams), num_iters=num_iters, sigma_inv=sigma_inv, weights=weights, kw=self.kw))
         return self.mesh.vertices
 
+    def refresh_normals(self):
+        _Recorder.refreshes += 1
+
 
 @pytest.fixture
 def recorder(monkeypatch):
     _Recorder.calls = []
+    _Recorder.refreshes = 0
     monkeypatch.setattr(mm, 'ShrinkwrapMeshConjGrad', _Recorder)
-    monkeypatch.setattr(mm, 'NativeContext', lambda device=0: object())
+
+    class _Native(object):
+        mesh_key = None
+    monkeypatch.setattr(mm, 'NativeContext', lambda device=0: _Native())
     return _Recorder
 
 
@@ -44,6 +52,8 @@ def test_block_schedule_and_lambda(recorder):
     its = [c['num_iters'] for c in recorder.calls]
     assert its == [5] * 7 + [4]                                     # blocks of remesh_frequency, last one truncated
     assert all(c['lams'] == [10.0] for c in recorder.calls)         # step_size*kc/2  (_membrane_mesh.pyx:1486)
+    assert recorder.refreshes == 8                                  # normals refreshed after every block (:1524-1527)
+    assert all(c['kw']['reuse_device_mesh'] for c in recorder.calls)
     assert np.allclose(recorder.calls[0]['sigma_inv'], 0.1) and recorder.calls[0]['sigma_inv'].shape == (21,)
     assert recorder.calls[0]['kw']['shield_sigma'] == pytest.approx(m._mean_edge_length / 2.0)
     # remesh target-length schedule (:1443-1455, :1544): linear from the initial mean edge length to minimum_edge_length
@@ -120,3 +130,32 @@ def test_two_blocks_against_oracle():
     assert m.S0.shape == m.vertices.shape and np.isfinite(m.point_dis).all() and np.isfinite(m.rms_point_sc).all()
     pi = m.point_influence
     assert np.allclose(pi, m.cg.point_influence, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_device_normal_refresh_matches_host_definition():
+    """Row f1: the block-boundary vertex-normal refresh on the device (nw_refresh_normals) against the host definition
+    (trimesh.TriMesh.update_geometry), and a new optimiser re-using the resident mesh restarts its history."""
+    from ch_shrinkwrap_amd import synth
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad, NativeContext
+    v, f = geodesic_sphere(10, 100.0)
+    pts = synth.sphere_cloud(8000, 90.0, 5.0, seed=1)
+    s = 1.0 / np.full(pts.size, 5.0, 'f4')
+    mesh = TriMesh(v, f)
+    nat = NativeContext(0)
+    cg = ShrinkwrapMeshConjGrad(mesh, pts, native=nat, reuse_device_mesh=True)
+    cg.search(pts, lams=[10.0], num_iters=3, sigma_inv=s)
+    dev = cg.refresh_normals().copy()
+    assert np.array_equal(mesh.vertex_normals, dev)
+    mesh.update_geometry()                                   # host definition on the same (written-back) positions
+    assert np.abs(mesh.vertex_normals - dev).max() < 2e-5
+    mesh._vertices['normal'][:] = dev
+    cg2 = ShrinkwrapMeshConjGrad(mesh, pts, native=nat, reuse_device_mesh=True)     # no mesh upload, history restarted
+    out = cg2.search(pts, lams=[10.0], num_iters=2, sigma_inv=s)
+    assert len(cg2.tests) == 2 and cg2.loopcount == 2
+    # same as a fresh context fed the same arrays
+    mesh3 = TriMesh(v, f)
+    mesh3._vertices['position'][:] = cg.fs
+    mesh3._vertices['normal'][:] = dev
+    out3 = ShrinkwrapMeshConjGrad(mesh3, pts).search(pts, lams=[10.0], num_iters=2, sigma_inv=s)
+    assert rel_rms(out, out3) <= 1e-6
