@@ -140,13 +140,20 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(args.warmup)
-    cg.set_profiling(True)
+    # timed region: HIP events only around the dominant kernel (the NN query); every event pair serialises the stream for a few
+    # microseconds, so the full per-stage breakdown is taken in a short extra pass AFTER the timed region
+    cg.set_profiling(1)
     fence()
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    stage = cg.stage_ms_total
+    nn_ms, nn_launches = cg.stage_ms_total['nn']
+    cg.set_profiling(2)
+    run_steps(2 * BLOCK)
+    fence()
+    stage = dict(cg.stage_ms_total)
+    n_extra = max(stage['update'][1], 1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,9 +168,12 @@ def main():
         per_kernel, per_iter = algorithmic_bytes(N, M, F)
         # dominant kernel by device time, from HIP events recorded around each launch on the library's stream
         kern = {'nn': 'k_nearest_face', 'attract': 'k_attract', 'as': 'k_subspace_point_sums', 'prior': 'k_prior_directions',
-                'update': 'k_solve_update', 'grid': 'grid_build'}
-        dom = max((k for k in kern), key=lambda k: stage[k][0])
-        ms_tot, launches = stage[dom]
+                'update': 'k_solve_update'}          # single-kernel stages (grid build and the NN fix-up are reported in stage_ms_per_iter)
+        dom = max((k for k in kern), key=lambda k: stage[k][0] / max(stage[k][1], 1))
+        if dom == 'nn':
+            ms_tot, launches = nn_ms, nn_launches            # measured live over the timed region
+        else:
+            ms_tot, launches = stage[dom]                    # (extra pass: the NN query is no longer the dominant kernel)
         avg_ms = ms_tot / max(launches, 1)
         achieved = per_kernel[kern[dom]] / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -194,10 +204,10 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': kern[dom], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': per_kernel[kern[dom]], 'avg_launch_ms': avg_ms, 'launches': launches},
-            'roofline_iteration': {'algorithmic_bytes': per_iter, 'device_ms': stage['total'][0] / max(stage['update'][1], 1),
-                                   'achieved': per_iter / (stage['total'][0] / max(stage['update'][1], 1) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                                   'unit': 'GB/s'},
-            'stage_ms_per_iter': {k: stage[k][0] / max(stage['update'][1], 1) for k in stage},
+            'roofline_iteration': {'algorithmic_bytes': per_iter, 'device_ms': stage['total'][0] / n_extra,
+                                   'achieved': per_iter / (stage['total'][0] / n_extra * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                                   'unit': 'GB/s', 'note': 'sum of per-stage HIP-event spans of %d extra iterations run after the timed region' % n_extra},
+            'stage_ms_per_iter': {k: stage[k][0] / n_extra for k in stage},
             'nn_max_ring': cg.nn_max_ring, 'mean_dist_nm': cg.mean_dist,
         }
         out['roofline_iteration']['frac'] = out['roofline_iteration']['achieved'] / HBM_PEAK_GBS

@@ -40,7 +40,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
-enum { ST_TOTAL = 0, ST_GRID = 1, ST_NN = 2, ST_ATTRACT = 3, ST_PRIOR = 4, ST_AS = 5, ST_UPDATE = 6, ST_COUNT = 7 };
+enum { ST_TOTAL = 0, ST_GRID = 1, ST_NN = 2, ST_ATTRACT = 3, ST_PRIOR = 4, ST_AS = 5, ST_UPDATE = 6, ST_FIXUP = 7, ST_COUNT = 8 };
 
 }  // namespace
 
@@ -110,7 +110,7 @@ struct nw_ctx {
     size_t pin_bytes = 0;
 
     // profiling
-    bool profiling = false;
+    int profiling = 0;                // 0 off, 1 = events around the NN query only (dominant kernel), 2 = every stage
     std::vector<hipEvent_t> events;
     size_t ev_used = 0;
     double stage_ms[ST_COUNT] = {0};
@@ -328,8 +328,9 @@ thread_local StageMarks g_marks;
 
 struct StageScope {
     nw_ctx *c; int stage; hipEvent_t a;
-    StageScope(nw_ctx *ctx, int s) : c(ctx), stage(s), a(nullptr) { if (c->profiling) a = next_event(c); }
-    ~StageScope() { if (c->profiling) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
+    bool on;
+    StageScope(nw_ctx *ctx, int s) : c(ctx), stage(s), a(nullptr), on(ctx->profiling >= 2 || (ctx->profiling == 1 && s == ST_NN)) { if (on) a = next_event(c); }
+    ~StageScope() { if (on) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
 };
 
 int alloc_work(nw_ctx *ctx)
@@ -607,6 +608,9 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
         else
             hipLaunchKernelGGL((k_nearest_face<256, 1024>), dim3(nb), dim3(256), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                                ctx->cent_tmp.p, ctx->face.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
+    }
+    {
+        StageScope s(ctx, ST_FIXUP);
         hipLaunchKernelGGL(k_nn_fixup, dim3(512), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->ambig_list.p, ctx->ambig_count.p, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, ctx->face.p, ctx->state.p, it);
     }
@@ -903,7 +907,7 @@ NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nb
 NW_EXPORT int nw_set_profiling(nw_ctx *ctx, int enable)
 {
     if (!ctx) return NW_ERR_BADARG;
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return NW_OK;
 }
 

@@ -334,10 +334,13 @@ class ShrinkwrapMeshConjGrad(object):
         return nrm
 
     # -- timing hooks for bench.py ------------------------------------------------------------------
-    def set_profiling(self, on=True):
-        self._native.check(self._L.nw_set_profiling(self._h, 1 if on else 0))
-        self._profiling = bool(on)
-        self.stage_ms_total = {k: (0.0, 0) for k in ('total', 'grid', 'nn', 'attract', 'prior', 'as', 'update')}
+    def set_profiling(self, level=2):
+        """0/False off; 1 = HIP events around the NN query only (cheap: what bench.py keeps on in its timed region);
+        2/True = around every stage (each event pair serialises the stream for a few microseconds)."""
+        level = 2 if level is True else int(level)
+        self._native.check(self._L.nw_set_profiling(self._h, level))
+        self._profiling = level > 0
+        self.stage_ms_total = {k: (0.0, 0) for k in ('total', 'grid', 'nn', 'attract', 'prior', 'as', 'update', 'fixup')}
 
     def _accumulate_stage_ms(self):
         # HIP-event timings of the last search() (per stage: summed ms, number of timed spans), accumulated over calls
@@ -348,7 +351,7 @@ class ShrinkwrapMeshConjGrad(object):
             self.stage_ms_total[k] = (a + ms, b + n)
 
     def stage_ms(self):
-        names = ['total', 'grid', 'nn', 'attract', 'prior', 'as', 'update']
+        names = ['total', 'grid', 'nn', 'attract', 'prior', 'as', 'update', 'fixup']
         out = {}
         for i, nme in enumerate(names):
             ms, n = ctypes.c_double(0), ctypes.c_int64(0)
