@@ -56,13 +56,14 @@ class MembraneMesh(TriMesh):
         self.cg = None
         # block-boundary topology hooks (PYME's job in the reference; see module docstring)
         self.remesher = None          # callable(mesh, n, target_edge_length, l, n_relax)
-        self.neck_remover = None      # callable(mesh, threshold_low, threshold_high)
+        self.neck_remover = None      # callable(mesh, vertex_ids): delete + repair + remesh (PYME's part of remove_necks)
         self.hole_puncher = None      # callable(mesh, points, eps)
         self.edge_cleaner = None      # callable(mesh)  (remove_extra_short_edges)
         self._device = device
         self._native = None
         self._warned_fixed_topology = False
         self.block_log = []
+        self.neck_log = []
         self._initialize_curvature_vectors()
         for key, value in kwargs.items():                # :119-120
             setattr(self, key, value)
@@ -79,6 +80,24 @@ class MembraneMesh(TriMesh):
             return False
         self.remesher(self, n, target_edge_length, l, n_relax)
         return True
+
+    def neck_vertices(self, neck_curvature_threshold_low=-1e-4, neck_curvature_threshold_high=1e-2):
+        """The selection half of `remove_necks` (_membrane_mesh.pyx:1201-1215): curvature refreshed by the GPU kernel,
+        then every vertex whose Gaussian curvature lies outside [low, high] is a neck candidate."""
+        self._populate_curvature_grad()
+        K = self.curvature_gaussian
+        return np.flatnonzero((K < neck_curvature_threshold_low) | (K > neck_curvature_threshold_high))
+
+    def remove_necks(self, neck_curvature_threshold_low=-1e-4, neck_curvature_threshold_high=1e-2):
+        """_membrane_mesh.pyx:1201-1219.  Deleting the selected vertices, repairing, remeshing and dropping inner
+        surfaces are PYME TriangleMesh operations; they run through the `neck_remover` hook.  Returns the selection."""
+        verts = self.neck_vertices(neck_curvature_threshold_low, neck_curvature_threshold_high)
+        if len(verts) > 0 and self.neck_remover is not None:
+            self.neck_remover(self, verts)
+            self.cg = None
+            if self._native is not None:
+                self._native.mesh_key = None
+        return verts
 
     # -- curvature (block-boundary kernel) --------------------------------------------------------------------
     def _neighbor_tables(self):
@@ -224,8 +243,9 @@ class MembraneMesh(TriMesh):
                 self.hole_puncher(self, points, self.delaunay_eps)
 
             if r and ((j % self.remesh_frequency) == 0):                                 # :1537-1549
-                if (neck_first_iter > 0) and (j > neck_first_iter) and self.neck_remover is not None:
-                    self.neck_remover(self, getattr(self, 'neck_threshold_low', -1e-4), getattr(self, 'neck_threshold_high', 1e-2))
+                if (neck_first_iter > 0) and (j > neck_first_iter):                      # :1538-1540
+                    verts = self.remove_necks(getattr(self, 'neck_threshold_low', -1e-4), getattr(self, 'neck_threshold_high', 1e-2))
+                    self.neck_log.append(dict(iteration=j, candidates=int(len(verts))))
                 if self.edge_cleaner is not None:
                     self.edge_cleaner(self)
                 target_length = (initial_length + m * (j + 1))                           # :1544

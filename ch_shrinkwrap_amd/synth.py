@@ -1,8 +1,12 @@
 """
 Synthetic localization clouds and start meshes for the BASELINE.json configurations.
 
-Own restatement of the few signed-distance primitives needed (sphere: /root/reference/ch_shrinkwrap/sdf.py:39-46,
-capsule: sdf.py:60-80, smooth-min union: shape.py:369-376) plus a surface sampler that replaces
+Own restatement of the signed-distance primitives needed (sphere: /root/reference/ch_shrinkwrap/sdf.py:39-46,
+capsule: sdf.py:60-80, round_box: sdf.py:250-269, sheet: sdf.py:271-292, smooth union / difference / rotation:
+shape.py:369-376, 403-410, 446-480, the `ThreeWayJunction` and `ERSim2` networks: shape.py:252-261, 288-313; all
+pinned against the reference's own values in tests/golden/sdf_shapes.npz), a sparse surface-nets mesher for
+shapes that are not star-shaped (the reference obtains its start mesh from PYME's dual marching cubes, which is
+not available), plus a surface sampler that replaces
 `PYME.simulation.locify.points_from_sdf` (shape.py:75, PYME is not available): points are drawn uniformly on
 the start mesh's faces, projected onto the zero level set by Newton steps along the SDF gradient, and jittered
 with isotropic Gaussian localization error.  All float32, all seeded.
@@ -22,6 +26,18 @@ def sphere_cloud(n, radius, sigma, seed, background=0.0, dtype='f4'):
     if nb:
         pts[:nb] = rng.uniform(-1.6 * radius, 1.6 * radius, size=(nb, 3))
     return pts.astype(dtype)
+
+
+def _pmap(fn, items, workers=None):
+    """thread-pool map (NumPy releases the GIL inside its loops); keeps order"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(items)
+    workers = workers or min(16, os.cpu_count() or 1)
+    if workers <= 1 or len(items) <= 1:
+        return [fn(x) for x in items]
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, items))
 
 
 # ---- signed distance functions (points are (N,3) float64 arrays) ---------------------------------------------
@@ -49,6 +65,173 @@ def sdf_two_lobe(p, radius=300.0, offset=250.0, k=50.0):
     return smooth_min(sdf_sphere(p, radius, (-offset, 0, 0)), sdf_sphere(p, radius, (offset, 0, 0)), k)
 
 
+def smooth_union(d0, d1, k):
+    """UnionShape.sdf as the reference writes it (shape.py:369-376); algebraically the same polynomial as `smooth_min`."""
+    res = np.minimum(d0, d1)
+    if k > 0:
+        h = np.maximum(k - np.abs(d0 - d1), 0.0)
+        return res - h * h * 0.25 / k
+    return res
+
+
+def smooth_difference(d0, d1, k):
+    """DifferenceShape(s0, s1).sdf: s1 with s0 carved out (shape.py:403-410)."""
+    res = np.maximum(-d0, d1)
+    if k > 0:
+        h = np.maximum(k - np.abs(-d0 - d1), 0.0)
+        return res + h * h * 0.25 / k
+    return res
+
+
+def sdf_round_box(p, halfwidth, r):
+    q = np.abs(p) - np.asarray(halfwidth, 'f8')[None, :]
+    return np.linalg.norm(np.maximum(q, 0.0), axis=1) + np.minimum(q.max(axis=1), 0.0) - r
+
+
+def sdf_sheet(p, halfwidth, r):
+    """box with a dumbbell (rounded, thickened) rim, sdf.py:271-292"""
+    w = np.asarray(halfwidth, 'f8')
+    q = np.abs(p) - w[None, :]
+    rim = np.hypot(np.maximum(q[:, 0], q[:, 1]) + r, q[:, 2] + w[2]) - r
+    return np.minimum(rim, q.max(axis=1))
+
+
+def rotate_z_inverse(p, rz):
+    """coordinates of p in the frame of a shape rotated by rz about z (RotationShape with rx = ry = 0, shape.py:446-480)"""
+    c, s = np.cos(rz), np.sin(rz)
+    rinv = np.linalg.inv(np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]]))
+    return p @ rinv.T
+
+
+def sdf_three_way_junction(p, h, r, k=0.0, centroid=(0.0, 0.0, 0.0)):
+    """three tubes of length h, radius r meeting at `centroid` (shape.py:252-261): the two upper arms are joined with
+    smoothing k, the lower arm with a sharp union."""
+    c = np.asarray(centroid, 'f8')
+    q = h / np.sqrt(2.0)
+    upper = smooth_union(sdf_capsule(p, c, c + [-q, q, 0], r), sdf_capsule(p, c, c + [q, q, 0], r), k)
+    return smooth_union(sdf_capsule(p, c, c + [0, -h, 0], r), upper, 0.0)
+
+
+def sdf_er_sim2(p):
+    """The reference's synthetic endoplasmic-reticulum network `ERSim2` (shape.py:288-313): three sheets and five tubes
+    joined by smooth unions (k = 25 nm), with a 50 nm fenestration punched through the central sheet.  As in the
+    reference, the `centroid` given to the third (rotated) sheet is discarded by RotationShape, so it sits at the origin."""
+    sh = 100.0
+    a, b = np.array([0.0, 0, 0]), np.array([400.0, -50, 0])
+    c, d = np.array([500.0, 250, 0]), np.array([0.0, 240, 0])
+    e, f = np.array([0.0, -600, 0]), np.array([-600.0, 0, 0])
+    g, h = np.array([-40.0, 0, -100]), np.array([-40.0, 0, 100])
+    k = sh / 4
+    sheet0 = sdf_sheet(rotate_z_inverse(p, np.pi / 4), (226, 200, sh / 3), sh / 3)
+    sheet1 = sdf_sheet(p - np.array([0.0, 133, 0])[None, :], (50, 50, sh / 3), 1)
+    sheet2 = sdf_sheet(rotate_z_inverse(p, 7 * np.pi / 3), (33, 33, sh / 3), sh / 2)
+    rt = sh // 2
+    cap0, cap1, cap2 = sdf_capsule(p, a, b, rt), sdf_capsule(p, b, c, rt), sdf_capsule(p, c, d, rt)
+    cap3, cap4, cap5 = sdf_capsule(p, a, e, rt), sdf_capsule(p, a, f, rt), sdf_capsule(p, g, h, 50)
+    u = smooth_union(cap1, smooth_union(sheet2, cap2, k), k)
+    u = smooth_union(sheet0, smooth_union(cap0, u, k), k)
+    u = smooth_union(smooth_union(smooth_union(u, sheet1, k), cap3, k), cap4, k)
+    return smooth_difference(cap5, u, k)
+
+
+def isosurface_mesh(sdf, lo, hi, cell, level=0.0, block=32, lipschitz=1.5, slack=0.0, project=2):
+    """Closed triangle mesh of `sdf == level` inside the box [lo, hi] by sparse surface nets: one vertex per grid cell
+    that the surface crosses (mean of the crossing points on the cell's edges), one quad per sign-changing grid edge
+    (split along its shorter diagonal), outward orientation (sdf < level is inside).  Only blocks of `block`^3 cells
+    whose centre is within lipschitz * half-diagonal + slack of the surface are evaluated.  `project` Newton steps
+    pull the vertices onto the level set afterwards.  Returns (vertices f4, faces i4)."""
+    lo = np.asarray(lo, 'f8')
+    hi = np.asarray(hi, 'f8')
+    ncell = np.maximum(np.ceil((hi - lo) / cell).astype(np.int64), 1)
+    NX, NY, NZ = (int(x) for x in ncell)
+    nblk = (ncell + block - 1) // block
+    bz, by, bx = np.meshgrid(np.arange(nblk[2]), np.arange(nblk[1]), np.arange(nblk[0]), indexing='ij')
+    corners = np.stack([bx.ravel(), by.ravel(), bz.ravel()], 1) * block
+    centres = lo[None, :] + (corners + 0.5 * block) * cell
+    half_diag = 0.5 * block * cell * np.sqrt(3.0)
+    active = np.abs(sdf(centres) - level) <= lipschitz * half_diag + slack
+    B = block
+    ar = np.arange(B + 1)
+
+    def do_block(c0):
+        vert_ids, vert_pos, quads = [], [], []
+        gz, gy, gx = np.meshgrid(c0[2] + ar, c0[1] + ar, c0[0] + ar, indexing='ij')
+        nodes = np.stack([gx.ravel(), gy.ravel(), gz.ravel()], 1)
+        d = (sdf(lo[None, :] + nodes * cell) - level).reshape(B + 1, B + 1, B + 1)        # [z, y, x]
+        inside = d < 0
+        if inside.all() or not inside.any():
+            return vert_ids, vert_pos, quads
+        acc = np.zeros((B, B, B, 3))
+        cnt = np.zeros((B, B, B), np.int32)
+        for axis in range(3):
+            # arrays re-oriented so that the edge axis is LAST and (u, v, axis) is a cyclic permutation of (x, y, z):
+            # axis x -> [z, y, x] (u = y, v = z), axis y -> [x, z, y], axis z -> [y, x, z]
+            perm = [(0, 1, 2), (2, 0, 1), (1, 2, 0)][axis]
+            dd = d.transpose(perm)
+            ins = inside.transpose(perm)
+            cross = ins[:, :, :-1] != ins[:, :, 1:]
+            t = np.where(cross, dd[:, :, :-1] / np.where(cross, dd[:, :, :-1] - dd[:, :, 1:], 1.0), 0.0)
+            # crossing positions in (global) grid units, stored per edge as xyz
+            gidx = [g.transpose(perm)[:, :, :-1].astype('f8') for g in (gx, gy, gz)]
+            gidx[axis] = gidx[axis] + t
+            E = np.stack(gidx, -1) * cross[..., None]
+            C = cross.astype(np.int32)
+            a4 = E[:-1, :-1] + E[1:, :-1] + E[:-1, 1:] + E[1:, 1:]
+            c4 = C[:-1, :-1] + C[1:, :-1] + C[:-1, 1:] + C[1:, 1:]
+            inv = np.argsort(perm)
+            acc += a4.transpose(*inv, 3)
+            cnt += c4.transpose(inv)
+            # quads of the edges this block owns (lower node inside the half-open block)
+            own = cross[:B, :B, :B]
+            if own.any():
+                ii = np.nonzero(own)
+                G = [g.transpose(perm)[:B, :B, :B][ii] for g in (gx, gy, gz)]      # global x, y, z of the lower node
+                ua, va = [(1, 2), (2, 0), (0, 1)][axis]                              # (u, v) axes, u x v = edge axis
+                quad = []
+                for du, dv in ((-1, -1), (0, -1), (0, 0), (-1, 0)):                  # counter-clockwise about +axis
+                    cc = [G[0].copy(), G[1].copy(), G[2].copy()]
+                    cc[ua] += du
+                    cc[va] += dv
+                    quad.append(cc)
+                ok = np.ones(ii[0].shape[0], bool)
+                for cc in quad:
+                    ok &= (cc[0] >= 0) & (cc[1] >= 0) & (cc[2] >= 0) & (cc[0] < NX) & (cc[1] < NY) & (cc[2] < NZ)
+                ids = np.stack([(cc[2] * NY + cc[1]) * NX + cc[0] for cc in quad], 1)
+                outward_plus = ins[:B, :B, :B][ii]                                   # inside at the lower node -> normal +axis
+                ids = np.where(outward_plus[:, None], ids, ids[:, ::-1])
+                quads.append(ids[ok])
+        m = cnt > 0
+        m[(gz[:B, :B, :B] >= NZ) | (gy[:B, :B, :B] >= NY) | (gx[:B, :B, :B] >= NX)] = False
+        if m.any():
+            vert_ids.append(((gz[:B, :B, :B][m] * NY + gy[:B, :B, :B][m]) * NX + gx[:B, :B, :B][m]).astype(np.int64))
+            vert_pos.append(lo[None, :] + (acc[m] / cnt[m][:, None]) * cell)
+        return vert_ids, vert_pos, quads
+
+    vert_ids, vert_pos, quads = [], [], []
+    for vi, vp, qd in _pmap(do_block, list(corners[active])):
+        vert_ids += vi
+        vert_pos += vp
+        quads += qd
+    if not vert_ids:
+        raise ValueError('isosurface_mesh: the level set does not cross the box')
+    vid = np.concatenate(vert_ids)
+    pos = np.concatenate(vert_pos)
+    order = np.argsort(vid)
+    vid, pos = vid[order], pos[order]
+    q = np.concatenate(quads)
+    qi = np.searchsorted(vid, q)
+    if (qi >= vid.shape[0]).any() or (vid[np.minimum(qi, vid.shape[0] - 1)] != q).any():
+        raise RuntimeError('isosurface_mesh: a surface cell was not evaluated (raise `lipschitz`/`slack`) or the surface touches the box')
+    if project:
+        pos = project_to_level(sdf, pos, level, iters=project)
+    d02 = np.linalg.norm(pos[qi[:, 0]] - pos[qi[:, 2]], axis=1)
+    d13 = np.linalg.norm(pos[qi[:, 1]] - pos[qi[:, 3]], axis=1)
+    s = (d02 <= d13)[:, None]
+    t1 = np.where(s, qi[:, [0, 1, 2]], qi[:, [0, 1, 3]])
+    t2 = np.where(s, qi[:, [0, 2, 3]], qi[:, [1, 2, 3]])
+    return pos.astype('f4'), np.concatenate([t1, t2]).astype('i4')
+
+
 def sdf_gradient(sdf, p, eps=1e-3):
     g = np.empty_like(p)
     for k in range(3):
@@ -60,12 +243,18 @@ def sdf_gradient(sdf, p, eps=1e-3):
     return g / n[:, None]
 
 
-def project_to_level(sdf, p, level=0.0, iters=8):
+def project_to_level(sdf, p, level=0.0, iters=8, chunk=1 << 17):
     p = np.array(p, 'f8')
-    for _ in range(iters):
-        d = sdf(p) - level
-        p -= sdf_gradient(sdf, p) * d[:, None]
-    return p
+
+    def run(q):
+        for _ in range(iters):
+            d = sdf(q) - level
+            q -= sdf_gradient(sdf, q) * d[:, None]
+        return q
+    if p.shape[0] <= chunk:
+        return run(p)
+    parts = _pmap(run, [p[i:i + chunk] for i in range(0, p.shape[0], chunk)])
+    return np.concatenate(parts)
 
 
 def star_mesh(sdf, freq, level=0.0, rmax=None, relax=10):
@@ -96,7 +285,7 @@ def star_mesh(sdf, freq, level=0.0, rmax=None, relax=10):
     return p.astype('f4'), f
 
 
-def sample_surface(sdf, verts, faces, n, sigma, seed, dtype='f4'):
+def sample_surface(sdf, verts, faces, n, sigma, seed, dtype='f4', iters=4):
     """n localizations: area-weighted uniform samples on the faces of a mesh of the zero level set, projected
     onto the level set, plus N(0, sigma^2) per axis."""
     rng = np.random.default_rng(seed)
@@ -107,7 +296,7 @@ def sample_surface(sdf, verts, faces, n, sigma, seed, dtype='f4'):
     r1 = np.sqrt(rng.random(n))
     r2 = rng.random(n)
     p = (1 - r1)[:, None] * a[fi] + (r1 * (1 - r2))[:, None] * b[fi] + (r1 * r2)[:, None] * c[fi]
-    p = project_to_level(sdf, p, 0.0, iters=4)
+    p = project_to_level(sdf, p, 0.0, iters=iters)
     p += rng.normal(scale=sigma, size=p.shape)
     return p.astype(dtype)
 
@@ -134,5 +323,12 @@ def make_config(name, scale=1.0, seed=0):
         v0, f = star_mesh(sdf, freq, level=0.0, relax=4)
         pts = sample_surface(sdf, v0, f, n, 10.0, seed)
         v, _ = star_mesh(sdf, freq, level=20.0, relax=4)
+        return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5)
+    if name == 'c4':      # ER-like tube/sheet network with a fenestration (ERSim2, twice life size): 5M localizations, ~800k vertices
+        sdf = lambda p: 2.0 * sdf_er_sim2(np.asarray(p, 'f8') * 0.5)
+        n = int(5000000 * scale)
+        cell = 2.71 / np.sqrt(scale)
+        v, f = isosurface_mesh(sdf, (-1500, -1500, -420), (1400, 900, 420), cell, level=20.0, slack=60.0)
+        pts = sample_surface(sdf, v, f, n, 10.0, seed, iters=6)
         return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5)
     raise ValueError(name)

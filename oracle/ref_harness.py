@@ -66,6 +66,31 @@ def load():
     return _mods
 
 
+def load_shapes():
+    """The reference's `ch_shrinkwrap.shape` module (CSG shapes over `sdf.py`).  Its module-level
+    `from PYME.simulation.locify import points_from_sdf` (shape.py:16) is only used by `Shape.points()`; a placeholder
+    that raises is registered so that the signed-distance functions can be evaluated."""
+    load()
+    for name in ('PYME.simulation', 'PYME.simulation.locify'):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    sys.modules['PYME'].simulation = sys.modules['PYME.simulation']
+    sys.modules['PYME.simulation'].locify = sys.modules['PYME.simulation.locify']
+
+    def points_from_sdf(*a, **k):
+        raise RuntimeError('PYME is not available')
+    sys.modules['PYME.simulation.locify'].points_from_sdf = points_from_sdf
+    import importlib.util
+    import ch_shrinkwrap
+    spec = importlib.util.spec_from_file_location('ch_shrinkwrap.shape', os.path.join(REF_ROOT, 'shape.py'))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules['ch_shrinkwrap.shape'] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def new_reference_optimiser(mesh, points, **kw):
     """Construct the reference ShrinkwrapMeshConjGrad against a duck-typed mesh (ch_shrinkwrap_amd.trimesh.TriMesh)
     exactly as `_membrane_mesh.pyx:1510-1512` does, and register it as `mesh.cg` (the mesh's `point_influence`

@@ -230,6 +230,26 @@ def golden_curvature():
          params=np.array([dN, kc, kg, c0]), jitter=jit, **{'out_' + n: a for n, a in r.items()})
 
 
+def golden_sdf_shapes():
+    """Signed distances of the reference's own CSG shapes (shape.py / sdf.py) at seeded sample positions: pins the
+    synthetic-cloud generator (ch_shrinkwrap_amd/synth.py) behind the BASELINE.json configs."""
+    sh = ref_harness.load_shapes()
+    rng = np.random.default_rng(2024)
+    P = rng.uniform(-700, 700, size=(3000, 3))
+    P[:, 2] *= 0.3
+    out = dict(points=P)
+    out['sphere_r100'] = sh.Sphere(radius=100.0).sdf(P.T)
+    out['capsule_c2'] = sh.Capsule([0, -500, 0], [0, 500, 0], 50.0).sdf(P.T)
+    out['two_lobe_c3'] = sh.UnionShape(sh.Sphere(radius=300, centroid=np.array([-250., 0, 0])),
+                                       sh.Sphere(radius=300, centroid=np.array([250., 0, 0])), k=50).sdf(P.T)
+    out['round_box'] = sh.Box(np.array([66, 83, 25.]), 25.0).sdf(P.T)
+    out['sheet'] = sh.Sheet(np.array([226, 200, 100 / 3]), 100 / 3).sdf(P.T)
+    out['three_way_junction'] = sh.ThreeWayJunction(300, 50, k=20).sdf(P.T)
+    out['er_sim2'] = sh.ERSim2().sdf(P.T)
+    out['difference'] = sh.DifferenceShape(sh.Capsule([-40, 0, -100], [-40, 0, 100], 50.0), sh.Sphere(radius=200.0), k=25).sdf(P.T)
+    save('sdf_shapes', **out)
+
+
 if __name__ == '__main__':
     if not ref_harness.available():
         raise SystemExit('reference not available here')
@@ -238,3 +258,4 @@ if __name__ == '__main__':
     golden_variants()
     golden_lfuncs()
     golden_curvature()
+    golden_sdf_shapes()

@@ -84,6 +84,22 @@ def test_sigma_forms_truncate_and_shrink_weight(recorder):
     assert len(recorder.calls) == 1 and recorder.calls[0]['sigma_inv'] == 10.0
 
 
+def test_neck_removal_schedule(recorder, monkeypatch):
+    """remove_necks runs at remesh boundaries once j > neck_first_iter (_membrane_mesh.pyx:1537-1540); the selection is
+    Gaussian curvature outside [low, high] (:1201-1215) and the surgery itself goes to the hook."""
+    m = _mesh(max_iter=20, remesh_frequency=5, delaunay_remesh_frequency=0, neck_first_iter=9, neck_threshold_low=-1e-3, neck_threshold_high=1e-2)
+    K = np.zeros(m.vertices.shape[0], 'f4')
+    K[[3, 17]] = [-0.5, 0.3]
+    K[5] = 5e-3                                                      # inside the band
+    monkeypatch.setattr(mm.MembraneMesh, '_populate_curvature_grad', lambda self: setattr(self, '_K', K))
+    removed = []
+    m.neck_remover = lambda mesh, verts: removed.append(verts.copy())
+    m.shrink_wrap(np.zeros((4, 3), 'f4'), 10.0)                      # thresholds are mesh attributes (surface_fitting.py:66-68)
+    assert [e['iteration'] for e in m.neck_log] == [10, 15, 20]     # j = 5 is not > neck_first_iter
+    assert all(e['candidates'] == 2 for e in m.neck_log)
+    assert len(removed) == 3 and all(np.array_equal(r, [3, 17]) for r in removed)
+
+
 def test_recipe_module_parameter_surface():
     r = mm.ShrinkwrapMembrane()
     # defaults of recipe_modules/surface_fitting.py:17-42
@@ -159,3 +175,23 @@ def test_device_normal_refresh_matches_host_definition():
     mesh3._vertices['normal'][:] = dev
     out3 = ShrinkwrapMeshConjGrad(mesh3, pts).search(pts, lams=[10.0], num_iters=2, sigma_inv=s)
     assert rel_rms(out, out3) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_neck_selection_on_network():
+    """BASELINE.json configs[3] in small: two blocks on the ER-like network with the curvature kernel at the block
+    boundary selecting neck candidates."""
+    from ch_shrinkwrap_amd import synth
+    c = synth.make_config('c4', scale=0.02, seed=4)
+    m = mm.MembraneMesh(c['vertices'], c['faces'], kc=1.0, step_size=20.0, max_iter=10, remesh_frequency=5, delaunay_remesh_frequency=0,
+                        neck_first_iter=4, neck_threshold_low=-1e-3, neck_threshold_high=1e-2)
+    picked = []
+    m.neck_remover = lambda mesh, verts: picked.append(verts.copy())
+    m.shrink_wrap(c['points'], c['sigma'])
+    assert [e['iteration'] for e in m.neck_log] == [5, 10]
+    K = m.curvature_gaussian
+    assert np.isfinite(K).all() and np.isfinite(m.curvature_mean).all()
+    want = np.flatnonzero((K < -1e-3) | (K > 1e-2))
+    assert np.array_equal(picked[-1], want)
+    # tubes of radius ~100-120 nm: |K| of the fitted surface stays far below the high threshold nearly everywhere
+    assert want.size < 0.05 * K.size
