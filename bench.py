@@ -66,10 +66,33 @@ def cpu_baseline(cfg, iters=2):
     dt = time.perf_counter() - t0
     M = int((mesh._vertices['halfedge'] != -1).sum())
     return dict(value=M * r.loopcount / dt, unit='vertex-updates/s', cores=os.cpu_count(), kind='port',
-                sample='%d full-size iterations of the oracle (oracle/nanowrap_oracle.py) on the same 1M-localization / %d-vertex '
+                sample='%d full-size iterations of the oracle (oracle/nanowrap_oracle.py) on the same %d-localization / %d-vertex '
                        'workload, %.1f s; cKDTree query uses all %d host threads, the rest is single-threaded NumPy/C like the reference'
-                       % (r.loopcount, M, dt, os.cpu_count()),
+                       % (r.loopcount, cfg['points'].shape[0], M, dt, os.cpu_count()),
                 s_per_iter=dt / max(r.loopcount, 1))
+
+
+WORKLOADS = {
+    'c1': 'BASELINE configs[0]: sphere R=100 nm, icosphere start mesh at 1.2 R',
+    'c2': 'BASELINE configs[1]: capped tube r=50 nm, L=1000 nm',
+    'c3': 'BASELINE configs[2]: two-lobe vesicle (smooth union of two R=300 nm spheres)',
+    'c4': 'BASELINE configs[3]: ERSim2 tube/sheet network with a fenestration (genus 2), twice life size',
+}
+
+
+def measured_copy_ceiling(torch, nbytes=1 << 30, reps=10):
+    """Device-to-device copy rate of this GPU (read + write bytes / time): the practical HBM ceiling beside the 8 TB/s spec."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device='cuda')
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -177,14 +200,15 @@ def main():
         avg_ms = ms_tot / max(launches, 1)
         achieved = per_kernel[kern[dom]] / (avg_ms * 1e-3) / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(tfile):
+        tfile = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')     # PMC passes of the headline workload (tools/pmc.sh)
+        if os.path.exists(tfile) and args.config == 'c3' and args.scale == 1.0:
             try:
                 traffic = json.load(open(tfile)).get(kern[dom])
             except Exception:
                 traffic = None
         out = {
-            'metric': 'vertex-updates/s (force+CG step) + achieved HBM GB/s, 1M pts/200k verts',
+            'metric': 'vertex-updates/s (force+CG step) + achieved HBM GB/s, 1M pts/200k verts' if args.config == 'c3' else
+                      'vertex-updates/s (force+CG step) + achieved HBM GB/s, %s' % args.config,
             'value': M_total * args.steps / dt,
             'unit': 'vertex-updates/s',
             'n_gpus': world,
@@ -196,14 +220,14 @@ def main():
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: two-lobe vesicle (smooth union of two R=300 nm spheres), %d localizations sigma=10 nm, '
-                                   '%d vertices / %d faces, lams=[10], blocks of %d iterations, fixed topology%s'
-                                   % (N, M, F, BLOCK, '' if args.scale == 1.0 else ' [SCALED x%.3g: debug run]' % args.scale),
+            'config': {'workload': '%s, %d localizations sigma=10 nm, %d vertices / %d faces, lams=[10], blocks of %d iterations, fixed topology%s'
+                                   % (WORKLOADS[args.config], N, M, F, BLOCK, '' if args.scale == 1.0 else ' [SCALED x%.3g: debug run]' % args.scale),
                        'localizations_per_gpu': N, 'vertices_per_gpu': M, 'faces_per_gpu': F, 'block': BLOCK,
                        'parallelism': 'tiles%d (one vesicle per GPU, 24-scalar RCCL all-reduce per iteration)' % world if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'kernel': kern[dom], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': per_kernel[kern[dom]], 'avg_launch_ms': avg_ms, 'launches': launches},
+                         'algorithmic_bytes_per_launch': per_kernel[kern[dom]], 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'measured_copy_peak': measured_copy_ceiling(torch)},
             'roofline_iteration': {'algorithmic_bytes': per_iter, 'device_ms': stage['total'][0] / n_extra,
                                    'achieved': per_iter / (stage['total'][0] / n_extra * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                                    'unit': 'GB/s', 'note': 'sum of per-stage HIP-event spans of %d extra iterations run after the timed region' % n_extra},

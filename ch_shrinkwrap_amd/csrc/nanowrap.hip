@@ -11,6 +11,11 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <atomic>
 
 #include "../../include/nanowrap.h"
 #include "nw_kernels.h"
@@ -44,6 +49,66 @@ enum { ST_TOTAL = 0, ST_GRID = 1, ST_NN = 2, ST_ATTRACT = 3, ST_PRIOR = 4, ST_AS
 
 }  // namespace
 
+// Small persistent host thread pool for the write-back (the strided copy into the caller's vertex records is host-memory
+// bound: one thread moves ~0.4 GB/s of 12-byte rows).  run(f) executes f(0..n-1), slice 0 on the calling thread.
+struct NwHostPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(int)> fn;
+    unsigned long generation = 0;
+    int pending = 0;
+    bool stop = false;
+    int n = 1;
+    void start(int threads, int device)
+    {
+        n = threads < 1 ? 1 : threads;
+        for (int t = 1; t < n; ++t)
+            th.emplace_back([this, t, device] {
+                (void)hipSetDevice(device);
+                unsigned long seen = 0;
+                for (;;) {
+                    std::function<void(int)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_work.wait(lk, [&] { return stop || generation != seen; });
+                        if (stop) return;
+                        seen = generation;
+                        f = fn;
+                    }
+                    f(t);
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        if (--pending == 0) cv_done.notify_one();
+                    }
+                }
+            });
+    }
+    void run(const std::function<void(int)> &f)
+    {
+        if (n > 1) {
+            std::lock_guard<std::mutex> lk(m);
+            fn = f; pending = n - 1; ++generation;
+        }
+        if (n > 1) cv_work.notify_all();
+        f(0);
+        if (n > 1) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return pending == 0; });
+        }
+    }
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : th) t.join();
+        th.clear();
+    }
+};
+
 struct nw_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -73,7 +138,11 @@ struct nw_ctx {
     // grid
     NwGrid grid{};
     bool grid_valid = false;
-    double last_mean_dist = -1.0, spacing = 0.0;
+    double last_mean_dist = -1.0, spacing = 0.0, est_mean_dist = -1.0;
+    double cell_tune = 1.0;           // autotuned multiplier on the cell-size rule (tune_grid)
+    double force_h = 0.0;             // > 0: build_grid uses exactly this cell (autotuner probes)
+    bool tuned = false;
+    int64_t tuned_N = -1;
     DevBuf<int> pcount, pstart, ccount, cstart, scan_tmp, item_count, item_start;
     DevBuf<NwWorkItem> items;
     int nitems = 0;
@@ -108,6 +177,9 @@ struct nw_ctx {
 
     void *pin = nullptr;              // pinned staging for the write-back
     size_t pin_bytes = 0;
+    NwHostPool *pool = nullptr;       // host threads of the write-back (created on first use)
+    std::vector<hipEvent_t> wb_events;
+    std::vector<unsigned char> valid_host;
 
     // profiling
     int profiling = 0;                // 0 off, 1 = events around the NN query only (dominant kernel), 2 = every stage
@@ -185,19 +257,24 @@ int minmax3(nw_ctx *ctx, const float *xyz, int64_t n, float lo[3], float hi[3], 
     return NW_OK;
 }
 
-// desired fine-cell edge from the mean NN distance of the last iteration and the centroid spacing: a fraction of the
-// typical search radius (several thin stages instead of one fat neighbourhood), but at least two centroid spacings so
-// that a cell holds a handful of candidates
-double desired_cell(double mean_dist, double spacing)
+// Desired fine-cell edge.  Measured on MI355X (tools/cell_sweep.py, DESIGN.md "cell size"): the cost of the staged query is
+// a sharp function of the ABSOLUTE cell size and its minimum follows the centroid spacing (how many candidates a stage
+// stages) and, weakly, the localizations-per-face ratio (how well the 256-lane workgroups fill); it hardly moves with the
+// point->surface distance until that distance exceeds the cell.  Fitted over the four BASELINE configurations and
+// 0.25x / 4x point densities:
+//     h = 10.5 nm * (spacing / 2.5 nm)^0.65 * (N / 2.5 F)^-0.11,   floor 0.6 x mean distance (far starts)
+// times ctx->cell_tune (1 unless the opt-in autotuner ran, NW_AUTOTUNE=1).
+double desired_cell(const nw_ctx *ctx, double mean_dist, double spacing)
 {
-    const char *e = getenv("NW_CELL_FACTOR");
-    const double f = (e && atof(e) > 0) ? atof(e) : 0.8;
-    return std::max(f * mean_dist, 2.0 * spacing);
+    const double ratio = std::max((double)ctx->N, 1.0) / (2.5 * std::max((double)ctx->F, 1.0));
+    double h = 10.5 * std::pow(std::max(spacing, 1e-30) / 2.5, 0.65) * std::pow(ratio, -0.11) * ctx->cell_tune;
+    const char *e = getenv("NW_CELL_FACTOR");             // developer knob: multiplies the rule
+    if (e && atof(e) > 0) h *= atof(e);
+    return std::max(h, 0.6 * mean_dist);
 }
 
 // ---- grid construction ---------------------------------------------------------------------------------
-// Cell size: ~1.5x the mean point->centroid distance (most points then finish in the first ring), but at
-// least two centroid spacings so that a cell holds a handful of candidates; dims capped at 2^25 cells.
+// Cell size: desired_cell() (or ctx->force_h while the autotuner probes); dims capped at 2^25 cells.
 int build_grid(nw_ctx *ctx, double mean_dist)
 {
     const int64_t N = ctx->N, F = ctx->F;
@@ -228,11 +305,12 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     }
     if (!(ext > 0)) ext = 1.0;
     ctx->spacing = spacing;
-    double h = desired_cell(mean_dist, spacing);
+    double h = ctx->force_h > 0 ? ctx->force_h : desired_cell(ctx, mean_dist, spacing);
     if (!(h > 0) || !std::isfinite(h)) h = ext / 16;
+    ctx->est_mean_dist = mean_dist;
     h = std::max(h, ext / 1024.0);                       // at most ~1024 fine cells per axis
     const char *env_h = getenv("NW_CELL_SIZE");
-    if (env_h && atof(env_h) > 0) h = atof(env_h);
+    if (env_h && atof(env_h) > 0 && !(ctx->force_h > 0)) h = atof(env_h);
     const char *env_b = getenv("NW_BRICK");
     const int B = (env_b && atoi(env_b) > 0) ? std::min(atoi(env_b), 8) : 2;
     NwGrid g;
@@ -300,10 +378,11 @@ int build_grid(nw_ctx *ctx, double mean_dist)
 int ensure_grid(nw_ctx *ctx)
 {
     if (ctx->grid_valid && ctx->last_mean_dist > 0) {
-        // keep the grid (and the cell-sorted localizations) unless the cell size drifted far from what the last
-        // iteration suggests: re-sorting N points costs more than a slightly off cell size
-        const double want = desired_cell(ctx->last_mean_dist, ctx->spacing);
-        if (want < 1.6 * ctx->grid.h && want > 0.6 * ctx->grid.h) return NW_OK;
+        // keep the grid (and the cell-sorted localizations) unless the wanted cell size drifted far from the current one
+        // (re-sorting N points costs about half an iteration)
+        const double want = desired_cell(ctx, ctx->last_mean_dist, ctx->spacing);
+        static const double band = getenv("NW_GRID_BAND") ? atof(getenv("NW_GRID_BAND")) : 1.15;
+        if (want < band * ctx->grid.h && want > ctx->grid.h / band) return NW_OK;
         if (getenv("NW_CELL_SIZE")) return NW_OK;
     } else if (ctx->grid_valid) {
         return NW_OK;
@@ -397,7 +476,9 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
+    if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    for (hipEvent_t e : ctx->wb_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -495,6 +576,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     if (valid) {
         NW_HIP(ctx->valid.ensure(M));
         NW_HIP(hipMemcpyAsync(ctx->valid.p, valid, M, hipMemcpyDefault, ctx->stream));
+        ctx->valid_host.assign(valid, valid + M);          // the write-back masks the caller's vertex records with it
     }
     NW_HIP(hipMemsetAsync(ctx->d_small.p, 0, 8 * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_nbr_transpose, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, ctx->nbr.p, (int)M, n_nbr, ctx->nbr_t.p, ctx->d_small.p);
@@ -557,6 +639,7 @@ NW_EXPORT int nw_set_positions(nw_ctx *ctx, const float *pos)
 }
 
 // ---- the iteration -------------------------------------------------------------------------------------------
+static int tune_grid(nw_ctx *ctx);
 NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags)
 {
     if (!ctx) return NW_ERR_BADARG;
@@ -568,6 +651,7 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     // start_guess: fs = vertices.copy() -> f restarts from the mesh positions (mesh_conj_grad.py:170, :1002-1007)
     NW_HIP(hipMemcpyAsync(ctx->pos.p, ctx->meshpos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     NW_TRY(ensure_grid(ctx));
+    NW_TRY(tune_grid(ctx));
     ctx->lam0 = lams[0];
     ctx->search_flags = flags;
     ctx->search_iters = num_iters;
@@ -583,14 +667,11 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     return NW_OK;
 }
 
-NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
+// centroid binning + staged nearest-face query + float64 fix-up of the ambiguous points, for the current positions
+static int launch_query(nw_ctx *ctx, int it)
 {
-    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_attract outside a search");
-    const int it = ctx->global_iter;
-    const int par = it & 1;
-    const int64_t N = ctx->N, F = ctx->F;
+    const int64_t F = ctx->F;
     const NwGrid g = ctx->grid;
-    double *sc = ctx->scalars.p + par * NW_SC_BLOCK;
     {
         StageScope s(ctx, ST_GRID);
         hipLaunchKernelGGL(k_face_centroids, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pos.p, ctx->faces.p, (int)F,
@@ -614,6 +695,86 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
         hipLaunchKernelGGL(k_nn_fixup, dim3(512), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->ambig_list.p, ctx->ambig_count.p, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, ctx->face.p, ctx->state.p, it);
     }
+    NW_HIP(hipGetLastError());
+    return NW_OK;
+}
+
+// Opt-in autotuner of the cell size (NW_AUTOTUNE=1, once per localization cloud): the query is exact for every grid, so the
+// same query is simply timed on a few grids around the rule's cell size (x0.8 / x1.25 steps, walking downhill, at most
+// five probes) and the fastest one is kept as a multiplier on the rule for all later meshes of this cloud.  Off by default:
+// the probes (a re-sort of the localizations and two queries each, ~2 ms at 1M localizations) cost more than a 39-iteration
+// fit gains; it is the tool the rule in desired_cell() was checked with, and pays off for long fits of one cloud.
+static int tune_grid(nw_ctx *ctx)
+{
+    if (ctx->tuned && ctx->tuned_N == ctx->N) return NW_OK;
+    ctx->tuned = true; ctx->tuned_N = ctx->N; ctx->cell_tune = 1.0;
+    const char *at = getenv("NW_AUTOTUNE");
+    if (!at || atoi(at) == 0 || getenv("NW_CELL_SIZE") || ctx->N < 20000) return NW_OK;
+    const int verbose = getenv("NW_VERBOSE") != nullptr;
+    const int it = ctx->global_iter;
+    const int prof = ctx->profiling;
+    ctx->profiling = 0;
+    hipEvent_t e0, e1;
+    NW_HIP(hipEventCreate(&e0)); NW_HIP(hipEventCreate(&e1));
+    const double md = ctx->est_mean_dist;
+    const double h_rule = ctx->grid.h;
+    int rc = NW_OK;
+    auto probe = [&](double h, double &ms) -> int {
+        if (std::fabs(h - ctx->grid.h) > 1e-6 * h) {
+            ctx->force_h = h;
+            const int r = build_grid(ctx, md);
+            ctx->force_h = 0.0;
+            if (r != NW_OK) return r;
+        }
+        float best = 1e30f;
+        for (int rep = 0; rep < 2; ++rep) {              // the first pass warms the caches for this grid
+            NW_HIP(hipEventRecord(e0, ctx->stream));
+            NW_TRY(launch_query(ctx, it));
+            NW_HIP(hipEventRecord(e1, ctx->stream));
+            NW_HIP(hipEventSynchronize(e1));
+            float t = 0; NW_HIP(hipEventElapsedTime(&t, e0, e1));
+            best = std::min(best, t);
+        }
+        ms = best;
+        if (verbose) fprintf(stderr, "[nanowrap] autotune: cell %.3f -> query %.4f ms\n", ctx->grid.h, ms);
+        return NW_OK;
+    };
+    double best_h = h_rule, best_t = 0, t = 0;
+    do {
+        if ((rc = probe(h_rule, best_t)) != NW_OK) break;
+        double hl = h_rule * 0.8, tl = 0, hr = h_rule * 1.25, tr = 0;
+        if ((rc = probe(hl, tl)) != NW_OK) break;
+        if ((rc = probe(hr, tr)) != NW_OK) break;
+        int dir = 0;
+        if (tl < best_t && tl <= tr) { best_h = hl; best_t = tl; dir = -1; }
+        else if (tr < best_t) { best_h = hr; best_t = tr; dir = +1; }
+        for (int step = 0; dir != 0 && step < 2; ++step) {          // keep walking while it improves
+            const double hn = best_h * (dir < 0 ? 0.8 : 1.25);
+            if ((rc = probe(hn, t)) != NW_OK) break;
+            if (t < best_t) { best_h = hn; best_t = t; } else break;
+        }
+    } while (0);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ctx->profiling = prof;
+    if (rc != NW_OK) return rc;
+    ctx->cell_tune = best_h / h_rule;
+    if (std::fabs(best_h - ctx->grid.h) > 1e-6 * best_h) {
+        ctx->force_h = best_h;
+        rc = build_grid(ctx, md);
+        ctx->force_h = 0.0;
+    }
+    if (verbose) fprintf(stderr, "[nanowrap] autotune: rule %.3f -> cell %.3f (x%.2f)\n", h_rule, best_h, ctx->cell_tune);
+    return rc;
+}
+
+NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
+{
+    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_attract outside a search");
+    const int it = ctx->global_iter;
+    const int par = it & 1;
+    const int64_t N = ctx->N, F = ctx->F;
+    double *sc = ctx->scalars.p + par * NW_SC_BLOCK;
+    NW_TRY(launch_query(ctx, it));
     {
         StageScope s(ctx, ST_ATTRACT);
         hipLaunchKernelGGL(k_attract, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
@@ -817,23 +978,49 @@ NW_EXPORT int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t 
     if (rows && row_stride_bytes < 12) return fail(ctx, NW_ERR_BADARG, "nw_write_back: bad stride");
     const int64_t M = ctx->M;
     const size_t bytes = (size_t)3 * M * sizeof(float);
-    if (ctx->pin_bytes < bytes + (size_t)M) {
+    if (ctx->pin_bytes < bytes) {
         if (ctx->pin) (void)hipHostFree(ctx->pin);
         ctx->pin = nullptr; ctx->pin_bytes = 0;
-        NW_HIP(hipHostMalloc(&ctx->pin, bytes + (size_t)M, hipHostMallocDefault));
-        ctx->pin_bytes = bytes + (size_t)M;
+        NW_HIP(hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault));
+        ctx->pin_bytes = bytes;
     }
     float *stage = (float *)ctx->pin;
-    unsigned char *vstage = (unsigned char *)ctx->pin + bytes;
-    NW_HIP(hipMemcpyAsync(stage, ctx->pos.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (rows && ctx->have_valid) NW_HIP(hipMemcpyAsync(vstage, ctx->valid.p, (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
-    NW_HIP(hipStreamSynchronize(ctx->stream));
-    if (contiguous) memcpy(contiguous, stage, bytes);
-    if (rows) {
-        char *dst = (char *)rows;
-        for (int64_t v = 0; v < M; ++v)
-            if (!ctx->have_valid || vstage[v]) memcpy(dst + v * row_stride_bytes, stage + 3 * v, 12);
+    const bool masked = rows && ctx->have_valid;
+    const unsigned char *vstage = masked ? ctx->valid_host.data() : nullptr;
+    // The positions come back in T slices; slice t is copied out (contiguous result + strided vertex records) by host
+    // thread t as soon as ITS part of the device-to-host transfer has landed, while the later slices are still in flight.
+    if (!ctx->pool) {
+        int T = 8;
+        if (const char *e = getenv("NW_HOST_THREADS")) T = atoi(e);
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && T > hw) T = hw;
+        ctx->pool = new NwHostPool();
+        ctx->pool->start(T, ctx->device);
+        ctx->wb_events.resize(ctx->pool->n);
+        for (auto &e : ctx->wb_events) NW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, M / 50000));      // ~50k vertex records per thread
+    std::vector<int64_t> cut(T + 1);
+    for (int t = 0; t <= T; ++t) cut[t] = M * t / T;
+    for (int t = 0; t < T; ++t) {
+        NW_HIP(hipMemcpyAsync(stage + 3 * cut[t], ctx->pos.p + 3 * cut[t], (size_t)(cut[t + 1] - cut[t]) * 12, hipMemcpyDeviceToHost, ctx->stream));
+        NW_HIP(hipEventRecord(ctx->wb_events[t], ctx->stream));
+    }
+    std::atomic<int> failed(0);
+    auto work = [&](int t) {
+        if (t >= T) return;
+        if (hipEventSynchronize(ctx->wb_events[t]) != hipSuccess) { failed = 1; return; }
+        const int64_t v0 = cut[t], v1 = cut[t + 1];
+        if (contiguous) memcpy(contiguous + 3 * v0, stage + 3 * v0, (size_t)(v1 - v0) * 12);
+        if (rows) {
+            char *dst = (char *)rows;
+            for (int64_t v = v0; v < v1; ++v)
+                if (!masked || vstage[v]) memcpy(dst + v * row_stride_bytes, stage + 3 * v, 12);
+        }
+    };
+    if (T == 1) work(0);
+    else ctx->pool->run(work);
+    if (failed.load()) return fail(ctx, NW_ERR_HIP, "nw_write_back: device-to-host transfer failed");
     return NW_OK;
 }
 

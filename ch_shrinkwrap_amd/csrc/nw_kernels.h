@@ -234,10 +234,13 @@ __global__ void k_fill_items(const int *__restrict__ pstart, const int *__restri
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell) return;
     const int p0 = pstart[c], p1 = pstart[c + 1];
+    if (p1 <= p0) return;
     int o = istart[c];
-    for (int p = p0; p < p1; p += chunk) {
+    const int n = (p1 - p0 + chunk - 1) / chunk;          // a crowded brick is cut into n EQUAL parts (not 256 + a small rest)
+    const int per = (p1 - p0 + n - 1) / n;
+    for (int p = p0; p < p1; p += per) {
         NwWorkItem w;
-        w.cell = c; w.p0 = p; w.p1 = min(p + chunk, p1);
+        w.cell = c; w.p0 = p; w.p1 = min(p + per, p1);
         items[o++] = w;
     }
 }

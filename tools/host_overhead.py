@@ -5,13 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ch_shrinkwrap_amd import synth, _lib as nw
 from ch_shrinkwrap_amd.trimesh import TriMesh
 from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
-c = synth.make_config('c3', scale=1.0, seed=0)
+c = synth.make_config(sys.argv[1] if len(sys.argv) > 1 else 'c3', scale=1.0, seed=0)
 pts, s = c['points'], 1.0 / c['sigma'].ravel()
 mesh = TriMesh(c['vertices'], c['faces'])
 cg = ShrinkwrapMeshConjGrad(mesh, pts)
 for _ in range(4):
     cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
-cg.set_profiling(True)
+cg.set_profiling(int(os.environ.get('NW_PROF', '2')))
 T = dict(upload=0.0, search=0.0, logs=0.0, stage=0.0, finish=0.0, total=0.0)
 lams_a = np.ascontiguousarray(c['lams'], dtype=np.float32)
 n = 10

@@ -1,0 +1,79 @@
+"""Turn one tools/profile_round.sh run (gpurun_out/prof_<tag>/) into the tracked evidence files under profiles/:
+  <tag>_kernel_stats.csv                 rocprofv3 --kernel-trace --stats summary of `bench.py --steps 50 --warmup 10`
+  <tag>_bench.json                       the bench line of the same round (no profiler attached)
+  <tag>_pmc_and_trace_summary.json       per-kernel HBM traffic from the FETCH_SIZE / WRITE_SIZE passes + average durations
+  <tag>_sq_counters.json                 per-kernel SQ counters (mean per dispatch)
+  r01_pmc_traffic.json                   what bench.py reports as roofline.traffic
+HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB and gfx950's FETCH_SIZE counts half of
+the wide coalesced reads (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).
+usage: python tools/summarize_round.py <tag>"""
+import csv, glob, json, os, shutil, sys, collections
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, 'gpurun_out', 'prof_' + tag)
+dst = os.path.join(root, 'profiles')
+
+
+def short(name):
+    n = name.split('(')[0]
+    if n.startswith('void '):
+        n = n[5:]
+    return n.split('<')[0]
+
+
+def counters(sub):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for fn in glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(fn)):
+            acc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    return acc
+
+
+def mean_tail(v, k):
+    """mean over the LAST k dispatches (the timed iterations; set-up launches of the same kernel come first)"""
+    v = v[-k:] if len(v) > k else v
+    return sum(v) / len(v)
+
+
+stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)[0]
+shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats.csv'))
+dur = {}
+for r in csv.DictReader(open(stats)):
+    dur[short(r['Name'])] = dict(calls=int(r['Calls']), avg_us=float(r['AverageNs']) / 1e3, pct=float(r['Percentage']))
+bench = json.loads(open(os.path.join(src, 'bench.log')).read().strip().splitlines()[-1])
+json.dump(bench, open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
+
+fetch, write = counters('fetch'), counters('write')
+iters = 10                                             # bench.py --steps 10 in the PMC passes
+traffic = {}
+for k in sorted(set(fetch) | set(write)):
+    f = fetch.get(k, {}).get('FETCH_SIZE', [0.0])
+    w = write.get(k, {}).get('WRITE_SIZE', [0.0])
+    per_iter = max(1, round(len(f) / (iters + 10 + 2 * 5)))      # launches per iteration (warm-up 10 + timed 10 + 10 extra)
+    fk, wk = mean_tail(f, iters * per_iter), mean_tail(w, iters * per_iter)
+    traffic[k] = dict(FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024, dispatches=len(f),
+                      avg_us=dur.get(k, {}).get('avg_us'), calls_in_trace=dur.get(k, {}).get('calls'))
+grid = ['k_face_centroids', 'k_scan_tile_sums', 'k_scan_bsums', 'k_scan_final', 'k_centroid_scatter']
+summary = dict(traffic_raw=traffic,
+               note='per-kernel means over the last dispatches of `bench.py --steps 10 --warmup 10` under rocprofv3 --pmc (FETCH_SIZE and '
+                    'WRITE_SIZE in separate passes); hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024; avg_us from the '
+                    '--kernel-trace --stats pass (' + tag + '_kernel_stats.csv)')
+json.dump(summary, open(os.path.join(dst, tag + '_pmc_and_trace_summary.json'), 'w'), indent=1)
+
+sq = counters('sq')
+json.dump({k: dict({c: sum(v) / len(v) for c, v in d.items()}, dispatches=max(len(v) for v in d.values())) for k, d in sorted(sq.items())},
+          open(os.path.join(dst, tag + '_sq_counters.json'), 'w'), indent=1)
+
+out = {k: traffic[k]['hbm_bytes_per_launch'] for k in ('k_nearest_face', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update')
+       if k in traffic}
+out['grid_build'] = sum(traffic[k]['hbm_bytes_per_launch'] * (3 if k.startswith('k_scan') and False else 1) for k in grid if k in traffic)
+out['_note'] = ('HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts half of '
+                'wide coalesced reads, MI355X_MICROARCH.md section HBM); mean of the timed iterations of bench.py --steps 10 --warmup 10; '
+                'profiles/' + tag + '_*')
+json.dump(out, open(os.path.join(dst, 'r01_pmc_traffic.json'), 'w'), indent=1)
+print(json.dumps(out, indent=1))
+for k in ('k_nearest_face', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update', 'k_face_centroids', 'k_centroid_scatter'):
+    if k in dur:
+        print('%-24s calls %5d avg %8.1f us  %5.1f %%' % (k, dur[k]['calls'], dur[k]['avg_us'], dur[k]['pct']))
+print('bench', bench['ms_per_step'], bench['value'], bench['roofline'])
