@@ -139,6 +139,7 @@ struct nw_ctx {
     NwGrid grid{};
     bool grid_valid = false;
     double last_mean_dist = -1.0, spacing = 0.0, est_mean_dist = -1.0;
+    double acc_quantum = 1.0;         // fixed-point quantum of the LDS scatter accumulators (k_attract): 2^-36 of the cloud extent
     double cell_tune = 1.0;           // autotuned multiplier on the cell-size rule (tune_grid)
     double force_h = 0.0;             // > 0: build_grid uses exactly this cell (autotuner probes)
     bool tuned = false;
@@ -543,6 +544,12 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
     bool bad = false;
     NW_TRY(minmax3(ctx, ctx->pts_in.p, N, ctx->pmin, ctx->pmax, &bad));
     if (bad) { ctx->have_points = false; return fail(ctx, NW_ERR_NONFINITE, "non-finite localization coordinate"); }
+    {
+        double ext = 0;
+        for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)ctx->pmax[k] - (double)ctx->pmin[k]);
+        if (!(ext > 0) || !std::isfinite(ext)) ext = 1.0;
+        ctx->acc_quantum = std::ldexp(1.0, (int)std::floor(std::log2(ext)) - 36);
+    }
     ctx->have_points = true;
     ctx->grid_valid = false;
     ctx->last_mean_dist = -1.0;
@@ -779,7 +786,7 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
         StageScope s(ctx, ST_ATTRACT);
         hipLaunchKernelGGL(k_attract, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
                            ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->sinv_scalar, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->w_scalar, ctx->mask.p,
-                           ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, sc, ctx->state.p, it);
+                           ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, sc, ctx->state.p, it, 1.0 / ctx->acc_quantum, ctx->acc_quantum);
     }
     NW_HIP(hipGetLastError());
     return NW_OK;

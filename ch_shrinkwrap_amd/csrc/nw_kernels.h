@@ -593,10 +593,15 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
 //   vacc[v_j] += {w_j*res, w_j}  -> S0 = A^T res and A^T 1 in ONE pass                        :253, conj_grad_utils.c:153-162,
 //                                                                                            _membrane_mesh.pyx:1633
 // Scatter: the localizations are brick-sorted, so the 256 points of a workgroup reference only a few hundred distinct
-// vertices.  Contributions are first summed per vertex in an LDS hash table (ds_add_f32), then flushed with ONE
-// global float atomic per (vertex, component), four adjacent lanes covering the vertex's contiguous float4, i.e. one
-// memory-side atomic request per touched vertex instead of twelve per point (MI355X_MICROARCH.md "Global float atomics":
-// scattered single-dword atomics run ~17x below the contiguous rate).
+// vertices.  Contributions are first summed per vertex in an LDS hash table, then flushed with ONE global float atomic
+// per (vertex, component), four adjacent lanes covering the vertex's contiguous float4, i.e. one memory-side atomic
+// request per touched vertex instead of twelve per point (MI355X_MICROARCH.md "Global float atomics": scattered
+// single-dword atomics run ~17x below the contiguous rate).
+// The LDS accumulators are 64-bit FIXED POINT (ds_add_u64), not float: measured on MI355X, the twelve ds_add_f32 per
+// point cost 67 us per launch at 1M points (LDS float atomics retire ~1 lane every 3 cycles per CU), twelve ds_add_u64
+// 25 us.  The quantum is a power of two, 2^-36 of the cloud's extent (`inv_q` = its exact reciprocal): ~10^-11 relative
+// resolution, far below the float32 rounding of each product, and 2^27 extents of headroom; a workgroup's partial sum
+// is then EXACT (order independent) and rounded once to float32 at the flush.
 #define NW_HT 1024
 
 __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4 *__restrict__ pts, const int *__restrict__ face, const float4 *__restrict__ cent_by_face, float *__restrict__ dist,
@@ -604,14 +609,14 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
                                                      const float *__restrict__ sinv, float sinv_scalar, const float *__restrict__ wnorm, float w_scalar,
                                                      const unsigned char *__restrict__ mask,
                                                      int *__restrict__ vidx, float *__restrict__ wout, float *__restrict__ res, float *__restrict__ vacc,
-                                                     double *__restrict__ sc, NwDevState *__restrict__ st, int it)
+                                                     double *__restrict__ sc, NwDevState *__restrict__ st, int it, double inv_q, double q)
 {
     if (it >= st->stop_at) return;
     __shared__ double s_part[4 * 4];
     __shared__ int s_key[NW_HT];
-    __shared__ float s_val[NW_HT * 4];
+    __shared__ unsigned long long s_val[NW_HT * 4];        // component-major [4][NW_HT], two's-complement fixed point
     for (int t = threadIdx.x; t < NW_HT; t += NW_BLOCK) s_key[t] = -1;
-    for (int t = threadIdx.x; t < NW_HT * 4; t += NW_BLOCK) s_val[t] = 0.0f;
+    for (int t = threadIdx.x; t < NW_HT * 4; t += NW_BLOCK) s_val[t] = 0ull;
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double red[4] = {0.0, 0.0, 0.0, 0.0};
@@ -681,18 +686,21 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
                 if (old == -1 || old == v[j]) break;
                 hsh = (hsh + 1) & (NW_HT - 1);
             }
-            float *a = s_val + 4 * hsh;
-            atomicAdd(a + 0, w[j] * r[0]);
-            atomicAdd(a + 1, w[j] * r[1]);
-            atomicAdd(a + 2, w[j] * r[2]);
-            atomicAdd(a + 3, w[j]);
+            unsigned long long *a = s_val + hsh;
+            const float c[4] = {w[j] * r[0], w[j] * r[1], w[j] * r[2], w[j]};     // float32 products, as the reference forms them
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double x = (double)c[k] * inv_q;                              // exact scaling (power of two)
+                bad |= !(fabs(x) < 9.0e18);                                         // overflow / inf / NaN: raise the NaN status
+                atomicAdd(a + k * NW_HT, (unsigned long long)__double2ll_rn(x));
+            }
         }
         if (bad) atomicCAS(&st->status, 0, -3 /* NW_ERR_NAN */);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < NW_HT * 4; t += NW_BLOCK) {
-        const int key = s_key[t >> 2];
-        if (key >= 0) atomicAdd(vacc + 4 * (int64_t)key + (t & 3), s_val[t]);
+        const int key = s_key[t >> 2];                     // four adjacent lanes flush the four components of one vertex
+        if (key >= 0) atomicAdd(vacc + 4 * (int64_t)key + (t & 3), (float)((double)(long long)s_val[(t & 3) * NW_HT + (t >> 2)] * q));
     }
     nw_block_reduce_atomic<4, true>(red, sc + (int64_t)SC_RES2 * NW_REPL * NW_RSTRIDE, s_part);
 }
