@@ -694,7 +694,7 @@ static int launch_query(nw_ctx *ctx, int it)
             hipLaunchKernelGGL((k_nearest_face<64, 256>), dim3(nb), dim3(64), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                                ctx->cent_tmp.p, ctx->face.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
         else
-            hipLaunchKernelGGL((k_nearest_face<256, 1024>), dim3(nb), dim3(256), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+            hipLaunchKernelGGL((k_nearest_face<256, 768>), dim3(nb), dim3(256), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                                ctx->cent_tmp.p, ctx->face.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
     }
     {
