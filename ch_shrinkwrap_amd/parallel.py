@@ -104,10 +104,17 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
     w_eff = weights if weights is not None else sigma_inv
     prenorm = None
     if not np.isscalar(w_eff):
-        w_eff = np.asarray(w_eff, dtype=np.float32).ravel()
-        t = ex.new_tensor([float(w_eff.astype(np.float64).sum()), float(w_eff.size)])
-        dist.all_reduce(t)
-        prenorm = (w_eff / np.float32(float(t[0]) / float(t[1]))).astype(np.float32)
+        # once per weights OBJECT (every rank passes the same object again for the next block of a fit, so all ranks hit or
+        # miss together): the global mean costs a blocking all-reduce and a pass over 3N floats on the host
+        cached = getattr(ex, '_prenorm_cache', None)
+        if cached is not None and cached[0] is w_eff:
+            prenorm = cached[1]
+        else:
+            w_arr = np.asarray(w_eff, dtype=np.float32).ravel()
+            t = ex.new_tensor([float(w_arr.astype(np.float64).sum()), float(w_arr.size)])
+            dist.all_reduce(t)
+            prenorm = (w_arr / np.float32(float(t[0]) / float(t[1]))).astype(np.float32)
+            ex._prenorm_cache = (w_eff, prenorm)
     ex.begin(data, lams, num_iters, sigma_inv, weights, prenorm, pos, last_step)
     n_red = ex.n_scalars if mode == 'tiles' else ex.n_point_scalars
     for _ in range(int(num_iters)):
