@@ -1,4 +1,5 @@
-"""One-off evidence run: HIP path vs the CPU oracle on the FULL headline workload (C3: 1M localizations, 198 812 vertices),
+"""One-off evidence run: HIP path vs the CPU oracle on a FULL-size workload (default C3: 1M localizations, 198 812 vertices;
+`python tools/parity_full.py c4` for the 5M-localization network),
 one block of 5 iterations + a second block; prints vertex RMS (relative to the bbox diagonal and in nm) and the number of
 nearest-face disagreements per iteration."""
 import os, sys, time
@@ -9,7 +10,9 @@ from ch_shrinkwrap_amd.trimesh import TriMesh
 from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
 from oracle import nanowrap_oracle as O
 
-c = synth.make_config('c3', scale=1.0, seed=0)
+name = sys.argv[1] if len(sys.argv) > 1 else 'c3'
+c = synth.make_config(name, scale=1.0, seed=0)
+print('%s: N=%d M=%d F=%d' % (name, c['points'].shape[0], c['vertices'].shape[0], c['faces'].shape[0]), flush=True)
 pts, s = c['points'], 1.0 / c['sigma'].ravel()
 mo, mg = TriMesh(c['vertices'], c['faces']), TriMesh(c['vertices'], c['faces'])
 cg = ShrinkwrapMeshConjGrad(mg, pts)
