@@ -1,6 +1,7 @@
 """
 Builds the native pieces in-tree (no pip, no JIT cache):
   * ch_shrinkwrap_amd/libnanowrap_hip.so  -- the HIP kernels + C-ABI (hipcc, --offload-arch=gfx950)
+  * ch_shrinkwrap_amd/libnw_remesh.so     -- the block-boundary remesher (host C++, g++; include/nw_remesh.h)
 The oracle (test infrastructure) is built by oracle/Makefile, see __graft_entry__.build().
 """
 import os
@@ -37,5 +38,22 @@ def build_hip_library(force=False, verbose=False):
     return LIB
 
 
+HOST_LIB = os.path.join(HERE, 'libnw_remesh.so')
+HOST_SRC = os.path.join(HERE, 'csrc', 'remesh.cpp')
+HOST_DEPS = [HOST_SRC, os.path.join(os.path.dirname(HERE), 'include', 'nw_remesh.h')]
+HOST_FLAGS = ['-O2', '-std=c++14', '-fPIC', '-shared', '-fvisibility=hidden', '-Wall']
+
+
+def build_host_library(force=False, verbose=False):
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in HOST_DEPS):
+        return HOST_LIB
+    cmd = [os.environ.get('CXX', 'g++')] + HOST_FLAGS + ['-o', HOST_LIB, HOST_SRC]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == '__main__':
     build_hip_library(force=True, verbose=True)
+    build_host_library(force=True, verbose=True)

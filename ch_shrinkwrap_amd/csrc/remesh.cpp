@@ -1,0 +1,394 @@
+// Block-boundary isotropic remesher (host code, C-ABI in include/nw_remesh.h).
+//
+// Stands in for PYME's TriangleMesh.remesh, which the reference calls between optimiser blocks
+// (/root/reference/ch_shrinkwrap/_membrane_mesh.pyx:1546, :1219) but which is not part of the reference tree.  Built from the
+// published algorithm (Botsch & Kobbelt 2004): split long edges, collapse short edges, flip towards degree six, optional
+// tangential relaxation, on an array-based half-edge structure.  Half-edge h points TO vert[h]; its origin is vert[prev[h]].
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/nw_remesh.h"
+
+#define NWR_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+struct V3 {
+    double x, y, z;
+};
+inline V3 operator-(const V3 &a, const V3 &b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator+(const V3 &a, const V3 &b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator*(const V3 &a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(const V3 &a, const V3 &b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double norm2(const V3 &a) { return dot(a, a); }
+
+struct HalfEdgeMesh {
+    std::vector<V3> pos;
+    std::vector<int> vhe;                       // an outgoing half-edge of the vertex, -1 = deleted / unreferenced
+    std::vector<int> val;                       // vertex degree
+    std::vector<unsigned char> boundary;        // vertex touches an unmatched edge: never modified
+    std::vector<int> vert, next, prev, twin, face;   // per half-edge; vert == -1 -> deleted
+    std::vector<int> fhe;                       // a half-edge of the face, -1 = deleted
+    int max_valence = 16;
+    int64_t n_split = 0, n_collapse = 0, n_flip = 0;
+    bool corrupt = false;
+
+    int from(int h) const { return vert[prev[h]]; }
+    double len2(int h) const { return norm2(pos[vert[h]] - pos[from(h)]); }
+
+    // outgoing half-edges of an interior vertex, counter-clockwise
+    template <class F>
+    void ring(int v, F f)
+    {
+        const int h0 = vhe[v];
+        int h = h0, guard = 0;
+        do {
+            f(h);
+            h = twin[prev[h]];
+            if (++guard > 256) { corrupt = true; return; }
+        } while (h != h0 && h >= 0);
+    }
+
+    bool connected(int a, int b)
+    {
+        bool hit = false;
+        ring(a, [&](int h) { hit |= (vert[h] == b); });
+        return hit;
+    }
+
+    int add_halfedge()
+    {
+        vert.push_back(-1); next.push_back(-1); prev.push_back(-1); twin.push_back(-1); face.push_back(-1);
+        return (int)vert.size() - 1;
+    }
+
+    V3 face_normal(int a, int b, int c) const { return cross(pos[b] - pos[a], pos[c] - pos[a]); }
+
+    int build(const float *vertices, int64_t nv, const int32_t *faces, int64_t nf)
+    {
+        pos.resize(nv);
+        for (int64_t i = 0; i < nv; ++i) pos[i] = {vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]};
+        vhe.assign(nv, -1); val.assign(nv, 0); boundary.assign(nv, 0);
+        const int64_t nh = 3 * nf;
+        vert.resize(nh); next.resize(nh); prev.resize(nh); twin.assign(nh, -1); face.resize(nh);
+        fhe.resize(nf);
+        std::vector<std::pair<uint64_t, int>> keys(nh);
+        for (int64_t f = 0; f < nf; ++f) {
+            for (int k = 0; k < 3; ++k) {
+                const int a = faces[3 * f + k], b = faces[3 * f + (k + 1) % 3];
+                if (a < 0 || a >= nv || b < 0 || b >= nv || a == b) return NWR_ERR_BADARG;
+                const int h = (int)(3 * f + k);
+                vert[h] = b; next[h] = (int)(3 * f + (k + 1) % 3); prev[h] = (int)(3 * f + (k + 2) % 3); face[h] = (int)f;
+                keys[h] = {((uint64_t)(uint32_t)a << 32) | (uint32_t)b, h};
+                vhe[a] = h;
+            }
+            fhe[f] = (int)(3 * f);
+        }
+        std::sort(keys.begin(), keys.end());
+        for (int64_t i = 1; i < nh; ++i)
+            if (keys[i].first == keys[i - 1].first) return NWR_ERR_NONMANIFOLD;      // same directed edge twice
+        for (int64_t i = 0; i < nh; ++i) {
+            const uint64_t k = keys[i].first;
+            const uint64_t rk = (k << 32) | (k >> 32);
+            auto it = std::lower_bound(keys.begin(), keys.end(), std::make_pair(rk, -1));
+            if (it != keys.end() && it->first == rk) twin[keys[i].second] = it->second;
+        }
+        for (int64_t h = 0; h < nh; ++h) {
+            val[from((int)h)] += 1;
+            if (twin[h] < 0) { boundary[from((int)h)] = 1; boundary[vert[h]] = 1; }
+        }
+        // a vertex whose fan does not close after `val` steps is a non-manifold ("bow-tie") vertex: leave it alone
+        for (int64_t v = 0; v < nv; ++v) {
+            if (vhe[v] < 0 || boundary[v]) continue;
+            int n = 0;
+            ring((int)v, [&](int) { ++n; });
+            if (n != val[v]) boundary[v] = 1;
+        }
+        corrupt = false;
+        return NWR_OK;
+    }
+
+    // split edge h (a->b) at its midpoint; both adjacent faces are cut in two
+    void split(int h)
+    {
+        const int t = twin[h];
+        const int hn = next[h], hp = prev[h], tn = next[t], tp = prev[t];
+        const int a = vert[t], b = vert[h], c = vert[hn], d = vert[tn];
+        const int f0 = face[h], f1 = face[t];
+        const int m = (int)pos.size();
+        pos.push_back((pos[a] + pos[b]) * 0.5);
+        vhe.push_back(-1); val.push_back(4); boundary.push_back(0);
+        const int h2 = add_halfedge(), e0 = add_halfedge(), e1 = add_halfedge();
+        const int t2 = add_halfedge(), e2 = add_halfedge(), e3 = add_halfedge();
+        const int f2 = (int)fhe.size(); fhe.push_back(h2);
+        const int f3 = (int)fhe.size(); fhe.push_back(t2);
+        // f0: h (a->m), e0 (m->c), hp (c->a)
+        vert[h] = m; vert[e0] = c;
+        next[h] = e0; prev[e0] = h; next[e0] = hp; prev[hp] = e0; next[hp] = h; prev[h] = hp;
+        face[e0] = f0; fhe[f0] = h;
+        // f2: h2 (m->b), hn (b->c), e1 (c->m)
+        vert[h2] = b; vert[e1] = m;
+        next[h2] = hn; prev[hn] = h2; next[hn] = e1; prev[e1] = hn; next[e1] = h2; prev[h2] = e1;
+        face[h2] = f2; face[hn] = f2; face[e1] = f2;
+        // f1: t (b->m), e2 (m->d), tp (d->b)
+        vert[t] = m; vert[e2] = d;
+        next[t] = e2; prev[e2] = t; next[e2] = tp; prev[tp] = e2; next[tp] = t; prev[t] = tp;
+        face[e2] = f1; fhe[f1] = t;
+        // f3: t2 (m->a), tn (a->d), e3 (d->m)
+        vert[t2] = a; vert[e3] = m;
+        next[t2] = tn; prev[tn] = t2; next[tn] = e3; prev[e3] = tn; next[e3] = t2; prev[t2] = e3;
+        face[t2] = f3; face[tn] = f3; face[e3] = f3;
+        twin[h] = t2; twin[t2] = h; twin[h2] = t; twin[t] = h2; twin[e0] = e1; twin[e1] = e0; twin[e2] = e3; twin[e3] = e2;
+        vhe[m] = h2;
+        val[c] += 1; val[d] += 1;
+        ++n_split;
+    }
+
+    // collapse a = from(h) into b = vert[h] (b keeps its position); returns false if not allowed
+    bool collapse(int h, double high2)
+    {
+        const int t = twin[h];
+        const int hn = next[h], hp = prev[h], tn = next[t], tp = prev[t];
+        const int a = vert[t], b = vert[h], c = vert[hn], d = vert[tn];
+        if (boundary[a] || boundary[b] || boundary[c] || boundary[d]) return false;
+        if (c == d || val[a] < 3 || val[b] < 3 || val[c] <= 3 || val[d] <= 3) return false;
+        if (val[a] + val[b] - 4 > max_valence || val[a] + val[b] - 4 < 3) return false;
+        // link condition: the only common neighbours of a and b are c and d
+        int ra[64], na = 0, rh[64];
+        bool overflow = false;
+        ring(a, [&](int o) { if (na < 64) { rh[na] = o; ra[na++] = vert[o]; } else overflow = true; });
+        if (overflow || corrupt || na != val[a]) return false;
+        int common = 0;
+        ring(b, [&](int o) { const int x = vert[o]; for (int i = 0; i < na; ++i) common += (ra[i] == x); });
+        if (common != 2) return false;
+        const V3 pb = pos[b];
+        for (int i = 0; i < na; ++i) {
+            const int x = ra[i];
+            if (x == b) continue;
+            if (norm2(pos[x] - pb) > high2) return false;                    // would create a long edge
+        }
+        // triangles around a that survive (a,x,y) -> (b,x,y) must keep their orientation and a sane shape
+        for (int i = 0; i < na; ++i) {
+            const int o = rh[i];
+            const int x = vert[o], y = vert[next[o]];
+            if (x == b || y == b) continue;
+            const V3 n0 = face_normal(a, x, y), n1 = face_normal(b, x, y);
+            const double d01 = dot(n0, n1);
+            if (!(d01 > 0.0) || d01 * d01 < 0.04 * norm2(n0) * norm2(n1)) return false;   // flips or turns by > ~78 degrees
+        }
+        const int hn_t = twin[hn], hp_t = twin[hp], tn_t = twin[tn], tp_t = twin[tp];
+        if (hn_t < 0 || hp_t < 0 || tn_t < 0 || tp_t < 0) return false;
+        // every half-edge that pointed to a now points to b
+        for (int i = 0; i < na; ++i) vert[twin[rh[i]]] = b;
+        twin[hn_t] = hp_t; twin[hp_t] = hn_t;
+        twin[tn_t] = tp_t; twin[tp_t] = tn_t;
+        vhe[b] = tp_t;                       // b->d, alive
+        if (vhe[c] == hp) vhe[c] = hn_t;     // c->b
+        if (vhe[d] == tp) vhe[d] = tn_t;     // d->(a, now b)
+        const int dead[6] = {h, hn, hp, t, tn, tp};
+        for (int k = 0; k < 6; ++k) vert[dead[k]] = -1;
+        fhe[face[h]] = -1; fhe[face[t]] = -1;
+        val[b] = val[a] + val[b] - 4; val[c] -= 1; val[d] -= 1;
+        val[a] = 0; vhe[a] = -1;
+        ++n_collapse;
+        return true;
+    }
+
+    // replace edge a-b (h) by c-d if that brings the four degrees closer to six
+    bool flip(int h)
+    {
+        const int t = twin[h];
+        const int hn = next[h], hp = prev[h], tn = next[t], tp = prev[t];
+        const int a = vert[t], b = vert[h], c = vert[hn], d = vert[tn];
+        if (boundary[a] || boundary[b] || boundary[c] || boundary[d] || c == d) return false;
+        if (val[a] <= 3 || val[b] <= 3 || val[c] + 1 > max_valence || val[d] + 1 > max_valence) return false;
+        const int before = std::abs(val[a] - 6) + std::abs(val[b] - 6) + std::abs(val[c] - 6) + std::abs(val[d] - 6);
+        const int after = std::abs(val[a] - 7) + std::abs(val[b] - 7) + std::abs(val[c] - 5) + std::abs(val[d] - 5);
+        if (after >= before) return false;
+        if (connected(c, d) || corrupt) return false;
+        const V3 n0 = face_normal(a, b, c), n1 = face_normal(b, a, d);
+        const double l0 = norm2(n0), l1 = norm2(n1);
+        if (!(l0 > 0) || !(l1 > 0)) return false;
+        if (dot(n0, n1) < 0.3 * std::sqrt(l0 * l1)) return false;           // do not flip across a crease
+        const V3 m0 = face_normal(a, d, c), m1 = face_normal(d, b, c);
+        const V3 navg = n0 * (1.0 / std::sqrt(l0)) + n1 * (1.0 / std::sqrt(l1));
+        const double q0 = dot(m0, navg), q1 = dot(m1, navg);
+        if (!(q0 > 0) || !(q1 > 0)) return false;                           // non-convex quad
+        if (q0 * q0 < 0.04 * norm2(m0) * norm2(navg) || q1 * q1 < 0.04 * norm2(m1) * norm2(navg)) return false;
+        // f0 = (a->d = tn, d->c = h, c->a = hp), f1 = (d->b = tp, b->c = hn, c->d = t)
+        const int f0 = face[h], f1 = face[t];
+        vert[h] = c; vert[t] = d;
+        next[tn] = h; prev[h] = tn; next[h] = hp; prev[hp] = h; next[hp] = tn; prev[tn] = hp;
+        next[tp] = hn; prev[hn] = tp; next[hn] = t; prev[t] = hn; next[t] = tp; prev[tp] = t;
+        face[tn] = f0; face[hn] = f1;
+        fhe[f0] = h; fhe[f1] = t;
+        if (vhe[a] == h) vhe[a] = tn;
+        if (vhe[b] == t) vhe[b] = hn;
+        val[a] -= 1; val[b] -= 1; val[c] += 1; val[d] += 1;
+        ++n_flip;
+        return true;
+    }
+
+    bool alive(int h) const { return vert[h] >= 0; }
+
+    void split_long_edges(double high2)
+    {
+        for (int pass = 0; pass < 8; ++pass) {
+            const int64_t before = n_split;
+            const size_t nh = vert.size();                 // edges created by this pass are looked at in the next one
+            for (size_t h = 0; h < nh; ++h) {
+                if (!alive((int)h)) continue;
+                const int t = twin[h];
+                if (t < 0 || (int)h > t) continue;         // each interior edge once
+                if (boundary[from((int)h)] && boundary[vert[h]]) continue;
+                if (len2((int)h) > high2) split((int)h);
+            }
+            if (n_split == before) break;
+        }
+    }
+
+    void collapse_short_edges(double low2, double high2)
+    {
+        const size_t nh = vert.size();
+        for (size_t h = 0; h < nh; ++h) {
+            if (!alive((int)h)) continue;
+            const int t = twin[h];
+            if (t < 0 || (int)h > t) continue;
+            if (len2((int)h) >= low2) continue;
+            if (!collapse((int)h, high2)) collapse(t, high2);
+            if (corrupt) return;
+        }
+    }
+
+    void equalize_valences()
+    {
+        const size_t nh = vert.size();
+        for (size_t h = 0; h < nh; ++h) {
+            if (!alive((int)h)) continue;
+            const int t = twin[h];
+            if (t < 0 || (int)h > t) continue;
+            flip((int)h);
+            if (corrupt) return;
+        }
+    }
+
+    // tangential relaxation: every interior vertex moves by l x (tangential part of the vector to its ring centroid)
+    void relax(double l, int n_relax)
+    {
+        const size_t nv = pos.size();
+        std::vector<V3> nrm(nv), upd(nv);
+        for (int it = 0; it < n_relax; ++it) {
+            std::fill(nrm.begin(), nrm.end(), V3{0, 0, 0});
+            for (size_t f = 0; f < fhe.size(); ++f) {
+                if (fhe[f] < 0) continue;
+                const int h = fhe[f];
+                const int a = vert[prev[h]], b = vert[h], c = vert[next[h]];
+                const V3 n = face_normal(a, b, c);             // length = 2 x area: area weighting
+                nrm[a] = nrm[a] + n; nrm[b] = nrm[b] + n; nrm[c] = nrm[c] + n;
+            }
+            for (size_t v = 0; v < nv; ++v) {
+                upd[v] = pos[v];
+                if (vhe[v] < 0 || boundary[v] || val[v] < 3) continue;
+                V3 g{0, 0, 0};
+                int n = 0;
+                ring((int)v, [&](int o) { g = g + pos[vert[o]]; ++n; });
+                if (corrupt || n == 0) continue;
+                const V3 d = g * (1.0 / n) - pos[v];
+                const double nn = norm2(nrm[v]);
+                V3 tang = d;
+                if (nn > 0) tang = d - nrm[v] * (dot(d, nrm[v]) / nn);
+                upd[v] = pos[v] + tang * l;
+            }
+            pos.swap(upd);
+        }
+    }
+};
+
+}  // namespace
+
+NWR_EXPORT int nwr_abi_version(void) { return 1; }
+
+NWR_EXPORT void nwr_free(void *p) { std::free(p); }
+
+NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
+                          int n_iterations, float target_edge_length, float relax_lambda, int n_relax, int max_valence,
+                          float **out_vertices, int64_t *out_n_vertices, int32_t **out_faces, int64_t *out_n_faces,
+                          nwr_stats *stats)
+{
+    if (!vertices || !faces || !out_vertices || !out_n_vertices || !out_faces || !out_n_faces) return NWR_ERR_BADARG;
+    if (n_vertices < 3 || n_faces < 1 || n_vertices > (1ll << 30) || n_faces > (1ll << 29) || n_iterations < 0 || n_relax < 0)
+        return NWR_ERR_BADARG;
+    *out_vertices = nullptr; *out_faces = nullptr; *out_n_vertices = 0; *out_n_faces = 0;
+    try {
+        HalfEdgeMesh m;
+        m.max_valence = max_valence > 0 ? std::min(max_valence, 60) : 16;
+        int rc = m.build(vertices, n_vertices, faces, n_faces);
+        if (rc != NWR_OK) return rc;
+        double L = target_edge_length;
+        if (!(L > 0)) {
+            double s = 0; int64_t n = 0;
+            for (size_t h = 0; h < m.vert.size(); ++h) { s += std::sqrt(m.len2((int)h)); ++n; }
+            L = n ? s / n : 1.0;
+        }
+        const double high = 4.0 / 3.0 * L, low = 4.0 / 5.0 * L;
+        for (int it = 0; it < n_iterations; ++it) {
+            m.split_long_edges(high * high);
+            m.collapse_short_edges(low * low, high * high);
+            m.equalize_valences();
+            if (n_relax > 0) m.relax(relax_lambda, n_relax);
+            if (m.corrupt) return NWR_ERR_NONMANIFOLD;
+        }
+        // splits can pile degree onto a vertex faster than one flip pass removes it: keep flipping while it helps
+        for (int extra = 0; extra < 6 && n_iterations > 0; ++extra) {
+            int mv = 0;
+            for (size_t v = 0; v < m.pos.size(); ++v) if (m.vhe[v] >= 0) mv = std::max(mv, m.val[v]);
+            if (mv <= m.max_valence) break;
+            const int64_t before = m.n_flip;
+            m.equalize_valences();
+            if (m.corrupt) return NWR_ERR_NONMANIFOLD;
+            if (m.n_flip == before) break;
+        }
+        // compact: faces that are alive, vertices they reference
+        std::vector<int> remap(m.pos.size(), -1);
+        int64_t nf = 0;
+        for (size_t f = 0; f < m.fhe.size(); ++f) nf += m.fhe[f] >= 0;
+        int32_t *of = (int32_t *)std::malloc(sizeof(int32_t) * 3 * (size_t)std::max<int64_t>(nf, 1));
+        if (!of) return NWR_ERR_NOMEM;
+        std::vector<unsigned char> used(m.pos.size(), 0);
+        int64_t k = 0;
+        for (size_t f = 0; f < m.fhe.size(); ++f) {
+            const int h = m.fhe[f];
+            if (h < 0) continue;
+            const int a = m.vert[m.prev[h]], b = m.vert[h], c = m.vert[m.next[h]];
+            of[3 * k] = a; of[3 * k + 1] = b; of[3 * k + 2] = c;
+            used[a] = used[b] = used[c] = 1;
+            ++k;
+        }
+        int64_t nv = 0;
+        for (size_t v = 0; v < m.pos.size(); ++v) if (used[v]) remap[v] = (int)nv++;
+        float *ov = (float *)std::malloc(sizeof(float) * 3 * (size_t)std::max<int64_t>(nv, 1));
+        if (!ov) { std::free(of); return NWR_ERR_NOMEM; }
+        for (size_t v = 0; v < m.pos.size(); ++v) {
+            if (remap[v] < 0) continue;
+            ov[3 * remap[v]] = (float)m.pos[v].x; ov[3 * remap[v] + 1] = (float)m.pos[v].y; ov[3 * remap[v] + 2] = (float)m.pos[v].z;
+        }
+        for (int64_t i = 0; i < 3 * nf; ++i) of[i] = remap[of[i]];
+        if (stats) {
+            stats->n_split = m.n_split; stats->n_collapse = m.n_collapse; stats->n_flip = m.n_flip;
+            double s = 0; int64_t n = 0; int mv = 0;
+            for (size_t h = 0; h < m.vert.size(); ++h) if (m.alive((int)h)) { s += std::sqrt(m.len2((int)h)); ++n; }
+            for (size_t v = 0; v < m.pos.size(); ++v) if (used[v]) mv = std::max(mv, m.val[v]);
+            stats->mean_edge_length = n ? s / n : 0.0; stats->max_valence = mv; stats->reserved = 0;
+        }
+        *out_vertices = ov; *out_n_vertices = nv; *out_faces = of; *out_n_faces = nf;
+        return NWR_OK;
+    } catch (const std::bad_alloc &) {
+        return NWR_ERR_NOMEM;
+    }
+}

@@ -9,10 +9,10 @@ Outer-loop driver for the NanoWrap hot path: the host-side mirror of
 built on this package's own half-edge substrate (trimesh.TriMesh) because the reference's base class is PYME's
 TriangleMesh (third party, absent).  What is in scope is the DRIVER: sigma handling, lambda, block sizes, one
 optimiser per block, the post-block normal refresh, the remesh target-length schedule and `truncate_at`.  What is
-out of scope this round is the topology surgery PYME performs at block boundaries --
-`remesh`, `remove_necks`, `punch_holes`, `remove_extra_short_edges`: they are exposed as hooks (`remesher`,
-`neck_remover`, `hole_puncher` callables) and, when no hook is installed, the topology is held fixed and that is
-logged once.  The numerical path of every block is the HIP library; there is no CPU fallback.
+PYME's part is the topology surgery at block boundaries -- `remesh`, the deletion half of `remove_necks`,
+`punch_holes`, `remove_extra_short_edges`: they are hooks (`remesher`, `neck_remover`, `hole_puncher`, `edge_cleaner`).
+For `remesh` this package ships its own implementation of the published algorithm (`remesher='builtin'`, remesh.py /
+csrc/remesh.cpp); when no hook is installed the topology is held fixed and that is logged once.  The numerical path of every block is the HIP library; there is no CPU fallback.
 """
 import math
 import numpy as np
@@ -55,7 +55,7 @@ class MembraneMesh(TriMesh):
         self._sigma = None
         self.cg = None
         # block-boundary topology hooks (PYME's job in the reference; see module docstring)
-        self.remesher = None          # callable(mesh, n, target_edge_length, l, n_relax)
+        self.remesher = None          # None | 'builtin' | callable(mesh, n, target_edge_length, l, n_relax)
         self.neck_remover = None      # callable(mesh, vertex_ids): delete + repair + remesh (PYME's part of remove_necks)
         self.hole_puncher = None      # callable(mesh, points, eps)
         self.edge_cleaner = None      # callable(mesh)  (remove_extra_short_edges)
@@ -70,15 +70,28 @@ class MembraneMesh(TriMesh):
 
     # -- topology hooks ---------------------------------------------------------------------------------------
     def _topology_changed(self, vertices, faces):
+        """Rebuild the half-edge tables for a new (vertices, faces) pair; the optimiser of the old topology is dropped."""
+        props, vprops = self.vertex_properties, self.vertex_vector_properties
         TriMesh.__init__(self, vertices, faces)
+        self.vertex_properties, self.vertex_vector_properties = props, vprops
+        self._initialize_curvature_vectors()
 
     def remesh(self, n=5, target_edge_length=-1, l=0.5, n_relax=10):
+        """TriangleMesh.remesh(n, target_edge_length, l, n_relax) as the reference calls it (_membrane_mesh.pyx:1546, :1219).
+        `self.remesher`: None = topology held fixed; 'builtin' = this package's isotropic remesher (remesh.py, host C++);
+        or any callable(mesh, n, target_edge_length, l, n_relax), e.g. one that drives PYME.  Returns True if it ran."""
         if self.remesher is None:
             if not self._warned_fixed_topology:
-                print('MembraneMesh: no remesher installed (PYME TriangleMesh.remesh is out of scope this round) -- topology held fixed')
+                print("MembraneMesh: no remesher installed (mesh.remesher = 'builtin' or a callable) -- topology held fixed")
                 self._warned_fixed_topology = True
             return False
-        self.remesher(self, n, target_edge_length, l, n_relax)
+        if isinstance(self.remesher, str):
+            if self.remesher != 'builtin':
+                raise ValueError("remesher must be None, 'builtin' or a callable")
+            from .remesh import builtin_remesher
+            builtin_remesher(self, n, target_edge_length, l, n_relax)
+        else:
+            self.remesher(self, n, target_edge_length, l, n_relax)
         return True
 
     def neck_vertices(self, neck_curvature_threshold_low=-1e-4, neck_curvature_threshold_high=1e-2):
@@ -341,6 +354,7 @@ class ShrinkwrapMembrane(object):
         self.minimum_edge_length = 5.0
         self.smooth_curvature = True
         self.device = 0
+        self.remesher = 'builtin'                  # not a trait upstream (PYME always remeshes): None holds the topology fixed
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError('unknown parameter %s' % k)
@@ -356,7 +370,7 @@ class ShrinkwrapMembrane(object):
                             remesh_frequency=self.remesh_frequency, delaunay_remesh_frequency=self.punch_frequency,
                             delaunay_eps=self.min_hole_radius, neck_threshold_low=self.neck_threshold_low,
                             neck_threshold_high=self.neck_threshold_high, neck_first_iter=self.neck_first_iter,
-                            shrink_weight=self.shrink_weight, truncate_at=self.truncate_at)
+                            shrink_weight=self.shrink_weight, truncate_at=self.truncate_at, remesher=self.remesher)
         namespace[self.output] = mesh
         src = namespace[self.points]
         pts = np.ascontiguousarray(np.vstack([src['x'], src['y'], src['z']]).T)

@@ -80,7 +80,8 @@ class ShrinkwrapMeshConjGrad(object):
         self._use_octreee = use_octree
         self.nn_max_ring = 0
         self.mean_dist = 0.0
-        self.iter_logs = []
+        self._raw_logs = []
+        self._iter_logs = []
 
         self._mesh_vertex_mask = mesh._vertices['halfedge'] != -1                      # :44
         self._all_valid = bool(self._mesh_vertex_mask.all())
@@ -210,9 +211,20 @@ class ShrinkwrapMeshConjGrad(object):
             self.wpreds = [np.float64(L.wpred)]
             self.nn_max_ring = max(self.nn_max_ring, int(L.nn_max_ring))
             self.mean_dist = float(L.mean_dist)
-            self.iter_logs.append(dict(test=L.test, res_norm=L.res_norm, prefs_norm=L.prefs_norm, cpred=L.cpred, wpred=L.wpred,
-                                       c=np.array(L.c[:]), H=np.array(L.H[:]).reshape(3, 3), G=np.array(L.G[:]),
-                                       mean_dist=L.mean_dist, n_search=int(L.n_search), nn_max_ring=int(L.nn_max_ring)))
+        if executed:
+            self._raw_logs.append((logs, executed))             # expanded on demand (iter_logs): keeps the per-block host time short
+
+    @property
+    def iter_logs(self):
+        """Per-iteration records of the normal equations (H, G, c), norms and query diagnostics, one dict per executed iteration."""
+        for logs, executed in self._raw_logs:
+            for i in range(executed):
+                L = logs[i]
+                self._iter_logs.append(dict(test=L.test, res_norm=L.res_norm, prefs_norm=L.prefs_norm, cpred=L.cpred, wpred=L.wpred,
+                                            c=np.array(L.c[:]), H=np.array(L.H[:]).reshape(3, 3), G=np.array(L.G[:]),
+                                            mean_dist=L.mean_dist, n_search=int(L.n_search), nn_max_ring=int(L.nn_max_ring)))
+        self._raw_logs = []
+        return self._iter_logs
 
     def _finish(self):
         """write-back (mesh_conj_grad.py:288-290): one D2H into pinned memory, then the (M,3) result array and the strided

@@ -1,0 +1,82 @@
+"""
+ctypes binding of include/nw_remesh.h (libnw_remesh.so): the block-boundary isotropic remesher.
+
+`remesh(vertices, faces, n, target_edge_length, l, n_relax)` mirrors the signature of the PYME method the reference
+calls between optimiser blocks, `self.remesh(5, target_length, 0.5, n_relax=0)`
+(/root/reference/ch_shrinkwrap/_membrane_mesh.pyx:1546); `builtin_remesher` is the hook form used by
+`MembraneMesh.remesher` (ch_shrinkwrap_amd/membrane_mesh.py).  PYME's own implementation is not in the reference tree;
+this is the published algorithm it follows (Botsch & Kobbelt 2004) -- parity with PYME is unpinned, see DESIGN.md.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libnw_remesh.so')
+SYMBOLS = ['nwr_abi_version', 'nwr_remesh', 'nwr_free']
+ERRORS = {-1: 'bad argument', -2: 'the mesh is not an oriented 2-manifold', -3: 'out of memory'}
+
+_lib = None
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [('n_split', ctypes.c_int64), ('n_collapse', ctypes.c_int64), ('n_flip', ctypes.c_int64),
+                ('mean_edge_length', ctypes.c_double), ('max_valence', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            from . import build
+            build.build_host_library()
+        L = ctypes.CDLL(LIB_PATH)
+        L.nwr_abi_version.restype = ctypes.c_int
+        L.nwr_remesh.restype = ctypes.c_int
+        L.nwr_remesh.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                 ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                 ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
+                                 ctypes.POINTER(Stats)]
+        L.nwr_free.restype = None
+        L.nwr_free.argtypes = [ctypes.c_void_p]
+        if L.nwr_abi_version() != 1:
+            raise RuntimeError('libnw_remesh.so ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def remesh(vertices, faces, n=5, target_edge_length=-1, l=0.5, n_relax=10, max_valence=16, return_stats=False):
+    """Returns (vertices float32 (V,3), faces int32 (F,3)) of the remeshed surface."""
+    L = load()
+    v = np.ascontiguousarray(vertices, np.float32)
+    f = np.ascontiguousarray(faces, np.int32)
+    if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3:
+        raise ValueError('vertices must be (V,3) and faces (F,3)')
+    ov, of = ctypes.c_void_p(), ctypes.c_void_p()
+    nv, nf = ctypes.c_int64(), ctypes.c_int64()
+    st = Stats()
+    rc = L.nwr_remesh(v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], int(n), float(target_edge_length), float(l), int(n_relax),
+                      int(max_valence), ctypes.byref(ov), ctypes.byref(nv), ctypes.byref(of), ctypes.byref(nf), ctypes.byref(st))
+    if rc != 0:
+        raise RuntimeError('nwr_remesh: %s' % ERRORS.get(rc, 'error %d' % rc))
+    try:
+        out_v = np.ctypeslib.as_array(ctypes.cast(ov, ctypes.POINTER(ctypes.c_float)), shape=(nv.value, 3)).copy()
+        out_f = np.ctypeslib.as_array(ctypes.cast(of, ctypes.POINTER(ctypes.c_int32)), shape=(nf.value, 3)).copy()
+    finally:
+        L.nwr_free(ov)
+        L.nwr_free(of)
+    if return_stats:
+        return out_v, out_f, dict(n_split=st.n_split, n_collapse=st.n_collapse, n_flip=st.n_flip,
+                                  mean_edge_length=st.mean_edge_length, max_valence=st.max_valence)
+    return out_v, out_f
+
+
+def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):
+    """`MembraneMesh.remesher` hook: remesh the valid part of `mesh` and rebuild its half-edge tables in place."""
+    valid = mesh._vertices['halfedge'] != -1
+    remap = np.cumsum(valid) - 1
+    v = mesh._vertices['position'][valid]
+    f = remap[mesh.faces]
+    nv, nf = remesh(v, f, n, target_edge_length, l, n_relax)
+    mesh._topology_changed(nv, nf)

@@ -195,3 +195,27 @@ def test_neck_selection_on_network():
     assert np.array_equal(picked[-1], want)
     # tubes of radius ~100-120 nm: |K| of the fitted surface stays far below the high threshold nearly everywhere
     assert want.size < 0.05 * K.size
+
+
+@pytest.mark.gpu
+def test_shrink_wrap_with_builtin_remesher():
+    """the outer loop with real remeshing between blocks (target edge length falling linearly to
+    `minimum_edge_length`, _membrane_mesh.pyx:1443-1455, :1544): every block runs on a new topology, the fit converges to
+    the sampled sphere and the final mesh is a closed manifold at the requested resolution."""
+    from ch_shrinkwrap_amd import synth
+    v, f = icosphere(3, 125.0)                                   # 642 vertices, edges ~19 nm
+    pts = synth.sphere_cloud(40000, 100.0, 5.0, seed=2)
+    sigma = np.full(pts.shape, 5.0, 'f4')
+    m = mm.MembraneMesh(v, f, kc=1.0, step_size=20.0, max_iter=25, remesh_frequency=5, delaunay_remesh_frequency=0, remesher='builtin')
+    n = m.shrink_wrap(pts, sigma, minimum_edge_length=7.0)
+    assert n == 25 and len(m.block_log) == 5
+    counts = [b['mean_length'] for b in m.block_log]
+    assert counts[0] > counts[-1] and abs(counts[-1] - m.block_log[-1]['target_length']) < 0.2 * counts[-1]
+    assert m.vertices.shape[0] > 4 * 642                          # refined: 19 nm -> 7 nm edges
+    fcs = m.faces
+    e = np.sort(np.concatenate([fcs[:, [0, 1]], fcs[:, [1, 2]], fcs[:, [2, 0]]]), 1)
+    ue, cn = np.unique(e, axis=0, return_counts=True)
+    assert (cn == 2).all() and m.vertices.shape[0] - ue.shape[0] + fcs.shape[0] == 2
+    r = np.linalg.norm(m.vertices, axis=1)
+    assert abs(r.mean() - 100.0) < 1.0 and r.std() < 1.5          # the cloud's sphere, noise averaged out
+    assert ((m._vertices['neighbors'] != -1).sum(1) <= 12).all()

@@ -1,0 +1,103 @@
+"""
+Block-boundary isotropic remesher (include/nw_remesh.h, ch_shrinkwrap_amd/csrc/remesh.cpp).
+PYME's TriangleMesh.remesh -- what the reference calls at `_membrane_mesh.pyx:1546` -- is not in the reference tree, so
+there is nothing to pin against; these tests check the properties the optimiser relies on: the result is a closed oriented
+2-manifold of the same genus, edge lengths gather around the target, vertex degrees around six and within the
+neighbour-table width, the surface stays where it was.  CPU only.
+"""
+import os
+import re
+import ctypes
+
+import numpy as np
+import pytest
+
+from ch_shrinkwrap_amd import remesh as R
+from ch_shrinkwrap_amd.trimesh import TriMesh, icosphere
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _edges(f):
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1)
+    return np.unique(e, axis=0, return_counts=True)
+
+
+def _volume(v, f):
+    a, b, c = (v[f[:, k]].astype('f8') for k in range(3))
+    return np.einsum('ij,ij->i', a, np.cross(b, c)).sum() / 6
+
+
+def test_library_exports_header_symbols():
+    from ch_shrinkwrap_amd import build
+    build.build_host_library()
+    txt = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'nw_remesh.h')).read(), flags=re.S)
+    names = sorted(set(re.findall(r'\b(nwr_[a-z_]+)\s*\(', txt)))
+    L = ctypes.CDLL(R.LIB_PATH)
+    assert names == sorted(R.SYMBOLS)
+    for n in names:
+        assert hasattr(L, n)
+    assert R.load().nwr_abi_version() == 1
+    assert ctypes.sizeof(R.Stats) == 3 * 8 + 8 + 2 * 4
+
+
+@pytest.mark.parametrize('target', [30.0, 12.0, 6.0])
+def test_sphere_to_target_edge_length(target):
+    v, f = icosphere(3, 100.0)                      # 642 vertices, edges ~15
+    nv, nf, st = R.remesh(v, f, 5, target, 0.5, 0, return_stats=True)
+    ue, cn = _edges(nf)
+    assert (cn == 2).all()                                               # closed 2-manifold
+    assert nv.shape[0] - ue.shape[0] + nf.shape[0] == 2                  # still a sphere
+    assert 0.95 < _volume(nv, nf) / (4 / 3 * np.pi * 1e6) <= 1.0         # outward, vertices stay on / inside the sphere (chords)
+    L = np.linalg.norm(nv[ue[:, 0]] - nv[ue[:, 1]], axis=1)
+    assert 0.85 * target < L.mean() < 1.15 * target
+    assert L.min() > 0.45 * target and L.max() < 2.0 * target
+    assert np.mean((L > 0.8 * target) & (L < 4 / 3 * target)) > 0.6     # without relaxation many edges sit just below 4/5 L (blocked collapses)
+    deg = np.bincount(ue.ravel(), minlength=nv.shape[0])
+    assert deg.min() >= 3 and deg.max() <= 9 and np.mean(np.abs(deg - 6) <= 1) > 0.9
+    assert st['max_valence'] == deg.max() and abs(st['mean_edge_length'] - L.mean()) < 1e-3 * target
+    assert np.linalg.norm(nv, axis=1).max() <= 100.0 + 1e-3
+    TriMesh(nv, nf)                                                      # the optimiser's substrate accepts it
+    # n = 0 is the identity (up to dropping unreferenced vertices)
+    zv, zf = R.remesh(v, f, 0, target, 0.5, 0)
+    assert np.array_equal(zv, v) and np.array_equal(zf, f)
+
+
+def test_relaxation_evens_out_edge_lengths_and_keeps_the_surface():
+    v, f = icosphere(3, 100.0)
+    a_v, a_f = R.remesh(v, f, 5, 12.0, 0.5, 0)
+    b_v, b_f = R.remesh(v, f, 5, 12.0, 0.5, 10)
+    sd = []
+    for xv, xf in ((a_v, a_f), (b_v, b_f)):
+        ue, _ = _edges(xf)
+        L = np.linalg.norm(xv[ue[:, 0]] - xv[ue[:, 1]], axis=1)
+        sd.append(L.std() / L.mean())
+    assert sd[1] < sd[0]
+    r = np.linalg.norm(b_v, axis=1)
+    assert r.min() > 98.5 and r.max() < 100.5                            # tangential moves only
+
+
+def test_genus_two_network_and_degenerate_input():
+    from ch_shrinkwrap_amd import synth
+    sdf = lambda p: 2.0 * synth.sdf_er_sim2(np.asarray(p, 'f8') * 0.5)
+    v, f = synth.isosurface_mesh(sdf, (-1500, -1500, -420), (1400, 900, 420), 19.0, level=20.0, slack=60.0)
+    ue, cn = _edges(f)
+    assert (cn == 2).all() and v.shape[0] - ue.shape[0] + f.shape[0] == -2
+    L0 = np.linalg.norm(v[ue[:, 0]] - v[ue[:, 1]], axis=1)
+    assert L0.min() < 0.05 * L0.mean()                                   # surface nets leave slivers
+    nv, nf = R.remesh(v, f, 3, -1, 0.5, 0)                               # target = mean edge length of the input
+    ue, cn = _edges(nf)
+    assert (cn == 2).all() and nv.shape[0] - ue.shape[0] + nf.shape[0] == -2
+    L = np.linalg.norm(nv[ue[:, 0]] - nv[ue[:, 1]], axis=1)
+    assert L.min() > 0.2 * L.mean()
+    assert np.abs(sdf(nv) - 20.0).max() < 6.0                            # new midpoints lie on chords of the old surface
+    # errors, not crashes
+    with pytest.raises(RuntimeError):
+        R.remesh(v, np.concatenate([f, f[:1]]), 1, -1, 0.5, 0)           # the same oriented face twice
+    with pytest.raises(ValueError):
+        R.remesh(v[:, :2], f)
+    # an open patch: boundary vertices are left where they are
+    keep = v[f].mean(1)[:, 2] > 0
+    pv, pf = R.remesh(v, f[keep], 2, -1, 0.5, 0)
+    ue, cn = _edges(pf)
+    assert set(np.unique(cn)) <= {1, 2} and (cn == 1).any()
