@@ -264,25 +264,47 @@ __global__ void k_nbr_transpose(const int *__restrict__ nbr, int M, int NB, int 
 // ============================================================================================================
 
 // K1: face centroids + cell histogram.  centroid = ((v0+v1)+v2)/3 in float32 = numpy's fv[faces].mean(1)
-// (mesh_conj_grad.py:443).
+// (mesh_conj_grad.py:443).  The rank of a face inside its cell (needed by the scatter) comes from the histogram's returning
+// atomic; 4e5 returning global atomics cost ~20 us, so the 256 faces of a workgroup -- neighbours on the surface for any
+// reasonably ordered mesh -- are first counted per cell in an LDS hash table (integer LDS atomics), and only one global
+// atomic per (workgroup, distinct cell) reserves the range.
+#define NW_FC_HT 512
 __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const float *__restrict__ pos, const int *__restrict__ faces, int F,
                                                             float4 *__restrict__ cent_tmp, int *__restrict__ fcell, int *__restrict__ frank, int *__restrict__ count,
                                                             int *__restrict__ ambig_count, const NwDevState *__restrict__ st, int it)
 {
     if (it >= st->stop_at) return;
+    __shared__ int s_key[NW_FC_HT], s_cnt[NW_FC_HT];
+    for (int t = threadIdx.x; t < NW_FC_HT; t += NW_BLOCK) { s_key[t] = -1; s_cnt[t] = 0; }
+    __syncthreads();
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f == 0) *ambig_count = 0;
-    if (f >= F) return;
-    const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
-    const float x = ((pos[3 * a] + pos[3 * b]) + pos[3 * c]) / 3.0f;
-    const float y = ((pos[3 * a + 1] + pos[3 * b + 1]) + pos[3 * c + 1]) / 3.0f;
-    const float z = ((pos[3 * a + 2] + pos[3 * b + 2]) + pos[3 * c + 2]) / 3.0f;
-    int ix, iy, iz;
-    nw_cell_coords(g, x, y, z, ix, iy, iz);
-    const int cell = nw_cell_index(g, ix, iy, iz);
-    cent_tmp[f] = make_float4(x, y, z, __int_as_float(f));
-    fcell[f] = cell;
-    frank[f] = atomicAdd(&count[cell], 1);        // rank inside the cell: the scatter needs no second atomic
+    int slot = 0, local = 0;
+    if (f < F) {
+        const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+        const float x = ((pos[3 * a] + pos[3 * b]) + pos[3 * c]) / 3.0f;
+        const float y = ((pos[3 * a + 1] + pos[3 * b + 1]) + pos[3 * c + 1]) / 3.0f;
+        const float z = ((pos[3 * a + 2] + pos[3 * b + 2]) + pos[3 * c + 2]) / 3.0f;
+        int ix, iy, iz;
+        nw_cell_coords(g, x, y, z, ix, iy, iz);
+        const int cell = nw_cell_index(g, ix, iy, iz);
+        cent_tmp[f] = make_float4(x, y, z, __int_as_float(f));
+        fcell[f] = cell;
+        slot = (int)(((unsigned)cell * 2654435761u) >> 23);            // 9 bits
+        for (;;) {
+            const int old = atomicCAS(&s_key[slot], -1, cell);
+            if (old == -1 || old == cell) break;
+            slot = (slot + 1) & (NW_FC_HT - 1);
+        }
+        local = atomicAdd(&s_cnt[slot], 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NW_FC_HT; t += NW_BLOCK) {
+        const int key = s_key[t];
+        if (key >= 0) s_cnt[t] = atomicAdd(&count[key], s_cnt[t]);      // base of this workgroup's faces in the cell
+    }
+    __syncthreads();
+    if (f < F) frank[f] = s_cnt[slot] + local;
 }
 
 // K3: scatter centroids into cell order
