@@ -1006,7 +1006,8 @@ NW_EXPORT int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t 
         ctx->wb_events.resize(ctx->pool->n);
         for (auto &e : ctx->wb_events) NW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, M / 50000));      // ~50k vertex records per thread
+    static const int64_t rows_per_thread = getenv("NW_WB_ROWS_PER_THREAD") ? std::max(1000, atoi(getenv("NW_WB_ROWS_PER_THREAD"))) : 50000;   // measured: more, smaller slices lose to thread wake-up latency
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, M / rows_per_thread));
     std::vector<int64_t> cut(T + 1);
     for (int t = 0; t <= T; ++t) cut[t] = M * t / T;
     for (int t = 0; t < T; ++t) {

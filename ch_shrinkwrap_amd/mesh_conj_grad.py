@@ -82,6 +82,7 @@ class ShrinkwrapMeshConjGrad(object):
         self.mean_dist = 0.0
         self._raw_logs = []
         self._iter_logs = []
+        self._fs_pool = []
 
         self._mesh_vertex_mask = mesh._vertices['halfedge'] != -1                      # :44
         self._all_valid = bool(self._mesh_vertex_mask.all())
@@ -226,10 +227,26 @@ class ShrinkwrapMeshConjGrad(object):
         self._raw_logs = []
         return self._iter_logs
 
+    def _result_buffer(self):
+        """(M,3) float32 array for the next result.  A fresh 2.4 MB array costs ~600 page faults per block; an array handed out
+        earlier is recycled ONLY when nothing but this pool still refers to it (the caller dropped the result and `self.fs` has
+        moved on), so a result the caller kept is never overwritten."""
+        import sys
+        pool = self._fs_pool
+        for i in range(len(pool)):
+            # an idle array is referenced by the pool list and by getrefcount's argument, nothing else
+            if sys.getrefcount(pool[i]) <= 2 and pool[i].shape == (self.M, 3):
+                return pool[i]
+        b = np.empty((self.M, 3), np.float32)
+        pool.append(b)
+        if len(pool) > 3:
+            del pool[0]
+        return b
+
     def _finish(self):
         """write-back (mesh_conj_grad.py:288-290): one D2H into pinned memory, then the (M,3) result array and the strided
         mesh._vertices['position'] rows (valid vertices only) are filled by the library."""
-        out = np.empty((self.M, 3), np.float32)
+        out = self._result_buffer()
         posv = self.mesh._vertices['position']
         stride = posv.strides[0]
         if posv.dtype == np.float32 and posv.strides[1] == 4 and stride >= 12:

@@ -100,6 +100,37 @@ def test_neck_removal_schedule(recorder, monkeypatch):
     assert len(removed) == 3 and all(np.array_equal(r, [3, 17]) for r in removed)
 
 
+def test_result_buffers_are_recycled_only_when_the_caller_dropped_them():
+    """search() returns a fresh (M,3) array every call as far as the caller can tell: an array is reused only when nothing
+    outside the optimiser refers to it any more."""
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+
+    class Stub(object):
+        M = 100
+        _result_buffer = ShrinkwrapMeshConjGrad._result_buffer
+
+        def __init__(self):
+            self._fs_pool = []
+
+        def step(self):                      # what _finish does with the buffer
+            out = self._result_buffer()
+            self.fs = out
+            self.f = out.ravel()
+            return np.real(self.fs)
+    s = Stub()
+    ids = []
+    for _ in range(6):                       # results dropped immediately: two buffers alternate
+        ids.append(s.step().__array_interface__['data'][0])
+    assert len(set(ids)) == 2
+    kept = s.step()
+    kept[:] = 7.0
+    others = [s.step() for _ in range(5)]
+    assert all(o is not kept for o in others) and (kept == 7.0).all()      # a kept result is never handed out again
+    view = s.step()[::2]                                                    # ... nor one that is only referenced through a view
+    later = [s.step() for _ in range(4)]
+    assert all(not np.shares_memory(view, o) for o in later)
+
+
 def test_recipe_module_parameter_surface():
     r = mm.ShrinkwrapMembrane()
     # defaults of recipe_modules/surface_fitting.py:17-42
