@@ -137,3 +137,45 @@ def test_singular_subspace_raises_linalgerror():
     cg = ShrinkwrapMeshConjGrad(TriMesh(v, f), pts)
     with pytest.raises(np.linalg.LinAlgError):
         cg.search(pts, lams=[0.0], num_iters=1, sigma_inv=0.1, weights=0.0)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_randomized_clouds_nearest_face_is_exact(seed):
+    """Randomised geometry against cKDTree (float64): anisotropically stretched, rotated and shifted meshes of random
+    resolution, and clouds mixing surface noise, far uniform background, tight clusters, exact duplicates and points sitting on
+    centroids -- whatever grid and stage schedule the library picks, every localization must get the float64 argmin."""
+    from ch_shrinkwrap_amd.trimesh import geodesic_sphere, TriMesh
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    from oracle import nanowrap_oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    freq = int(rng.integers(3, 28))
+    v, f = geodesic_sphere(freq, 1.0, dtype='f8')
+    scale = rng.uniform(20.0, 400.0) * rng.uniform(1.0, 6.0, size=3) ** rng.choice([0.0, 1.0])      # isotropic or up to 6:1
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    shift = rng.uniform(-1.0, 1.0, size=3) * rng.choice([0.0, 1e2, 1e4])
+    v = ((v * scale[None, :]) @ q.T + shift[None, :]).astype('f4')
+    n = int(rng.integers(200, 60000))
+    cent = O.face_centroids(v, f)
+    kinds = rng.choice(5, size=n, p=[0.55, 0.15, 0.15, 0.1, 0.05])
+    ext = float(np.ptp(v, axis=0).max())
+    base = cent[rng.integers(0, cent.shape[0], size=n)].astype('f8')
+    pts = base + rng.normal(scale=rng.uniform(0.002, 0.2) * ext, size=(n, 3))                       # 0: surface + noise
+    bg = kinds == 1
+    pts[bg] = shift[None, :] + rng.uniform(-2.5, 2.5, size=(int(bg.sum()), 3)) * ext                 # 1: far background
+    cl = kinds == 2
+    pts[cl] = base[cl][:1] + rng.normal(scale=1e-3 * ext, size=(int(cl.sum()), 3))                   # 2: one tight cluster
+    du = kinds == 3
+    if du.any():
+        pts[du] = pts[np.nonzero(~du)[0][0]] if (~du).any() else pts[0]                              # 3: exact duplicates
+    oc = kinds == 4
+    pts[oc] = base[oc]                                                                               # 4: exactly on centroids
+    pts = np.ascontiguousarray(pts, 'f4')
+    sigma_inv = np.full(pts.size, 1.0 / max(1e-3 * ext, 1e-3), 'f4')
+    mesh = TriMesh(v, f)
+    cg = ShrinkwrapMeshConjGrad(mesh, pts)
+    cg.search(pts, lams=[10.0], num_iters=1, sigma_inv=sigma_inv)
+    d_ref, f_ref = O.nearest_faces(cent, pts)
+    _assert_same_nn(cg, pts, v, f, f_ref)
+    assert np.allclose(cg.d[:, 0], d_ref, rtol=2e-6, atol=0)
+    v_idx, w = cg.w
+    assert np.array_equal(v_idx, f[cg.nearest_face]) and np.allclose(w.sum(1), 1.0, atol=1e-5)
