@@ -235,6 +235,18 @@ def main():
             'nn_max_ring': cg.nn_max_ring, 'mean_dist_nm': cg.mean_dist,
         }
         out['roofline_iteration']['frac'] = out['roofline_iteration']['achieved'] / HBM_PEAK_GBS
+        # The dominant kernel is not an HBM kernel (25 MB algorithmic, 37 MB measured per launch): it is bound by instruction
+        # issue.  VALU wave-instructions per launch from the SQ_INSTS_VALU pass (tools/pmc.sh) against the issue peak of
+        # 256 CUs x 4 SIMD-32 x 2.4 GHz x 1 wave64 instruction per 2 cycles (MI355X_MICROARCH.md).
+        if traffic is not None and dom == 'nn':
+            try:
+                vi = json.load(open(tfile)).get('k_nearest_face_valu_wave_instructions')
+            except Exception:
+                vi = None
+            if vi:
+                peak = 256 * 4 * 2.4e9 * 0.5
+                out['roofline']['valu_issue'] = {'wave_instructions_per_launch': vi, 'achieved': vi / (avg_ms * 1e-3), 'peak': peak,
+                                                 'unit': 'wave-instructions/s', 'frac': vi / (avg_ms * 1e-3) / peak}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(synth.make_config(args.config, scale=args.scale, seed=rank), args.cpu_iters)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']

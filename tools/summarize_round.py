@@ -82,6 +82,8 @@ json.dump({k: dict({c: sum(v) / len(v) for c, v in d.items()}, dispatches=max(le
 out = {k: traffic[k]['hbm_bytes_per_launch'] for k in ('k_nearest_face', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update')
        if k in traffic}
 out['grid_build'] = sum(traffic[k]['hbm_bytes_per_launch'] * (3 if k.startswith('k_scan') and False else 1) for k in grid if k in traffic)
+if 'k_nearest_face' in sq and 'SQ_INSTS_VALU' in sq['k_nearest_face']:
+    out['k_nearest_face_valu_wave_instructions'] = mean_tail(sq['k_nearest_face']['SQ_INSTS_VALU'], iters)
 out['_note'] = ('HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts half of '
                 'wide coalesced reads, MI355X_MICROARCH.md section HBM); mean of the timed iterations of bench.py --steps 10 --warmup 10; '
                 'profiles/' + tag + '_*')
