@@ -43,6 +43,10 @@ struct DevBuf {
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
 };
 
 enum { ST_TOTAL = 0, ST_GRID = 1, ST_NN = 2, ST_ATTRACT = 3, ST_PRIOR = 4, ST_AS = 5, ST_UPDATE = 6, ST_FIXUP = 7, ST_COUNT = 8 };
@@ -561,7 +565,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
                           int64_t n_vertices, int64_t n_faces, int n_nbr)
 {
     if (!ctx) return NW_ERR_BADARG;
-    if (!pos || !nrm || !nbr || !faces || n_vertices <= 0 || n_faces <= 0 || n_nbr <= 0 || n_vertices > 0x7fffffff / 16 || n_faces > 0x7fffffff / 4)
+    if (!pos || !faces || n_vertices <= 0 || n_faces <= 0 || n_nbr <= 0 || n_nbr > 64 || n_vertices > 0x7fffffff / 16 || n_faces > 0x7fffffff / 4)
         return fail(ctx, NW_ERR_BADARG, "nw_set_mesh: bad array/size");
     NW_HIP(hipSetDevice(ctx->device));
     const int64_t M = n_vertices, F = n_faces;
@@ -576,8 +580,6 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     NW_HIP(ctx->d_small.ensure(8));
     NW_HIP(hipMemcpyAsync(ctx->pos.p, pos, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
     NW_HIP(hipMemcpyAsync(ctx->meshpos.p, pos, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
-    NW_HIP(hipMemcpyAsync(ctx->nrm.p, nrm, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
-    NW_HIP(hipMemcpyAsync(ctx->nbr.p, nbr, (size_t)M * n_nbr * sizeof(int), hipMemcpyDefault, ctx->stream));
     NW_HIP(hipMemcpyAsync(ctx->faces.p, faces, 3 * F * sizeof(int), hipMemcpyDefault, ctx->stream));
     ctx->have_valid = valid != nullptr;
     if (valid) {
@@ -585,12 +587,41 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
         NW_HIP(hipMemcpyAsync(ctx->valid.p, valid, M, hipMemcpyDefault, ctx->stream));
         ctx->valid_host.assign(valid, valid + M);          // the write-back masks the caller's vertex records with it
     }
+    if (nbr) {
+        NW_HIP(hipMemcpyAsync(ctx->nbr.p, nbr, (size_t)M * n_nbr * sizeof(int), hipMemcpyDefault, ctx->stream));
+    } else {
+        // 1-ring table (and, unless given, the valid flags) from the faces array on the device
+        DevBuf<int> cnt;
+        DevBuf<int4> pairs;
+        NW_HIP(cnt.ensure(M)); NW_HIP(pairs.ensure((size_t)M * n_nbr));
+        NW_HIP(ctx->valid.ensure(M));
+        NW_HIP(hipMemsetAsync(cnt.p, 0, M * sizeof(int), ctx->stream));
+        NW_HIP(hipMemsetAsync(ctx->d_small.p, 0, 8 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_ring_collect, dim3(nblk(3 * F)), dim3(NW_BLOCK), 0, ctx->stream, ctx->faces.p, (int)F, (int)M, n_nbr, cnt.p, pairs.p, ctx->d_small.p);
+        DevBuf<unsigned char> vtmp;
+        NW_HIP(vtmp.ensure(M));
+        hipLaunchKernelGGL(k_ring_order, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, (int)M, n_nbr, cnt.p, pairs.p, ctx->nbr.p, valid ? vtmp.p : ctx->valid.p);
+        NW_HIP(hipGetLastError());
+        int err[2] = {0, 0};
+        NW_HIP(hipMemcpyAsync(err, ctx->d_small.p, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
+        if (!valid) {
+            ctx->valid_host.resize(M);
+            NW_HIP(hipMemcpyAsync(ctx->valid_host.data(), ctx->valid.p, M, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->have_valid = true;
+        }
+        NW_HIP(hipStreamSynchronize(ctx->stream));
+        cnt.release(); pairs.release(); vtmp.release();
+        if (err[1]) { ctx->have_mesh = false; return fail(ctx, NW_ERR_BADARG, "nw_set_mesh: a face refers to a vertex outside [0, n_vertices)"); }
+        if (err[0]) { ctx->have_mesh = false; return fail(ctx, NW_ERR_BADARG, "nw_set_mesh: a vertex has more neighbours than the table holds (n_nbr)"); }
+    }
     NW_HIP(hipMemsetAsync(ctx->d_small.p, 0, 8 * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_nbr_transpose, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, ctx->nbr.p, (int)M, n_nbr, ctx->nbr_t.p, ctx->d_small.p);
     NW_HIP(hipGetLastError());
     NW_HIP(hipMemcpyAsync(&ctx->maxdeg, ctx->d_small.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     NW_HIP(hipStreamSynchronize(ctx->stream));
     ctx->have_mesh = true;
+    if (nrm) NW_HIP(hipMemcpyAsync(ctx->nrm.p, nrm, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    else NW_TRY(nw_refresh_normals(ctx, nullptr));         // area-weighted vertex normals from positions + faces on the device
     if (topo_change) { ctx->grid_valid = false; }
     // a new mesh object = a new optimiser in the reference (_membrane_mesh.pyx:1510): history restarts
     NwDevState st{};
@@ -935,6 +966,9 @@ NW_EXPORT int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes)
     case NW_ARR_FDEF: p = ctx->fdef.p; nb = 3 * ctx->M * 4; break;
     case NW_ARR_PI: p = ctx->pi.p; nb = ctx->M * 4; break;
     case NW_ARR_VACC: p = ctx->vacc.p; nb = 4 * ctx->M * 4; break;
+    case NW_ARR_NBR: p = ctx->nbr.p; nb = (int64_t)ctx->NB * ctx->M * 4; break;
+    case NW_ARR_NRM: p = ctx->nrm.p; nb = 3 * ctx->M * 4; break;
+    case NW_ARR_VALID: p = ctx->have_valid ? ctx->valid.p : nullptr; nb = ctx->M; break;
     case NW_ARR_SCALARS: p = ctx->scalars.p ? ctx->scalars.p + (ctx->global_iter & 1) * NW_SC_BLOCK : nullptr; nb = (int64_t)NW_SC_BLOCK * 8; break;
     default: return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array is not device-addressable in caller order");
     }

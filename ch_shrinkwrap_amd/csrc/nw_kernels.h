@@ -245,6 +245,53 @@ __global__ void k_fill_items(const int *__restrict__ pstart, const int *__restri
     }
 }
 
+// 1-ring table from the faces array alone, pass 1: every face corner (a -> b, then c, counter-clockwise)
+// deposits {b, c, half-edge id 3f+k} in a slot of its vertex a.  err[0] counts vertices whose degree exceeds the table width.
+__global__ void k_ring_collect(const int *__restrict__ faces, int F, int M, int NB, int *__restrict__ cnt, int4 *__restrict__ pairs, int *__restrict__ err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * F) return;
+    const int f = i / 3, k = i - 3 * f;
+    const int a = faces[3 * f + k], b = faces[3 * f + (k + 1) % 3], c = faces[3 * f + (k + 2) % 3];
+    if ((unsigned)a >= (unsigned)M || (unsigned)b >= (unsigned)M || (unsigned)c >= (unsigned)M) { atomicAdd(err + 1, 1); return; }
+    const int slot = atomicAdd(&cnt[a], 1);
+    if (slot < NB) pairs[(int64_t)a * NB + slot] = make_int4(b, c, i, 0);
+    else atomicAdd(err, 1);
+}
+
+// pass 2: order each vertex's fan exactly as the host substrate does (trimesh.TriMesh._build_rings): start at the
+// lowest-numbered outgoing half-edge -- for a boundary vertex at the outgoing half-edge that has no twin -- and walk
+// counter-clockwise (the neighbour after b is the third corner c of the face that holds a -> b) until the fan closes or ends.
+// Open fans list their outgoing half-edges only.  valid[a] = the vertex has at least one face.
+__global__ void k_ring_order(int M, int NB, const int *__restrict__ cnt, const int4 *__restrict__ pairs, int *__restrict__ nbr, unsigned char *__restrict__ valid)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= M) return;
+    const int n = min(cnt[a], NB);
+    const int4 *P = pairs + (int64_t)a * NB;
+    int *out = nbr + (int64_t)a * NB;
+    valid[a] = n > 0;
+    int start = -1, start_he = 0x7fffffff, bstart = -1, bstart_he = -1;
+    for (int i = 0; i < n; ++i) {
+        const int4 p = P[i];
+        if (p.z < start_he) { start_he = p.z; start = i; }
+        bool has_twin = false;                       // a -> b has a twin iff some face of the fan ends in b (c_j == b)
+        for (int j = 0; j < n; ++j) has_twin |= (P[j].y == p.x);
+        if (!has_twin && p.z > bstart_he) { bstart_he = p.z; bstart = i; }
+    }
+    if (bstart >= 0) start = bstart;
+    int cur = start, s = 0;
+    while (cur >= 0 && s < NB) {
+        const int4 p = P[cur];
+        out[s++] = p.x;
+        int nxt = -1;
+        for (int j = 0; j < n; ++j) if (P[j].x == p.y) { nxt = j; break; }
+        if (nxt == start) break;
+        cur = nxt;
+    }
+    for (; s < NB; ++s) out[s] = -1;
+}
+
 // neighbour table (M, NB) row-major -> slot-major ELL nbr_t[s*M + v] (coalesced over vertices) + max degree
 __global__ void k_nbr_transpose(const int *__restrict__ nbr, int M, int NB, int *__restrict__ nbr_t, int *__restrict__ maxdeg)
 {

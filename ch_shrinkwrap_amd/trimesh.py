@@ -180,12 +180,12 @@ class TriMesh(object):
         nhe = he.shape[0]
         origin = self._origin
         twin, prev = he['twin'], he['prev']
-        # choose the start half-edge per vertex: lowest-numbered outgoing; boundary vertices start at
-        # the outgoing half-edge whose prev has no twin (so that the walk covers the whole fan)
+        # choose the start half-edge per vertex: lowest-numbered outgoing; boundary vertices start at the outgoing
+        # half-edge that has no twin (nothing precedes it), so that the counter-clockwise walk covers the whole fan
         start = np.full(M, -1, 'i4')
         order = np.arange(nhe - 1, -1, -1, dtype='i4')
         start[origin[order]] = order                      # lowest index wins (written last)
-        bnd = np.nonzero(twin[prev] == -1)[0]
+        bnd = np.nonzero(twin == -1)[0]
         if bnd.size:
             start[origin[bnd]] = bnd.astype('i4')
         self._vertices['halfedge'] = start

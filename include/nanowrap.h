@@ -81,7 +81,10 @@ typedef enum nw_array {
     NW_ARR_PI = 8,          /* (M,)    f32  point influence ||A^T 1||, _membrane_mesh.pyx:1625-1634              */
     NW_ARR_MESHPOS = 9,     /* (M, 3)  f32  mesh._vertices['position'] as written back at :289                   */
     NW_ARR_VACC = 10,       /* (M, 4)  f32  device-only: per-vertex accumulator {A^T res, sum w} (multi-GPU all-reduce) */
-    NW_ARR_SCALARS = 11     /* f64 device-only: normal-equation partial sums of the current iteration (multi-GPU all-reduce), see nw_scalar_stride */
+    NW_ARR_SCALARS = 11,    /* f64 device-only: normal-equation partial sums of the current iteration (multi-GPU all-reduce), see nw_scalar_stride */
+    NW_ARR_NBR = 12,        /* (M, NB) i32  1-ring vertex ids, -1 padded (as given to, or built by, nw_set_mesh)          */
+    NW_ARR_NRM = 13,        /* (M, 3)  f32  vertex normals in use (nw_set_mesh / nw_set_normals / nw_refresh_normals)     */
+    NW_ARR_VALID = 14       /* (M,)    u8   valid flags (only when given to, or built by, nw_set_mesh)                   */
 } nw_array;
 
 #define NW_N_SCALARS 32
@@ -106,7 +109,12 @@ int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points,
 /* mesh arrays the optimiser reads: positions `mesh._vertices['position']` (M,3), block-stale vertex normals
  * `mesh.vertex_normals` (M,3), 1-ring VERTEX ids (M,NB), -1 padded (= mesh._halfedges['vertex'][mesh._vertices
  * ['neighbors']], mesh_conj_grad.py:50-54), valid = (mesh._vertices['halfedge'] != -1) (M bytes or NULL = all
- * valid, :44), faces (F,3) (:47). */
+ * valid, :44), faces (F,3) (:47).
+ * Block-boundary refresh on the device (what _membrane_mesh.pyx:1524-1527 asks PYME for): nbr == NULL builds the 1-ring
+ * table from `faces` (counter-clockwise fans starting at the vertex's lowest-numbered outgoing half-edge 3f+k, at the
+ * twin-less one for a boundary vertex; open fans list their outgoing half-edges) and, if valid is NULL too, marks the
+ * vertices without faces invalid; nrm == NULL computes area-weighted vertex normals from pos and faces.  A vertex with
+ * more than n_nbr neighbours is an error (the reference's table has 20 slots, membrane_mesh_utils.h:29). */
 int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const int32_t *nbr, const uint8_t *valid,
                 const int32_t *faces, int64_t n_vertices, int64_t n_faces, int n_nbr);
 /* cheap refresh between blocks with unchanged topology (_membrane_mesh.pyx:1524-1527) */

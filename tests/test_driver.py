@@ -146,6 +146,19 @@ def test_recipe_module_parameter_surface():
         r.execute({'surf': Few(), 'filtered_localizations': {}})
 
 
+def test_ring_tables_of_open_meshes_cover_the_whole_fan():
+    v, f = icosphere(1, 10.0)
+    f = f[v[f].mean(1)[:, 2] > 0]                                   # a cap with a boundary loop
+    m = TriMesh(v, f)
+    val = (m.neighbor_vertex_table() >= 0).sum(1)
+    e, cn = np.unique(np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1), axis=0, return_counts=True)
+    deg = np.bincount(e.ravel(), minlength=v.shape[0])
+    on_boundary = np.zeros(v.shape[0], bool)
+    on_boundary[e[cn == 1].ravel()] = True
+    assert (val[~on_boundary] == deg[~on_boundary]).all()           # closed fans: every neighbour once
+    assert (val[on_boundary] == deg[on_boundary] - 1).all()         # open fans: their outgoing half-edges (documented convention)
+
+
 def test_geometry_refresh_matches_definition():
     v, f = geodesic_sphere(6, 30.0)
     m = TriMesh(v, f)

@@ -268,3 +268,47 @@ def test_uniform_background_is_exact_and_terminates():
     assert np.allclose(cg.d[:, 0], d_ref, rtol=1e-6)
     print('background case: N=%d (10%% background), one iteration incl. set-up %.1f ms, max stage %d' % (pts.shape[0], dt * 1e3, cg.nn_max_ring))
     assert dt < 5.0
+
+
+@pytest.mark.parametrize('case', ['icosphere', 'network', 'open_patch', 'spare_slots'])
+def test_device_built_ring_table_matches_host_substrate(case):
+    """nw_set_mesh with nbr / nrm / valid = NULL builds the 1-ring table, the valid flags and the
+    area-weighted vertex normals on the device from positions + faces; the table must equal the host substrate's
+    (trimesh.TriMesh, the convention the optimiser's golden vectors were made with) entry by entry."""
+    import ctypes
+    from ch_shrinkwrap_amd import _lib as nw, synth
+    from ch_shrinkwrap_amd.trimesh import TriMesh, icosphere
+    from ch_shrinkwrap_amd.mesh_conj_grad import NativeContext
+    if case == 'network':
+        c = synth.make_config('c4', scale=0.02, seed=2)
+        v, f, extra = c['vertices'], c['faces'], 0
+    else:
+        v, f = icosphere(3, 80.0)
+        extra = 0
+        if case == 'open_patch':
+            f = f[v[f].mean(1)[:, 2] > 10.0]                  # a cap: boundary fans + vertices without any face
+        if case == 'spare_slots':
+            extra = 37                                        # unused vertex slots at the end (halfedge == -1)
+    mesh = TriMesh(v, f, max_vertices=v.shape[0] + extra)
+    M = mesh._vertices.shape[0]
+    pos = np.ascontiguousarray(mesh._vertices['position'], 'f4')
+    faces = np.ascontiguousarray(mesh.faces, 'i4')
+    nat = NativeContext(0)
+    nat.check(nat.L.nw_set_mesh(nat.h, nw.ptr(pos), None, None, None, nw.ptr(faces), M, faces.shape[0], 20))
+    nbr = np.empty((M, 20), 'i4')
+    nrm = np.empty((M, 3), 'f4')
+    valid = np.empty(M, 'u1')
+    nat.check(nat.L.nw_get(nat.h, nw.NW_ARR_NBR, nw.ptr(nbr), nbr.nbytes))
+    nat.check(nat.L.nw_get(nat.h, nw.NW_ARR_NRM, nw.ptr(nrm), nrm.nbytes))
+    nat.check(nat.L.nw_get(nat.h, nw.NW_ARR_VALID, nw.ptr(valid), valid.nbytes))
+    assert np.array_equal(nbr, mesh.neighbor_vertex_table())
+    assert np.array_equal(valid.astype(bool), mesh._vertices['halfedge'] != -1)
+    ok = valid.astype(bool)
+    assert np.allclose(nrm[ok], mesh.vertex_normals[ok], atol=2e-5)
+    # a vertex with more neighbours than the table holds is an error, not a truncated fan
+    hub = np.zeros((30, 3), 'f4')
+    ang = np.linspace(0, 2 * np.pi, 28, endpoint=False)
+    hub[1:29, 0], hub[1:29, 1] = np.cos(ang), np.sin(ang)
+    hub[29, 2] = 1.0
+    fan = np.array([[0, 1 + i, 1 + (i + 1) % 28] for i in range(28)], 'i4')
+    assert nat.L.nw_set_mesh(nat.h, nw.ptr(hub), None, None, None, nw.ptr(fan), 30, 28, 20) == nw.NW_ERR_BADARG
