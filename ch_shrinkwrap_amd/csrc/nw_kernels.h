@@ -738,17 +738,17 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
             const double si = sinv ? (double)sinv[3 * i + k] : (double)sinv_scalar;
             const double wd = 1.0 / ((double)d * si / 2.0 + 1.0);
             r[k] = (float)((double)r0 * wd);
-            res[3 * i + k] = r[k];
             const double r2 = (double)r[k] * (double)r[k];
             red[0] += r2;
             if (m & (1u << k)) red[1] += r2;
         }
         red[2] = (double)d;
         red[3] = 1.0;
+        __builtin_memcpy(res + 3 * (int64_t)i, r, 12);           // three 12-byte stores instead of nine dword stores
+        __builtin_memcpy(vidx + 3 * (int64_t)i, v, 12);
+        __builtin_memcpy(wout + 3 * (int64_t)i, w, 12);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            vidx[3 * i + j] = v[j];
-            wout[3 * i + j] = w[j];
             unsigned hsh = ((unsigned)v[j] * 2654435761u) >> 22;      // 10 bits
             for (;;) {
                 const int old = atomicCAS(&s_key[hsh], -1, v[j]);
@@ -911,7 +911,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
         for (int j = 0; j < 3; ++j) {
             const int v = vidx[3 * i + j];
             const float wj = w[3 * i + j];
-            const float *row = S + (int64_t)v * 9;
+            // the vertex's 9 floats in three wide loads (4 + 4 + 1) instead of nine scattered dword gathers
+            float row[9];
+            __builtin_memcpy(row, S + (int64_t)v * 9, sizeof(row));
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 as[0][c] = as[0][c] + row[3 * c + 0] * wj;
