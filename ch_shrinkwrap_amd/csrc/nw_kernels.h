@@ -579,23 +579,20 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
     if (tid == 0 && stage > g.s0) atomicMax(&st->nn_max_ring, stage);
 }
 
-// exact float64 re-resolution of the ambiguous points (runner-up inside the float32 error band of the best): one
-// workgroup per point.  Phase 1: every fine cell of the box around the ball of radius dist*(1+1e-4)+eps gets a thread that
-// fetches its candidate range; a block scan lays the ranges end to end.  Phase 2: the candidates are spread over the
-// threads (binary search in the scanned offsets), evaluated in float64, and reduced (lowest face id on exact ties).
+// exact float64 re-resolution of the ambiguous points (runner-up inside the float32 error band of the best): one wave
+// per point.  Phase 1: every (z,y) row of fine cells of the box around the ball of radius dist*(1+1e-4)+eps gets a lane that
+// fetches its candidate range; a wave scan lays the ranges end to end.  Phase 2: the candidates are spread over the
+// lanes (binary search in the scanned offsets through shuffles), evaluated in float64, and reduced (lowest face id on exact ties).
 __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__restrict__ ambig_list, const int *__restrict__ ambig_count, const float4 *__restrict__ pts,
                                                       const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face,
                                                       int *__restrict__ face_out, const NwDevState *__restrict__ st, int it)
 {
     if (it >= st->stop_at) return;
-    __shared__ int s_rs[NW_BLOCK];
-    __shared__ int s_ro[NW_BLOCK + 1];
-    __shared__ int s_wtot[4];
-    __shared__ double s_bd[4];
-    __shared__ int s_bfid[4];
     const int na = *ambig_count;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int a = blockIdx.x; a < na; a += gridDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    // one WAVE per ambiguous point: the box around its ball is a few dozen (z,y) rows, one lane each; no workgroup barrier
+    for (int a = wave; a < na; a += nwaves) {
         const int gi = ambig_list[a];
         const float4 P = pts[gi];
         const float4 C0 = cent_by_face[face_out[gi]];
@@ -606,36 +603,35 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
         const int ny = hy - ly + 1, nrow = ny * (hz - lz + 1);
         double best = INFINITY;
         int bf = 0x7fffffff;
-        for (int rb = 0; rb < nrow; rb += NW_BLOCK) {
+        for (int rb = 0; rb < nrow; rb += 64) {
             int start = 0, len = 0;
-            const int rr = rb + tid;
+            const int rr = rb + lane;
             if (rr < nrow) {
                 const int z = lz + rr / ny, y = ly + rr % ny;
                 const int c0 = nw_cell_index(g, lx, y, z);
                 start = cstart[c0];
                 len = cstart[c0 + (hx - lx) + 1] - start;
             }
-            s_rs[tid] = start;
-            const int inc = nw_wave_incl_scan(len, lane);
-            if (lane == 63) s_wtot[wv] = inc;
-            __syncthreads();
-            int woff = 0;
-            for (int w = 0; w < wv; ++w) woff += s_wtot[w];
-            s_ro[tid + 1] = woff + inc;
-            if (tid == 0) s_ro[0] = 0;
-            __syncthreads();
-            const int total = s_ro[NW_BLOCK];
-            for (int e = tid; e < total; e += NW_BLOCK) {
-                int lo = 0, hi = NW_BLOCK;
+            const int inc = nw_wave_incl_scan(len, lane);           // candidates up to and including this lane's row
+            const int total = __shfl(inc, 63, 64);
+            for (int base = 0; base < total; base += 64) {           // uniform trip count: every lane takes part in the shuffles
+                const int e = min(base + lane, total - 1);
+                int lo = 0;                                          // first row whose inclusive count exceeds e
 #pragma unroll
-                for (int stp = 0; stp < 8; ++stp) { const int mid = (lo + hi) >> 1; if (s_ro[mid] <= e) lo = mid; else hi = mid; }
-                const float4 C = cent[s_rs[lo] + (e - s_ro[lo])];
-                const double dx = (double)P.x - (double)C.x, dy = (double)P.y - (double)C.y, dz = (double)P.z - (double)C.z;
-                const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-                const int fid = __float_as_int(C.w);
-                if (d2 < best || (d2 == best && fid < bf)) { best = d2; bf = fid; }
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int probe = __shfl(inc, lo + step - 1, 64);
+                    if (probe <= e) lo += step;
+                }
+                const int row_start = __shfl(start, lo, 64);
+                const int row_excl = __shfl(inc, lo, 64) - __shfl(len, lo, 64);
+                if (base + lane < total) {
+                    const float4 C = cent[row_start + (e - row_excl)];
+                    const double dx = (double)P.x - (double)C.x, dy = (double)P.y - (double)C.y, dz = (double)P.z - (double)C.z;
+                    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                    const int fid = __float_as_int(C.w);
+                    if (d2 < best || (d2 == best && fid < bf)) { best = d2; bf = fid; }
+                }
             }
-            __syncthreads();
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -643,14 +639,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
             const int of = __shfl_xor(bf, off, 64);
             if (od < best || (od == best && of < bf)) { best = od; bf = of; }
         }
-        if (lane == 0) { s_bd[wv] = best; s_bfid[wv] = bf; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (s_bd[w] < best || (s_bd[w] == best && s_bfid[w] < bf)) { best = s_bd[w]; bf = s_bfid[w]; }
-            face_out[gi] = bf;
-        }
-        __syncthreads();
+        if (lane == 0) face_out[gi] = bf;
     }
 }
 
