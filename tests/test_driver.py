@@ -100,6 +100,33 @@ def test_neck_removal_schedule(recorder, monkeypatch):
     assert len(removed) == 3 and all(np.array_equal(r, [3, 17]) for r in removed)
 
 
+def test_builtin_remesher_in_the_block_schedule(recorder):
+    """remesher='builtin' (host C++, runs without a GPU): every remesh boundary hands the next optimiser a new topology at
+    the scheduled target edge length (_membrane_mesh.pyx:1443-1455, :1544-1546)."""
+    m = _mesh(kc=1.0, step_size=20.0, max_iter=15, remesh_frequency=5, delaunay_remesh_frequency=0, remesher='builtin')
+    sizes = []
+    orig = recorder.search
+
+    def search(self, *a, **k):
+        sizes.append((self.mesh.vertices.shape[0], self.mesh.faces.shape[0]))
+        return orig(self, *a, **k)
+    recorder.search = search
+    try:
+        L0 = m._mean_edge_length
+        m.shrink_wrap(np.zeros((5, 3), 'f4'), 10.0, minimum_edge_length=L0 / 3)
+    finally:
+        recorder.search = orig
+    assert len(sizes) == 3 and sizes[0] == (162, 320)
+    assert sizes[1][0] > sizes[0][0] and sizes[2][0] > sizes[1][0]             # edges shrink -> more vertices every block
+    assert all(f == 2 * v - 4 for v, f in sizes)                                # still closed, genus 0
+    for b in m.block_log:
+        assert abs(b['mean_length'] - b['target_length']) < 0.2 * b['target_length']
+    assert m.block_log[0]['target_length'] > m.block_log[-1]['target_length']
+    assert m._vertices['neighbors'].shape[0] == m.vertices.shape[0] and m.cg is None
+    with pytest.raises(ValueError):
+        _mesh(remesher='pyme').remesh()
+
+
 def test_result_buffers_are_recycled_only_when_the_caller_dropped_them():
     """search() returns a fresh (M,3) array every call as far as the caller can tell: an array is reused only when nothing
     outside the optimiser refers to it any more."""
