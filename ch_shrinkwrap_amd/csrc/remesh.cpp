@@ -28,6 +28,30 @@ inline double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z
 inline V3 cross(const V3 &a, const V3 &b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline double norm2(const V3 &a) { return dot(a, a); }
 
+// twin[3f+k] = the half-edge running the other way along edge (faces[f][k], faces[f][k+1]), -1 on a boundary.  Linear time:
+// the half-edges are bucketed by their origin vertex, and the twin of a->b is looked up among the handful leaving b.
+int match_twins(const int32_t *faces, int64_t nf, int64_t nv, int *twin)
+{
+    const int64_t nh = 3 * nf;
+    std::vector<int> first(nv + 1, 0), out(nh);
+    for (int64_t h = 0; h < nh; ++h) first[faces[h] + 1] += 1;
+    for (int64_t v = 0; v < nv; ++v) first[v + 1] += first[v];
+    {
+        std::vector<int> fill(first.begin(), first.end() - 1);
+        for (int64_t h = 0; h < nh; ++h) out[fill[faces[h]]++] = (int)h;
+    }
+    auto target = [&](int h) { const int f = h / 3, k = h - 3 * f; return faces[3 * f + (k + 1) % 3]; };
+    for (int64_t h = 0; h < nh; ++h) {
+        const int a = faces[h], b = target((int)h);
+        int t = -1, same = 0;
+        for (int i = first[b]; i < first[b + 1]; ++i) if (target(out[i]) == a) { if (t >= 0) return NWR_ERR_NONMANIFOLD; t = out[i]; }
+        for (int i = first[a]; i < first[a + 1]; ++i) same += (target(out[i]) == b);
+        if (same != 1) return NWR_ERR_NONMANIFOLD;             // the same directed edge twice
+        twin[h] = t;
+    }
+    return NWR_OK;
+}
+
 struct HalfEdgeMesh {
     std::vector<V3> pos;
     std::vector<int> vhe;                       // an outgoing half-edge of the vertex, -1 = deleted / unreferenced
@@ -78,27 +102,17 @@ struct HalfEdgeMesh {
         const int64_t nh = 3 * nf;
         vert.resize(nh); next.resize(nh); prev.resize(nh); twin.assign(nh, -1); face.resize(nh);
         fhe.resize(nf);
-        std::vector<std::pair<uint64_t, int>> keys(nh);
         for (int64_t f = 0; f < nf; ++f) {
             for (int k = 0; k < 3; ++k) {
                 const int a = faces[3 * f + k], b = faces[3 * f + (k + 1) % 3];
                 if (a < 0 || a >= nv || b < 0 || b >= nv || a == b) return NWR_ERR_BADARG;
                 const int h = (int)(3 * f + k);
                 vert[h] = b; next[h] = (int)(3 * f + (k + 1) % 3); prev[h] = (int)(3 * f + (k + 2) % 3); face[h] = (int)f;
-                keys[h] = {((uint64_t)(uint32_t)a << 32) | (uint32_t)b, h};
                 vhe[a] = h;
             }
             fhe[f] = (int)(3 * f);
         }
-        std::sort(keys.begin(), keys.end());
-        for (int64_t i = 1; i < nh; ++i)
-            if (keys[i].first == keys[i - 1].first) return NWR_ERR_NONMANIFOLD;      // same directed edge twice
-        for (int64_t i = 0; i < nh; ++i) {
-            const uint64_t k = keys[i].first;
-            const uint64_t rk = (k << 32) | (k >> 32);
-            auto it = std::lower_bound(keys.begin(), keys.end(), std::make_pair(rk, -1));
-            if (it != keys.end() && it->first == rk) twin[keys[i].second] = it->second;
-        }
+        if (match_twins(faces, nf, nv, twin.data()) != NWR_OK) return NWR_ERR_NONMANIFOLD;
         for (int64_t h = 0; h < nh; ++h) {
             val[from((int)h)] += 1;
             if (twin[h] < 0) { boundary[from((int)h)] = 1; boundary[vert[h]] = 1; }
@@ -315,6 +329,17 @@ struct HalfEdgeMesh {
 NWR_EXPORT int nwr_abi_version(void) { return 1; }
 
 NWR_EXPORT void nwr_free(void *p) { std::free(p); }
+
+NWR_EXPORT int nwr_halfedge_twins(const int32_t *faces, int64_t n_faces, int64_t n_vertices, int32_t *twin)
+{
+    if (!faces || !twin || n_faces < 1 || n_vertices < 1 || n_faces > (1ll << 29)) return NWR_ERR_BADARG;
+    for (int64_t i = 0; i < 3 * n_faces; ++i) if (faces[i] < 0 || faces[i] >= n_vertices) return NWR_ERR_BADARG;
+    try {
+        return match_twins(faces, n_faces, n_vertices, twin);
+    } catch (const std::bad_alloc &) {
+        return NWR_ERR_NOMEM;
+    }
+}
 
 NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
                           int n_iterations, float target_edge_length, float relax_lambda, int n_relax, int max_valence,

@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libnw_remesh.so')
-SYMBOLS = ['nwr_abi_version', 'nwr_remesh', 'nwr_free']
+SYMBOLS = ['nwr_abi_version', 'nwr_remesh', 'nwr_free', 'nwr_halfedge_twins']
 ERRORS = {-1: 'bad argument', -2: 'the mesh is not an oriented 2-manifold', -3: 'out of memory'}
 
 _lib = None
@@ -38,6 +38,8 @@ def load():
                                  ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                  ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                  ctypes.POINTER(Stats)]
+        L.nwr_halfedge_twins.restype = ctypes.c_int
+        L.nwr_halfedge_twins.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
         L.nwr_free.restype = None
         L.nwr_free.argtypes = [ctypes.c_void_p]
         if L.nwr_abi_version() != 1:
@@ -70,6 +72,17 @@ def remesh(vertices, faces, n=5, target_edge_length=-1, l=0.5, n_relax=10, max_v
         return out_v, out_f, dict(n_split=st.n_split, n_collapse=st.n_collapse, n_flip=st.n_flip,
                                   mean_edge_length=st.mean_edge_length, max_valence=st.max_valence)
     return out_v, out_f
+
+
+def halfedge_twins(faces, n_vertices):
+    """twin[3f+k] for an oriented (F,3) face array (-1 on boundaries); raises on non-manifold edges."""
+    L = load()
+    f = np.ascontiguousarray(faces, np.int32)
+    twin = np.empty(3 * f.shape[0], np.int32)
+    rc = L.nwr_halfedge_twins(f.ctypes.data, f.shape[0], int(n_vertices), twin.ctypes.data)
+    if rc != 0:
+        raise RuntimeError('nwr_halfedge_twins: %s' % ERRORS.get(rc, 'error %d' % rc))
+    return twin
 
 
 def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):

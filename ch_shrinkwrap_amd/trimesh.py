@@ -138,7 +138,14 @@ def _build_halfedges(faces, n_vertices):
     he['next'] = 3 * fi + (k + 1) % 3
     he['prev'] = 3 * fi + (k + 2) % 3
     he['component'] = 0
-    # twins: match (origin,dest) with (dest,origin)
+    # twins: match (origin,dest) with (dest,origin) -- linear-time native pairing (include/nw_remesh.h) when the mesh is an
+    # oriented 2-manifold, the sort-based NumPy pairing below otherwise (it tolerates non-manifold edges)
+    try:
+        from .remesh import halfedge_twins
+        he['twin'] = halfedge_twins(faces, n_vertices)
+        return he, origin.astype('i4')
+    except (RuntimeError, OSError):
+        pass
     nv = np.int64(n_vertices)
     key = origin.astype('i8') * nv + dest
     rkey = dest.astype('i8') * nv + origin

@@ -51,6 +51,12 @@ int nwr_remesh(const float *vertices, int64_t n_vertices, const int32_t *faces, 
 
 void nwr_free(void *p);
 
+/* Half-edge pairing of an oriented triangle mesh in linear time: half-edge 3f+k runs from faces[f][k] to faces[f][(k+1)%3];
+ * twin[3f+k] = the half-edge running the other way along the same edge, -1 on a boundary.  This is the table a half-edge
+ * substrate (PYME's TriangleMesh upstream, trimesh.TriMesh here) builds first after every topology change.
+ * NWR_ERR_NONMANIFOLD if an edge is used twice in the same direction or by more than two faces. */
+int nwr_halfedge_twins(const int32_t *faces, int64_t n_faces, int64_t n_vertices, int32_t *twin /* int32[3 * n_faces] */);
+
 #ifdef __cplusplus
 }
 #endif
