@@ -30,7 +30,8 @@ typedef enum nw_status {
     NW_OK = 0,
     NW_ERR_BADARG = -1,      /* NULL pointer, non-positive size, call order (mesh/points not set) */
     NW_ERR_HIP = -2,         /* a HIP runtime call failed; text in nw_last_error */
-    NW_ERR_NAN = -3,         /* NaN detected where the reference asserts: mesh_conj_grad.py:514,548,580 */
+    NW_ERR_NAN = -3,         /* NaN detected where the reference asserts: mesh_conj_grad.py:514,548,580 (also: a residual so large that the
+                                fixed-point A^T accumulators would overflow, > 2^27 cloud extents) */
     NW_ERR_SINGULAR = -4,    /* subspace normal equations singular: numpy.linalg.solve raises LinAlgError, conj_grad.py:219 */
     NW_ERR_NONFINITE = -5,   /* non-finite localization or vertex coordinate (cKDTree cannot index it) */
     NW_ERR_NOMEM = -6,
@@ -61,7 +62,7 @@ typedef struct nw_iter_log {
     double c[3];            /* subspace coefficients                                                    */
     double H[9];            /* regularised normal matrix actually solved (float32 values), row-major 3x3 */
     double G[3];
-    double mean_dist;       /* mean point -> nearest-centroid distance (drives the grid cell size)      */
+    double mean_dist;       /* mean point -> nearest-centroid distance (lower bound of the grid cell size) */
     int32_t n_search;       /* 2 in the first iteration of a search() call, 3 afterwards               */
     int32_t nn_max_ring;    /* largest ring any point needed in the exact NN query                      */
     int32_t status;         /* NW_OK or the nw_status raised in this iteration                          */
