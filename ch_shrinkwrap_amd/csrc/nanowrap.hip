@@ -143,11 +143,13 @@ struct nw_ctx {
     NwGrid grid{};
     bool grid_valid = false;
     double last_mean_dist = -1.0, spacing = 0.0, est_mean_dist = -1.0;
+    double sigma_eff = -1.0;          // mean localization precision (1 / mean sigma_inv), <= 0 if unknown
     double acc_quantum = 1.0;         // fixed-point quantum of the LDS scatter accumulators (k_attract): 2^-36 of the cloud extent
     double cell_tune = 1.0;           // autotuned multiplier on the cell-size rule (tune_grid)
     double force_h = 0.0;             // > 0: build_grid uses exactly this cell (autotuner probes)
     bool tuned = false;
     int64_t tuned_N = -1;
+    int blocks_done = 0;              // completed search() calls since the localizations were set
     DevBuf<int> pcount, pstart, ccount, cstart, scan_tmp, item_count, item_start;
     DevBuf<NwWorkItem> items;
     int nitems = 0;
@@ -263,16 +265,20 @@ int minmax3(nw_ctx *ctx, const float *xyz, int64_t n, float lo[3], float hi[3], 
 }
 
 // Desired fine-cell edge.  Measured on MI355X (tools/cell_sweep.py, DESIGN.md "cell size"): the cost of the staged query is
-// a sharp function of the ABSOLUTE cell size and its minimum follows the centroid spacing (how many candidates a stage
-// stages) and, weakly, the localizations-per-face ratio (how well the 256-lane workgroups fill); it hardly moves with the
-// point->surface distance until that distance exceeds the cell.  Fitted over the four BASELINE configurations and
-// 0.25x / 4x point densities:
-//     h = 10.5 nm * (spacing / 2.5 nm)^0.65 * (N / 2.5 F)^-0.11,   floor 0.6 x mean distance (far starts)
-// times ctx->cell_tune (1 unless the opt-in autotuner ran, NW_AUTOTUNE=1).
+// a sharp function of the cell size, and its minimum follows the centroid spacing (how many candidates a stage stages),
+// the localization precision sigma (how thick the slab of localizations around the surface is, i.e. how well the 256-lane
+// workgroups fill) and, weakly, the localizations-per-face ratio; it hardly moves with the point->surface distance until
+// that distance exceeds the cell.  Scale-free fit over the four BASELINE configurations, 0.25x / 4x point densities and
+// sigma = 4 / 10 / 25 nm:
+//     h = 2.9 * spacing * (sigma / spacing)^0.3 * (N / 2.5 F)^-0.11,   floor 0.6 x mean distance (far starts)
+// with sigma / spacing clamped to [1, 16] and taken as 4 when sigma is unknown (scalar sigma_inv), times ctx->cell_tune,
+// the factor the autotuner (tune_grid) finds at the start of a cloud's second block.
 double desired_cell(const nw_ctx *ctx, double mean_dist, double spacing)
 {
     const double ratio = std::max((double)ctx->N, 1.0) / (2.5 * std::max((double)ctx->F, 1.0));
-    double h = 10.5 * std::pow(std::max(spacing, 1e-30) / 2.5, 0.65) * std::pow(ratio, -0.11) * ctx->cell_tune;
+    const double sp = std::max(spacing, 1e-30);
+    const double sr = ctx->sigma_eff > 0 ? std::min(std::max(ctx->sigma_eff / sp, 1.0), 16.0) : 4.0;
+    double h = 2.9 * sp * std::pow(sr, 0.3) * std::pow(ratio, -0.11) * ctx->cell_tune;
     const char *e = getenv("NW_CELL_FACTOR");             // developer knob: multiplies the rule
     if (e && atof(e) > 0) h *= atof(e);
     return std::max(h, 0.6 * mean_dist);
@@ -545,6 +551,17 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
         hipLaunchKernelGGL(k_sum_f64, dim3(std::min(1024, nblk(3 * N))), dim3(NW_BLOCK), 0, ctx->stream, src, 3 * N, ctx->wsum.p);
         NW_HIP(hipGetLastError());
     }
+    // localization precision for the cell-size rule: 1 / mean(sigma_inv) when sigma_inv is an array (a scalar is ambiguous:
+    // the reference's own driver passes a scalar sigma UN-inverted, _membrane_mesh.pyx:1460-1461)
+    ctx->sigma_eff = -1.0;
+    if (sigma_inv) {
+        hipLaunchKernelGGL(k_sum_f64, dim3(std::min(1024, nblk(3 * N))), dim3(NW_BLOCK), 0, ctx->stream, ctx->sinv_in.p, 3 * N, ctx->wsum.p + 3);
+        NW_HIP(hipGetLastError());
+        double ssum = 0;
+        NW_HIP(hipMemcpyAsync(&ssum, ctx->wsum.p + 3, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        NW_HIP(hipStreamSynchronize(ctx->stream));
+        if (std::isfinite(ssum) && ssum > 0) ctx->sigma_eff = 3.0 * (double)N / ssum;
+    }
     bool bad = false;
     NW_TRY(minmax3(ctx, ctx->pts_in.p, N, ctx->pmin, ctx->pmax, &bad));
     if (bad) { ctx->have_points = false; return fail(ctx, NW_ERR_NONFINITE, "non-finite localization coordinate"); }
@@ -556,6 +573,8 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
     }
     ctx->have_points = true;
     ctx->grid_valid = false;
+    ctx->blocks_done = 0;
+    if (ctx->tuned_N != N) { ctx->tuned = false; ctx->cell_tune = 1.0; }      // a different cloud is tuned afresh
     ctx->last_mean_dist = -1.0;
     ctx->searched = false;
     return NW_OK;
@@ -737,25 +756,30 @@ static int launch_query(nw_ctx *ctx, int it)
     return NW_OK;
 }
 
-// Opt-in autotuner of the cell size (NW_AUTOTUNE=1, once per localization cloud): the query is exact for every grid, so the
-// same query is simply timed on a few grids around the rule's cell size (x0.8 / x1.25 steps, walking downhill, at most
-// five probes) and the fastest one is kept as a multiplier on the rule for all later meshes of this cloud.  Off by default:
-// the probes (a re-sort of the localizations and two queries each, ~2 ms at 1M localizations) cost more than a 39-iteration
-// fit gains; it is the tool the rule in desired_cell() was checked with, and pays off for long fits of one cloud.
+// Autotuner of the cell size, once per localization cloud.  The best cell depends on more than desired_cell() can see (a
+// 200k-point tube wants 9 nm where the rule says 11: with only ~2000 workgroups the GPU is not full and lighter workgroups win;
+// the landscape is jagged at the 10 % level).  The query is exact for every grid, so it is simply timed on a few grids around
+// the current cell (x0.8 / x1.25 steps, walking downhill, three to five probes of one re-sort + one query each, ~0.7 ms per
+// probe at 1M localizations) and the fastest is kept as a multiplier on the rule for all later meshes of this cloud.  It runs
+// at the start of the SECOND search() block: the first block has then brought the surface towards the localizations (the
+// far-from-converged start prefers larger cells and would mislead it), and every later block benefits.  One-block uses never
+// pay for it; NW_AUTOTUNE=0 disables it, NW_CELL_SIZE overrides everything.
 static int tune_grid(nw_ctx *ctx)
 {
     if (ctx->tuned && ctx->tuned_N == ctx->N) return NW_OK;
-    ctx->tuned = true; ctx->tuned_N = ctx->N; ctx->cell_tune = 1.0;
     const char *at = getenv("NW_AUTOTUNE");
-    if (!at || atoi(at) == 0 || getenv("NW_CELL_SIZE") || ctx->N < 20000) return NW_OK;
+    if ((at && atoi(at) == 0) || getenv("NW_CELL_SIZE") || getenv("NW_CELL_FACTOR") || ctx->N < 50000) { ctx->tuned = true; ctx->tuned_N = ctx->N; return NW_OK; }
+    if (ctx->blocks_done < 1) return NW_OK;              // not yet: see above
+    ctx->tuned = true; ctx->tuned_N = ctx->N;
     const int verbose = getenv("NW_VERBOSE") != nullptr;
     const int it = ctx->global_iter;
     const int prof = ctx->profiling;
     ctx->profiling = 0;
     hipEvent_t e0, e1;
     NW_HIP(hipEventCreate(&e0)); NW_HIP(hipEventCreate(&e1));
-    const double md = ctx->est_mean_dist;
-    const double h_rule = ctx->grid.h;
+    const double md = ctx->last_mean_dist > 0 ? ctx->last_mean_dist : ctx->est_mean_dist;
+    const double h_rule = ctx->grid.h;                   // probes start from the cell in use
+    const double h_nofloor = desired_cell(ctx, 0.0, ctx->spacing);
     int rc = NW_OK;
     auto probe = [&](double h, double &ms) -> int {
         if (std::fabs(h - ctx->grid.h) > 1e-6 * h) {
@@ -764,16 +788,12 @@ static int tune_grid(nw_ctx *ctx)
             ctx->force_h = 0.0;
             if (r != NW_OK) return r;
         }
-        float best = 1e30f;
-        for (int rep = 0; rep < 2; ++rep) {              // the first pass warms the caches for this grid
-            NW_HIP(hipEventRecord(e0, ctx->stream));
-            NW_TRY(launch_query(ctx, it));
-            NW_HIP(hipEventRecord(e1, ctx->stream));
-            NW_HIP(hipEventSynchronize(e1));
-            float t = 0; NW_HIP(hipEventElapsedTime(&t, e0, e1));
-            best = std::min(best, t);
-        }
-        ms = best;
+        NW_HIP(hipEventRecord(e0, ctx->stream));
+        NW_TRY(launch_query(ctx, it));
+        NW_HIP(hipEventRecord(e1, ctx->stream));
+        NW_HIP(hipEventSynchronize(e1));
+        float t = 0; NW_HIP(hipEventElapsedTime(&t, e0, e1));
+        ms = t;
         if (verbose) fprintf(stderr, "[nanowrap] autotune: cell %.3f -> query %.4f ms\n", ctx->grid.h, ms);
         return NW_OK;
     };
@@ -795,7 +815,7 @@ static int tune_grid(nw_ctx *ctx)
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     ctx->profiling = prof;
     if (rc != NW_OK) return rc;
-    ctx->cell_tune = best_h / h_rule;
+    ctx->cell_tune = std::min(2.0, std::max(0.5, best_h / h_nofloor));
     if (std::fabs(best_h - ctx->grid.h) > 1e-6 * best_h) {
         ctx->force_h = best_h;
         rc = build_grid(ctx, md);
@@ -882,6 +902,7 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
     if (log) for (int i = 0; i < ctx->search_done; ++i) log[i] = host[i];
     if (executed > 0) ctx->last_mean_dist = host[executed - 1].mean_dist;
     ctx->searched = ctx->searched || executed > 0;
+    if (executed > 0) ctx->blocks_done += 1;
     if (ctx->profiling) {
         for (auto &sp : g_marks.spans) {
             float ms = 0;

@@ -267,7 +267,8 @@ def test_uniform_background_is_exact_and_terminates():
     assert np.array_equal(cg.nearest_face, f_ref)
     assert np.allclose(cg.d[:, 0], d_ref, rtol=1e-6)
     print('background case: N=%d (10%% background), one iteration incl. set-up %.1f ms, max stage %d' % (pts.shape[0], dt * 1e3, cg.nn_max_ring))
-    assert dt < 5.0
+    assert cg.nn_max_ring <= 64          # geometric stage growth: a handful of doublings, not a cell-by-cell crawl
+    assert dt < 60.0                     # (normally ~2 ms; generous because a shared box can be slow)
 
 
 @pytest.mark.parametrize('case', ['icosphere', 'network', 'open_patch', 'spare_slots'])
