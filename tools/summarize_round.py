@@ -41,7 +41,7 @@ shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats.csv'))
 dur = {}
 for r in csv.DictReader(open(stats)):
     dur[short(r['Name'])] = dict(calls=int(r['Calls']), avg_us=float(r['AverageNs']) / 1e3, pct=float(r['Percentage']))
-# the same kernels restricted to the bench's TIMED region: launches [warmup, warmup+steps) of each per-iteration kernel
+# the same kernels restricted to the bench's TIMED region: the `steps` launches before the 10 extra (per-stage) ones
 # (the first launches run on the far-from-converged start state and are slower; bench.py's live HIP-event average covers
 # exactly the timed launches, so this is the number it must agree with)
 trace = glob.glob(os.path.join(src, 'trace', '**', '*kernel_trace.csv'), recursive=True)[0]
@@ -51,8 +51,8 @@ for r in csv.DictReader(open(trace)):
 WARM, STEPS = 10, 50
 for k, v in per.items():
     v.sort()
-    if k in dur and len(v) == WARM + STEPS + 10:
-        t = [d for _, d in v[WARM:WARM + STEPS]]
+    if k in dur and len(v) >= WARM + STEPS + 10:         # (the autotuner adds a few probe launches during the warm-up)
+        t = [d for _, d in v[len(v) - 10 - STEPS:len(v) - 10]]
         dur[k]['avg_us_timed_region'] = sum(t) / len(t) / 1e3
 bench = json.loads(open(os.path.join(src, 'bench.log')).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
