@@ -835,7 +835,7 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
     NW_TRY(launch_query(ctx, it));
     {
         StageScope s(ctx, ST_ATTRACT);
-        hipLaunchKernelGGL(k_attract, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
+        hipLaunchKernelGGL(k_attract, dim3(8 * ((nblk(N) + 7) / 8)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
                            ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->sinv_scalar, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->w_scalar, ctx->mask.p,
                            ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, sc, ctx->state.p, it, 1.0 / ctx->acc_quantum, ctx->acc_quantum);
     }
@@ -857,7 +857,7 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
     }
     {
         StageScope s(ctx, ST_AS);
-        hipLaunchKernelGGL(k_subspace_point_sums, dim3(nblk(ctx->N)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
+        hipLaunchKernelGGL(k_subspace_point_sums, dim3(8 * ((nblk(ctx->N) + 7) / 8)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
                            ctx->mask.p, ctx->S.p, sc, ctx->state.p, it, n_search);
     }
     NW_HIP(hipGetLastError());

@@ -676,7 +676,10 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
     for (int t = threadIdx.x; t < NW_HT; t += NW_BLOCK) s_key[t] = -1;
     for (int t = threadIdx.x; t < NW_HT * 4; t += NW_BLOCK) s_val[t] = 0ull;
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // each XCD takes one contiguous range of the brick-sorted localizations: the vertices its workgroups gather and the
+    // accumulator lines their atomics touch then live in ONE L2 instead of being spread round-robin over all eight
+    const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK - 1) / NW_BLOCK);
+    const int i = blk < 0 ? N : blk * blockDim.x + threadIdx.x;
     double red[4] = {0.0, 0.0, 0.0, 0.0};
     const int f_raw = i < N ? face[i] : 0;
     // a face id outside [0, F) can only come from a bug in the NN query: never dereference it (a faulting kernel can
@@ -885,7 +888,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
 {
     if (it >= st->stop_at) return;
     __shared__ double s_part[9 * 4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK - 1) / NW_BLOCK);      // see k_attract
+    const int i = blk < 0 ? N : blk * blockDim.x + threadIdx.x;
     double red[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) red[k] = 0.0;
