@@ -247,6 +247,9 @@ def main():
                 peak = 256 * 4 * 2.4e9 * 0.5
                 out['roofline']['valu_issue'] = {'wave_instructions_per_launch': vi, 'achieved': vi / (avg_ms * 1e-3), 'peak': peak,
                                                  'unit': 'wave-instructions/s', 'frac': vi / (avg_ms * 1e-3) / peak}
+        # a shared box is occasionally throttled (every kernel 5-50x slower for a whole call, seen twice this round): flag it
+        cp = out['roofline'].get('measured_copy_peak', 0.0)
+        out['device_health'] = 'ok' if cp >= 3000.0 else 'degraded: device-to-device copy ran at %.0f GB/s (normally ~5100)' % cp
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(synth.make_config(args.config, scale=args.scale, seed=rank), args.cpu_iters)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
