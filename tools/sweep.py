@@ -1,6 +1,7 @@
 """Developer tool: time the headline workload (C3) per stage for several grid settings in ONE process
 (interleaved A/B as cdna_hip_programming.md section 5.4 rule 24 asks).  Usage: python tools/sweep.py "F:B" "F:B" ...
-where F = NW_CELL_FACTOR and B = NW_BRICK; optional :S0 (NW_STAGE0) and :TB (NW_NN_BLOCK)."""
+where F = NW_CELL_FACTOR (a multiplier on the cell-size rule; setting it switches the autotuner off) and B = NW_BRICK;
+optional :S0 (NW_STAGE0) and :TB (NW_NN_BLOCK).  tools/cell_sweep.py sweeps the ABSOLUTE cell size instead."""
 import os
 import sys
 import time
@@ -16,7 +17,7 @@ cfgname = os.environ.get('SWEEP_CONFIG', 'c3')
 scale = float(os.environ.get('SWEEP_SCALE', '1.0'))
 cfg = synth.make_config(cfgname, scale=scale, seed=0)
 pts, s = cfg['points'], 1.0 / cfg['sigma'].ravel()
-settings = sys.argv[1:] or ['0.6:2']
+settings = sys.argv[1:] or ['1.0:2']
 rounds = int(os.environ.get('SWEEP_ROUNDS', '2'))
 ref = None
 for rnd in range(rounds):
