@@ -103,7 +103,7 @@ def main():
     ap.add_argument('--config', default='c3')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the workload (debug only; the reported config says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-iters', type=int, default=2)
+    ap.add_argument('--cpu-iters', type=int, default=0, help='oracle iterations for cpu_baseline (0 = about 10-20 s of CPU work: 10 up to 2M localizations, else 3)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -251,7 +251,8 @@ def main():
         cp = out['roofline'].get('measured_copy_peak', 0.0)
         out['device_health'] = 'ok' if cp >= 3000.0 else 'degraded: device-to-device copy ran at %.0f GB/s (normally ~5100)' % cp
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(synth.make_config(args.config, scale=args.scale, seed=rank), args.cpu_iters)
+            cpu_iters = args.cpu_iters if args.cpu_iters > 0 else (10 if N <= 2000000 else 3)
+            out['cpu_baseline'] = cpu_baseline(synth.make_config(args.config, scale=args.scale, seed=rank), cpu_iters)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out))
     if world > 1:
