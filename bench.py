@@ -235,6 +235,15 @@ def main():
             'nn_max_ring': cg.nn_max_ring, 'mean_dist_nm': cg.mean_dist,
         }
         out['roofline_iteration']['frac'] = out['roofline_iteration']['achieved'] / HBM_PEAK_GBS
+        # BASELINE.json north_star: ">= 40 % of the HBM-bandwidth roofline on the curvature+attraction kernel" (SURVEY 8d:
+        # <= 0.17 ms/iter for them at C3): the attraction/scatter, curvature-prior, A.S and update kernels together, their
+        # SURVEY-8d algorithmic bytes over their HIP-event spans
+        ca = ('attract', 'prior', 'as', 'update')
+        ca_bytes = sum(per_kernel[kern[k]] for k in ca)
+        ca_ms = sum(stage[k][0] for k in ca) / n_extra
+        out['roofline_attraction_curvature'] = {'kernels': [kern[k] for k in ca], 'algorithmic_bytes': ca_bytes, 'device_ms': ca_ms,
+                                                'achieved': ca_bytes / (ca_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                                'frac': ca_bytes / (ca_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # The dominant kernel is not an HBM kernel (25 MB algorithmic, 37 MB measured per launch): it is bound by instruction
         # issue.  VALU wave-instructions per launch from the SQ_INSTS_VALU pass (tools/pmc.sh) against the issue peak of
         # 256 CUs x 4 SIMD-32 x 2.4 GHz x 1 wave64 instruction per 2 cycles (MI355X_MICROARCH.md).
