@@ -341,6 +341,68 @@ NWR_EXPORT int nwr_halfedge_twins(const int32_t *faces, int64_t n_faces, int64_t
     }
 }
 
+// Face normals / areas, half-edge lengths and area-weighted vertex normals, arithmetic step for step what
+// trimesh.TriMesh.update_geometry does in NumPy (float32 products and differences rounded individually, three-term sums left
+// to right, vertex normals accumulated in float64 corner-major), so that both paths give bit-identical arrays.
+NWR_EXPORT int nwr_mesh_geometry(const void *positions, int64_t pos_stride_bytes, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
+                                 float *face_normal, float *face_area, float *halfedge_length, float *vertex_normal)
+{
+    if (!positions || !faces || !face_normal || !face_area || !halfedge_length || n_vertices < 1 || n_faces < 1 || pos_stride_bytes < 12)
+        return NWR_ERR_BADARG;
+    const char *base = (const char *)positions;
+    auto P = [&](int v) { return (const float *)(base + (int64_t)v * pos_stride_bytes); };
+    for (int64_t i = 0; i < 3 * n_faces; ++i) if (faces[i] < 0 || faces[i] >= n_vertices) return NWR_ERR_BADARG;
+    try {
+        std::vector<float> cr(vertex_normal ? 3 * (size_t)n_faces : 0);
+        for (int64_t f = 0; f < n_faces; ++f) {
+            const float *p0 = P(faces[3 * f]), *p1 = P(faces[3 * f + 1]), *p2 = P(faces[3 * f + 2]);
+            const float a0 = p1[0] - p0[0], a1 = p1[1] - p0[1], a2 = p1[2] - p0[2];
+            const float b0 = p2[0] - p0[0], b1 = p2[1] - p0[1], b2 = p2[2] - p0[2];
+            volatile float m0 = a1 * b2, m1 = a2 * b1, m2 = a2 * b0, m3 = a0 * b2, m4 = a0 * b1, m5 = a1 * b0;   // no contraction
+            const float c0 = m0 - m1, c1 = m2 - m3, c2 = m4 - m5;
+            volatile float q0 = c0 * c0, q1 = c1 * c1, q2 = c2 * c2;
+            volatile float s01 = q0 + q1;
+            const float n = std::sqrt((float)(s01 + q2));
+            float n0 = c0 / n, n1 = c1 / n, n2 = c2 / n;
+            if (!std::isfinite(n0)) n0 = 0;
+            if (!std::isfinite(n1)) n1 = 0;
+            if (!std::isfinite(n2)) n2 = 0;
+            face_normal[3 * f] = n0; face_normal[3 * f + 1] = n1; face_normal[3 * f + 2] = n2;
+            face_area[f] = 0.5f * n;
+            if (vertex_normal) { cr[3 * f] = c0; cr[3 * f + 1] = c1; cr[3 * f + 2] = c2; }
+            for (int k = 0; k < 3; ++k) {
+                const float *o = P(faces[3 * f + k]), *d = P(faces[3 * f + (k + 1) % 3]);
+                const float e0 = d[0] - o[0], e1 = d[1] - o[1], e2 = d[2] - o[2];
+                volatile float r0 = e0 * e0, r1 = e1 * e1, r2 = e2 * e2;
+                volatile float t01 = r0 + r1;
+                halfedge_length[3 * f + k] = std::sqrt((float)(t01 + r2));
+            }
+        }
+        if (vertex_normal) {
+            std::vector<double> vn(3 * (size_t)n_vertices, 0.0);
+            for (int corner = 0; corner < 3; ++corner)
+                for (int64_t f = 0; f < n_faces; ++f) {
+                    const int v = faces[3 * f + corner];
+                    vn[3 * (size_t)v] += (double)cr[3 * f]; vn[3 * (size_t)v + 1] += (double)cr[3 * f + 1]; vn[3 * (size_t)v + 2] += (double)cr[3 * f + 2];
+                }
+            for (int64_t v = 0; v < n_vertices; ++v) {
+                const double x = vn[3 * v], y = vn[3 * v + 1], z = vn[3 * v + 2];
+                volatile double xx = x * x, yy = y * y, zz = z * z;
+                volatile double sxy = xx + yy;
+                const double l = std::sqrt((double)(sxy + zz));
+                double u0 = x / l, u1 = y / l, u2 = z / l;
+                if (!std::isfinite(u0)) u0 = 0;
+                if (!std::isfinite(u1)) u1 = 0;
+                if (!std::isfinite(u2)) u2 = 0;
+                vertex_normal[3 * v] = (float)u0; vertex_normal[3 * v + 1] = (float)u1; vertex_normal[3 * v + 2] = (float)u2;
+            }
+        }
+        return NWR_OK;
+    } catch (const std::bad_alloc &) {
+        return NWR_ERR_NOMEM;
+    }
+}
+
 NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
                           int n_iterations, float target_edge_length, float relax_lambda, int n_relax, int max_valence,
                           float **out_vertices, int64_t *out_n_vertices, int32_t **out_faces, int64_t *out_n_faces,

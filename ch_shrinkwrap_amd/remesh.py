@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libnw_remesh.so')
-SYMBOLS = ['nwr_abi_version', 'nwr_remesh', 'nwr_free', 'nwr_halfedge_twins']
+SYMBOLS = ['nwr_abi_version', 'nwr_remesh', 'nwr_free', 'nwr_halfedge_twins', 'nwr_mesh_geometry']
 ERRORS = {-1: 'bad argument', -2: 'the mesh is not an oriented 2-manifold', -3: 'out of memory'}
 
 _lib = None
@@ -40,6 +40,8 @@ def load():
                                  ctypes.POINTER(Stats)]
         L.nwr_halfedge_twins.restype = ctypes.c_int
         L.nwr_halfedge_twins.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+        L.nwr_mesh_geometry.restype = ctypes.c_int
+        L.nwr_mesh_geometry.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4
         L.nwr_free.restype = None
         L.nwr_free.argtypes = [ctypes.c_void_p]
         if L.nwr_abi_version() != 1:
@@ -83,6 +85,26 @@ def halfedge_twins(faces, n_vertices):
     if rc != 0:
         raise RuntimeError('nwr_halfedge_twins: %s' % ERRORS.get(rc, 'error %d' % rc))
     return twin
+
+
+def mesh_geometry(positions, faces, vertex_normals=True):
+    """(face normals (F,3), face areas (F,), half-edge lengths (3F,), vertex normals (V,3) or None) of a mesh whose
+    positions are a float32 (V,3) array, possibly a strided view into vertex records."""
+    L = load()
+    pos = positions
+    if pos.dtype != np.float32 or pos.ndim != 2 or pos.shape[1] != 3 or pos.strides[1] != 4 or pos.strides[0] < 12:
+        pos = np.ascontiguousarray(positions, np.float32)
+    f = np.ascontiguousarray(faces, np.int32)
+    V, F = pos.shape[0], f.shape[0]
+    fn = np.empty((F, 3), np.float32)
+    fa = np.empty(F, np.float32)
+    hl = np.empty(3 * F, np.float32)
+    vn = np.empty((V, 3), np.float32) if vertex_normals else None
+    rc = L.nwr_mesh_geometry(pos.ctypes.data, pos.strides[0], V, f.ctypes.data, F, fn.ctypes.data, fa.ctypes.data, hl.ctypes.data,
+                             vn.ctypes.data if vn is not None else None)
+    if rc != 0:
+        raise RuntimeError('nwr_mesh_geometry: %s' % ERRORS.get(rc, 'error %d' % rc))
+    return fn, fa, hl, vn
 
 
 def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):

@@ -222,6 +222,18 @@ class TriMesh(object):
         current positions.  This is the block-boundary refresh the reference triggers at _membrane_mesh.pyx:1524-1527."""
         pos = self._vertices['position']
         f = self._faces_arr
+        if not getattr(self, '_numpy_geometry', False):
+            try:                                              # native, bit-identical to the NumPy definition below
+                from .remesh import mesh_geometry
+                fn, fa, hl, vn = mesh_geometry(pos, f, vertex_normals)
+                self._faces['normal'] = fn
+                self._faces['area'] = fa
+                self._halfedges['length'] = hl
+                if vertex_normals:
+                    self._vertices['normal'] = vn
+                return
+            except (RuntimeError, OSError):
+                pass
         v0, v1, v2 = pos[f[:, 0]], pos[f[:, 1]], pos[f[:, 2]]
         cr = np.cross(v1 - v0, v2 - v0)                      # f32, |cr| = 2*area
         nrm = np.sqrt((cr * cr).sum(1))

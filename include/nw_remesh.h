@@ -57,6 +57,14 @@ void nwr_free(void *p);
  * NWR_ERR_NONMANIFOLD if an edge is used twice in the same direction or by more than two faces. */
 int nwr_halfedge_twins(const int32_t *faces, int64_t n_faces, int64_t n_vertices, int32_t *twin /* int32[3 * n_faces] */);
 
+/* Block-boundary geometry refresh on the host (what the reference asks PYME for at _membrane_mesh.pyx:1524-1527, here the
+ * substrate's TriMesh.update_geometry): unit face normals (F,3), face areas (F,), half-edge lengths (3F,: half-edge 3f+k runs
+ * from faces[f][k] to faces[f][(k+1)%3]) and, if vertex_normal is not NULL, area-weighted unit vertex normals (V,3).
+ * `positions` points at the first vertex's xyz (float32), consecutive vertices pos_stride_bytes apart (120 for PYME's vertex_t,
+ * 12 for a packed array).  Bit-identical to the NumPy definition it replaces. */
+int nwr_mesh_geometry(const void *positions, int64_t pos_stride_bytes, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
+                      float *face_normal, float *face_area, float *halfedge_length, float *vertex_normal /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,3 +101,37 @@ def test_genus_two_network_and_degenerate_input():
     pv, pf = R.remesh(v, f[keep], 2, -1, 0.5, 0)
     ue, cn = _edges(pf)
     assert set(np.unique(cn)) <= {1, 2} and (cn == 1).any()
+
+
+@pytest.mark.parametrize('case', ['icosphere', 'network', 'open_with_spare_slots'])
+def test_native_geometry_refresh_is_bit_identical_to_the_numpy_definition(case):
+    """nwr_mesh_geometry / nwr_halfedge_twins against the NumPy code they replace in trimesh.TriMesh (the definition the
+    optimiser's golden inputs were produced with): face normals, areas, half-edge lengths, vertex normals, twins."""
+    from ch_shrinkwrap_amd import trimesh as T
+    if case == 'network':
+        from ch_shrinkwrap_amd import synth
+        c = synth.make_config('c4', scale=0.02, seed=5)
+        v, f, extra = c['vertices'], c['faces'], 0
+    else:
+        v, f = icosphere(3, 73.0)
+        v = (v * np.array([1.0, 0.6, 1.7], 'f4') + np.array([1e3, -2e3, 5e2], 'f4')).astype('f4')
+        extra = 0
+        if case == 'open_with_spare_slots':
+            f = f[v[f].mean(1)[:, 2] > 5e2]
+            extra = 11
+    a = TriMesh(v, f, max_vertices=v.shape[0] + extra)
+    b = TriMesh(v, f, max_vertices=v.shape[0] + extra)
+    b._numpy_geometry = True
+    b.update_geometry()
+    for name in ('normal', 'area'):
+        assert np.array_equal(a._faces[name], b._faces[name]), name
+    assert np.array_equal(a._halfedges['length'], b._halfedges['length'])
+    assert np.array_equal(a._vertices['normal'], b._vertices['normal'])
+    # the linear-time pairing against the sort-based one
+    nv = np.int64(a._vertices.shape[0])
+    origin, dest = a._origin.astype('i8'), a._halfedges['vertex'].astype('i8')
+    key, rkey = origin * nv + dest, dest * nv + origin
+    order = np.argsort(key, kind='stable')
+    posn = np.minimum(np.searchsorted(key[order], rkey), key.shape[0] - 1)
+    cand = order[posn]
+    assert np.array_equal(a._halfedges['twin'], np.where(key[cand] == rkey, cand, -1))
