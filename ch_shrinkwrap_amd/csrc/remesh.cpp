@@ -425,11 +425,14 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
         }
         const double high = 4.0 / 3.0 * L, low = 4.0 / 5.0 * L;
         for (int it = 0; it < n_iterations; ++it) {
+            const int64_t ops_before = m.n_split + m.n_collapse + m.n_flip;
             m.split_long_edges(high * high);
             m.collapse_short_edges(low * low, high * high);
             m.equalize_valences();
             if (n_relax > 0) m.relax(relax_lambda, n_relax);
             if (m.corrupt) return NWR_ERR_NONMANIFOLD;
+            // a pass that changed nothing would be repeated unchanged by every later iteration (no relaxation to move vertices)
+            if (n_relax == 0 && m.n_split + m.n_collapse + m.n_flip == ops_before) break;
         }
         // splits can pile degree onto a vertex faster than one flip pass removes it: keep flipping while it helps
         for (int extra = 0; extra < 6 && n_iterations > 0; ++extra) {

@@ -144,7 +144,7 @@ def _build_halfedges(faces, n_vertices):
         from .remesh import halfedge_twins
         he['twin'] = halfedge_twins(faces, n_vertices)
         return he, origin.astype('i4')
-    except (RuntimeError, OSError):
+    except Exception:                                 # library unavailable or input it rejects: NumPy definition below
         pass
     nv = np.int64(n_vertices)
     key = origin.astype('i8') * nv + dest
@@ -232,7 +232,7 @@ class TriMesh(object):
                 if vertex_normals:
                     self._vertices['normal'] = vn
                 return
-            except (RuntimeError, OSError):
+            except Exception:                                 # library unavailable or input it rejects: NumPy definition below
                 pass
         v0, v1, v2 = pos[f[:, 0]], pos[f[:, 1]], pos[f[:, 2]]
         cr = np.cross(v1 - v0, v2 - v0)                      # f32, |cr| = 2*area
