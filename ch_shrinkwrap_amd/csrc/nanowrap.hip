@@ -739,7 +739,7 @@ static int launch_query(nw_ctx *ctx, int it)
     }
     {
         StageScope s(ctx, ST_NN);
-        const int nb = 8 * ((ctx->nitems + 7) / 8);
+        const int nb = ctx->nitems;
         if (ctx->nn_block == 64)
             hipLaunchKernelGGL((k_nearest_face<64, 256>), dim3(nb), dim3(64), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                                ctx->cent_tmp.p, ctx->face.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);

@@ -423,8 +423,11 @@ __global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem 
                                                           int *__restrict__ ambig_count, NwDevState *__restrict__ st, int it)
 {
     if (it >= st->stop_at) return;
-    const int wi = nw_xcd_remap(blockIdx.x, nitems);
-    if (wi < 0) return;
+    // Plain round-robin of the work items over the XCDs.  Handing each XCD one contiguous slab of the brick list (nw_xcd_remap)
+    // was measured 12 % SLOWER here: the work per slab differs (surface area, stage counts) and the kernel then waits for the
+    // busiest XCD, while the L2 locality it buys is worth little to a kernel that moves 37 MB.
+    const int wi = blockIdx.x;
+    if (wi >= nitems) return;
     // staged candidates in BRICK-LOCAL coordinates, expanded form: {-2x', -2y', -2z', |c'|^2} so that
     // |p' - c'|^2 - |p'|^2 = fma(px', X, fma(py', Y, fma(pz', Z, W))) -- three FMAs per candidate
     __shared__ float4 s_cand[CAP];
