@@ -197,7 +197,7 @@ def test_against_oracle_fresh_inputs(name, scale):
 
 @pytest.mark.parametrize('name,n_brute', [('c3', 3000), ('c4', 600)])
 def test_full_size_properties(name, n_brute):
-    """BASELINE.json configs[2] (1M localizations, 198 812 vertices) and configs[3] (5M localizations, 809 956 vertices,
+    """BASELINE.json configs[2] (1M localizations, 198 812 vertices) and configs[3] (5M localizations, ≈810 000 vertices,
     genus-2 tube/sheet network) at full size: size-independent properties."""
     TriMesh, CG = _imports()
     from ch_shrinkwrap_amd import synth
