@@ -38,7 +38,7 @@ def algorithmic_bytes(N, M, F):
     (4-byte elements, each named array read/written once per stage)."""
     per_kernel = {
         # NN query 12 r + 8 w per point; candidate reads >= 12 per face
-        'k_nearest_face': 20 * N + 12 * F,
+        'k_nn_wave': 20 * N + 12 * F,
         # weights 28 r + 24 w, A f + residual 64 r + 12 w, A^T res 36 r, A^T 1 24 r per point;
         # weight gather 12 + A f 12 + A^T outputs 12 + 4 per vertex
         'k_attract': 188 * N + 40 * M,
@@ -190,7 +190,7 @@ def main():
     if rank == 0:
         per_kernel, per_iter = algorithmic_bytes(N, M, F)
         # dominant kernel by device time, from HIP events recorded around each launch on the library's stream
-        kern = {'nn': 'k_nearest_face', 'attract': 'k_attract', 'as': 'k_subspace_point_sums', 'prior': 'k_prior_directions',
+        kern = {'nn': 'k_nn_wave', 'attract': 'k_attract', 'as': 'k_subspace_point_sums', 'prior': 'k_prior_directions',
                 'update': 'k_solve_update'}          # single-kernel stages (grid build and the NN fix-up are reported in stage_ms_per_iter)
         dom = max((k for k in kern), key=lambda k: stage[k][0] / max(stage[k][1], 1))
         if dom == 'nn':
@@ -249,7 +249,7 @@ def main():
         # 256 CUs x 4 SIMD-32 x 2.4 GHz x 1 wave64 instruction per 2 cycles (MI355X_MICROARCH.md).
         if traffic is not None and dom == 'nn':
             try:
-                vi = json.load(open(tfile)).get('k_nearest_face_valu_wave_instructions')
+                vi = json.load(open(tfile)).get('k_nn_wave_valu_wave_instructions')
             except Exception:
                 vi = None
             if vi:

@@ -10,7 +10,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libnanowrap_hip.so')
 SRC = os.path.join(HERE, 'csrc', 'nanowrap.hip')
-DEPS = [SRC, os.path.join(HERE, 'csrc', 'nw_kernels.h'), os.path.join(HERE, 'csrc', 'nw_device.h'),
+SRC_SORT = os.path.join(HERE, 'csrc', 'nw_sort.hip')      # set-up radix sort (hipCUB), its own translation unit
+OBJ_SORT = os.path.join(HERE, 'csrc', 'nw_sort.o')
+OBJ_MAIN = os.path.join(HERE, 'csrc', 'nanowrap.o')
+DEPS = [SRC, SRC_SORT, os.path.join(HERE, 'csrc', 'nw_kernels.h'), os.path.join(HERE, 'csrc', 'nw_nn.h'), os.path.join(HERE, 'csrc', 'nw_device.h'),
         os.path.join(os.path.dirname(HERE), 'include', 'nanowrap.h')]
 
 # -ffp-contract=off : the parity-critical float32 arithmetic must round products before adding, exactly like
@@ -31,10 +34,16 @@ def build_hip_library(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + HIPCC_FLAGS + ['-o', LIB, SRC]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+
+    if force or not os.path.exists(OBJ_SORT) or os.path.getmtime(OBJ_SORT) < os.path.getmtime(SRC_SORT):
+        run([hipcc, '-O3', '--offload-arch=gfx950', '-fPIC', '-fvisibility=hidden', '-Wno-unused-value', '-c', '-o', OBJ_SORT, SRC_SORT])
+    run([hipcc] + [f for f in HIPCC_FLAGS if f != '-shared'] + ['-c', '-o', OBJ_MAIN, SRC])
+    run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB, OBJ_MAIN, OBJ_SORT])
     return LIB
 
 

@@ -20,6 +20,9 @@
 #include "../../include/nanowrap.h"
 #include "nw_kernels.h"
 
+// stable LSD radix sort of (key, value) pairs on the device (csrc/nw_sort.hip, hipCUB); returns a hipError_t as int
+int nw_sort_pairs_u32(const unsigned *key_in, unsigned *key_out, const int *val_in, int *val_out, int n, int bits, hipStream_t stream);
+
 static_assert(sizeof(NwIterLogDev) == sizeof(nw_iter_log), "device/host log record mismatch");
 static_assert(SC_COUNT <= NW_N_SCALARS, "scalar slots");
 static_assert(NW_REPL == 32 && SC_COUNT * 8 <= NW_BLOCK, "nw_gather_scalars layout");
@@ -43,6 +46,7 @@ struct DevBuf {
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -133,9 +137,12 @@ struct nw_ctx {
     float pmin[3] = {0, 0, 0}, pmax[3] = {0, 0, 0};
     DevBuf<double> wsum;
 
-    // localizations in cell order
+    // localizations in Morton order (sorted once per nw_set_points; the order never changes afterwards)
     DevBuf<float4> pts;
-    DevBuf<int> perm, pt_cell;
+    DevBuf<int> perm;                 // sorted slot -> caller index
+    DevBuf<unsigned> mkey;            // sorted Morton keys (work items are cut from them)
+    float proj_unit = 1.0f;
+    float morton_unit = 1.0f;         // edge of one Morton quantum (cloud bounding cube / 1024)
     DevBuf<float> sinv, wnorm;
     DevBuf<unsigned char> mask;
 
@@ -145,15 +152,18 @@ struct nw_ctx {
     double last_mean_dist = -1.0, spacing = 0.0, est_mean_dist = -1.0;
     double sigma_eff = -1.0;          // mean localization precision (1 / mean sigma_inv), <= 0 if unknown
     double acc_quantum = 1.0;         // fixed-point quantum of the LDS scatter accumulators (k_attract): 2^-36 of the cloud extent
-    double cell_tune = 1.0;           // autotuned multiplier on the cell-size rule (tune_grid)
-    double force_h = 0.0;             // > 0: build_grid uses exactly this cell (autotuner probes)
-    bool tuned = false;
-    int64_t tuned_N = -1;
-    int blocks_done = 0;              // completed search() calls since the localizations were set
-    DevBuf<int> pcount, pstart, ccount, cstart, scan_tmp, item_count, item_start;
-    DevBuf<NwWorkItem> items;
+    double cell_tune = 1.0;           // multiplier on the cell-size rule (nw_tune_grid)
+    double force_h = 0.0;             // > 0: build_grid uses exactly this cell (nw_tune_grid probes)
+    DevBuf<int> ccount, cstart, scan_tmp;
+    DevBuf<NwItem> items;             // work list of the NN query: runs of <= 64 Morton-consecutive localizations
     int nitems = 0;
-    int nn_block = 256;               // threads per NN workgroup (64 = one wave per work item)
+    int item_level = -1;              // Morton level (block edge = morton_unit * 2^level) the items were cut at
+    int64_t cent_pad_F = -1;
+    DevBuf<unsigned long long> nn_stats;   // developer counters of the NN query (nw_debug_nn_stats); null unless enabled
+    DevBuf<unsigned> proj_key;        // projection keys of the last completed query (second sort, see k_projection_keys)
+    DevBuf<int> proj_idx;
+    bool proj_ready = false, proj_sorted = false;
+    bool face_warm = false;           // `face` holds the previous iteration's nearest faces of THIS topology (warm start)
 
     // mesh
     DevBuf<float> pos, meshpos, nrm;
@@ -284,8 +294,42 @@ double desired_cell(const nw_ctx *ctx, double mean_dist, double spacing)
     return std::max(h, 0.6 * mean_dist);
 }
 
+// ---- work list of the NN query ---------------------------------------------------------------------------
+// Items = runs of <= 64 consecutive localizations of the Morton-sorted list that stay inside one aligned Morton block of edge
+// morton_unit * 2^level (about four cells): a dense block is cut into equal runs, a sparse one is a single under-filled wave.
+int build_items(nw_ctx *ctx, int level)
+{
+    if (level == ctx->item_level && ctx->nitems > 0) return NW_OK;
+    const int64_t N = ctx->N;
+    DevBuf<int> head, hscan, bstart, icount, istart;
+    NW_HIP(head.ensure(N)); NW_HIP(hscan.ensure(N + 1));
+    hipLaunchKernelGGL(k_block_heads, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, ctx->mkey.p, (int)N, 3 * level, head.p);
+    NW_TRY(scan_exclusive(ctx, head.p, (int)N, hscan.p));
+    int nblocks = 0;
+    NW_HIP(hipMemcpyAsync(&nblocks, hscan.p + N, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    NW_HIP(bstart.ensure((size_t)nblocks + 1)); NW_HIP(icount.ensure((size_t)nblocks)); NW_HIP(istart.ensure((size_t)nblocks + 1));
+    hipLaunchKernelGGL(k_block_starts, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, head.p, hscan.p, (int)N, bstart.p);
+    hipLaunchKernelGGL(k_block_item_counts, dim3(nblk(nblocks)), dim3(NW_BLOCK), 0, ctx->stream, bstart.p, nblocks, icount.p);
+    NW_TRY(scan_exclusive(ctx, icount.p, nblocks, istart.p));
+    int nitems = 0;
+    NW_HIP(hipMemcpyAsync(&nitems, istart.p + nblocks, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    NW_HIP(ctx->items.ensure((size_t)nitems));
+    hipLaunchKernelGGL(k_block_fill_items, dim3(nblk(nblocks)), dim3(NW_BLOCK), 0, ctx->stream, bstart.p, istart.p, nblocks, ctx->items.p);
+    NW_HIP(hipGetLastError());
+    NW_HIP(hipStreamSynchronize(ctx->stream));          // the temporaries die with this scope
+    ctx->nitems = nitems;
+    ctx->item_level = level;
+    if (getenv("NW_VERBOSE"))
+        fprintf(stderr, "[nanowrap] work list: Morton level %d (block %.2f), %d blocks, %d items (%.1f localizations per wave)\n", level,
+                ctx->morton_unit * (float)(1 << level), nblocks, nitems, (double)N / std::max(nitems, 1));
+    return NW_OK;
+}
+
 // ---- grid construction ---------------------------------------------------------------------------------
-// Cell size: desired_cell() (or ctx->force_h while the autotuner probes); dims capped at 2^25 cells.
+// Cell size: desired_cell() (or ctx->force_h while nw_tune_grid probes); dims capped at 2^25 cells.  Only the CENTROID lattice
+// and the work list depend on it; the localizations keep their Morton order.
 int build_grid(nw_ctx *ctx, double mean_dist)
 {
     const int64_t N = ctx->N, F = ctx->F;
@@ -319,25 +363,19 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     double h = ctx->force_h > 0 ? ctx->force_h : desired_cell(ctx, mean_dist, spacing);
     if (!(h > 0) || !std::isfinite(h)) h = ext / 16;
     ctx->est_mean_dist = mean_dist;
-    h = std::max(h, ext / 1024.0);                       // at most ~1024 fine cells per axis
+    h = std::max(h, ext / 1024.0);                       // at most ~1024 cells per axis
     const char *env_h = getenv("NW_CELL_SIZE");
     if (env_h && atof(env_h) > 0 && !(ctx->force_h > 0)) h = atof(env_h);
-    const char *env_b = getenv("NW_BRICK");
-    const int B = (env_b && atoi(env_b) > 0) ? std::min(atoi(env_b), 8) : 2;
     NwGrid g;
     for (;;) {
         const double margin = 0.5 * h;
         g.ox = (float)(lo[0] - margin); g.oy = (float)(lo[1] - margin); g.oz = (float)(lo[2] - margin);
-        g.bx = std::max(1, (int)std::ceil((hi[0] + margin - g.ox) / (h * B)));
-        g.by = std::max(1, (int)std::ceil((hi[1] + margin - g.oy) / (h * B)));
-        g.bz = std::max(1, (int)std::ceil((hi[2] + margin - g.oz) / (h * B)));
-        g.gx = g.bx * B; g.gy = g.by * B; g.gz = g.bz * B;
+        g.gx = std::max(1, (int)std::ceil((hi[0] + margin - g.ox) / h));
+        g.gy = std::max(1, (int)std::ceil((hi[1] + margin - g.oy) / h));
+        g.gz = std::max(1, (int)std::ceil((hi[2] + margin - g.oz) / h));
         if ((double)g.gx * g.gy * g.gz <= (double)(1 << 25)) break;
         h *= 1.26;
     }
-    g.B = B;
-    { const char *e0 = getenv("NW_STAGE0"); g.s0 = (e0 && atoi(e0) > 0) ? std::min(atoi(e0), 8) : 1; }
-    g.nbrick = g.bx * g.by * g.bz;
     g.h = (float)h;
     g.inv_h = 1.0f / g.h;
     g.ncell = g.gx * g.gy * g.gz;
@@ -346,43 +384,18 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     g.eps = (float)(1e-3 * h + 2e-6 * maxc);
     ctx->grid = g;
 
-    { const char *et = getenv("NW_NN_BLOCK"); ctx->nn_block = (et && atoi(et) == 64) ? 64 : 256; }
-    const size_t nc = (size_t)g.ncell, nbk = (size_t)g.nbrick;
-    NW_HIP(ctx->pcount.ensure(nbk));
-    NW_HIP(ctx->pstart.ensure(nbk + 1));
+    const size_t nc = (size_t)g.ncell;
     NW_HIP(ctx->ccount.ensure(nc));
     NW_HIP(ctx->cstart.ensure(nc + 1));
-    NW_HIP(ctx->item_count.ensure(nbk));
-    NW_HIP(ctx->item_start.ensure(nbk + 1));
-    NW_HIP(hipMemsetAsync(ctx->pcount.p, 0, nbk * sizeof(int), ctx->stream));
     NW_HIP(hipMemsetAsync(ctx->ccount.p, 0, nc * sizeof(int), ctx->stream));
-
-    // sort the localizations into cell order, baking the residual weighting
-    NW_HIP(ctx->pts.ensure(N));
-    NW_HIP(ctx->perm.ensure(N));
-    NW_HIP(ctx->pt_cell.ensure(N));
-    NW_HIP(ctx->mask.ensure(N));
-    if (ctx->sinv_array) NW_HIP(ctx->sinv.ensure(3 * N));
-    if (ctx->w_array) NW_HIP(ctx->wnorm.ensure(3 * N));
-    hipLaunchKernelGGL(k_point_cells, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pts_in.p, (int)N, ctx->pt_cell.p, ctx->pcount.p);
-    NW_TRY(scan_exclusive(ctx, ctx->pcount.p, g.nbrick, ctx->pstart.p));
-    const float *w_src = ctx->w_array ? ((ctx->w_mode == NW_WEIGHTS_ARRAY || ctx->w_mode == NW_WEIGHTS_PRENORMALIZED) ? ctx->w_in.p : ctx->sinv_in.p) : nullptr;
-    hipLaunchKernelGGL(k_point_scatter, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts_in.p, ctx->pt_cell.p, ctx->pstart.p, ctx->pcount.p,
-                       ctx->sinv_array ? ctx->sinv_in.p : nullptr, w_src, ctx->wsum.p, ctx->w_array ? (ctx->w_mode == NW_WEIGHTS_PRENORMALIZED ? 2 : 1) : 0,
-                       ctx->pts.p, ctx->perm.p, ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->mask.p);
-    // work list
-    hipLaunchKernelGGL(k_count_items, dim3(nblk(g.nbrick)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pstart.p, g.nbrick, ctx->nn_block, ctx->item_count.p);
-    NW_TRY(scan_exclusive(ctx, ctx->item_count.p, g.nbrick, ctx->item_start.p));
-    int nitems = 0;
-    NW_HIP(hipMemcpyAsync(&nitems, ctx->item_start.p + g.nbrick, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    NW_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->nitems = nitems;
-    NW_HIP(ctx->items.ensure((size_t)nitems));
-    hipLaunchKernelGGL(k_fill_items, dim3(nblk(g.nbrick)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pstart.p, ctx->item_start.p, g.nbrick, ctx->nn_block, ctx->items.p);
-    NW_HIP(hipGetLastError());
+    // work list: Morton blocks of about NW_ITEM_BLOCK_CELLS cells per edge
+    const double block_cells = getenv("NW_ITEM_BLOCK_CELLS") ? atof(getenv("NW_ITEM_BLOCK_CELLS")) : 4.0;
+    int level = (int)std::lround(std::log2(std::max(block_cells * h / (double)ctx->morton_unit, 1.0)));
+    level = std::min(std::max(level, 0), 10);
+    NW_TRY(build_items(ctx, level));
     ctx->grid_valid = true;
     if (getenv("NW_VERBOSE"))
-        fprintf(stderr, "[nanowrap] grid %dx%dx%d h=%.3f brick=%d s0=%d tb=%d (mean_dist %.3f, spacing %.3f) items=%d\n", g.gx, g.gy, g.gz, g.h, g.B, g.s0, ctx->nn_block, mean_dist, spacing, nitems);
+        fprintf(stderr, "[nanowrap] grid %dx%dx%d h=%.3f (mean_dist %.3f, spacing %.3f) items=%d\n", g.gx, g.gy, g.gz, g.h, mean_dist, spacing, ctx->nitems);
     return NW_OK;
 }
 
@@ -427,7 +440,14 @@ int alloc_work(nw_ctx *ctx)
 {
     const int64_t N = ctx->N, M = ctx->M, F = ctx->F;
     NW_HIP(ctx->cent_tmp.ensure(F));
-    NW_HIP(ctx->cent.ensure(F));
+    NW_HIP(ctx->cent.ensure(F + NW_CENT_PAD));
+    if (ctx->cent_pad_F != F) {
+        // far-away pad entries behind the last centroid: the NN kernel reads candidates four at a time, one batch ahead
+        float pad[4 * NW_CENT_PAD];
+        for (int k = 0; k < 4 * NW_CENT_PAD; ++k) pad[k] = (k & 3) == 3 ? 0.0f : 1e18f;
+        NW_HIP(hipMemcpy(ctx->cent.p + F, pad, sizeof(pad), hipMemcpyHostToDevice));
+        ctx->cent_pad_F = F;
+    }
     NW_HIP(ctx->fcell.ensure(F));
     NW_HIP(ctx->frank.ensure(F));
     NW_HIP(ctx->face.ensure(N));
@@ -479,9 +499,8 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pts_in.release(); ctx->sinv_in.release(); ctx->w_in.release(); ctx->wsum.release();
-    ctx->pts.release(); ctx->perm.release(); ctx->pt_cell.release(); ctx->sinv.release(); ctx->wnorm.release(); ctx->mask.release();
-    ctx->pcount.release(); ctx->pstart.release(); ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release();
-    ctx->item_count.release(); ctx->item_start.release(); ctx->items.release();
+    ctx->pts.release(); ctx->perm.release(); ctx->mkey.release(); ctx->proj_key.release(); ctx->proj_idx.release(); ctx->sinv.release(); ctx->wnorm.release(); ctx->mask.release();
+    ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_stats.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->d_small.release();
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
@@ -565,16 +584,39 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
     bool bad = false;
     NW_TRY(minmax3(ctx, ctx->pts_in.p, N, ctx->pmin, ctx->pmax, &bad));
     if (bad) { ctx->have_points = false; return fail(ctx, NW_ERR_NONFINITE, "non-finite localization coordinate"); }
+    double ext = 0;
+    for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)ctx->pmax[k] - (double)ctx->pmin[k]);
+    if (!(ext > 0) || !std::isfinite(ext)) ext = 1.0;
+    ctx->acc_quantum = std::ldexp(1.0, (int)std::floor(std::log2(ext)) - 36);
+    // Morton order, once: 30-bit code of the position inside the cloud's bounding cube, stable radix sort (deterministic order)
     {
-        double ext = 0;
-        for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)ctx->pmax[k] - (double)ctx->pmin[k]);
-        if (!(ext > 0) || !std::isfinite(ext)) ext = 1.0;
-        ctx->acc_quantum = std::ldexp(1.0, (int)std::floor(std::log2(ext)) - 36);
+        ctx->morton_unit = (float)(ext / 1024.0);
+        DevBuf<unsigned> key_in;
+        DevBuf<int> idx_in;
+        NW_HIP(key_in.ensure(N)); NW_HIP(idx_in.ensure(N));
+        NW_HIP(ctx->mkey.ensure(N)); NW_HIP(ctx->perm.ensure(N));
+        hipLaunchKernelGGL(k_morton_keys, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pts_in.p, (int)N, ctx->pmin[0], ctx->pmin[1], ctx->pmin[2],
+                           1.0f / ctx->morton_unit, key_in.p, idx_in.p);
+        NW_HIP(hipGetLastError());
+        const int se = nw_sort_pairs_u32(key_in.p, ctx->mkey.p, idx_in.p, ctx->perm.p, (int)N, 30, ctx->stream);
+        if (se != 0) return fail(ctx, NW_ERR_HIP, std::string("radix sort of the Morton keys: ") + hipGetErrorString((hipError_t)se));
+        NW_HIP(ctx->pts.ensure(N));
+        NW_HIP(ctx->mask.ensure(N));
+        if (ctx->sinv_array) NW_HIP(ctx->sinv.ensure(3 * N));
+        if (ctx->w_array) NW_HIP(ctx->wnorm.ensure(3 * N));
+        const float *w_src = ctx->w_array ? ((ctx->w_mode == NW_WEIGHTS_ARRAY || ctx->w_mode == NW_WEIGHTS_PRENORMALIZED) ? ctx->w_in.p : ctx->sinv_in.p) : nullptr;
+        hipLaunchKernelGGL(k_point_gather, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts_in.p, ctx->perm.p,
+                           ctx->sinv_array ? ctx->sinv_in.p : nullptr, w_src, ctx->wsum.p, ctx->w_array ? (ctx->w_mode == NW_WEIGHTS_PRENORMALIZED ? 2 : 1) : 0,
+                           ctx->pts.p, ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->mask.p);
+        NW_HIP(hipGetLastError());
+        NW_HIP(hipStreamSynchronize(ctx->stream));      // key_in / idx_in die with this scope
     }
     ctx->have_points = true;
     ctx->grid_valid = false;
-    ctx->blocks_done = 0;
-    if (ctx->tuned_N != N) { ctx->tuned = false; ctx->cell_tune = 1.0; }      // a different cloud is tuned afresh
+    ctx->item_level = -1;
+    ctx->nitems = 0;
+    ctx->face_warm = false;
+    ctx->proj_ready = false; ctx->proj_sorted = false;
     ctx->last_mean_dist = -1.0;
     ctx->searched = false;
     return NW_OK;
@@ -642,6 +684,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     if (nrm) NW_HIP(hipMemcpyAsync(ctx->nrm.p, nrm, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
     else NW_TRY(nw_refresh_normals(ctx, nullptr));         // area-weighted vertex normals from positions + faces on the device
     if (topo_change) { ctx->grid_valid = false; }
+    ctx->face_warm = false;                               // face ids of another topology are no starting guess
     // a new mesh object = a new optimiser in the reference (_membrane_mesh.pyx:1510): history restarts
     NwDevState st{};
     st.stop_at = 0x7fffffff;
@@ -695,8 +738,41 @@ NW_EXPORT int nw_set_positions(nw_ctx *ctx, const float *pos)
     return NW_OK;
 }
 
+// Second sort of the localizations, by the foot point on the surface (k_projection_keys): once per cloud, at the start of the
+// first block after a completed query.  Everything per-localization that survives a block boundary moves along; the cached
+// weight matrix / residual of the previous block (cg.w, cg.res, Afunc/Ahfunc) are recomputed by the block that starts now.
+static int resort_by_projection(nw_ctx *ctx)
+{
+    const int64_t N = ctx->N;
+    DevBuf<int> order;
+    DevBuf<float4> pts2;
+    DevBuf<int> perm2, face2;
+    DevBuf<float> sinv2, wnorm2;
+    DevBuf<unsigned char> mask2;
+    NW_HIP(order.ensure(N)); NW_HIP(pts2.ensure(N)); NW_HIP(perm2.ensure(N)); NW_HIP(face2.ensure(N)); NW_HIP(mask2.ensure(N));
+    if (ctx->sinv_array) NW_HIP(sinv2.ensure(3 * N));
+    if (ctx->w_array) NW_HIP(wnorm2.ensure(3 * N));
+    const int se = nw_sort_pairs_u32(ctx->proj_key.p, ctx->mkey.p, ctx->proj_idx.p, order.p, (int)N, 30, ctx->stream);
+    if (se != 0) return fail(ctx, NW_ERR_HIP, std::string("radix sort of the projection keys: ") + hipGetErrorString((hipError_t)se));
+    hipLaunchKernelGGL(k_point_regather, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, order.p, ctx->pts.p, ctx->perm.p,
+                       ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->mask.p, ctx->face.p,
+                       pts2.p, perm2.p, sinv2.p, wnorm2.p, mask2.p, face2.p);
+    NW_HIP(hipGetLastError());
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->pts.swap(pts2); ctx->perm.swap(perm2); ctx->mask.swap(mask2); ctx->face.swap(face2);
+    if (ctx->sinv_array) ctx->sinv.swap(sinv2);
+    if (ctx->w_array) ctx->wnorm.swap(wnorm2);
+    ctx->morton_unit = ctx->proj_unit;
+    ctx->item_level = -1; ctx->nitems = 0;
+    ctx->grid_valid = false;                 // the work list is cut again (build_grid)
+    ctx->proj_sorted = true; ctx->proj_ready = false;
+    ctx->searched = false;                   // cached per-localization results are in the old order
+    ctx->proj_key.release(); ctx->proj_idx.release();
+    if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] localizations re-sorted by their foot point on the surface\n");
+    return NW_OK;
+}
+
 // ---- the iteration -------------------------------------------------------------------------------------------
-static int tune_grid(nw_ctx *ctx);
 NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags)
 {
     if (!ctx) return NW_ERR_BADARG;
@@ -707,8 +783,8 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     NW_TRY(alloc_work(ctx));
     // start_guess: fs = vertices.copy() -> f restarts from the mesh positions (mesh_conj_grad.py:170, :1002-1007)
     NW_HIP(hipMemcpyAsync(ctx->pos.p, ctx->meshpos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    if (ctx->proj_ready && !ctx->proj_sorted && num_iters > 0 && !getenv("NW_NO_PROJ_SORT")) NW_TRY(resort_by_projection(ctx));
     NW_TRY(ensure_grid(ctx));
-    NW_TRY(tune_grid(ctx));
     ctx->lam0 = lams[0];
     ctx->search_flags = flags;
     ctx->search_iters = num_iters;
@@ -739,13 +815,12 @@ static int launch_query(nw_ctx *ctx, int it)
     }
     {
         StageScope s(ctx, ST_NN);
-        const int nb = ctx->nitems;
-        if (ctx->nn_block == 64)
-            hipLaunchKernelGGL((k_nearest_face<64, 256>), dim3(nb), dim3(64), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                               ctx->cent_tmp.p, ctx->face.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
-        else
-            hipLaunchKernelGGL((k_nearest_face<256, 768>), dim3(nb), dim3(256), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                               ctx->cent_tmp.p, ctx->face.p, ctx->ambig_list.p, ctx->ambig_count.p, ctx->state.p, it);
+        static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
+        const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;   // one wave = one work item
+        hipLaunchKernelGGL(k_nn_wave, dim3(8 * ((nb + 7) / 8)), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | (getenv("NW_NN_XCD_SLABS") ? 0 : 2), ctx->ambig_list.p, ctx->ambig_count.p,
+                           ctx->state.p, it, ctx->nn_stats.p);
+        ctx->face_warm = true;
     }
     {
         StageScope s(ctx, ST_FIXUP);
@@ -754,75 +829,6 @@ static int launch_query(nw_ctx *ctx, int it)
     }
     NW_HIP(hipGetLastError());
     return NW_OK;
-}
-
-// Autotuner of the cell size, once per localization cloud.  The best cell depends on more than desired_cell() can see (a
-// 200k-point tube wants 9 nm where the rule says 11: with only ~2000 workgroups the GPU is not full and lighter workgroups win;
-// the landscape is jagged at the 10 % level).  The query is exact for every grid, so it is simply timed on a few grids around
-// the current cell (x0.8 / x1.25 steps, walking downhill, three to five probes of one re-sort + one query each, ~0.7 ms per
-// probe at 1M localizations) and the fastest is kept as a multiplier on the rule for all later meshes of this cloud.  It runs
-// at the start of the SECOND search() block: the first block has then brought the surface towards the localizations (the
-// far-from-converged start prefers larger cells and would mislead it), and every later block benefits.  One-block uses never
-// pay for it; NW_AUTOTUNE=0 disables it, NW_CELL_SIZE overrides everything.
-static int tune_grid(nw_ctx *ctx)
-{
-    if (ctx->tuned && ctx->tuned_N == ctx->N) return NW_OK;
-    const char *at = getenv("NW_AUTOTUNE");
-    if ((at && atoi(at) == 0) || getenv("NW_CELL_SIZE") || getenv("NW_CELL_FACTOR") || ctx->N < 50000) { ctx->tuned = true; ctx->tuned_N = ctx->N; return NW_OK; }
-    if (ctx->blocks_done < 1) return NW_OK;              // not yet: see above
-    ctx->tuned = true; ctx->tuned_N = ctx->N;
-    const int verbose = getenv("NW_VERBOSE") != nullptr;
-    const int it = ctx->global_iter;
-    const int prof = ctx->profiling;
-    ctx->profiling = 0;
-    hipEvent_t e0, e1;
-    NW_HIP(hipEventCreate(&e0)); NW_HIP(hipEventCreate(&e1));
-    const double md = ctx->last_mean_dist > 0 ? ctx->last_mean_dist : ctx->est_mean_dist;
-    const double h_rule = ctx->grid.h;                   // probes start from the cell in use
-    const double h_nofloor = desired_cell(ctx, 0.0, ctx->spacing);
-    int rc = NW_OK;
-    auto probe = [&](double h, double &ms) -> int {
-        if (std::fabs(h - ctx->grid.h) > 1e-6 * h) {
-            ctx->force_h = h;
-            const int r = build_grid(ctx, md);
-            ctx->force_h = 0.0;
-            if (r != NW_OK) return r;
-        }
-        NW_HIP(hipEventRecord(e0, ctx->stream));
-        NW_TRY(launch_query(ctx, it));
-        NW_HIP(hipEventRecord(e1, ctx->stream));
-        NW_HIP(hipEventSynchronize(e1));
-        float t = 0; NW_HIP(hipEventElapsedTime(&t, e0, e1));
-        ms = t;
-        if (verbose) fprintf(stderr, "[nanowrap] autotune: cell %.3f -> query %.4f ms\n", ctx->grid.h, ms);
-        return NW_OK;
-    };
-    double best_h = h_rule, best_t = 0, t = 0;
-    do {
-        if ((rc = probe(h_rule, best_t)) != NW_OK) break;
-        double hl = h_rule * 0.8, tl = 0, hr = h_rule * 1.25, tr = 0;
-        if ((rc = probe(hl, tl)) != NW_OK) break;
-        if ((rc = probe(hr, tr)) != NW_OK) break;
-        int dir = 0;
-        if (tl < best_t && tl <= tr) { best_h = hl; best_t = tl; dir = -1; }
-        else if (tr < best_t) { best_h = hr; best_t = tr; dir = +1; }
-        for (int step = 0; dir != 0 && step < 2; ++step) {          // keep walking while it improves
-            const double hn = best_h * (dir < 0 ? 0.8 : 1.25);
-            if ((rc = probe(hn, t)) != NW_OK) break;
-            if (t < best_t) { best_h = hn; best_t = t; } else break;
-        }
-    } while (0);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    ctx->profiling = prof;
-    if (rc != NW_OK) return rc;
-    ctx->cell_tune = std::min(2.0, std::max(0.5, best_h / h_nofloor));
-    if (std::fabs(best_h - ctx->grid.h) > 1e-6 * best_h) {
-        ctx->force_h = best_h;
-        rc = build_grid(ctx, md);
-        ctx->force_h = 0.0;
-    }
-    if (verbose) fprintf(stderr, "[nanowrap] autotune: rule %.3f -> cell %.3f (x%.2f)\n", h_rule, best_h, ctx->cell_tune);
-    return rc;
 }
 
 NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
@@ -902,7 +908,18 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
     if (log) for (int i = 0; i < ctx->search_done; ++i) log[i] = host[i];
     if (executed > 0) ctx->last_mean_dist = host[executed - 1].mean_dist;
     ctx->searched = ctx->searched || executed > 0;
-    if (executed > 0) ctx->blocks_done += 1;
+    if (executed > 0 && !ctx->proj_sorted && !ctx->proj_ready && ctx->face_warm) {
+        // foot points of this block's last query -> keys of the second sort (applied at the start of the next block)
+        const NwGrid &g = ctx->grid;
+        const double ext = std::max({(double)g.gx, (double)g.gy, (double)g.gz}) * g.h;
+        ctx->proj_unit = (float)(ext / 1024.0);
+        NW_HIP(ctx->proj_key.ensure(ctx->N)); NW_HIP(ctx->proj_idx.ensure(ctx->N));
+        hipLaunchKernelGGL(k_projection_keys, dim3(nblk(ctx->N)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->face.p, (int)ctx->F, ctx->cent_tmp.p, ctx->pts.p,
+                           g.ox, g.oy, g.oz, 1.0f / ctx->proj_unit, ctx->proj_key.p, ctx->proj_idx.p);
+        NW_HIP(hipGetLastError());
+        NW_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->proj_ready = true;
+    }
     if (ctx->profiling) {
         for (auto &sp : g_marks.spans) {
             float ms = 0;
@@ -1151,6 +1168,27 @@ NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nb
     } while (0);
     d_next.release(); d_area.release(); d_out.release(); d_jit.release();
     if (rc != NW_OK) return fail(ctx, rc, "nw_curvature: HIP failure");
+    return NW_OK;
+}
+
+// developer aid (not part of the drop-in surface): counters of the NN query accumulated since the last call.
+// out[0..7] = candidates evaluated (x64 lanes each), non-empty rows listed, rows visited, cells tested, cells visited, box rows,
+// rounds, small runs; out[8] = work items.  The first call switches the counting on.
+NW_EXPORT int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out)
+{
+    if (!ctx || !out) return NW_ERR_BADARG;
+    if (!ctx->nn_stats.p) {
+        NW_HIP(ctx->nn_stats.ensure(NWS_COUNT));
+        NW_HIP(hipMemset(ctx->nn_stats.p, 0, NWS_COUNT * sizeof(unsigned long long)));
+        for (int k = 0; k < 9; ++k) out[k] = 0;
+        return NW_OK;
+    }
+    unsigned long long h[NWS_COUNT];
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    NW_HIP(hipMemcpy(h, ctx->nn_stats.p, sizeof(h), hipMemcpyDeviceToHost));
+    NW_HIP(hipMemset(ctx->nn_stats.p, 0, sizeof(h)));
+    for (int k = 0; k < NWS_COUNT; ++k) out[k] = (int64_t)h[k];
+    out[8] = ctx->nitems;
     return NW_OK;
 }
 

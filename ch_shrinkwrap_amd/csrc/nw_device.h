@@ -7,18 +7,14 @@
 #define NW_WAVE 64
 
 // ---- uniform grid ------------------------------------------------------------------------------------------
-// Two resolutions share one lattice: face centroids are binned into FINE cells of edge h (x fastest), the
-// localizations are grouped into BRICKS of B x B x B fine cells (one workgroup per brick in the NN query).
+// Face centroids are binned into the cells of edge h of one dense lattice (x fastest: a (z,y) row of cells is one contiguous
+// candidate range of the cell-sorted centroid array).  The localizations are NOT binned: they are Morton-sorted once (nw_nn.h).
 struct NwGrid {
     float ox, oy, oz;      // origin (lower corner)
-    float h, inv_h;        // fine cell edge
-    float eps;             // safety slack for the stage-termination bound (rounding of cell assignment)
-    int gx, gy, gz;        // fine cells per axis (multiples of B)
+    float h, inv_h;        // cell edge
+    float eps;             // safety slack for the rounding of the cell assignment
+    int gx, gy, gz;        // cells per axis
     int ncell;
-    int B;                 // brick edge in fine cells
-    int bx, by, bz;        // bricks per axis
-    int nbrick;
-    int s0;                // margin (fine cells) of the first NN stage
 };
 
 __device__ __forceinline__ int nw_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -33,11 +29,6 @@ __device__ __forceinline__ void nw_cell_coords(const NwGrid &g, float x, float y
 __device__ __forceinline__ int nw_cell_index(const NwGrid &g, int ix, int iy, int iz)
 {
     return ix + g.gx * (iy + g.gy * iz);
-}
-
-__device__ __forceinline__ int nw_brick_index(const NwGrid &g, int ix, int iy, int iz)
-{
-    return (ix / g.B) + g.bx * ((iy / g.B) + g.by * (iz / g.B));
 }
 
 // ---- wave / block reductions (wave64 shuffles; no LDS for the intra-wave part) ------------------------------

@@ -30,8 +30,6 @@ struct NwDevState {
     int pad;
 };
 
-struct NwWorkItem { int cell, p0, p1; };
-
 // ============================================================================================================
 // generic exclusive scan of int32 counts (3 launches): out[0..n] with out[n] = total
 // ============================================================================================================
@@ -179,72 +177,6 @@ __global__ __launch_bounds__(NW_BLOCK) void k_sample_nn(const float *__restrict_
     if (threadIdx.x == 0) atomicAdd(out_sum, (double)sqrtf(fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]))));
 }
 
-__global__ void k_point_cells(NwGrid g, const float *__restrict__ xyz, int N, int *__restrict__ pt_cell, int *__restrict__ count)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    int ix, iy, iz;
-    nw_cell_coords(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], ix, iy, iz);
-    const int c = nw_brick_index(g, ix, iy, iz);      // localizations are grouped by brick
-    pt_cell[i] = c;
-    atomicAdd(&count[c], 1);
-}
-
-// counting-sort scatter of the localizations into cell order.  Also bakes the residual weighting of
-// search() (mesh_conj_grad.py:156-164): weights = weights/weights.mean(), mask = weights > 0 (array) or
-// isfinite(data) (scalar).  `count` holds the per-cell counts and is decremented back to zero.
-__global__ void k_point_scatter(int N, const float *__restrict__ xyz, const int *__restrict__ pt_cell, const int *__restrict__ start, int *__restrict__ count,
-                                const float *__restrict__ sinv_in, const float *__restrict__ w_in, const double *__restrict__ wsum, int w_is_array,
-                                float4 *__restrict__ pts, int *__restrict__ perm, float *__restrict__ sinv, float *__restrict__ wnorm, unsigned char *__restrict__ mask)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int c = pt_cell[i];
-    const int slot = start[c] + atomicSub(&count[c], 1) - 1;
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    pts[slot] = make_float4(x, y, z, __int_as_float(i));
-    perm[slot] = i;
-    if (sinv_in)
-        for (int k = 0; k < 3; ++k) sinv[3 * slot + k] = sinv_in[3 * i + k];
-    unsigned m = 0;
-    if (w_is_array) {
-        const float mean = (float)(wsum[0] / (3.0 * (double)N));
-        for (int k = 0; k < 3; ++k) {
-            const float w = w_in[3 * i + k];
-            wnorm[3 * slot + k] = (w_is_array == 2) ? w : w / mean;      // 2: already divided by the global mean
-            m |= (w > 0.0f) ? (1u << k) : 0u;
-        }
-    } else {
-        m = (isfinite(x) ? 1u : 0u) | (isfinite(y) ? 2u : 0u) | (isfinite(z) ? 4u : 0u);
-    }
-    mask[slot] = (unsigned char)m;
-}
-
-// work list for the NN kernel: one item per (non-empty cell, chunk of <= 256 of its points)
-__global__ void k_count_items(const int *__restrict__ pstart, int ncell, int chunk, int *__restrict__ nitems)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncell) return;
-    const int np = pstart[c + 1] - pstart[c];
-    nitems[c] = (np + chunk - 1) / chunk;
-}
-
-__global__ void k_fill_items(const int *__restrict__ pstart, const int *__restrict__ istart, int ncell, int chunk, NwWorkItem *__restrict__ items)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncell) return;
-    const int p0 = pstart[c], p1 = pstart[c + 1];
-    if (p1 <= p0) return;
-    int o = istart[c];
-    const int n = (p1 - p0 + chunk - 1) / chunk;          // a crowded brick is cut into n EQUAL parts (not 256 + a small rest)
-    const int per = (p1 - p0 + n - 1) / n;
-    for (int p = p0; p < p1; p += per) {
-        NwWorkItem w;
-        w.cell = c; w.p0 = p; w.p1 = min(p + per, p1);
-        items[o++] = w;
-    }
-}
-
 // 1-ring table from the faces array alone, pass 1: every face corner (a -> b, then c, counter-clockwise)
 // deposits {b, c, half-edge id 3f+k} in a slot of its vertex a.  err[0] counts vertices whose degree exceeds the table width.
 __global__ void k_ring_collect(const int *__restrict__ faces, int F, int M, int NB, int *__restrict__ cnt, int4 *__restrict__ pairs, int *__restrict__ err)
@@ -365,222 +297,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const floa
     cent[start[fcell[f]] + frank[f]] = cent_tmp[f];
 }
 
-// K4a: exact nearest face centroid of every localization (replaces cKDTree build + query,
-// mesh_conj_grad.py:451-454: exact Euclidean 1-NN in float64).
-//
-// One workgroup per work item = the (<=256) localizations of one BRICK (B^3 fine cells).  Candidate centroids are
-// walked in STAGES: stage s covers the cube "brick +- s fine cells" minus what earlier stages covered.  Every
-// (z,y) row of a stage is one (or, for interior rows of a shell, two) contiguous range(s) of the cell-sorted
-// centroid array (x is the fastest cell index), so a stage is a handful of coalesced float4 range copies into LDS,
-// shared by all points of the brick.  The 256 threads are split into groups of G lanes per unfinished point
-// (G = largest power of two with n*G <= 256, re-balanced after every stage as points finish): each lane scans
-// every G-th staged candidate from LDS (ds_read_b128, broadcast across groups), then the group reduces with wave
-// shuffles.  After stage s a point is FINAL once best <= s*h + (distance to its brick's wall) - eps, which proves no
-// unexplored cell can hold a closer centroid.
-//
-// Arithmetic: distances are evaluated in float32 (relative error < 4e-7), keeping the best AND the second-best
-// value; a point whose runner-up lies within (1 + 2e-6) of its best is "ambiguous" and is re-resolved exactly in
-// float64 by k_nn_fixup (a handful of points per million), so the result is the float64 argmin for every point.
-#define NW_NN_AMBIG 2e-6f
-
-// segment q of the stage that grows the covered cube from "brick +- sp" to "brick +- s" (sp < 0: nothing covered yet):
-// rows r = q>>1 over the (W x W) (z,y) extent of the new cube; rows inside the old cube's (z,y) extent contribute the two
-// x-runs left and right of it (e = q&1), all other rows one full run.  Every run is a contiguous range of fine cells.
-__device__ __forceinline__ void nw_stage_segment(int sp, int s, int q, int x0, int y0, int z0, const NwGrid &g, int &cell_lo, int &ncells)
-{
-    const int B = g.B;
-    const int W = B + 2 * s;
-    const int e = q & 1, r = q >> 1;
-    const int iz = (int)(((float)r + 0.5f) * (1.0f / (float)W));     // exact r / W for the small ints involved, no integer division
-    const int iy = r - iz * W;
-    const int y = y0 - s + iy, z = z0 - s + iz;
-    ncells = 0; cell_lo = 0;
-    if (y < 0 || y >= g.gy || z < 0 || z >= g.gz) return;
-    int xa, xb;
-    const int t = s - sp;                                            // shell thickness in cells
-    const bool interior = (sp >= 0) && iz >= t && iz <= W - 1 - t && iy >= t && iy <= W - 1 - t;
-    if (!interior) {
-        if (e) return;
-        xa = x0 - s; xb = x0 + B - 1 + s;
-    } else if (e == 0) {
-        xa = x0 - s; xb = x0 - sp - 1;
-    } else {
-        xa = x0 + B + sp; xb = x0 + B - 1 + s;
-    }
-    xa = xa < 0 ? 0 : xa;
-    xb = xb >= g.gx ? g.gx - 1 : xb;
-    if (xb < xa) return;
-    cell_lo = nw_cell_index(g, xa, y, z);
-    ncells = xb - xa + 1;
-}
-
-#define NW_STAGE_DOUBLE 4      // stages grow by one cell up to this margin, then double (far / background localizations)
-
-template <int TB, int CAP>
-__global__ __launch_bounds__(TB) void k_nearest_face(NwGrid g, const NwWorkItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
-                                                          const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face,
-                                                          int *__restrict__ face_out, int *__restrict__ ambig_list,
-                                                          int *__restrict__ ambig_count, NwDevState *__restrict__ st, int it)
-{
-    if (it >= st->stop_at) return;
-    // Plain round-robin of the work items over the XCDs.  Handing each XCD one contiguous slab of the brick list (nw_xcd_remap)
-    // was measured 12 % SLOWER here: the work per slab differs (surface area, stage counts) and the kernel then waits for the
-    // busiest XCD, while the L2 locality it buys is worth little to a kernel that moves 37 MB.
-    const int wi = blockIdx.x;
-    if (wi >= nitems) return;
-    // staged candidates in BRICK-LOCAL coordinates, expanded form: {-2x', -2y', -2z', |c'|^2} so that
-    // |p' - c'|^2 - |p'|^2 = fma(px', X, fma(py', Y, fma(pz', Z, W))) -- three FMAs per candidate
-    __shared__ float4 s_cand[CAP];
-    __shared__ int s_fid[CAP];
-    __shared__ int s_rs[TB];
-    __shared__ int s_ro[TB + 1];
-    __shared__ int s_wtot[TB / 64];
-    // per-point state of the unfinished points (compacted after every stage)
-    __shared__ int s_idx[TB];
-    __shared__ float s_b1[TB], s_b2[TB];
-    __shared__ int s_bf[TB];
-    __shared__ int s_n[2];
-
-    const NwWorkItem item = items[wi];
-    const int tid = threadIdx.x;
-    const int brick = item.cell;
-    const int Bz = brick / (g.bx * g.by), By = (brick / g.bx) % g.by, Bx = brick % g.bx;
-    const int x0 = Bx * g.B, y0 = By * g.B, z0 = Bz * g.B;
-    const float bw = g.B * g.h;
-    const float blx = g.ox + x0 * g.h, bly = g.oy + y0 * g.h, blz = g.oz + z0 * g.h;
-    const float ccx = blx + 0.5f * bw, ccy = bly + 0.5f * bw, ccz = blz + 0.5f * bw;     // local origin = brick centre
-    int n = item.p1 - item.p0;            // unfinished points
-    if (tid < n) { s_idx[tid] = tid; s_b1[tid] = INFINITY; s_b2[tid] = INFINITY; s_bf[tid] = 0x7fffffff; }
-    // the stage after which the cube covers the whole grid
-    int maxS = max(max(max(x0, g.gx - (x0 + g.B)), max(y0, g.gy - (y0 + g.B))), max(z0, g.gz - (z0 + g.B)));
-    if (maxS < 1) maxS = 1;
-    if (maxS < g.s0) maxS = g.s0;
-    int stage = g.s0, prev = -1;
-    __syncthreads();
-    for (;;) {
-        int G = 1;
-        while (((G << 1) * n <= TB) && G < 64) G <<= 1;      // lanes per unfinished point
-        const int slot = tid / G, sub = tid & (G - 1);
-        const bool has = slot < n;
-        int lidx = 0;
-        // b1/b2 hold (distance^2 - |p'|^2): the point-constant term is added back only where absolute values matter
-        float b1 = INFINITY, b2 = INFINITY;
-        int bf = 0x7fffffff;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (has) {
-            lidx = s_idx[slot];
-            const float4 P = pts[item.p0 + lidx];
-            px = P.x - ccx; py = P.y - ccy; pz = P.z - ccz;
-            if (sub == 0) { b1 = s_b1[slot]; b2 = s_b2[slot]; bf = s_bf[slot]; }
-        }
-        __syncthreads();                                   // everyone has read the compacted state
-        const int W = g.B + 2 * stage;
-        const int nq = 2 * W * W;
-        for (int qb = 0; qb < nq; qb += TB) {
-            {
-                int start = 0, len = 0;
-                const int q = qb + tid;
-                if (q < nq) {
-                    int lo, nc;
-                    nw_stage_segment(prev, stage, q, x0, y0, z0, g, lo, nc);
-                    if (nc > 0) { start = cstart[lo]; len = cstart[lo + nc] - start; }
-                }
-                s_rs[tid] = start;
-                const int inc = nw_wave_incl_scan(len, tid & 63);
-                if (TB > 64) {
-                    if ((tid & 63) == 63) s_wtot[tid >> 6] = inc;
-                    __syncthreads();
-                    int woff = 0;
-                    for (int w = 0; w < (tid >> 6); ++w) woff += s_wtot[w];
-                    s_ro[tid + 1] = woff + inc;
-                } else {
-                    s_ro[tid + 1] = inc;
-                }
-                if (tid == 0) s_ro[0] = 0;
-            }
-            __syncthreads();
-            const int total = s_ro[TB];
-            for (int base = 0; base < total; base += CAP) {
-                const int nc = min(CAP, total - base);
-                for (int e = tid; e < nc; e += TB) {
-                    const int ge = base + e;
-                    int lo = 0, hi = TB;
-#pragma unroll
-                    for (int stp = 0; stp < (TB == 64 ? 6 : 8); ++stp) { const int mid = (lo + hi) >> 1; if (s_ro[mid] <= ge) lo = mid; else hi = mid; }
-                    const float4 C = cent[s_rs[lo] + (ge - s_ro[lo])];
-                    const float x = C.x - ccx, y = C.y - ccy, z = C.z - ccz;
-                    s_cand[e] = make_float4(-2.0f * x, -2.0f * y, -2.0f * z, fmaf(z, z, fmaf(y, y, x * x)));
-                    s_fid[e] = __float_as_int(C.w);
-                }
-                __syncthreads();
-                if (has) {
-                    int bi = -1;                           // LDS slot of the best candidate seen in THIS chunk
-                    int c = sub;
-                    for (; c + G < nc; c += 2 * G) {
-                        const float4 C0 = s_cand[c];
-                        const float4 C1 = s_cand[c + G];
-                        const float d0 = fmaf(px, C0.x, fmaf(py, C0.y, fmaf(pz, C0.z, C0.w)));
-                        const float d1 = fmaf(px, C1.x, fmaf(py, C1.y, fmaf(pz, C1.z, C1.w)));
-                        bi = d0 < b1 ? c : bi;
-                        b2 = __builtin_amdgcn_fmed3f(b1, b2, d0);      // b1 <= b2: the runner-up is the median of {b1, b2, d}
-                        b1 = fminf(b1, d0);
-                        bi = d1 < b1 ? c + G : bi;
-                        b2 = __builtin_amdgcn_fmed3f(b1, b2, d1);
-                        b1 = fminf(b1, d1);
-                    }
-                    if (c < nc) {
-                        const float4 C0 = s_cand[c];
-                        const float d0 = fmaf(px, C0.x, fmaf(py, C0.y, fmaf(pz, C0.z, C0.w)));
-                        bi = d0 < b1 ? c : bi;
-                        b2 = __builtin_amdgcn_fmed3f(b1, b2, d0);
-                        b1 = fminf(b1, d0);
-                    }
-                    if (bi >= 0) bf = s_fid[bi];
-                }
-                __syncthreads();
-            }
-            if (total == 0) __syncthreads();
-        }
-        // group reduction of (best, face, runner-up)
-        for (int off = G >> 1; off > 0; off >>= 1) {
-            const float o1 = __shfl_xor(b1, off, 64);
-            const float o2 = __shfl_xor(b2, off, 64);
-            const int of = __shfl_xor(bf, off, 64);
-            if (o1 < b1) { b2 = fminf(b1, o2); b1 = o1; bf = of; }
-            else { b2 = fminf(b2, o1); }
-        }
-        // termination test + compaction of the unfinished points
-        if (tid == 0) s_n[stage & 1] = 0;
-        __syncthreads();
-        bool fin = false;
-        if (has && sub == 0) {
-            const float hb = 0.5f * bw;
-            const float m = fmaxf(fminf(fminf(hb - fabsf(px), hb - fabsf(py)), hb - fabsf(pz)), 0.0f);     // distance to the brick wall
-            const float bound = (float)stage * g.h + m - g.eps;
-            const float pn = fmaf(pz, pz, fmaf(py, py, px * px));
-            // float32 error of the expanded form: < 4 ulp of the largest intermediate, |coordinates| <= Rc
-            const float Rc = hb + (float)stage * g.h + g.eps;
-            const float tol = 6e-6f * Rc * Rc;
-            fin = (stage >= maxS) || (bound > 0.0f && (b1 + pn) + tol <= bound * bound);
-            if (fin) {
-                const int gi = item.p0 + lidx;
-                face_out[gi] = bf;          // the float64 distance to the winner is taken by k_attract
-                // runner-up within the float32 error band -> exact float64 re-resolution (k_nn_fixup)
-                if (b2 - b1 <= 2.0f * tol + NW_NN_AMBIG * (b1 + pn)) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
-            } else {
-                const int k = atomicAdd(&s_n[stage & 1], 1);
-                // safe: all threads loaded their slot state before the stage's first barrier
-                s_idx[k] = lidx; s_b1[k] = b1; s_b2[k] = b2; s_bf[k] = bf;
-            }
-        }
-        __syncthreads();
-        n = s_n[stage & 1];
-        if (n == 0) break;
-        prev = stage;
-        stage = stage < NW_STAGE_DOUBLE ? stage + 1 : min(2 * stage, maxS);
-    }
-    if (tid == 0 && stage > g.s0) atomicMax(&st->nn_max_ring, stage);
-}
+// K4a: the exact nearest-face query (k_nn_wave) and the set-up kernels of its work list
+#include "nw_nn.h"
 
 // exact float64 re-resolution of the ambiguous points (runner-up inside the float32 error band of the best): one wave
 // per point.  Phase 1: every (z,y) row of fine cells of the box around the ball of radius dist*(1+1e-4)+eps gets a lane that

@@ -1,0 +1,419 @@
+// Exact nearest-face-centroid query, wave-autonomous form (replaces cKDTree build + query, mesh_conj_grad.py:451-454:
+// exact Euclidean 1-NN in float64).  MI355X (gfx950), wave64.  No LDS, no workgroup barriers, no MFMA.
+//
+// Layout.  Localizations are sorted ONCE (nw_set_points) by the 30-bit Morton code of their position inside the cloud's
+// bounding box, so every contiguous run of the sorted list is spatially compact at every scale.  A work item is a run of
+// <= 64 consecutive localizations that does not leave one aligned Morton block (edge ~4 fine cells); one WAVE owns one item,
+// lane = localization.  Face centroids are binned per iteration into the fine cells of the uniform grid (cell-sorted float4
+// {x, y, z, face id}, x fastest: a (z,y) row of cells is one contiguous candidate range, `cstart` = dense cell table).
+//
+// Walk.  Every lane keeps its best squared distance b1 (and runner-up b2).  The ball of radius sqrt(b1) around the
+// localization bounds where a closer centroid can be; the wave visits the bounding box (in cells) of its lanes' balls:
+//   * lane = (z,y) ROW of the box: two gathers from `cstart` give the row's candidate range; a ballot keeps the non-empty rows;
+//   * lane = LOCALIZATION again: a non-empty row is visited only if some lane's ball reaches its (y,z) square, and inside the
+//     row a non-empty CELL only if some lane's ball reaches the cell (exact box-distance tests against the lane's CURRENT b1);
+//   * the candidates of the surviving cells are streamed through the SCALAR cache (s_load: the candidate is wave-uniform, it
+//     sits in SGPRs and costs no vector-memory or LDS traffic) and evaluated by all 64 lanes at once in float32.
+// Warm start: the previous iteration's nearest face (the sorted order never changes) gives every lane a tight starting radius,
+// so one visit of the box settles the wave.  Cold start (first iteration, new topology): own cell +- 1, then the ball box of
+// what that found; lanes that have seen no candidate yet double their margin until the box covers the grid.
+// A lane is final once its ball lies inside the visited box; the visited region only grows and b1 only shrinks.
+//
+// Arithmetic.  d^2 = (px-cx)^2 + (py-cy)^2 + (pz-cz)^2 in float32 straight from the stored coordinates: each difference
+// is correctly rounded (relative error 2^-24 whatever the coordinate offset), so the value is within 4 ulp of the float64 one.
+// Cells are culled against b1 * (1 + 4e-6) (+ the rounding slack of the cell assignment), so every centroid whose float32
+// distance is within the error band of the winner IS evaluated and is seen by the runner-up; a lane whose runner-up lies
+// within NW_NN_BAND of its best is re-resolved in float64 by k_nn_fixup (a few dozen per million).  The result is the float64
+// argmin for every localization (lowest face id on exact ties; SciPy's tie order is unspecified).
+#pragma once
+#include "nw_device.h"
+
+#define NW_NN_BAND 6e-6f          // relative error band of the keys: 16 ulp of truncation (1.9e-6) on both + 4 roundings of 2^-24
+#define NW_NN_CULL 1.2e-5f        // cells are culled against b1 * (1 + NW_NN_CULL)
+#define NW_ITEM_POINTS 64
+
+struct NwItem { int p0, n; };
+
+// ---- set-up: Morton keys, work items ------------------------------------------------------------------------
+__device__ __forceinline__ unsigned nw_spread10(unsigned v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// key = Morton code of the position quantised to 1024^3 over the cloud's bounding cube (edge `ext`, lower corner lo)
+__global__ void k_morton_keys(const float *__restrict__ xyz, int N, float lox, float loy, float loz, float inv_unit, unsigned *__restrict__ key, int *__restrict__ idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int qx = nw_clampi((int)((xyz[3 * i] - lox) * inv_unit), 0, 1023);
+    const int qy = nw_clampi((int)((xyz[3 * i + 1] - loy) * inv_unit), 0, 1023);
+    const int qz = nw_clampi((int)((xyz[3 * i + 2] - loz) * inv_unit), 0, 1023);
+    key[i] = nw_spread10((unsigned)qx) | (nw_spread10((unsigned)qy) << 1) | (nw_spread10((unsigned)qz) << 2);
+    idx[i] = i;
+}
+
+// gather the localizations into sorted order, baking the residual weighting of search() (mesh_conj_grad.py:156-164):
+// weights = weights / weights.mean(), mask = weights > 0 (array) or isfinite(data) (scalar)
+__global__ void k_point_gather(int N, const float *__restrict__ xyz, const int *__restrict__ order,
+                               const float *__restrict__ sinv_in, const float *__restrict__ w_in, const double *__restrict__ wsum, int w_is_array,
+                               float4 *__restrict__ pts, float *__restrict__ sinv, float *__restrict__ wnorm, unsigned char *__restrict__ mask)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= N) return;
+    const int i = order[slot];
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    pts[slot] = make_float4(x, y, z, __int_as_float(i));
+    if (sinv_in)
+        for (int k = 0; k < 3; ++k) sinv[3 * slot + k] = sinv_in[3 * i + k];
+    unsigned m = 0;
+    if (w_is_array) {
+        const float mean = (float)(wsum[0] / (3.0 * (double)N));
+        for (int k = 0; k < 3; ++k) {
+            const float w = w_in[3 * i + k];
+            wnorm[3 * slot + k] = (w_is_array == 2) ? w : w / mean;      // 2: already divided by the global mean
+            m |= (w > 0.0f) ? (1u << k) : 0u;
+        }
+    } else {
+        m = (isfinite(x) ? 1u : 0u) | (isfinite(y) ? 2u : 0u) | (isfinite(z) ? 4u : 0u);
+    }
+    mask[slot] = (unsigned char)m;
+}
+
+// Projection order (second sort, once per cloud after the first completed query): key = Morton code of the CENTROID of the
+// localization's nearest face, i.e. of its foot point on the surface.  Localizations over the same patch of surface become
+// neighbours in the list whatever their height above it, so a wave's 64 localizations share one small set of candidate cells
+// (in the plain 3-D Morton order a wave's box is as wide as its localizations are scattered in height).  Speed only.
+__global__ void k_projection_keys(int N, const int *__restrict__ face, int F, const float4 *__restrict__ cent_by_face, const float4 *__restrict__ pts,
+                                  float lox, float loy, float loz, float inv_unit, unsigned *__restrict__ key, int *__restrict__ idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int f = face[i];
+    const float4 C = ((unsigned)f < (unsigned)F) ? cent_by_face[f] : pts[i];
+    const int qx = nw_clampi((int)((C.x - lox) * inv_unit), 0, 1023);
+    const int qy = nw_clampi((int)((C.y - loy) * inv_unit), 0, 1023);
+    const int qz = nw_clampi((int)((C.z - loz) * inv_unit), 0, 1023);
+    key[i] = nw_spread10((unsigned)qx) | (nw_spread10((unsigned)qy) << 1) | (nw_spread10((unsigned)qz) << 2);
+    idx[i] = i;
+}
+
+// move the per-localization inputs (and the warm-start faces) from the old sorted order to the new one: new slot s <- old slot order[s]
+__global__ void k_point_regather(int N, const int *__restrict__ order, const float4 *__restrict__ pts_o, const int *__restrict__ perm_o,
+                                 const float *__restrict__ sinv_o, const float *__restrict__ wnorm_o, const unsigned char *__restrict__ mask_o, const int *__restrict__ face_o,
+                                 float4 *__restrict__ pts, int *__restrict__ perm, float *__restrict__ sinv, float *__restrict__ wnorm, unsigned char *__restrict__ mask,
+                                 int *__restrict__ face)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int o = order[s];
+    pts[s] = pts_o[o];
+    perm[s] = perm_o[o];
+    mask[s] = mask_o[o];
+    face[s] = face_o[o];
+    if (sinv_o)
+        for (int k = 0; k < 3; ++k) sinv[3 * s + k] = sinv_o[3 * o + k];
+    if (wnorm_o)
+        for (int k = 0; k < 3; ++k) wnorm[3 * s + k] = wnorm_o[3 * o + k];
+}
+
+// block heads of the sorted key list: head[i] = 1 where the aligned Morton block (key >> shift) changes
+__global__ void k_block_heads(const unsigned *__restrict__ key, int N, int shift, int *__restrict__ head)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    head[i] = (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift)) ? 1 : 0;
+}
+
+// bid = exclusive scan of head (+ head) - 1; every head records where its block starts
+__global__ void k_block_starts(const int *__restrict__ head, const int *__restrict__ scan, int N, int *__restrict__ bstart)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (head[i]) bstart[scan[i]] = i;
+    if (i == N - 1) bstart[scan[i] + head[i]] = N;
+}
+
+__global__ void k_block_item_counts(const int *__restrict__ bstart, int nblocks, int *__restrict__ nitems)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    nitems[b] = (bstart[b + 1] - bstart[b] + NW_ITEM_POINTS - 1) / NW_ITEM_POINTS;
+}
+
+__global__ void k_block_fill_items(const int *__restrict__ bstart, const int *__restrict__ istart, int nblocks, NwItem *__restrict__ items)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const int p0 = bstart[b], p1 = bstart[b + 1];
+    const int n = (p1 - p0 + NW_ITEM_POINTS - 1) / NW_ITEM_POINTS;        // a crowded block is cut into n EQUAL runs
+    if (n <= 0) return;
+    const int per = (p1 - p0 + n - 1) / n;
+    int o = istart[b];
+    for (int p = p0; p < p1; p += per) {
+        NwItem w;
+        w.p0 = p; w.n = min(per, p1 - p);
+        items[o++] = w;
+    }
+}
+
+// ---- the query ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nw_wave_min_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int nw_wave_max_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// developer counters of one launch (nw_debug_nn_stats): candidates evaluated, rows listed / visited, cells tested / visited, ...
+enum { NWS_CAND = 0, NWS_ROWS_NONEMPTY, NWS_ROWS_PASS, NWS_CELLS_TESTED, NWS_CELLS_PASS, NWS_BOX_ROWS, NWS_ROUNDS, NWS_SMALL_RUNS, NWS_COUNT };
+struct NwStats { int v[NWS_COUNT]; };
+
+// Best / runner-up are kept as integer KEYS: the float32 bits of d^2 (non-negative, so they order like unsigned integers)
+// with the low 4 mantissa bits replaced by the candidate's position inside its chunk of 16.  One v_and_or + v_med3_u32 +
+// v_min_u32 per candidate, all on vector registers, replace compare + select + move-from-scalar (measured on MI355X: a VALU
+// instruction that reads a scalar register or writes/reads VCC issues at ~4.3 cycles per wave, a pure-VGPR one at ~2.6).
+// The truncation (16 ulp = 1.9e-6 relative) is inside the ambiguity band: such near-ties go to the float64 fix-up.
+#define NW_KEY_BITS 4
+#define NW_KEY_MASK 0xfffffff0u
+#define NW_KEY_INF 0x7f800000u
+
+struct NwLane {
+    float px, py, pz;        // the localization
+    float ux, uy, uz;        // the same in cell units: (p - origin) * inv_h
+    float ax, ay, az;        // u + eps      } distance (cell units) from u to the slab [k - eps, k + 1 + eps] of cell index k:
+    float bx, by, bz;        // u - 1 - eps  }   max(k - a, b - k, 0)
+    unsigned b1, b2;         // best / runner-up key
+    int bbase;               // first slot of the chunk the best candidate came from (-1: none yet); slot = bbase + (b1 & 15)
+    unsigned keymask;        // NW_KEY_MASK, pinned in a vector register
+};
+
+__device__ __forceinline__ float nw_best_d2(const NwLane &L) { return __uint_as_float(L.b1); }
+
+// one candidate (wave-uniform: scalar registers) against all lanes; K = its position in the chunk (an inline constant)
+template <int K>
+__device__ __forceinline__ void nw_eval(NwLane &L, const float4 C)
+{
+    const float dx = L.px - C.x, dy = L.py - C.y, dz = L.pz - C.z;
+    const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    unsigned key, b2;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(d), "v"(L.keymask), "n"(K));
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(b2) : "v"(L.b1), "v"(L.b2), "v"(key));      // b1 <= b2: the runner-up is the median of {b1, b2, key}
+    L.b2 = b2;
+    L.b1 = min(L.b1, key);
+}
+
+struct alignas(16) NwCand4 { float4 c[4]; };
+template <int K0>
+__device__ __forceinline__ void nw_eval4(NwLane &L, const NwCand4 &A)
+{
+    nw_eval<K0>(L, A.c[0]);
+    nw_eval<K0 + 1>(L, A.c[1]);
+    nw_eval<K0 + 2>(L, A.c[2]);
+    nw_eval<K0 + 3>(L, A.c[3]);
+}
+
+// candidates [s, e) of the cell-sorted array, in chunks of 16; eight candidates (two s_load_dwordx16) are requested per wait.
+// The array is padded by NW_CENT_PAD entries, so reading up to e + 7 is safe, and evaluating a neighbour cell's centroid is
+// harmless (it is a real candidate).
+#define NW_CENT_PAD 8
+__device__ __forceinline__ void nw_eval_range(NwLane &L, const float4 *__restrict__ cent, int s, int e, NwStats &S)
+{
+    S.v[NWS_CAND] += (e - s + 3) & ~3;
+    for (int c = s; c < e; c += 16) {
+        const unsigned before = L.b1;
+        const NwCand4 *__restrict__ q = reinterpret_cast<const NwCand4 *>(cent + c);
+        {
+            const NwCand4 A = q[0], B = q[1];
+            nw_eval4<0>(L, A);
+            if (c + 4 < e) nw_eval4<4>(L, B);
+        }
+        if (c + 8 < e) {
+            const NwCand4 A = q[2], B = q[3];
+            nw_eval4<8>(L, A);
+            if (c + 12 < e) nw_eval4<12>(L, B);
+        }
+        L.bbase = (L.b1 != before) ? c : L.bbase;
+    }
+}
+
+// distance (cell units) from the lane's coordinate to the slab [k - eps, k + 1 + eps] of cell index k (a, b: see NwLane)
+__device__ __forceinline__ float nw_slab_d(float a, float b, float kf)
+{
+    return fmaxf(fmaxf(kf - a, b - kf), 0.0f);
+}
+
+// visit the cells [xa, xb] of the row (y, z): candidates [s, e).  dyz2 = per-lane squared (y,z) distance to the row (cell units).
+// lane k fetches the start of cell k's candidates (one round trip for the run); every non-empty cell is then tested against the
+// lanes' CURRENT bests (ball against cell box), and the surviving cells are evaluated run by run.
+__device__ __forceinline__ void nw_visit_run(NwLane &L, const NwGrid &g, const int *__restrict__ cstart, const float4 *__restrict__ cent,
+                                             int rowbase, int xa, int xb, int s, int e, float dyz2, float epsu, float cullk, int lane, NwStats &S)
+{
+    if (e - s <= 8) { S.v[NWS_SMALL_RUNS] += 1; nw_eval_range(L, cent, s, e, S); return; }       // too few to be worth a per-cell test
+    for (int xc = xa; xc <= xb; xc += 63) {
+        const int n = min(63, xb - xc + 1);
+        const int cs = cstart[rowbase + xc + min(lane, n)];            // lane k: first candidate of cell xc + k (k = n: end)
+        const int nx = __shfl_down(cs, 1, 64);
+        unsigned long long ne = __ballot(lane < n && nx > cs);
+        unsigned long long pass = 0ull;
+        unsigned long long t = ne;
+        const float r2u = nw_best_d2(L) * cullk + epsu;                 // culling radius^2, cell units
+        while (t) {
+            const int k = __builtin_ctzll(t);
+            t &= t - 1ull;
+            const float dx = nw_slab_d(L.ax, L.bx, (float)(xc + k));
+            S.v[NWS_CELLS_TESTED] += 1;
+            if (__any(fmaf(dx, dx, dyz2) <= r2u)) { pass |= 1ull << k; S.v[NWS_CELLS_PASS] += 1; }
+        }
+        // runs of surviving cells; empty cells in between join a run for free
+        const unsigned long long joinable = pass | ~ne;
+        while (pass) {
+            const int k0 = __builtin_ctzll(pass);
+            const unsigned long long stop = ~joinable >> k0;            // first cell >= k0 that is non-empty and culled
+            const int len = stop ? __builtin_ctzll(stop) : 64 - k0;
+            const int k1 = min(k0 + len, n);
+            const int c0 = __builtin_amdgcn_readlane(cs, k0), c1 = __builtin_amdgcn_readlane(cs, k1);
+            nw_eval_range(L, cent, c0, c1, S);
+            pass = (k1 >= 64) ? 0ull : (pass >> k1) << k1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
+                                                 const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,
+                                                 int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
+                                                 NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats)
+{
+    if (it >= st->stop_at) return;
+    NwStats S;
+#pragma unroll
+    for (int k = 0; k < NWS_COUNT; ++k) S.v[k] = 0;
+    const int lane = threadIdx.x & 63;
+    // (warm & 2): plain round-robin of the workgroups over the XCDs (default; measured 5 % faster here than one contiguous slab of
+    // the work list per XCD, nw_xcd_remap: the slabs' work differs and the launch waits for the slowest XCD)
+    const int wpb = (int)blockDim.x >> 6, nwb = (nitems + wpb - 1) / wpb;       // waves (= work items) per workgroup, workgroups with work
+    const int wb = (warm & 2) ? ((int)blockIdx.x < nwb ? (int)blockIdx.x : -1) : nw_xcd_remap(blockIdx.x, nwb);
+    const int wi = __builtin_amdgcn_readfirstlane(wb * wpb + (int)(threadIdx.x >> 6));
+    if (wi < 0 || wi >= nitems) return;
+    const NwItem item = items[wi];
+    const bool active = lane < item.n;
+    const int gi = item.p0 + (active ? lane : 0);                        // idle lanes shadow lane 0 (they never write)
+    NwLane L;
+    {
+        const float4 P = pts[gi];
+        L.px = P.x; L.py = P.y; L.pz = P.z;
+        L.ux = (P.x - g.ox) * g.inv_h; L.uy = (P.y - g.oy) * g.inv_h; L.uz = (P.z - g.oz) * g.inv_h;
+    }
+    const float epsu = g.eps * g.inv_h;                                  // rounding slack of the cell assignment, cell units
+    L.ax = L.ux + epsu; L.ay = L.uy + epsu; L.az = L.uz + epsu;
+    L.bx = L.ux - 1.0f - epsu; L.by = L.uy - 1.0f - epsu; L.bz = L.uz - 1.0f - epsu;
+    L.b1 = NW_KEY_INF; L.b2 = NW_KEY_INF; L.bbase = -1;
+    L.keymask = NW_KEY_MASK;
+    asm volatile("" : "+v"(L.keymask));
+    int prev = -1;
+    if (warm & 1) {
+        prev = face_io[gi];
+        if ((unsigned)prev < (unsigned)F) {
+            const float4 C = cent_by_face[prev];
+            const float dx = L.px - C.x, dy = L.py - C.y, dz = L.pz - C.z;
+            // strictly above the value the walk will compute for this very centroid, so the walk re-finds it (and its slot)
+            L.b1 = __float_as_uint(fmaf(dz, dz, fmaf(dy, dy, dx * dx)) * (1.0f + 1e-5f) + 1e-30f) | 15u;
+        } else prev = -1;
+    }
+    const float cullk = g.inv_h * g.inv_h * (1.0f + NW_NN_CULL);
+    // own cell (clamped like nw_cell_coords)
+    const int cx = nw_clampi((int)floorf(L.ux), 0, g.gx - 1), cy = nw_clampi((int)floorf(L.uy), 0, g.gy - 1), cz = nw_clampi((int)floorf(L.uz), 0, g.gz - 1);
+    int Exl = 0, Exh = -1, Eyl = 0, Eyh = -1, Ezl = 0, Ezh = -1;         // visited box (cells), empty
+    int margin = 1, rounds = 0;
+    for (;;) {
+        // ---- the box this round must cover: the lanes' balls (finite b1) or their own cell +- margin (nothing seen yet)
+        const bool seen = L.b1 < NW_KEY_INF;
+        const bool any_unseen = __any(active && !seen);
+        int lxl, lxh, lyl, lyh, lzl, lzh;
+        if (seen) {
+            const float ru = fminf(sqrtf(nw_best_d2(L) * cullk) + 2.0f * epsu + 1e-3f, 4096.0f);     // (a lane that has only seen pad entries)
+            lxl = (int)floorf(L.ux - ru); lxh = (int)floorf(L.ux + ru);
+            lyl = (int)floorf(L.uy - ru); lyh = (int)floorf(L.uy + ru);
+            lzl = (int)floorf(L.uz - ru); lzh = (int)floorf(L.uz + ru);
+        } else {
+            lxl = cx - margin; lxh = cx + margin; lyl = cy - margin; lyh = cy + margin; lzl = cz - margin; lzh = cz + margin;
+        }
+        if (!active) { lxl = lyl = lzl = 0x7fffffff; lxh = lyh = lzh = -0x7fffffff; }
+        int Nxl = max(nw_wave_min_i(lxl), 0), Nxh = min(nw_wave_max_i(lxh), g.gx - 1);
+        int Nyl = max(nw_wave_min_i(lyl), 0), Nyh = min(nw_wave_max_i(lyh), g.gy - 1);
+        int Nzl = max(nw_wave_min_i(lzl), 0), Nzh = min(nw_wave_max_i(lzh), g.gz - 1);
+        const bool Eok = Exh >= Exl;
+        if (Eok) {
+            Nxl = min(Nxl, Exl); Nxh = max(Nxh, Exh); Nyl = min(Nyl, Eyl); Nyh = max(Nyh, Eyh); Nzl = min(Nzl, Ezl); Nzh = max(Nzh, Ezh);
+            if (Nxl == Exl && Nxh == Exh && Nyl == Eyl && Nyh == Eyh && Nzl == Ezl && Nzh == Ezh) {
+                if (!any_unseen) break;                                  // every ball lies inside the visited box
+                const bool whole = Exl == 0 && Eyl == 0 && Ezl == 0 && Exh == g.gx - 1 && Eyh == g.gy - 1 && Ezh == g.gz - 1;
+                if (whole) break;                                        // no centroid anywhere (cannot happen with F >= 1)
+                margin <<= 1;
+                continue;
+            }
+        }
+        ++rounds;
+        // ---- visit N \ E: lane = (z,y) row of N
+        const int ny = Nyh - Nyl + 1, nrows = ny * (Nzh - Nzl + 1);
+        const float inv_ny = 1.0f / (float)ny;
+        S.v[NWS_BOX_ROWS] += nrows;
+        for (int rb = 0; rb < nrows; rb += 64) {
+            const int r = rb + lane;
+            const bool ok = r < nrows;
+            const int rz = (int)(((float)r + 0.5f) * inv_ny);             // exact r / ny for the small ints involved
+            const int y = Nyl + (r - rz * ny), z = Nzl + rz;
+            const bool inE = Eok && y >= Eyl && y <= Eyh && z >= Ezl && z <= Ezh;
+            const int rowbase = g.gx * (y + g.gy * z);
+            // rows that cross the visited box contribute the two x-runs left and right of it
+            const int xb0 = inE ? Exl - 1 : Nxh;
+            const int xa1 = Exh + 1, xb1 = inE ? Nxh : Exh;
+            int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+            if (ok && xb0 >= Nxl) { s0 = cstart[rowbase + Nxl]; e0 = cstart[rowbase + xb0 + 1]; }
+            if (ok && xb1 >= xa1) { s1 = cstart[rowbase + xa1]; e1 = cstart[rowbase + xb1 + 1]; }
+            unsigned long long rows = __ballot(e0 > s0 || e1 > s1);
+            S.v[NWS_ROWS_NONEMPTY] += __popcll(rows);
+            while (rows) {
+                const int j = __builtin_ctzll(rows);
+                rows &= rows - 1ull;
+                const int yj = __builtin_amdgcn_readlane(y, j), zj = __builtin_amdgcn_readlane(z, j);
+                const float dy = nw_slab_d(L.ay, L.by, (float)yj), dz = nw_slab_d(L.az, L.bz, (float)zj);
+                const float dyz2 = fmaf(dz, dz, dy * dy);
+                if (!__any(dyz2 <= nw_best_d2(L) * cullk + epsu)) continue;       // no lane's ball reaches this row
+                S.v[NWS_ROWS_PASS] += 1;
+                const int rbj = g.gx * (yj + g.gy * zj);
+                const int a0 = __builtin_amdgcn_readlane(s0, j), b0 = __builtin_amdgcn_readlane(e0, j);
+                const int a1 = __builtin_amdgcn_readlane(s1, j), b1_ = __builtin_amdgcn_readlane(e1, j);
+                const int xb0j = __builtin_amdgcn_readlane(xb0, j), xb1j = __builtin_amdgcn_readlane(xb1, j);
+                if (b0 > a0) nw_visit_run(L, g, cstart, cent, rbj, Nxl, xb0j, a0, b0, dyz2, epsu, cullk, lane, S);
+                if (b1_ > a1) nw_visit_run(L, g, cstart, cent, rbj, xa1, xb1j, a1, b1_, dyz2, epsu, cullk, lane, S);
+            }
+        }
+        Exl = Nxl; Exh = Nxh; Eyl = Nyl; Eyh = Nyh; Ezl = Nzl; Ezh = Nzh;
+        if (!any_unseen) break;          // the box was built from every lane's ball and b1 only shrinks: all lanes are final
+    }
+    if (active) {
+        int fid = prev;
+        if (L.bbase >= 0) fid = __float_as_int(cent[L.bbase + (int)(L.b1 & 15u)].w);
+        face_io[gi] = fid;
+        // runner-up inside the error band (or the walk did not re-find the warm-start face): float64 re-resolution
+        const float d1 = __uint_as_float(L.b1), d2 = __uint_as_float(L.b2);
+        if (L.bbase < 0 || d2 - d1 <= NW_NN_BAND * d1) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
+    }
+    if (lane == 0 && rounds > 1) atomicMax(&st->nn_max_ring, rounds);
+    if (stats && lane == 0) {
+        S.v[NWS_ROUNDS] = rounds;
+#pragma unroll
+        for (int k = 0; k < NWS_COUNT; ++k) atomicAdd(stats + k, (unsigned long long)S.v[k]);
+    }
+}

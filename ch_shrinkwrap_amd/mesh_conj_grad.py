@@ -379,6 +379,13 @@ class ShrinkwrapMeshConjGrad(object):
             a, b = self.stage_ms_total[k]
             self.stage_ms_total[k] = (a + ms, b + n)
 
+    def nn_stats(self):
+        """developer counters of the nearest-face query since the previous call (first call: switches them on)"""
+        out = (ctypes.c_int64 * 9)()
+        self._native.check(self._L.nw_debug_nn_stats(self._h, out))
+        names = ['candidates', 'rows_nonempty', 'rows_visited', 'cells_tested', 'cells_visited', 'box_rows', 'rounds', 'small_runs', 'items']
+        return dict(zip(names, [int(v) for v in out]))
+
     def stage_ms(self):
         names = ['total', 'grid', 'nn', 'attract', 'prior', 'as', 'update', 'fixup']
         out = {}

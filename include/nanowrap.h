@@ -196,6 +196,11 @@ int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, co
 int nw_set_profiling(nw_ctx *ctx, int enable);
 int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
 
+/* developer aid, no reference counterpart: counters of the exact nearest-face query accumulated since the previous call (the first
+ * call switches the counting on).  out[9]: candidate evaluations per wave summed, non-empty rows listed, rows visited, cells
+ * tested, cells visited, rows of the boxes, rounds, small runs, work items. */
+int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,17 +79,17 @@ sq = counters('sq')
 json.dump({k: dict({c: sum(v) / len(v) for c, v in d.items()}, dispatches=max(len(v) for v in d.values())) for k, d in sorted(sq.items())},
           open(os.path.join(dst, tag + '_sq_counters.json'), 'w'), indent=1)
 
-out = {k: traffic[k]['hbm_bytes_per_launch'] for k in ('k_nearest_face', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update')
+out = {k: traffic[k]['hbm_bytes_per_launch'] for k in ('k_nn_wave', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update')
        if k in traffic}
 out['grid_build'] = sum(traffic[k]['hbm_bytes_per_launch'] * (3 if k.startswith('k_scan') and False else 1) for k in grid if k in traffic)
-if 'k_nearest_face' in sq and 'SQ_INSTS_VALU' in sq['k_nearest_face']:
-    out['k_nearest_face_valu_wave_instructions'] = mean_tail(sq['k_nearest_face']['SQ_INSTS_VALU'], iters)
+if 'k_nn_wave' in sq and 'SQ_INSTS_VALU' in sq['k_nn_wave']:
+    out['k_nn_wave_valu_wave_instructions'] = mean_tail(sq['k_nn_wave']['SQ_INSTS_VALU'], iters)
 out['_note'] = ('HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts half of '
                 'wide coalesced reads, MI355X_MICROARCH.md section HBM); mean of the timed iterations of bench.py --steps 10 --warmup 10; '
                 'profiles/' + tag + '_*')
 json.dump(out, open(os.path.join(dst, 'r01_pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
-for k in ('k_nearest_face', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update', 'k_face_centroids', 'k_centroid_scatter'):
+for k in ('k_nn_wave', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update', 'k_face_centroids', 'k_centroid_scatter'):
     if k in dur:
         print('%-24s calls %5d avg %8.1f us (timed region %8.1f us)  %5.1f %%' % (k, dur[k]['calls'], dur[k]['avg_us'], dur[k].get('avg_us_timed_region', float('nan')), dur[k]['pct']))
 print('bench', bench['ms_per_step'], bench['value'], bench['roofline'])
