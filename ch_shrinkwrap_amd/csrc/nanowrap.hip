@@ -25,8 +25,6 @@ int nw_sort_pairs_u32(const unsigned *key_in, unsigned *key_out, const int *val_
 
 static_assert(sizeof(NwIterLogDev) == sizeof(nw_iter_log), "device/host log record mismatch");
 static_assert(SC_COUNT <= NW_N_SCALARS, "scalar slots");
-static_assert(NW_REPL == 32 && SC_COUNT * 8 <= NW_BLOCK, "nw_gather_scalars layout");
-#define NW_SC_BLOCK (NW_N_SCALARS * NW_REPL * NW_RSTRIDE)   // doubles per parity: replicated, line-padded slots
 
 #define NW_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -151,6 +149,8 @@ struct nw_ctx {
     bool grid_valid = false;
     double last_mean_dist = -1.0, spacing = 0.0, est_mean_dist = -1.0;
     double sigma_eff = -1.0;          // mean localization precision (1 / mean sigma_inv), <= 0 if unknown
+    double scene_ext = 1.0;           // extent of localizations + mesh at the last grid build
+    double quantum_override = 0.0;    // > 0: nw_accumulator_quantum fixed it (multi-GPU: every rank must use the same)
     double acc_quantum = 1.0;         // fixed-point quantum of the LDS scatter accumulators (k_attract): 2^-36 of the cloud extent
     double cell_tune = 1.0;           // multiplier on the cell-size rule (nw_tune_grid)
     double force_h = 0.0;             // > 0: build_grid uses exactly this cell (nw_tune_grid probes)
@@ -176,8 +176,12 @@ struct nw_ctx {
     // per-iteration work arrays
     DevBuf<float4> cent_tmp, cent;
     DevBuf<int> fcell, frank, face, vidx, ambig_list, ambig_count;
-    DevBuf<float> dist, w, res, vacc, S, fdef, pi;
-    DevBuf<double> scalars;           // [2][NW_N_SCALARS]
+    DevBuf<float> dist, w, res, S, fdef, pi;
+    DevBuf<long long> vacc;           // (M, 4) fixed-point accumulator {A^T res, sum w}: exact, order-independent sums
+    DevBuf<double> scalars;           // [NW_N_SCALARS] final sums of the current iteration (k_reduce_scalars)
+    DevBuf<double> part_a, part_p, part_s;   // per-workgroup partial sums of k_attract / k_prior_directions / k_subspace_point_sums
+    double w_quantum = 1.0;           // fixed-point quantum of the {w} column
+    double w_bound = 1.0;             // largest |weight| after normalisation (bounds |res| together with the cloud extent)
     DevBuf<NwDevState> state;
     DevBuf<NwIterLogDev> logs;
     DevBuf<float> mm;                 // min/max scratch
@@ -359,6 +363,7 @@ int build_grid(nw_ctx *ctx, double mean_dist)
         ext = std::max(ext, (double)hi[k] - lo[k]);
     }
     if (!(ext > 0)) ext = 1.0;
+    ctx->scene_ext = ext;
     ctx->spacing = spacing;
     double h = ctx->force_h > 0 ? ctx->force_h : desired_cell(ctx, mean_dist, spacing);
     if (!(h > 0) || !std::isfinite(h)) h = ext / 16;
@@ -436,6 +441,9 @@ struct StageScope {
     ~StageScope() { if (on) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
 };
 
+inline int attract_blocks(const nw_ctx *ctx) { return 8 * ((nblk(ctx->N) + 7) / 8); }      // k_attract / k_subspace_point_sums (XCD-remapped grids)
+inline int prior_blocks(const nw_ctx *ctx) { return std::min(nblk(ctx->M), 512); }
+
 int alloc_work(nw_ctx *ctx)
 {
     const int64_t N = ctx->N, M = ctx->M, F = ctx->F;
@@ -461,7 +469,10 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->S.ensure(9 * M));
     NW_HIP(ctx->fdef.ensure(3 * M));
     NW_HIP(ctx->pi.ensure(M));
-    NW_HIP(ctx->scalars.ensure(2 * NW_SC_BLOCK));
+    NW_HIP(ctx->scalars.ensure(NW_N_SCALARS));
+    NW_HIP(ctx->part_a.ensure((size_t)4 * attract_blocks(ctx)));
+    NW_HIP(ctx->part_s.ensure((size_t)9 * attract_blocks(ctx)));
+    NW_HIP(ctx->part_p.ensure((size_t)11 * prior_blocks(ctx)));
     return NW_OK;
 }
 
@@ -471,7 +482,7 @@ int alloc_work(nw_ctx *ctx)
 NW_EXPORT int nw_abi_version(void) { return NW_ABI_VERSION; }
 NW_EXPORT int nw_n_point_scalars(void) { return SC_NPOINT; }
 NW_EXPORT int nw_n_scalars(void) { return SC_COUNT; }
-NW_EXPORT int nw_scalar_stride(void) { return NW_REPL * NW_RSTRIDE; }
+NW_EXPORT int nw_scalar_stride(void) { return 1; }
 
 NW_EXPORT int nw_create(int device, nw_ctx **out)
 {
@@ -505,7 +516,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->valid.release(); ctx->d_small.release();
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
-    ctx->scalars.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
+    ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
     if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (hipEvent_t e : ctx->wb_events) (void)hipEventDestroy(e);
@@ -570,6 +581,24 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
         hipLaunchKernelGGL(k_sum_f64, dim3(std::min(1024, nblk(3 * N))), dim3(NW_BLOCK), 0, ctx->stream, src, 3 * N, ctx->wsum.p);
         NW_HIP(hipGetLastError());
     }
+    // largest |weight| after normalisation: together with the scene extent it bounds |res| (quantum of the fixed-point scatter)
+    ctx->w_bound = std::fabs((double)ctx->w_scalar);
+    if (ctx->w_array) {
+        const float *src = (weights_mode == NW_WEIGHTS_ARRAY || weights_mode == NW_WEIGHTS_PRENORMALIZED) ? ctx->w_in.p : ctx->sinv_in.p;
+        NW_HIP(ctx->d_small.ensure(8));
+        NW_HIP(hipMemsetAsync(ctx->d_small.p, 0, 8 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_absmax_f32, dim3(std::min(1024, nblk(3 * N))), dim3(NW_BLOCK), 0, ctx->stream, src, 3 * N, ctx->d_small.p);
+        NW_HIP(hipGetLastError());
+        int mbits = 0;
+        double wsum_h = 0;
+        NW_HIP(hipMemcpyAsync(&mbits, ctx->d_small.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        NW_HIP(hipMemcpyAsync(&wsum_h, ctx->wsum.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        NW_HIP(hipStreamSynchronize(ctx->stream));
+        float wmax; memcpy(&wmax, &mbits, 4);
+        const double mean = weights_mode == NW_WEIGHTS_PRENORMALIZED ? 1.0 : wsum_h / (3.0 * (double)N);
+        ctx->w_bound = (mean > 0 && std::isfinite(mean)) ? (double)wmax / mean : (double)wmax;
+    }
+    if (!(ctx->w_bound > 0) || !std::isfinite(ctx->w_bound)) ctx->w_bound = 1.0;
     // localization precision for the cell-size rule: 1 / mean(sigma_inv) when sigma_inv is an array (a scalar is ambiguous:
     // the reference's own driver passes a scalar sigma UN-inverted, _membrane_mesh.pyx:1460-1461)
     ctx->sigma_eff = -1.0;
@@ -587,7 +616,6 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
     double ext = 0;
     for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)ctx->pmax[k] - (double)ctx->pmin[k]);
     if (!(ext > 0) || !std::isfinite(ext)) ext = 1.0;
-    ctx->acc_quantum = std::ldexp(1.0, (int)std::floor(std::log2(ext)) - 36);
     // Morton order, once: 30-bit code of the position inside the cloud's bounding cube, stable radix sort (deterministic order)
     {
         ctx->morton_unit = (float)(ext / 1024.0);
@@ -785,6 +813,10 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     NW_HIP(hipMemcpyAsync(ctx->pos.p, ctx->meshpos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->proj_ready && !ctx->proj_sorted && num_iters > 0 && !getenv("NW_NO_PROJ_SORT")) NW_TRY(resort_by_projection(ctx));
     NW_TRY(ensure_grid(ctx));
+    // fixed-point quanta of the scatter (k_attract): 2^-36 of a bound on |w res| <= largest weight x scene extent; 2^-40 for sum w
+    ctx->acc_quantum = ctx->quantum_override > 0 ? ctx->quantum_override
+                                                 : std::ldexp(1.0, (int)std::ceil(std::log2(std::max(ctx->scene_ext * ctx->w_bound, 1e-300))) - 36);
+    ctx->w_quantum = std::ldexp(1.0, -40);
     ctx->lam0 = lams[0];
     ctx->search_flags = flags;
     ctx->search_iters = num_iters;
@@ -793,8 +825,7 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     NW_HIP(hipMemsetAsync(ctx->logs.p, 0, (size_t)std::max(num_iters, 1) * sizeof(NwIterLogDev), ctx->stream));
     NW_HIP(hipMemsetAsync(ctx->S.p, 0, 9 * ctx->M * sizeof(float), ctx->stream));         // S = zeros (:207)
     NW_HIP(hipMemsetAsync(ctx->res.p, 0, 3 * ctx->N * sizeof(float), ctx->stream));       // res = 0*data (:181)
-    NW_HIP(hipMemsetAsync(ctx->vacc.p, 0, 4 * ctx->M * sizeof(float), ctx->stream));
-    NW_HIP(hipMemsetAsync(ctx->scalars.p, 0, 2 * NW_SC_BLOCK * sizeof(double), ctx->stream));
+    NW_HIP(hipMemsetAsync(ctx->vacc.p, 0, 4 * ctx->M * sizeof(long long), ctx->stream));
     if (ctx->profiling) { ctx->ev_used = 0; g_marks.spans.clear(); for (int k = 0; k < ST_COUNT; ++k) { ctx->stage_ms[k] = 0; ctx->stage_launches[k] = 0; } }
     ctx->in_search = true;
     return NW_OK;
@@ -835,15 +866,13 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_attract outside a search");
     const int it = ctx->global_iter;
-    const int par = it & 1;
     const int64_t N = ctx->N, F = ctx->F;
-    double *sc = ctx->scalars.p + par * NW_SC_BLOCK;
     NW_TRY(launch_query(ctx, it));
     {
         StageScope s(ctx, ST_ATTRACT);
-        hipLaunchKernelGGL(k_attract, dim3(8 * ((nblk(N) + 7) / 8)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
+        hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
                            ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->sinv_scalar, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->w_scalar, ctx->mask.p,
-                           ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, sc, ctx->state.p, it, 1.0 / ctx->acc_quantum, ctx->acc_quantum);
+                           ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, ctx->part_a.p, ctx->state.p, it, 1.0 / ctx->acc_quantum, 1.0 / ctx->w_quantum);
     }
     NW_HIP(hipGetLastError());
     return NW_OK;
@@ -853,18 +882,20 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_directions outside a search");
     const int it = ctx->global_iter;
-    const int par = it & 1;
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
-    double *sc = ctx->scalars.p + par * NW_SC_BLOCK;
     {
         StageScope s(ctx, ST_PRIOR);
-        hipLaunchKernelGGL(k_prior_directions, dim3(std::min(nblk(ctx->M), 512)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->maxdeg, ctx->nbr_t.p, ctx->pos.p,
-                           ctx->meshpos.p, ctx->nrm.p, ctx->vacc.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, sc, ctx->state.p, it, n_search);
+        hipLaunchKernelGGL(k_prior_directions, dim3(prior_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->maxdeg, ctx->nbr_t.p, ctx->pos.p,
+                           ctx->meshpos.p, ctx->nrm.p, ctx->vacc.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->part_p.p, ctx->state.p, it, n_search,
+                           ctx->acc_quantum, ctx->w_quantum);
     }
     {
         StageScope s(ctx, ST_AS);
-        hipLaunchKernelGGL(k_subspace_point_sums, dim3(8 * ((nblk(ctx->N) + 7) / 8)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
-                           ctx->mask.p, ctx->S.p, sc, ctx->state.p, it, n_search);
+        hipLaunchKernelGGL(k_subspace_point_sums, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
+                           ctx->mask.p, ctx->S.p, ctx->part_s.p, ctx->state.p, it, n_search);
+        // the 24 sums of this iteration, added in a fixed order (deterministic); multi-GPU runs all-reduce them after this call
+        hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, ctx->stream, ctx->part_a.p, attract_blocks(ctx), ctx->part_p.p, prior_blocks(ctx),
+                           ctx->part_s.p, attract_blocks(ctx), ctx->scalars.p, ctx->state.p, it);
     }
     NW_HIP(hipGetLastError());
     return NW_OK;
@@ -875,14 +906,11 @@ NW_EXPORT int nw_iter_update(nw_ctx *ctx)
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_update outside a search");
     if (ctx->search_done >= ctx->search_iters) return fail(ctx, NW_ERR_BADARG, "nw_iter_update: more iterations than announced");
     const int it = ctx->global_iter;
-    const int par = it & 1;
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
-    double *sc = ctx->scalars.p + par * NW_SC_BLOCK;
-    double *sc_next = ctx->scalars.p + (par ^ 1) * NW_SC_BLOCK;
     {
         StageScope s(ctx, ST_UPDATE);
         hipLaunchKernelGGL(k_solve_update, dim3(std::min(nblk(ctx->M), 512)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->lam0, n_search, ctx->search_flags,
-                           ctx->have_valid ? ctx->valid.p : nullptr, ctx->pos.p, ctx->meshpos.p, ctx->S.p, ctx->vacc.p, sc, sc_next, ctx->state.p,
+                           ctx->have_valid ? ctx->valid.p : nullptr, ctx->pos.p, ctx->meshpos.p, ctx->S.p, ctx->vacc.p, ctx->scalars.p, ctx->state.p,
                            ctx->logs.p + ctx->search_done, it);
     }
     NW_HIP(hipGetLastError());
@@ -1003,11 +1031,11 @@ NW_EXPORT int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes)
     case NW_ARR_MESHPOS: p = ctx->meshpos.p; nb = 3 * ctx->M * 4; break;
     case NW_ARR_FDEF: p = ctx->fdef.p; nb = 3 * ctx->M * 4; break;
     case NW_ARR_PI: p = ctx->pi.p; nb = ctx->M * 4; break;
-    case NW_ARR_VACC: p = ctx->vacc.p; nb = 4 * ctx->M * 4; break;
+    case NW_ARR_VACC: p = ctx->vacc.p; nb = 4 * ctx->M * 8; break;
     case NW_ARR_NBR: p = ctx->nbr.p; nb = (int64_t)ctx->NB * ctx->M * 4; break;
     case NW_ARR_NRM: p = ctx->nrm.p; nb = 3 * ctx->M * 4; break;
     case NW_ARR_VALID: p = ctx->have_valid ? ctx->valid.p : nullptr; nb = ctx->M; break;
-    case NW_ARR_SCALARS: p = ctx->scalars.p ? ctx->scalars.p + (ctx->global_iter & 1) * NW_SC_BLOCK : nullptr; nb = (int64_t)NW_SC_BLOCK * 8; break;
+    case NW_ARR_SCALARS: p = ctx->scalars.p; nb = (int64_t)NW_N_SCALARS * 8; break;
     default: return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array is not device-addressable in caller order");
     }
     if (!p) return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array not allocated yet");
@@ -1189,6 +1217,23 @@ NW_EXPORT int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out)
     NW_HIP(hipMemset(ctx->nn_stats.p, 0, sizeof(h)));
     for (int k = 0; k < NWS_COUNT; ++k) out[k] = (int64_t)h[k];
     out[8] = ctx->nitems;
+    return NW_OK;
+}
+
+// Quantum of the fixed-point A^T accumulator (NW_ARR_VACC = int64 counts of this quantum).  *q > 0 on entry fixes it for all later
+// searches (ranks that all-reduce NW_ARR_VACC must agree on it: take the MAX of their own values); on return *q = the quantum the
+// CURRENT / next search uses.  May be called between nw_search_begin and the first nw_iter_attract (then it applies at once).
+NW_EXPORT int nw_accumulator_quantum(nw_ctx *ctx, double *q)
+{
+    if (!ctx || !q) return NW_ERR_BADARG;
+    if (*q > 0 && std::isfinite(*q)) {
+        int e = 0;
+        const double m = std::frexp(*q, &e);
+        ctx->quantum_override = std::ldexp(1.0, m == 0.5 ? e - 1 : e);          // a power of two (scaling must be exact)
+        if (ctx->in_search && ctx->search_done > 0) return fail(ctx, NW_ERR_BADARG, "nw_accumulator_quantum: cannot change the quantum between the iterations of a search");
+        if (ctx->in_search) ctx->acc_quantum = ctx->quantum_override;           // between nw_search_begin and the first iteration: applies at once
+    }
+    *q = ctx->quantum_override > 0 ? ctx->quantum_override : ctx->acc_quantum;
     return NW_OK;
 }
 

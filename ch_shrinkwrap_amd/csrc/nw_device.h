@@ -49,16 +49,26 @@ __device__ __forceinline__ int nw_wave_incl_scan(int v, int lane)
     return v;
 }
 
-// Normal-equation partial sums live in REPLICATED slots: slot k, replica r is the double at sc[(k*NW_REPL + r)*NW_RSTRIDE]
-// (one 64-byte line per replica).  A workgroup adds into replica (blockIdx % NW_REPL), so the thousands of per-block
-// float64 atomics of one kernel spread over NW_REPL memory-side lines instead of serialising on one address
-// (MI355X_MICROARCH.md "Global float atomics", row contention); the consumer sums the replicas with one wave.
-#define NW_REPL 32
-#define NW_RSTRIDE 8
+// Normal-equation sums are DETERMINISTIC: every workgroup reduces its NV partial sums in a fixed order (wave shuffles, then the
+// four waves in order) and stores them as plain doubles into its own row part[blockIdx][0..NV); k_reduce_scalars then adds the rows
+// in a fixed order.  No floating-point atomics: two runs of the same inputs give bit-identical sums, whatever the order in which
+// the workgroups happen to finish.
+template <int NV>
+__device__ __forceinline__ void nw_block_reduce_store(double (&v)[NV], double *__restrict__ part, double *s_part /* [NV*4] */)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = nw_wave_sum(v[k]);
+        if (lane == 0) s_part[k * 4 + wv] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV)
+        part[(int64_t)blockIdx.x * NV + threadIdx.x] = (s_part[threadIdx.x * 4 + 0] + s_part[threadIdx.x * 4 + 1]) + (s_part[threadIdx.x * 4 + 2] + s_part[threadIdx.x * 4 + 3]);
+}
 
-// Sum NV doubles over the block; the first NV threads then add the block totals atomically into slots out[0..NV)
-// (REPLICATED = false: plain consecutive doubles; true: the replicated slot layout above).
-template <int NV, bool REPLICATED>
+// plain (non-replicated) variant with float64 atomics for the set-up reductions (mesh area, weight sums): not on the iteration path
+template <int NV>
 __device__ __forceinline__ void nw_block_reduce_atomic(double (&v)[NV], double *out, double *s_part /* [NV*4] */)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -68,28 +78,9 @@ __device__ __forceinline__ void nw_block_reduce_atomic(double (&v)[NV], double *
         if (lane == 0) s_part[k * 4 + wv] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NV) {
-        double s = (s_part[threadIdx.x * 4 + 0] + s_part[threadIdx.x * 4 + 1]) + (s_part[threadIdx.x * 4 + 2] + s_part[threadIdx.x * 4 + 3]);
-        if (REPLICATED) atomicAdd(out + ((int64_t)threadIdx.x * NW_REPL + (blockIdx.x % NW_REPL)) * NW_RSTRIDE, s);
-        else atomicAdd(out + threadIdx.x, s);
-    }
+    if (threadIdx.x < NV)
+        atomicAdd(out + threadIdx.x, (s_part[threadIdx.x * 4 + 0] + s_part[threadIdx.x * 4 + 1]) + (s_part[threadIdx.x * 4 + 2] + s_part[threadIdx.x * 4 + 3]));
     __syncthreads();
-}
-
-// the workgroup sums the replicas of `count` (<= 32) consecutive slots into dst[0..count) (LDS): 8 lanes per slot, each
-// adding 4 replicas (independent loads), then a 3-step shuffle reduction.  Needs blockDim >= 8*count; caller syncs after.
-__device__ __forceinline__ void nw_gather_scalars(const double *__restrict__ sc, int count, double *dst)
-{
-    const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
-    double v = 0.0;
-    if (k < count) {
-        const double *p = sc + ((int64_t)k * NW_REPL + j) * NW_RSTRIDE;
-        v = (p[0] + p[8 * NW_RSTRIDE]) + (p[16 * NW_RSTRIDE] + p[24 * NW_RSTRIDE]);
-    }
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
-    if (k < count && j == 0) dst[k] = v;
 }
 
 // XCD-aware remap of a 1-D grid: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the

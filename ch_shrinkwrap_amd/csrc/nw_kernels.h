@@ -3,7 +3,7 @@
 #pragma once
 #include "nw_device.h"
 
-// ---- scalar slots (double), double-buffered by iteration parity ------------------------------------------
+// ---- scalar slots (double): final sums of one iteration, written by k_reduce_scalars ---------------------------------
 enum {
     // point-side partial sums (all-reduced across ranks in multi-GPU runs)
     SC_RES2 = 0,     // sum res^2            -> ress log          mesh_conj_grad.py:270
@@ -135,7 +135,20 @@ __global__ __launch_bounds__(NW_BLOCK) void k_sum_f64(const float *__restrict__ 
     __shared__ double s_part[4];
     double s[1] = {0.0};
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s[0] += (double)x[i];
-    nw_block_reduce_atomic<1, false>(s, out, s_part);
+    nw_block_reduce_atomic<1>(s, out, s_part);
+}
+
+// largest |x| of a float array (order-independent: integer atomicMax on the bits of the non-negative values)
+__global__ __launch_bounds__(NW_BLOCK) void k_absmax_f32(const float *__restrict__ x, int64_t n, int *__restrict__ out)
+{
+    float m = 0.0f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i]);
+        m = (v > m && v < INFINITY) ? v : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_int(m));
 }
 
 // total mesh area (sum over faces of |cross|/2) in float64: sets the centroid spacing for the grid cell size
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_mesh_area(const float *__restrict_
         const float cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
         s[0] += 0.5 * sqrt((double)cx * cx + (double)cy * cy + (double)cz * cz);
     }
-    nw_block_reduce_atomic<1, false>(s, out, s_part);
+    nw_block_reduce_atomic<1>(s, out, s_part);
 }
 
 // brute-force NN distance of a strided sample of the points against ALL face centroids (calibration of the
@@ -376,19 +389,21 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
 // per (vertex, component), four adjacent lanes covering the vertex's contiguous float4, i.e. one memory-side atomic
 // request per touched vertex instead of twelve per point (MI355X_MICROARCH.md "Global float atomics": scattered
 // single-dword atomics run ~17x below the contiguous rate).
-// The LDS accumulators are 64-bit FIXED POINT (ds_add_u64), not float: measured on MI355X, the twelve ds_add_f32 per
-// point cost 67 us per launch at 1M points (LDS float atomics retire ~1 lane every 3 cycles per CU), twelve ds_add_u64
-// 25 us.  The quantum is a power of two, 2^-36 of the cloud's extent (`inv_q` = its exact reciprocal): ~10^-11 relative
-// resolution, far below the float32 rounding of each product, and 2^27 extents of headroom; a workgroup's partial sum
-// is then EXACT (order independent) and rounded once to float32 at the flush.
+// The accumulators are 64-bit FIXED POINT, in LDS (ds_add_u64) and in HBM (`vacc`, global_atomic_add_x2), not float: measured on
+// MI355X, the twelve ds_add_f32 per point cost 67 us per launch at 1M points (LDS float atomics retire ~1 lane every 3 cycles
+// per CU), twelve ds_add_u64 25 us.  The quanta are powers of two (scaling a float32 product by one is exact): for {w res} 2^-36
+// of (cloud extent x largest weight), a bound on |res| -- ~10^-11 relative resolution, far below the float32 rounding of each
+// product, 2^27 such terms of headroom; for {w} 2^-40 (w <= 1).  Integer addition is associative, so the sums are EXACT and
+// independent of the order in which lanes, waves and workgroups arrive: the scatter is bitwise reproducible (the reference's is a
+// serial, deterministic loop, conj_grad_utils.c:153-162); k_prior_directions rounds each sum once to float32.
 #define NW_HT 1024
 
 __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4 *__restrict__ pts, const int *__restrict__ face, const float4 *__restrict__ cent_by_face, float *__restrict__ dist,
                                                      const int *__restrict__ faces, const float *__restrict__ pos,
                                                      const float *__restrict__ sinv, float sinv_scalar, const float *__restrict__ wnorm, float w_scalar,
                                                      const unsigned char *__restrict__ mask,
-                                                     int *__restrict__ vidx, float *__restrict__ wout, float *__restrict__ res, float *__restrict__ vacc,
-                                                     double *__restrict__ sc, NwDevState *__restrict__ st, int it, double inv_q, double q)
+                                                     int *__restrict__ vidx, float *__restrict__ wout, float *__restrict__ res, long long *__restrict__ vacc,
+                                                     double *__restrict__ part, NwDevState *__restrict__ st, int it, double inv_q, double inv_qw)
 {
     if (it >= st->stop_at) return;
     __shared__ double s_part[4 * 4];
@@ -472,8 +487,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
             const float c[4] = {w[j] * r[0], w[j] * r[1], w[j] * r[2], w[j]};     // float32 products, as the reference forms them
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const double x = (double)c[k] * inv_q;                              // exact scaling (power of two)
-                bad |= !(fabs(x) < 9.0e18);                                         // overflow / inf / NaN: raise the NaN status
+                const double x = (double)c[k] * (k < 3 ? inv_q : inv_qw);           // exact scaling (powers of two)
+                bad |= !(fabs(x) < 7.0e13);                                         // far beyond the bound behind the quantum / inf / NaN: raise the NaN status
                 atomicAdd(a + k * NW_HT, (unsigned long long)__double2ll_rn(x));
             }
         }
@@ -482,9 +497,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
     __syncthreads();
     for (int t = threadIdx.x; t < NW_HT * 4; t += NW_BLOCK) {
         const int key = s_key[t >> 2];                     // four adjacent lanes flush the four components of one vertex
-        if (key >= 0) atomicAdd(vacc + 4 * (int64_t)key + (t & 3), (float)((double)(long long)s_val[(t & 3) * NW_HT + (t >> 2)] * q));
+        if (key >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + 4 * (int64_t)key + (t & 3), s_val[(t & 3) * NW_HT + (t >> 2)]);
     }
-    nw_block_reduce_atomic<4, true>(red, sc + (int64_t)SC_RES2 * NW_REPL * NW_RSTRIDE, s_part);
+    nw_block_reduce_store<4>(red, part, s_part);
 }
 
 // K5: curvature prior + search directions S0, S1 + all vertex-side dot products.  One thread per vertex;
@@ -496,8 +511,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
 //   prefs = f - fdef (f64), stored f32; S1 = -prefs                                    :257-258
 __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg, const int *__restrict__ nbr_t, const float *__restrict__ pos,
                                                               const float *__restrict__ meshpos, const float *__restrict__ nrm,
-                                                              const float *__restrict__ vacc, float *__restrict__ S, float *__restrict__ fdef_out,
-                                                              float *__restrict__ pi_out, double *__restrict__ sc, NwDevState *__restrict__ st, int it, int n_search)
+                                                              const long long *__restrict__ vacc, float *__restrict__ S, float *__restrict__ fdef_out,
+                                                              float *__restrict__ pi_out, double *__restrict__ part, NwDevState *__restrict__ st, int it, int n_search,
+                                                              double q, double qw)
 {
     if (it >= st->stop_at) return;
     __shared__ double s_part[11 * 4];
@@ -505,12 +521,12 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
 #pragma unroll
     for (int k = 0; k < 11; ++k) red[k] = 0.0;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < M; v += gridDim.x * blockDim.x) {
-        const float4 acc = *reinterpret_cast<const float4 *>(vacc + 4 * (int64_t)v);
+        const longlong2 a01 = *reinterpret_cast<const longlong2 *>(vacc + 4 * (int64_t)v), a23 = *reinterpret_cast<const longlong2 *>(vacc + 4 * (int64_t)v + 2);
+        const float4 acc = make_float4((float)((double)a01.x * q), (float)((double)a01.y * q), (float)((double)a23.x * q), (float)((double)a23.y * qw));
         const float sw = acc.w;
         const float pi = sqrtf((sw * sw + sw * sw) + sw * sw);
         const float gate = fminf(pi * pi, 1.0f);
         pi_out[v] = pi;
-        if (isnan(acc.x) || isnan(acc.y) || isnan(acc.z) || isnan(sw)) atomicCAS(&st->status, 0, -3);
         // the first 8 ring slots are fetched with independent (unrolled, predicated) loads so that their latencies
         // overlap; valence > 8 falls through to the generic tail loops
         int nb[8];
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
             red[10] += (double)p32 * (double)p32;
         }
     }
-    nw_block_reduce_atomic<11, true>(red, sc + (int64_t)SC_SS * NW_REPL * NW_RSTRIDE, s_part);
+    nw_block_reduce_store<11>(red, part, s_part);
 }
 
 // K6: A.S_k for the n_search directions and the point-side normal-equation sums, never materialising AS:
@@ -604,7 +620,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
 //   Hc = AS^T AS, Gc = AS^T res over the masked entries (conj_grad.py:198-203)
 // S is stored (3M,3) row-major exactly as the reference's `cg.S`, so the 9 floats of one vertex are contiguous.
 __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const int *__restrict__ vidx, const float *__restrict__ w, const float *__restrict__ res,
-                                                                 const unsigned char *__restrict__ mask, const float *__restrict__ S, double *__restrict__ sc,
+                                                                 const unsigned char *__restrict__ mask, const float *__restrict__ S, double *__restrict__ part,
                                                                  const NwDevState *__restrict__ st, int it, int n_search)
 {
     if (it >= st->stop_at) return;
@@ -645,7 +661,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
             }
         }
     }
-    nw_block_reduce_atomic<9, true>(red, sc + (int64_t)SC_HC * NW_REPL * NW_RSTRIDE, s_part);
+    nw_block_reduce_store<9>(red, part, s_part);
 }
 
 // K7: <=3x3 regularised normal equations (every workgroup solves them redundantly from the reduced sums),
@@ -719,16 +735,12 @@ struct NwIterLogDev {   // mirrors nw_iter_log in include/nanowrap.h
 };
 
 __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int n_search, unsigned flags, const unsigned char *__restrict__ valid,
-                                                          float *__restrict__ pos, float *__restrict__ meshpos, float *__restrict__ S, float *__restrict__ vacc,
-                                                          const double *__restrict__ sc_repl, double *__restrict__ sc_next, NwDevState *__restrict__ st,
+                                                          float *__restrict__ pos, float *__restrict__ meshpos, float *__restrict__ S, long long *__restrict__ vacc,
+                                                          const double *__restrict__ sc, NwDevState *__restrict__ st,
                                                           NwIterLogDev *__restrict__ logrec, int it)
 {
     if (it >= st->stop_at) return;
     __shared__ NwSolve s_sol;
-    __shared__ double s_sc[SC_COUNT];
-    nw_gather_scalars(sc_repl, SC_COUNT, s_sc);
-    __syncthreads();
-    const double *sc = s_sc;
     if (threadIdx.x == 0) { if (n_search > 2) nw_solve_small<3>(sc, lam, s_sol); else nw_solve_small<2>(sc, lam, s_sol); }
     __syncthreads();
     const NwSolve sol = s_sol;
@@ -749,7 +761,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
             if (ok) meshpos[3 * v + c] = fn;
         }
       }
-      *reinterpret_cast<float4 *>(vacc + 4 * (int64_t)v) = make_float4(0.f, 0.f, 0.f, 0.f);   // ready for the next scatter
+      *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)v) = make_longlong2(0, 0);          // ready for the next scatter
+      *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)v + 2) = make_longlong2(0, 0);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // logs (mesh_conj_grad.py:262-274)
@@ -791,8 +804,37 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
         if (st->ntests >= 3 && (test < b) && (b < a) && (a < 1e-6f)) st->stop_at = it + 1;
         if (st->status != 0) st->stop_at = it + 1;
     }
-    if (blockIdx.x == 0)
-        for (int k = threadIdx.x; k < SC_COUNT * NW_REPL; k += blockDim.x) sc_next[(int64_t)k * NW_RSTRIDE] = 0.0;
+}
+
+// The per-workgroup partial sums of the three reduction kernels (rows of 4 / 11 / 9 doubles) are added in a FIXED order by one
+// workgroup: thread t takes rows t, t + 1024, ... of its column, then the 1024 threads are combined by waves and by a serial sum
+// over the 16 waves.  Deterministic (no atomics); ~0.4 MB of reads at 1M localizations.
+__global__ __launch_bounds__(1024) void k_reduce_scalars(const double *__restrict__ part_a, int nblk_a, const double *__restrict__ part_p, int nblk_p,
+                                                         const double *__restrict__ part_s, int nblk_s, double *__restrict__ sc,
+                                                         const NwDevState *__restrict__ st, int it)
+{
+    if (it >= st->stop_at) return;
+    __shared__ double s_w[24][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int k = 0; k < 24; ++k) {
+        // slot k <- column of one of the three partial arrays
+        const double *src; int nb, nv, col;
+        if (k < 4) { src = part_a; nb = nblk_a; nv = 4; col = k; }
+        else if (k < 13) { src = part_s; nb = nblk_s; nv = 9; col = k - 4; }
+        else { src = part_p; nb = nblk_p; nv = 11; col = k - 13; }
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nb; b += 1024) s += src[(int64_t)b * nv + col];
+        s = nw_wave_sum(s);
+        if (lane == 0) s_w[k][wv] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += s_w[threadIdx.x][w];
+        sc[threadIdx.x] = s;
+    }
 }
 
 // ============================================================================================================

@@ -40,7 +40,7 @@ class HipExecutor(object):
     def __init__(self, cg):
         self.cg = cg
         self.L, self.h, self.native = cg._L, cg._h, cg._native
-        stride = self.L.nw_scalar_stride()          # doubles per slot (replicated, line-padded partial sums)
+        stride = self.L.nw_scalar_stride()          # doubles per slot (1: k_reduce_scalars leaves plain sums)
         self.n_point_scalars = self.L.nw_n_point_scalars() * stride
         self.n_scalars = self.L.nw_n_scalars() * stride
         self._views = {}
@@ -77,11 +77,18 @@ class HipExecutor(object):
         return self._views[key]
 
     def scalars(self, count):
-        # the scalar block of the CURRENT iteration's parity (double-buffered on the device)
+        # the 24 sums of the current iteration (first nw_n_point_scalars(): point side)
         return self._view(nw.NW_ARR_SCALARS, count, '<f8')
 
     def vertex_accumulator(self):
-        return self._view(nw.NW_ARR_VACC, 4 * self.cg.M, '<f4')
+        # (M, 4) int64 fixed-point sums {A^T res, sum w}: integer all-reduce = exact, order independent
+        return self._view(nw.NW_ARR_VACC, 4 * self.cg.M, '<i8')
+
+    def quantum(self, value=0.0):
+        """quantum of the fixed-point accumulator; value > 0 fixes it (ranks that all-reduce the accumulator must agree)"""
+        q = ctypes.c_double(float(value))
+        self.native.check(self.L.nw_accumulator_quantum(self.h, ctypes.byref(q)))
+        return q.value
 
     def end(self):
         cg = self.cg
@@ -116,6 +123,11 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
             prenorm = (w_arr / np.float32(float(t[0]) / float(t[1]))).astype(np.float32)
             ex._prenorm_cache = (w_eff, prenorm)
     ex.begin(data, lams, num_iters, sigma_inv, weights, prenorm, pos, last_step)
+    if mode != 'tiles' and hasattr(ex, 'quantum'):
+        # the ranks add their integer accumulators: one common quantum (the coarsest any rank chose for its own localizations)
+        t = ex.new_tensor([ex.quantum()])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ex.quantum(float(t[0]))
     n_red = ex.n_scalars if mode == 'tiles' else ex.n_point_scalars
     for _ in range(int(num_iters)):
         ex.attract()

@@ -81,7 +81,8 @@ typedef enum nw_array {
     NW_ARR_FDEF = 7,        /* (M, 3)  f32  curvature prior of the last iteration (float32 copy), :770-820        */
     NW_ARR_PI = 8,          /* (M,)    f32  point influence ||A^T 1||, _membrane_mesh.pyx:1625-1634              */
     NW_ARR_MESHPOS = 9,     /* (M, 3)  f32  mesh._vertices['position'] as written back at :289                   */
-    NW_ARR_VACC = 10,       /* (M, 4)  f32  device-only: per-vertex accumulator {A^T res, sum w} (multi-GPU all-reduce) */
+    NW_ARR_VACC = 10,       /* (M, 4)  i64  device-only: per-vertex fixed-point accumulator {A^T res, sum w} in units of nw_accumulator_quantum
+                               (xyz) / 2^-40 (w): exact, order-independent sums (multi-GPU all-reduce of integers) */
     NW_ARR_SCALARS = 11,    /* f64 device-only: normal-equation partial sums of the current iteration (multi-GPU all-reduce), see nw_scalar_stride */
     NW_ARR_NBR = 12,        /* (M, NB) i32  1-ring vertex ids, -1 padded (as given to, or built by, nw_set_mesh)          */
     NW_ARR_NRM = 13,        /* (M, 3)  f32  vertex normals in use (nw_set_mesh / nw_set_normals / nw_refresh_normals)     */
@@ -195,6 +196,10 @@ int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, co
  * each event pair costs a few microseconds of stream serialisation); 2 = around every stage. */
 int nw_set_profiling(nw_ctx *ctx, int enable);
 int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
+
+/* quantum of NW_ARR_VACC's xyz columns (a power of two).  *q > 0 on entry fixes it for all later searches -- ranks that all-reduce
+ * NW_ARR_VACC must agree on it (all-reduce MAX of their own values); on return *q is the quantum the next nw_search_begin uses. */
+int nw_accumulator_quantum(nw_ctx *ctx, double *q);
 
 /* developer aid, no reference counterpart: counters of the exact nearest-face query accumulated since the previous call (the first
  * call switches the counting on).  out[9]: candidate evaluations per wave summed, non-empty rows listed, rows visited, cells

@@ -313,3 +313,26 @@ def test_device_built_ring_table_matches_host_substrate(case):
     hub[29, 2] = 1.0
     fan = np.array([[0, 1 + i, 1 + (i + 1) % 28] for i in range(28)], 'i4')
     assert nat.L.nw_set_mesh(nat.h, nw.ptr(hub), None, None, None, nw.ptr(fan), 30, 28, 20) == nw.NW_ERR_BADARG
+
+
+def test_two_identical_runs_are_bit_identical():
+    """The scatter A^T res accumulates in 64-bit fixed point (integer atomics in LDS and HBM) and the normal-equation sums are
+    added in a fixed order, so -- like the reference's serial loop (conj_grad_utils.c:153-162) -- the fit is deterministic: two
+    runs of 30 iterations on the headline configuration give bit-identical positions, logs and residuals."""
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    c = synth.make_config('c3', scale=1.0, seed=5)
+    pts, s = c['points'], 1.0 / c['sigma'].ravel()
+    outs = []
+    for _ in range(2):
+        mesh = TriMesh(c['vertices'].copy(), c['faces'])
+        cg = CG(mesh, pts)
+        for _blk in range(6):
+            out = cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+        outs.append((out.copy(), np.array(cg.tests), np.array(cg.ress), cg.res.copy(), cg.nearest_face.copy()))
+        del cg
+    a, b = outs
+    assert np.array_equal(a[4], b[4]), 'nearest faces differ between two identical runs'
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), 'positions differ by up to %.3e' % np.abs(a[0] - b[0]).max()
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32))
