@@ -21,6 +21,8 @@ enum {
     SC_COUNT = 24
 };
 
+#define NW_SPARTS 32      // ordered partial sums per scalar slot (k_reduce_scalars)
+
 struct NwDevState {
     int stop_at;          // first iteration index (global, per ctx) that must not execute (stop condition)
     int ntests;           // number of test statistics recorded so far (history survives search() calls)
@@ -73,9 +75,12 @@ __global__ __launch_bounds__(1024) void k_scan_bsums(int *__restrict__ bsum, int
     }
 }
 
-__global__ __launch_bounds__(NW_BLOCK) void k_scan_final(int *__restrict__ in, int n, const int *__restrict__ bsum, int *__restrict__ out, int zero_input)
+// bsum_is_raw: `bsum` holds the raw tile sums (k_scan_bsums was skipped); the workgroup adds the sums of the tiles before its own
+// itself (tile counts up to a few thousand: one load per thread and pass) -- two launches instead of three.
+__global__ __launch_bounds__(NW_BLOCK) void k_scan_final(int *__restrict__ in, int n, const int *__restrict__ bsum, int *__restrict__ out, int zero_input, int bsum_is_raw)
 {
     __shared__ int s_w[4];
+    __shared__ int s_pre[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int base = blockIdx.x * NW_SCAN_TILE + threadIdx.x * 8;
     int v[8];
@@ -87,8 +92,15 @@ __global__ __launch_bounds__(NW_BLOCK) void k_scan_final(int *__restrict__ in, i
         for (int k = 0; k < 8; ++k) if (base + k < n) in[base + k] = 0;
     const int inc = nw_wave_incl_scan(s, lane);
     if (lane == 63) s_w[wv] = inc;
+    int pre = 0;
+    if (bsum_is_raw) {
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += NW_BLOCK) pre += bsum[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
+        if (lane == 0) s_pre[wv] = pre;
+    }
     __syncthreads();
-    int off = bsum[blockIdx.x] + inc - s;
+    int off = (bsum_is_raw ? (s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]) : bsum[blockIdx.x]) + inc - s;
     for (int w = 0; w < wv; ++w) off += s_w[w];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -101,8 +113,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_scan_final(int *__restrict__ in, i
 // ============================================================================================================
 // set-up kernels (once per nw_set_points / grid change)
 // ============================================================================================================
-__global__ void k_minmax3(const float *__restrict__ xyz, int64_t n, float *__restrict__ mm /* [6]: min xyz, max xyz */, int *__restrict__ nonfinite)
+__global__ __launch_bounds__(NW_BLOCK) void k_minmax3(const float *__restrict__ xyz, int64_t n, float *__restrict__ mm /* [6]: min xyz, max xyz */, int *__restrict__ nonfinite)
 {
+    __shared__ float s_lo[3][4], s_hi[3][4];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     int bad = 0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -118,13 +131,17 @@ __global__ void k_minmax3(const float *__restrict__ xyz, int64_t n, float *__res
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
         }
+        if ((threadIdx.x & 63) == 0) { s_lo[k][threadIdx.x >> 6] = lo[k]; s_hi[k][threadIdx.x >> 6] = hi[k]; }
     }
-    if ((threadIdx.x & 63) == 0) {
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        // one pair of atomics per workgroup and axis (six same-address atomics per WAVE serialised: 225 us for 12 MB);
         // float atomic min/max through the monotone int mapping
-        for (int k = 0; k < 3; ++k) {
-            atomicMin((int *)&mm[k], lo[k] >= 0 ? __float_as_int(lo[k]) : (int)(0x80000000u - (unsigned)__float_as_int(lo[k])));
-            atomicMax((int *)&mm[3 + k], hi[k] >= 0 ? __float_as_int(hi[k]) : (int)(0x80000000u - (unsigned)__float_as_int(hi[k])));
-        }
+        const int k = threadIdx.x;
+        const float l = fminf(fminf(s_lo[k][0], s_lo[k][1]), fminf(s_lo[k][2], s_lo[k][3]));
+        const float h = fmaxf(fmaxf(s_hi[k][0], s_hi[k][1]), fmaxf(s_hi[k][2], s_hi[k][3]));
+        atomicMin((int *)&mm[k], l >= 0 ? __float_as_int(l) : (int)(0x80000000u - (unsigned)__float_as_int(l)));
+        atomicMax((int *)&mm[3 + k], h >= 0 ? __float_as_int(h) : (int)(0x80000000u - (unsigned)__float_as_int(h)));
     }
     if (bad) atomicOr(nonfinite, 1);
 }
@@ -736,11 +753,20 @@ struct NwIterLogDev {   // mirrors nw_iter_log in include/nanowrap.h
 
 __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int n_search, unsigned flags, const unsigned char *__restrict__ valid,
                                                           float *__restrict__ pos, float *__restrict__ meshpos, float *__restrict__ S, long long *__restrict__ vacc,
-                                                          const double *__restrict__ sc, NwDevState *__restrict__ st,
+                                                          const double *__restrict__ sc_parts, NwDevState *__restrict__ st,
                                                           NwIterLogDev *__restrict__ logrec, int it)
 {
     if (it >= st->stop_at) return;
     __shared__ NwSolve s_sol;
+    __shared__ double s_sc[SC_COUNT];
+    if (threadIdx.x < SC_COUNT) {
+        double t = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < NW_SPARTS; ++b) t += sc_parts[threadIdx.x * NW_SPARTS + b];
+        s_sc[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const double *sc = s_sc;
     if (threadIdx.x == 0) { if (n_search > 2) nw_solve_small<3>(sc, lam, s_sol); else nw_solve_small<2>(sc, lam, s_sol); }
     __syncthreads();
     const NwSolve sol = s_sol;
@@ -806,35 +832,45 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
     }
 }
 
-// The per-workgroup partial sums of the three reduction kernels (rows of 4 / 11 / 9 doubles) are added in a FIXED order by one
-// workgroup: thread t takes rows t, t + 1024, ... of its column, then the 1024 threads are combined by waves and by a serial sum
-// over the 16 waves.  Deterministic (no atomics); ~0.4 MB of reads at 1M localizations.
-__global__ __launch_bounds__(1024) void k_reduce_scalars(const double *__restrict__ part_a, int nblk_a, const double *__restrict__ part_p, int nblk_p,
-                                                         const double *__restrict__ part_s, int nblk_s, double *__restrict__ sc,
-                                                         const NwDevState *__restrict__ st, int it)
+// The per-workgroup partial sums of the three reduction kernels (rows of 4 / 9 / 11 doubles, ~0.45 MB at 1M localizations) are
+// added in a FIXED order in two steps (deterministic, no atomics): NW_SPARTS workgroups each add one contiguous share of the rows
+// (one workgroup alone is limited by the ~25 GB/s a single CU pulls: 23 us) into sc[slot * NW_SPARTS + part]; the consumer
+// (k_solve_update, every workgroup for itself) adds the NW_SPARTS values of a slot in order.  Each share is read flat and
+// coalesced by a number of threads that is a multiple of the row length, so a thread stays on one column.
+template <int NV, int NT>
+__device__ __forceinline__ void nw_reduce_columns(const double *__restrict__ part, int nblk, double *s_acc /* [NT] */, double *__restrict__ sc, int slot0)
 {
-    if (it >= st->stop_at) return;
-    __shared__ double s_w[24][16];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll 1
-    for (int k = 0; k < 24; ++k) {
-        // slot k <- column of one of the three partial arrays
-        const double *src; int nb, nv, col;
-        if (k < 4) { src = part_a; nb = nblk_a; nv = 4; col = k; }
-        else if (k < 13) { src = part_s; nb = nblk_s; nv = 9; col = k - 4; }
-        else { src = part_p; nb = nblk_p; nv = 11; col = k - 13; }
-        double s = 0.0;
-        for (int b = threadIdx.x; b < nb; b += 1024) s += src[(int64_t)b * nv + col];
-        s = nw_wave_sum(s);
-        if (lane == 0) s_w[k][wv] = s;
+    static_assert(NT % NV == 0 && NT <= NW_BLOCK, "thread count must be a multiple of the row length");
+    const int t = threadIdx.x;
+    const int per = (nblk + NW_SPARTS - 1) / NW_SPARTS;
+    const int r0 = min((int)blockIdx.x * per, nblk), r1 = min(r0 + per, nblk);
+    const double *__restrict__ p = part + (int64_t)r0 * NV;
+    const int64_t total = (int64_t)(r1 - r0) * NV;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;       // four independent chains: loads in flight, fixed association
+    if (t < NT) {
+        int64_t e = t;
+        for (; e + 3 * NT < total; e += 4 * NT) { a0 += p[e]; a1 += p[e + NT]; a2 += p[e + 2 * NT]; a3 += p[e + 3 * NT]; }
+        for (; e < total; e += NT) a0 += p[e];
+        s_acc[t] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-    if (threadIdx.x < 24) {
+    if (t < NV) {
         double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) s += s_w[threadIdx.x][w];
-        sc[threadIdx.x] = s;
+        for (int k = t; k < NT; k += NV) s += s_acc[k];
+        sc[(slot0 + t) * NW_SPARTS + blockIdx.x] = s;
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_reduce_scalars(const double *__restrict__ part_a, int nblk_a, const double *__restrict__ part_p, int nblk_p,
+                                                            const double *__restrict__ part_s, int nblk_s, double *__restrict__ sc,
+                                                            const NwDevState *__restrict__ st, int it)
+{
+    if (it >= st->stop_at) return;
+    __shared__ double s_acc[NW_BLOCK];
+    nw_reduce_columns<4, 256>(part_a, nblk_a, s_acc, sc, SC_RES2);        // k_attract: res^2, masked res^2, sum d, count
+    nw_reduce_columns<9, 252>(part_s, nblk_s, s_acc, sc, SC_HC);          // k_subspace_point_sums: Hc (6), Gc (3)
+    nw_reduce_columns<11, 253>(part_p, nblk_p, s_acc, sc, SC_SS);         // k_prior_directions: S^T S (6), S.prefs (3), |prefs|^2 (2)
 }
 
 // ============================================================================================================

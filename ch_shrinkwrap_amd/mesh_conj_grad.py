@@ -194,11 +194,22 @@ class ShrinkwrapMeshConjGrad(object):
         logs = (nw.IterLog * max(num_iters, 1))()
         lc = ctypes.c_int(0)
         self._cache = {}
-        code = self._L.nw_search(self._h, nw.ptr(lams_a), lams_a.size, num_iters, flags, None, logs, ctypes.byref(lc))
+        # write-back (mesh_conj_grad.py:288-290) inside the call: the library copies the positions out in slices (the (M,3) result and
+        # the strided mesh._vertices['position'] rows of the valid vertices) while the rest of the transfer is still in flight
+        out = self._result_buffer()
+        posv = self.mesh._vertices['position']
+        direct = posv.dtype == np.float32 and posv.strides[1] == 4 and posv.strides[0] >= 12
+        self._native.check(self._L.nw_set_write_back(self._h, ctypes.c_void_p(posv.ctypes.data) if direct else None, posv.strides[0] if direct else 0))
+        code = self._L.nw_search(self._h, nw.ptr(lams_a), lams_a.size, num_iters, flags, nw.ptr(out), logs, ctypes.byref(lc))
+        self._native.check(self._L.nw_set_write_back(self._h, None, 0))
         self._native.check(code)
         self._consume_logs(logs, lc.value)
         self._accumulate_stage_ms()
-        self._finish()
+        if not direct:                          # exotic vertex layout: let NumPy do the strided copy
+            np.copyto(posv, out, where=self._mesh_vertex_mask[:, None])
+        self.fs = out
+        self.f = self.fs.ravel()
+        self.mesh._initialize_curvature_vectors()
         return np.real(self.fs)
 
     def _consume_logs(self, logs, executed):
@@ -378,6 +389,10 @@ class ShrinkwrapMeshConjGrad(object):
         for k, (ms, n) in self.stage_ms().items():
             a, b = self.stage_ms_total[k]
             self.stage_ms_total[k] = (a + ms, b + n)
+
+    def optimize_layout(self):
+        """do the library's pending one-off set-up now (the projection re-sort after the first block) instead of at the next search()"""
+        self._native.check(self._L.nw_optimize_layout(self._h))
 
     def nn_stats(self):
         """developer counters of the nearest-face query since the previous call (first call: switches them on)"""

@@ -40,7 +40,7 @@ class HipExecutor(object):
     def __init__(self, cg):
         self.cg = cg
         self.L, self.h, self.native = cg._L, cg._h, cg._native
-        stride = self.L.nw_scalar_stride()          # doubles per slot (1: k_reduce_scalars leaves plain sums)
+        stride = self.L.nw_scalar_stride()          # doubles per slot (its ordered partial sums, k_reduce_scalars)
         self.n_point_scalars = self.L.nw_n_point_scalars() * stride
         self.n_scalars = self.L.nw_n_scalars() * stride
         self._views = {}

