@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, 'libnanowrap_hip.so')
 NW_OK = 0
 NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM = -1, -2, -3, -4, -5, -6
 NW_WEIGHTS_FROM_SIGMA_INV, NW_WEIGHTS_SCALAR, NW_WEIGHTS_ARRAY, NW_WEIGHTS_PRENORMALIZED = 0, 1, 2, 3
-NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP = 1, 2
+NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP, NW_FLAG_WFUNC = 1, 2, 4
 (NW_ARR_S, NW_ARR_RES, NW_ARR_VIDX, NW_ARR_W, NW_ARR_DIST, NW_ARR_FACE, NW_ARR_POS, NW_ARR_FDEF, NW_ARR_PI,
  NW_ARR_MESHPOS, NW_ARR_VACC, NW_ARR_SCALARS, NW_ARR_NBR, NW_ARR_NRM, NW_ARR_VALID) = range(15)
 NW_N_SCALARS = 32

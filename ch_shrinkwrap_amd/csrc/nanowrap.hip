@@ -179,6 +179,7 @@ struct nw_ctx {
     DevBuf<float> dist, w, res, S, fdef, pi;
     DevBuf<long long> vacc;           // (M, 4) fixed-point accumulator {A^T res, sum w}: exact, order-independent sums
     DevBuf<double> scalars;           // [NW_N_SCALARS][NW_SPARTS] sums of the current iteration, NW_SPARTS ordered parts per slot (k_reduce_scalars)
+    DevBuf<float> wv;                 // per-vertex weights of the 'wfunc' regulariser (NW_FLAG_WFUNC)
     DevBuf<double> part_a, part_p, part_s;   // per-workgroup partial sums of k_attract / k_prior_directions / k_subspace_point_sums
     double w_quantum = 1.0;           // fixed-point quantum of the {w} column
     double w_bound = 1.0;             // largest |weight| after normalisation (bounds |res| together with the cloud extent)
@@ -475,7 +476,8 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->scalars.ensure(NW_N_SCALARS * NW_SPARTS));
     NW_HIP(ctx->part_a.ensure((size_t)4 * attract_blocks(ctx)));
     NW_HIP(ctx->part_s.ensure((size_t)9 * attract_blocks(ctx)));
-    NW_HIP(ctx->part_p.ensure((size_t)11 * prior_blocks(ctx)));
+    NW_HIP(ctx->part_p.ensure((size_t)14 * prior_blocks(ctx)));
+    NW_HIP(ctx->wv.ensure(ctx->M));
     return NW_OK;
 }
 
@@ -519,7 +521,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->valid.release(); ctx->d_small.release();
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
-    ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
+    ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->wv.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
     if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (hipEvent_t e : ctx->wb_events) (void)hipEventDestroy(e);
@@ -902,9 +904,12 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
     {
         StageScope s(ctx, ST_PRIOR);
+        const bool wfunc = (ctx->search_flags & NW_FLAG_WFUNC) != 0;
+        if (wfunc)
+            hipLaunchKernelGGL(k_vertex_area_weights, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->NB, ctx->nbr.p, ctx->pos.p, ctx->wv.p, ctx->state.p, it);
         hipLaunchKernelGGL(k_prior_directions, dim3(prior_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->maxdeg, ctx->nbr_t.p, ctx->pos.p,
                            ctx->meshpos.p, ctx->nrm.p, ctx->vacc.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->part_p.p, ctx->state.p, it, n_search,
-                           ctx->acc_quantum, ctx->w_quantum);
+                           ctx->acc_quantum, ctx->w_quantum, wfunc ? ctx->wv.p : nullptr);
     }
     {
         StageScope s(ctx, ST_AS);

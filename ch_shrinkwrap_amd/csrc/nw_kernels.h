@@ -18,7 +18,9 @@ enum {
     SC_SP = 19,      // 3: S_k . prefs64 (Gw = -SP)               conj_grad.py:212
     SC_PP64 = 22,    // sum prefs64^2 -> wpreds                   conj_grad.py:192
     SC_PP32 = 23,    // sum prefs32^2 -> prefs log                mesh_conj_grad.py:271
-    SC_COUNT = 24
+    SC_T = 24,       // 3: S0.S0, S0.S1, S1.S1 of the RAW directions -> test statistic (mesh_conj_grad.py:262-265); equal to SC_SS
+                     //    entries 0, 1, 3 unless a regulariser other than the identity scales the directions (wfunc)
+    SC_COUNT = 27
 };
 
 #define NW_SPARTS 32      // ordered partial sums per scalar slot (k_reduce_scalars)
@@ -530,13 +532,13 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
                                                               const float *__restrict__ meshpos, const float *__restrict__ nrm,
                                                               const long long *__restrict__ vacc, float *__restrict__ S, float *__restrict__ fdef_out,
                                                               float *__restrict__ pi_out, double *__restrict__ part, NwDevState *__restrict__ st, int it, int n_search,
-                                                              double q, double qw)
+                                                              double q, double qw, const float *__restrict__ wv)
 {
     if (it >= st->stop_at) return;
-    __shared__ double s_part[11 * 4];
-    double red[11];
+    __shared__ double s_part[14 * 4];
+    double red[14];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) red[k] = 0.0;
+    for (int k = 0; k < 14; ++k) red[k] = 0.0;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < M; v += gridDim.x * blockDim.x) {
         const longlong2 a01 = *reinterpret_cast<const longlong2 *>(vacc + 4 * (int64_t)v), a23 = *reinterpret_cast<const longlong2 *>(vacc + 4 * (int64_t)v + 2);
         const float4 acc = make_float4((float)((double)a01.x * q), (float)((double)a01.y * q), (float)((double)a23.x * q), (float)((double)a23.y * qw));
@@ -606,30 +608,57 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
             fd[0] = meshpos[3 * v]; fd[1] = meshpos[3 * v + 1]; fd[2] = meshpos[3 * v + 2];
         }
         const float s0[3] = {acc.x, acc.y, acc.z};
+        // regulariser: identity (Lfuncs = ["I"], mesh_conj_grad.py:38) or the diagonal 'wfunc' (:724-735), L x = x * wv
+        const float lw = wv ? wv[v] : 1.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const double p64 = (double)pos[3 * v + c] - fd[c];
-            const float p32 = (float)p64;
-            const float s1 = -1.0f * p32;
+            double p64 = (double)pos[3 * v + c] - fd[c];
+            if (wv) p64 = p64 * (double)lw;                       // wfunc(f - fdef): float64 * float32 -> float64 (:257, conj_grad.py:191)
+            const float p32 = (float)p64;                         // prefs[:, 0] is a float32 array
+            const float s1 = wv ? -1.0f * (p32 * lw) : -1.0f * p32;      // S[:, 1] = -Lh(prefs) (:258)
             float *row = S + (int64_t)(3 * v + c) * 3;
             const float s2 = (n_search > 2) ? row[2] : 0.0f;
             row[0] = s0[c];
             row[1] = s1;
             fdef_out[3 * v + c] = (float)fd[c];
-            red[0] += (double)s0[c] * s0[c];
-            red[1] += (double)s0[c] * s1;
-            red[2] += (double)s0[c] * s2;
-            red[3] += (double)s1 * s1;
-            red[4] += (double)s1 * s2;
-            red[5] += (double)s2 * s2;
-            red[6] += (double)s0[c] * p64;
-            red[7] += (double)s1 * p64;
-            red[8] += (double)s2 * p64;
+            // LS_k = L(S_k) in float32 (conj_grad.py:199); Hw = LS^T LS, Gw = -LS^T prefs64 (:211-212)
+            const float l0 = wv ? s0[c] * lw : s0[c], l1 = wv ? s1 * lw : s1, l2 = wv ? s2 * lw : s2;
+            red[0] += (double)l0 * l0;
+            red[1] += (double)l0 * l1;
+            red[2] += (double)l0 * l2;
+            red[3] += (double)l1 * l1;
+            red[4] += (double)l1 * l2;
+            red[5] += (double)l2 * l2;
+            red[6] += (double)l0 * p64;
+            red[7] += (double)l1 * p64;
+            red[8] += (double)l2 * p64;
             red[9] += p64 * p64;
             red[10] += (double)p32 * (double)p32;
+            red[11] += (double)s0[c] * s0[c];
+            red[12] += (double)s0[c] * s1;
+            red[13] += (double)s1 * s1;
         }
     }
-    nw_block_reduce_store<11>(red, part, s_part);
+    nw_block_reduce_store<14>(red, part, s_part);
+}
+
+// weights of the 'wfunc' regulariser from the CURRENT estimate f (mesh_conj_grad.py:733 -> vertex_area_weights,
+// conj_grad_utils.c:500-548): 1/sqrt(sum_n |f_n - f_i|^2 + 1), float32 sums in slot order; 0 for a vertex without neighbours.
+__global__ __launch_bounds__(NW_BLOCK) void k_vertex_area_weights(int M, int NB, const int *__restrict__ nbr, const float *__restrict__ f, float *__restrict__ wv,
+                                                                 const NwDevState *__restrict__ st, int it)
+{
+    if (it >= st->stop_at) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int *row = nbr + (int64_t)i * NB;
+    float w = 0;
+    for (int k = 0; k < NB; ++k) {
+        const int n = row[k]; if (n == -1) break;
+        float d2 = 0;
+        for (int j = 0; j < 3; ++j) { const float dd = f[3 * n + j] - f[3 * i + j]; d2 += dd * dd; }
+        w += d2;
+    }
+    wv[i] = (w > 0) ? (float)(1.0 / (double)sqrtf(w + 1)) : 0.0f;
 }
 
 // K6: A.S_k for the n_search directions and the point-side normal-equation sums, never materialising AS:
@@ -792,7 +821,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // logs (mesh_conj_grad.py:262-274)
-        const double s00 = sc[SC_SS + 0], s01 = sc[SC_SS + 1], s11 = sc[SC_SS + 3];
+        const double s00 = sc[SC_T + 0], s01 = sc[SC_T + 1], s11 = sc[SC_T + 2];
         const float test = 1.0f - (float)(fabs(s01) / (sqrt(s00) * sqrt(s11)));
         NwIterLogDev L;
         L.test = test;
@@ -870,7 +899,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_reduce_scalars(const double *__res
     __shared__ double s_acc[NW_BLOCK];
     nw_reduce_columns<4, 256>(part_a, nblk_a, s_acc, sc, SC_RES2);        // k_attract: res^2, masked res^2, sum d, count
     nw_reduce_columns<9, 252>(part_s, nblk_s, s_acc, sc, SC_HC);          // k_subspace_point_sums: Hc (6), Gc (3)
-    nw_reduce_columns<11, 253>(part_p, nblk_p, s_acc, sc, SC_SS);         // k_prior_directions: S^T S (6), S.prefs (3), |prefs|^2 (2)
+    nw_reduce_columns<14, 252>(part_p, nblk_p, s_acc, sc, SC_SS);         // k_prior_directions: LS^T LS (6), LS.prefs (3), |prefs|^2 (2), raw S.S (3)
 }
 
 // ============================================================================================================

@@ -192,84 +192,92 @@ class MembraneMesh(TriMesh):
     curvature_gaussian = property(lambda self: self._curv('_K'))                              # :170-174
 
     # -- the driver -------------------------------------------------------------------------------------------
-    def opt_conjugate_gradient(self, points, sigma, max_iter=10, step_size=1.0, weights=None, **kwargs):
-        """_membrane_mesh.pyx:1427-1560."""
-        r = (self.remesh_frequency != 0) and (self.remesh_frequency <= max_iter)
-        dr = (self.delaunay_remesh_frequency != 0) and (self.delaunay_remesh_frequency <= max_iter)
-        if r and dr:
-            rf = math.gcd(self.remesh_frequency, self.delaunay_remesh_frequency)
-        elif r:
-            rf = self.remesh_frequency
-        elif dr:
-            rf = self.delaunay_remesh_frequency
-        else:
-            rf = max_iter
+    # Outer loop of the fit (_membrane_mesh.pyx:1427-1560), decomposed into: the block plan (how many iterations run on one
+    # topology, which target edge length each remesh gets), the per-block optimiser run, and the block boundary.
+    class _BlockPlan(object):
+        """Block length = greatest common divisor of the active surgery periods (:1430-1441); the remesh target length moves
+        linearly from the current mean edge length to the final one over the planned iterations (:1443-1455, :1544)."""
 
-        if r:
-            initial_length = self._mean_edge_length
-            if kwargs.get('minimum_edge_length', -1) < 0:
-                final_length = np.clip(np.min(sigma) / 2.5, 1.0, 50.0)
-            else:
-                final_length = kwargs.get('minimum_edge_length')
-            m = (final_length - initial_length) / (rf * np.ceil(max_iter / rf))          # :1455 (linear in edge length)
+        def __init__(self, mesh, max_iter, sigma, minimum_edge_length):
+            periods = [p for p in (mesh.remesh_frequency, mesh.delaunay_remesh_frequency) if p != 0 and p <= max_iter]
+            self.remesh = mesh.remesh_frequency != 0 and mesh.remesh_frequency <= max_iter
+            self.punch = mesh.delaunay_remesh_frequency != 0 and mesh.delaunay_remesh_frequency <= max_iter
+            self.block = max_iter
+            if periods:
+                self.block = periods[0] if len(periods) == 1 else math.gcd(*periods)
+            self.n_iter = min(max_iter, getattr(mesh, 'truncate_at', max_iter))                      # :1490
+            self.length0 = self.slope = None
+            if self.remesh:
+                self.length0 = mesh._mean_edge_length
+                final = np.clip(np.min(sigma) / 2.5, 1.0, 50.0) if minimum_edge_length < 0 else minimum_edge_length
+                self.slope = (final - self.length0) / (self.block * np.ceil(max_iter / self.block))
 
-        neck_first_iter = getattr(self, 'neck_first_iter', -1)
+        def target_length(self, iterations_done):
+            return self.length0 + self.slope * (iterations_done + 1)
 
-        # sigma -> s (:1460-1473).  NB the scalar branch passes sigma through UN-inverted, as the reference does.
+    @staticmethod
+    def _inverse_sigma(points, sigma):
+        """sigma -> the `sigma_inv` argument of search() (:1460-1473).  NB a scalar sigma is passed through UN-inverted, as upstream."""
         if np.isscalar(sigma):
-            s = float(sigma)
-        elif (len(sigma.shape) == 1) and (sigma.shape[0] == points.shape[0]):
-            s = 1.0 / np.repeat(sigma, points.shape[1])
-        elif (len(sigma.shape) == 2) and (sigma.shape[0] == points.shape[0]) and (sigma.shape[1] == points.shape[1]):
-            s = (1.0 / sigma.ravel())
-        else:
-            raise ValueError('Sigma must be of shape (%d,) or (%d,%d).' % (points.shape[0], points.shape[0], points.shape[1]))
+            return float(sigma)
+        n, d = points.shape
+        if sigma.ndim == 1 and sigma.shape[0] == n:
+            return 1.0 / np.repeat(sigma, d)
+        if sigma.ndim == 2 and sigma.shape == (n, d):
+            return 1.0 / sigma.ravel()
+        raise ValueError('Sigma must be of shape (%d,) or (%d,%d).' % (n, n, d))
 
-        last_area = self.area()
-        self.cg = None
-        j = 0
-        if self.shrink_weight > 0:                                                       # :1483-1486
-            lams = [step_size * self.kc / 2.0, self.shrink_weight]
-        else:
-            lams = [step_size * self.kc / 2.0, ]
+    def _host_mesh_changed(self):
+        """The HBM copy of the mesh (positions, normals, 1-ring table, valid flags) no longer mirrors this object: the next optimiser
+        uploads it again.  Called wherever host code may have touched the mesh -- at the start of every fit (the caller may have
+        edited or smoothed positions since the last one) and after every surgery hook."""
+        if self._native is not None:
+            self._native.mesh_key = None
 
-        n_iter = min(max_iter, getattr(self, 'truncate_at', max_iter))                   # :1490
+    def _block_boundary(self, points, done, plan):
+        # :1524-1527 -- geometry refreshed from the new positions: vertex normals on the device (they feed the next block's
+        # curvature prior; positions and normals stay resident), face areas / edge lengths on the host
+        self.cg.refresh_normals()
+        self.update_geometry(vertex_normals=False)
+        if plan.punch and done % self.delaunay_remesh_frequency == 0 and self.hole_puncher is not None:   # :1530-1532
+            self.hole_puncher(self, points, self.delaunay_eps)
+            self._host_mesh_changed()
+        if plan.remesh and done % self.remesh_frequency == 0:                                             # :1537-1549
+            first = getattr(self, 'neck_first_iter', -1)
+            if first > 0 and done > first:                                                                # :1538-1540
+                verts = self.remove_necks(getattr(self, 'neck_threshold_low', -1e-4), getattr(self, 'neck_threshold_high', 1e-2))
+                self.neck_log.append(dict(iteration=done, candidates=int(len(verts))))
+                self._host_mesh_changed()
+            if self.edge_cleaner is not None:
+                self.edge_cleaner(self)
+                self._host_mesh_changed()
+            target = plan.target_length(done)
+            if self.remesh(5, target, 0.5, n_relax=0):
+                self.cg = None
+                self._host_mesh_changed()
+            self.block_log.append(dict(iteration=done, target_length=float(target), mean_length=float(self._mean_edge_length)))
+
+    def opt_conjugate_gradient(self, points, sigma, max_iter=10, step_size=1.0, weights=None, **kwargs):
+        """_membrane_mesh.pyx:1427-1560: blocks of iterations on a fixed topology, mesh surgery between them."""
+        plan = self._BlockPlan(self, max_iter, sigma, kwargs.get('minimum_edge_length', -1))
+        s = self._inverse_sigma(points, sigma)
+        lams = [step_size * self.kc / 2.0] + ([self.shrink_weight] if self.shrink_weight > 0 else [])   # :1483-1486
         if self._native is None:
             self._native = NativeContext(self._device)      # localizations stay in HBM across blocks
-
-        while j < n_iter:
-            # a new optimiser per block (:1510-1512).  The localizations stay resident in HBM; while the topology is unchanged
-            # the mesh does too (positions and device-refreshed normals are already current) and only the history restarts
+        self._host_mesh_changed()
+        self.cg = None
+        done = 0
+        while done < plan.n_iter:
+            # a new optimiser per block (:1510-1512).  The localizations stay resident in HBM; while nothing touched the host mesh
+            # the device copy is current (positions written by the last block, normals refreshed on the device) and only the
+            # optimiser's history restarts
             self.cg = ShrinkwrapMeshConjGrad(self, points, search_k=self.search_k, search_rad=self.search_rad,
-                                             shield_sigma=self._mean_edge_length / 2.0, native=self._native,
-                                             reuse_device_mesh=True)
-            n_it = min(n_iter - j, rf)
-            self.cg.search(points, lams=lams, num_iters=n_it, sigma_inv=s, weights=weights)   # :1516-1517
-            j += n_it
-
-            # :1524-1527 -- face normals / vertex normals / neighbours refreshed from the new positions: vertex normals on
-            # the device (they feed the next block's curvature prior), face areas / edge lengths on the host
-            self.cg.refresh_normals()
-            self.update_geometry(vertex_normals=False)
-
-            if dr and ((j % self.delaunay_remesh_frequency) == 0) and self.hole_puncher is not None:   # :1530-1532
-                self.hole_puncher(self, points, self.delaunay_eps)
-
-            if r and ((j % self.remesh_frequency) == 0):                                 # :1537-1549
-                if (neck_first_iter > 0) and (j > neck_first_iter):                      # :1538-1540
-                    verts = self.remove_necks(getattr(self, 'neck_threshold_low', -1e-4), getattr(self, 'neck_threshold_high', 1e-2))
-                    self.neck_log.append(dict(iteration=j, candidates=int(len(verts))))
-                if self.edge_cleaner is not None:
-                    self.edge_cleaner(self)
-                target_length = (initial_length + m * (j + 1))                           # :1544
-                if self.remesh(5, target_length, 0.5, n_relax=0):
-                    self.cg = None
-                    self._native.mesh_key = None            # topology changed: the next optimiser uploads the new mesh
-                self.block_log.append(dict(iteration=j, target_length=float(target_length), mean_length=float(self._mean_edge_length)))
-
-            area = self.area()                                                           # :1552-1558 (convergence break disabled upstream)
-            last_area = area
-        return j
+                                             shield_sigma=self._mean_edge_length / 2.0, native=self._native, reuse_device_mesh=True)
+            n = min(plan.n_iter - done, plan.block)
+            self.cg.search(points, lams=lams, num_iters=n, sigma_inv=s, weights=weights)                  # :1516-1517
+            done += n
+            self._block_boundary(points, done, plan)
+        return done
 
     def shrink_wrap(self, points=None, sigma=None, method='conjugate_gradient', max_iter=None, **kwargs):
         """_membrane_mesh.pyx:1641-1669."""

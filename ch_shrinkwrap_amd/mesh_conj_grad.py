@@ -178,6 +178,18 @@ class ShrinkwrapMeshConjGrad(object):
         else:
             self.mask = np.isfinite(self._points_f32.ravel())
 
+    def _regulariser_flag(self):
+        """Lfuncs / Lhfuncs are selected by name (mesh_conj_grad.py:36-39, 257-258).  ["I"] is the live setting; ["wfunc"] is the
+        one alternative that runs upstream.  "Lfunc", "Lfunc2", "Lfunc3", "Lfunc4" fail in the reference's first iteration (they
+        hand the float64 `f - _ncc()` to conj_grad_utils.c, which reads it as float32 and asserts on the NaNs), so there is no
+        behaviour to reproduce; nw_lfunc() offers those operators on their own."""
+        L, Lh = list(self.Lfuncs), list(self.Lhfuncs)
+        if L == ["I"] and Lh == ["I"]:
+            return 0
+        if L == ["wfunc"] and Lh == ["wfunc"]:
+            return nw.NW_FLAG_WFUNC
+        raise NotImplementedError('Lfuncs=%r / Lhfuncs=%r: only ["I"] and ["wfunc"] run in the reference\'s loop' % (L, Lh))
+
     # -- the hot path ---------------------------------------------------------------------------
     def search(self, data, lams, defaults=None, num_iters=10, weights=None, sigma_inv=1.0, pos=False, last_step=True):
         """mesh_conj_grad.py:150-292.  Returns the (M,3) float32 vertex estimate."""
@@ -190,7 +202,7 @@ class ShrinkwrapMeshConjGrad(object):
         lams_a = np.ascontiguousarray(lams, dtype=np.float32)
         self._upload_points(sigma_inv, weights)
         num_iters = int(num_iters)
-        flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP)
+        flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP) | self._regulariser_flag()
         logs = (nw.IterLog * max(num_iters, 1))()
         lc = ctypes.c_int(0)
         self._cache = {}

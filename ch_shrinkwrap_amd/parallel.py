@@ -53,7 +53,7 @@ class HipExecutor(object):
         cg = self.cg
         cg._upload_points(sigma_inv, weights, prenormalized)
         lams_a = np.ascontiguousarray(lams, dtype=np.float32)
-        flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP)
+        flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP) | cg._regulariser_flag()
         cg._cache = {}
         self.native.check(self.L.nw_search_begin(self.h, nw.ptr(lams_a), lams_a.size, int(num_iters), flags))
         self._num_iters = int(num_iters)

@@ -50,6 +50,10 @@ typedef enum nw_weights_mode {
 /* nw_search flags -- keyword arguments of search(), mesh_conj_grad.py:150 */
 #define NW_FLAG_POSITIVITY   1u      /* pos=True        (mesh_conj_grad.py:277-278) */
 #define NW_FLAG_NO_LAST_STEP 2u      /* last_step=False (mesh_conj_grad.py:281-283) */
+#define NW_FLAG_WFUNC        4u      /* Lfuncs = Lhfuncs = ["wfunc"] (mesh_conj_grad.py:36-39, 724-735) instead of ["I"]: prefs = w (f - fdef),
+                                        S1 = -w prefs, LS_k = w S_k with w = vertex_area_weights(f) (conj_grad_utils.c:500-548).  The other
+                                        names the reference offers (Lfunc, Lfunc2..4) fail upstream in the first iteration: they hand the
+                                        float64 `f - _ncc()` to float32 C code (conj_grad_utils.c:286-302 reads it blindly) */
 
 /* per-iteration record; the reference keeps these as Python lists / attributes:
  * tests, ress, prefs (mesh_conj_grad.py:269-271), cpred, wpreds (:274, conj_grad.py:223-225) */

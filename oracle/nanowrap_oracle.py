@@ -154,18 +154,28 @@ def ncc_prior(pos, nrm, nbr, pi):
     return vc
 
 
-def subspace_solve(f0, res_m, fdef, apply_A_masked, lams, S):
-    """conj_grad.py:183-229 (subsearch) with Lfuncs = ['I'] (mesh_conj_grad.py:38).
+def vertex_area_weights(f, nbr):
+    """mesh_conj_grad.py:724-735 (wfunc's weights) -> conj_grad_utils.c:500-548: 1/sqrt(sum_n |f_n - f_i|^2 + 1) per vertex,
+    repeated over the three coordinates (float32)."""
+    M, NB = nbr.shape
+    w = np.zeros(3 * M, 'f4')
+    lib().nwo_vertex_area_weights(_ptr(np.ascontiguousarray(f, dtype=np.float32)), _ptr(np.ascontiguousarray(nbr, dtype=np.int32)), M, NB, _ptr(w))
+    return w
+
+
+def subspace_solve(f0, res_m, fdef, apply_A_masked, lams, S, L=None):
+    """conj_grad.py:183-229 (subsearch) with Lfuncs = ['I'] (mesh_conj_grad.py:38), or, with `L` = the diagonal weights of
+    'wfunc' (mesh_conj_grad.py:724-735), Lfuncs = ['wfunc'].
     Returns fnew, cpred, wpreds, and the small matrices for tracing."""
     n_search = S.shape[1]
     c0 = (res_m * res_m).sum()
-    prefs = [f0 - fdef]                                   # float64 (not the f32 copy kept by search())
+    prefs = [f0 - fdef] if L is None else [(f0 - fdef) * L]      # float64 (not the f32 copy kept by search())
     wpreds = [(p * p).sum() for p in prefs]
     AS = np.zeros((res_m.size, n_search), 'f')
     LS = np.zeros((prefs[0].size, n_search, 1), 'f')
     for k in range(n_search):
         AS[:, k] = apply_A_masked(S[:, k])
-        LS[:, k, 0] = S[:, k]
+        LS[:, k, 0] = S[:, k] if L is None else S[:, k] * L
     Hc = np.dot(AS.T, AS)
     Gc = np.dot(AS.T, res_m)
     Hc0, Gc0 = Hc.copy(), Gc.copy()
@@ -203,13 +213,14 @@ class OracleResult(object):
 
 
 def search(pos, nrm, nbr, faces, points, lams, num_iters=10, sigma_inv=1.0, weights=None, valid=None,
-           pos_constraint=False, last_step=True, tests=None, trace=None, workers=-1, brute_nn=False):
+           pos_constraint=False, last_step=True, tests=None, trace=None, workers=-1, brute_nn=False, regulariser='I'):
     """mesh_conj_grad.py:150-292 for one fixed-topology block.
 
     pos (M,3) f4 vertex positions at block start, nrm (M,3) f4 block-stale vertex normals, nbr (M,NB) i4 1-ring
     vertex ids, faces (F,3) i4, points (N,3) f4.  `tests` = history list carried by the optimiser object
     (the stop condition looks at it before the first iteration).  If `trace` is a list, one dict of
-    intermediates is appended per iteration.  Returns an OracleResult with the final positions and logs."""
+    intermediates is appended per iteration.  regulariser: 'I' (mesh_conj_grad.py:38, the live setting) or 'wfunc' (:724-735; the
+    other names hand float64 data to float32 C code upstream and fail in the first iteration).  Returns an OracleResult with the final positions and logs."""
     M = pos.shape[0]
     N = points.shape[0]
     if valid is None:
@@ -255,8 +266,16 @@ def search(pos, nrm, nbr, faces, points, lams, num_iters=10, sigma_inv=1.0, weig
         res *= wd
         # 5./6. search directions                                                       (:253-258)
         S[:, 0] = apply_At(res, v_idx, w, M)
-        prefs[:, 0] = f - fdef
-        S[:, 1] = -1.0 * prefs[:, 0]
+        Lw = None
+        if regulariser == 'wfunc':
+            Lw = vertex_area_weights(f, nbr)                                             # from the CURRENT estimate (:733)
+            prefs[:, 0] = (f - fdef) * Lw                                                # float64 product, float32 store (:257)
+            S[:, 1] = -1.0 * (prefs[:, 0] * Lw)                                          # float32 (:258)
+        elif regulariser == 'I':
+            prefs[:, 0] = f - fdef
+            S[:, 1] = -1.0 * prefs[:, 0]
+        else:
+            raise ValueError(regulariser)
         # 7. test statistic and logs                                                    (:262-271)
         test = 1.0
         test -= abs((S[:, 0] * S[:, 1]).sum() / (np.linalg.norm(S[:, 0]) * np.linalg.norm(S[:, 1])))
@@ -265,7 +284,7 @@ def search(pos, nrm, nbr, faces, points, lams, num_iters=10, sigma_inv=1.0, weig
         out.prefs.append(np.linalg.norm(prefs, axis=0))
         # 8. subspace minimisation                                                      (:274)
         fnew, out.cpred, out.wpreds, small = subspace_solve(
-            f, res[mask], fdef, lambda x: apply_A(x, v_idx, w, points)[mask], lams, S[:, 0:n_search])
+            f, res[mask], fdef, lambda x: apply_A(x, v_idx, w, points)[mask], lams, S[:, 0:n_search], L=Lw)
         if pos_constraint:
             fnew = fnew * (fnew > 0)
         if trace is not None:

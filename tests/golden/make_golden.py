@@ -166,6 +166,45 @@ def golden_variants():
     save('variants_642', **arrays)
 
 
+def golden_f64_and_regulariser():
+    """(a) float64 localizations: the reference's residual, A f and Gc follow the dtype of `points` (mesh_conj_grad.py:179-181,
+    537-545); the MI355X path computes in float32.  Same C1-like cloud given as float64 -- once with exactly the float32 values
+    (isolates the arithmetic) and once un-rounded (adds the input rounding) -- so that the deviation can be asserted.
+    (b) a non-identity regulariser selected by name (mesh_conj_grad.py:36-39, 257-258): Lfuncs = Lhfuncs = ["wfunc"]."""
+    v, f = icosphere(3, 120.0)
+    N = 4000
+    arrays = {}
+    mesh = TriMesh(v, f)
+    arrays.update({'mesh_' + k: a for k, a in mesh_inputs(mesh).items()})
+    raw = sphere_cloud(N, 100.0, 10.0, seed=6, dtype='f8')
+    p32 = raw.astype('f4')
+    sig = np.full((N, 3), 10.0, 'f4')
+    s = 1.0 / sig.ravel()
+    arrays['points_f64_raw'] = raw
+    arrays['points_f32'] = p32
+    for name, pts in (('f32', p32), ('f64_same', p32.astype('f8')), ('f64_raw', raw)):
+        mesh = TriMesh(v, f)
+        cg, out, _ = run_reference(mesh, pts, [10.0], 5, s)
+        arrays[name + '_positions'] = out
+        arrays[name + '_res_dtype'] = np.array(str(cg.res.dtype))
+        arrays.update({name + '_log_' + k: a for k, a in logs(cg).items()})
+    # (b) Lfuncs = Lhfuncs = ["wfunc"]: the one alternate regulariser that RUNS in the reference's loop.  ("Lfunc", "Lfunc2", "Lfunc3",
+    # "Lfunc4" hand `f - _ncc()` -- float64 because of _ncc's integer division -- to conj_grad_utils.c, which reads the buffer as
+    # float32 (no dtype check, :286-302): NaN / AssertionError in the first iteration; tests/test_oracle_golden.py shows it live.)
+    mesh = TriMesh(v, f)
+    cg = ref_harness.new_reference_optimiser(mesh, p32, search_k=200, search_rad=100, shield_sigma=float(mesh._mean_edge_length) / 2.0)
+    cg.Lfuncs, cg.Lhfuncs = ["wfunc"], ["wfunc"]
+    cg, out, rec = run_reference(mesh, p32, [100.0], 4, s, record=True, cg=cg)
+    arrays['wfunc_lams'] = np.array([100.0])
+    arrays['wfunc_positions'] = out
+    arrays['wfunc_S_final'] = cg.S.copy()
+    arrays.update({'wfunc_log_' + k: a for k, a in logs(cg).items()})
+    for it, r in enumerate(rec):
+        arrays['wfunc_it%d_fnew' % it] = r['fnew']
+        arrays['wfunc_it%d_S' % it] = r['S']
+    save('f64_and_wfunc', **arrays)
+
+
 def golden_lfuncs():
     """Outputs of the reference's compiled C helpers (conj_grad_utils.c) on a small sphere."""
     _, _, cgu = ref_harness.load()
@@ -256,6 +295,7 @@ if __name__ == '__main__':
     golden_stages()
     golden_c1()
     golden_variants()
+    golden_f64_and_regulariser()
     golden_lfuncs()
     golden_curvature()
     golden_sdf_shapes()
