@@ -21,13 +21,13 @@ NW_N_SCALARS = 32
 SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set_stream', 'nw_synchronize',
            'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_refresh_normals', 'nw_reset_history', 'nw_search', 'nw_search_begin',
            'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
-           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back']
+           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned']
 
 
 class IterLog(ctypes.Structure):
     _fields_ = [('test', ctypes.c_double), ('res_norm', ctypes.c_double), ('prefs_norm', ctypes.c_double),
                 ('cpred', ctypes.c_double), ('wpred', ctypes.c_double), ('c', ctypes.c_double * 3),
-                ('H', ctypes.c_double * 9), ('G', ctypes.c_double * 3), ('mean_dist', ctypes.c_double),
+                ('H', ctypes.c_double * 9), ('G', ctypes.c_double * 3), ('mean_dist', ctypes.c_double), ('max_dist', ctypes.c_double),
                 ('n_search', ctypes.c_int32), ('nn_max_ring', ctypes.c_int32), ('status', ctypes.c_int32),
                 ('executed', ctypes.c_int32)]
 
@@ -72,6 +72,7 @@ def load():
     L.nw_get.argtypes = [vp, i32, vp, i64]
     L.nw_write_back.argtypes = [vp, vp, vp, i64]
     L.nw_set_write_back.argtypes = [vp, vp, i64]
+    L.nw_set_owned.argtypes = [vp, vp]
     L.nw_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     L.nw_lfunc.argtypes = [vp, i32, vp, vp, vp]
     L.nw_curvature.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32] + [vp] * 12

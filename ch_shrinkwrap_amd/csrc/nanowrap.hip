@@ -168,8 +168,8 @@ struct nw_ctx {
     // mesh
     DevBuf<float> pos, meshpos, nrm;
     DevBuf<int> nbr, nbr_t, faces;
-    DevBuf<unsigned char> valid;
-    bool have_valid = false;
+    DevBuf<unsigned char> valid, owned;
+    bool have_valid = false, have_owned = false;
     int maxdeg = 0;
     DevBuf<int> d_small;              // small int scratch (maxdeg, flags)
 
@@ -518,7 +518,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->pts.release(); ctx->perm.release(); ctx->mkey.release(); ctx->proj_key.release(); ctx->proj_idx.release(); ctx->sinv.release(); ctx->wnorm.release(); ctx->mask.release();
     ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_stats.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
-    ctx->valid.release(); ctx->d_small.release();
+    ctx->valid.release(); ctx->owned.release(); ctx->d_small.release();
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->wv.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
@@ -718,6 +718,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     else NW_TRY(nw_refresh_normals(ctx, nullptr));         // area-weighted vertex normals from positions + faces on the device
     if (topo_change) { ctx->grid_valid = false; }
     ctx->face_warm = false;                               // face ids of another topology are no starting guess
+    ctx->have_owned = false;
     // a new mesh object = a new optimiser in the reference (_membrane_mesh.pyx:1510): history restarts
     NwDevState st{};
     st.stop_at = 0x7fffffff;
@@ -725,6 +726,18 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     NW_HIP(hipStreamSynchronize(ctx->stream));
     ctx->global_iter = 0;
     ctx->searched = false;
+    return NW_OK;
+}
+
+NW_EXPORT int nw_set_owned(nw_ctx *ctx, const uint8_t *owned)
+{
+    if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_owned: mesh not set");
+    ctx->have_owned = owned != nullptr;
+    if (owned) {
+        NW_HIP(ctx->owned.ensure(ctx->M));
+        NW_HIP(hipMemcpyAsync(ctx->owned.p, owned, ctx->M, hipMemcpyDefault, ctx->stream));
+        NW_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return NW_OK;
 }
 
@@ -909,7 +922,7 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
             hipLaunchKernelGGL(k_vertex_area_weights, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->NB, ctx->nbr.p, ctx->pos.p, ctx->wv.p, ctx->state.p, it);
         hipLaunchKernelGGL(k_prior_directions, dim3(prior_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->maxdeg, ctx->nbr_t.p, ctx->pos.p,
                            ctx->meshpos.p, ctx->nrm.p, ctx->vacc.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->part_p.p, ctx->state.p, it, n_search,
-                           ctx->acc_quantum, ctx->w_quantum, wfunc ? ctx->wv.p : nullptr);
+                           ctx->acc_quantum, ctx->w_quantum, wfunc ? ctx->wv.p : nullptr, ctx->have_owned ? ctx->owned.p : nullptr);
     }
     {
         StageScope s(ctx, ST_AS);

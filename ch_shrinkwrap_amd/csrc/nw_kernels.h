@@ -31,7 +31,7 @@ struct NwDevState {
     float tests[3];       // last three test statistics, oldest first
     int status;           // sticky nw_status raised on the device
     int nn_max_ring;
-    int pad;
+    int max_dist_bits;    // float bits of the largest point -> nearest-centroid distance of the current iteration (atomicMax; reset by k_solve_update)
 };
 
 // ============================================================================================================
@@ -436,6 +436,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
     const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK - 1) / NW_BLOCK);
     const int i = blk < 0 ? N : blk * blockDim.x + threadIdx.x;
     double red[4] = {0.0, 0.0, 0.0, 0.0};
+    float dmax = 0.0f;
     const int f_raw = i < N ? face[i] : 0;
     // a face id outside [0, F) can only come from a bug in the NN query: never dereference it (a faulting kernel can
     // take the whole node down), raise the internal-error status instead
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
         }
         red[2] = (double)d;
         red[3] = 1.0;
+        dmax = d;
         __builtin_memcpy(res + 3 * (int64_t)i, r, 12);           // three 12-byte stores instead of nine dword stores
         __builtin_memcpy(vidx + 3 * (int64_t)i, v, 12);
         __builtin_memcpy(wout + 3 * (int64_t)i, w, 12);
@@ -518,6 +520,10 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
         const int key = s_key[t >> 2];                     // four adjacent lanes flush the four components of one vertex
         if (key >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + 4 * (int64_t)key + (t & 3), s_val[(t & 3) * NW_HT + (t >> 2)]);
     }
+    // largest NN distance of the launch (a sharded run checks it against its halo radius): order-independent integer max
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(&st->max_dist_bits, __float_as_int(dmax));
     nw_block_reduce_store<4>(red, part, s_part);
 }
 
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
                                                               const float *__restrict__ meshpos, const float *__restrict__ nrm,
                                                               const long long *__restrict__ vacc, float *__restrict__ S, float *__restrict__ fdef_out,
                                                               float *__restrict__ pi_out, double *__restrict__ part, NwDevState *__restrict__ st, int it, int n_search,
-                                                              double q, double qw, const float *__restrict__ wv)
+                                                              double q, double qw, const float *__restrict__ wv, const unsigned char *__restrict__ owned)
 {
     if (it >= st->stop_at) return;
     __shared__ double s_part[14 * 4];
@@ -621,7 +627,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
             row[0] = s0[c];
             row[1] = s1;
             fdef_out[3 * v + c] = (float)fd[c];
-            // LS_k = L(S_k) in float32 (conj_grad.py:199); Hw = LS^T LS, Gw = -LS^T prefs64 (:211-212)
+            // LS_k = L(S_k) in float32 (conj_grad.py:199); Hw = LS^T LS, Gw = -LS^T prefs64 (:211-212).  A sharded mesh counts every
+            // vertex once: on the rank that owns it
+            if (owned && !owned[v]) continue;
             const float l0 = wv ? s0[c] * lw : s0[c], l1 = wv ? s1 * lw : s1, l2 = wv ? s2 * lw : s2;
             red[0] += (double)l0 * l0;
             red[1] += (double)l0 * l1;
@@ -776,7 +784,7 @@ __device__ __forceinline__ void nw_solve_small(const double *__restrict__ sc, fl
 }
 
 struct NwIterLogDev {   // mirrors nw_iter_log in include/nanowrap.h
-    double test, res_norm, prefs_norm, cpred, wpred, c[3], H[9], G[3], mean_dist;
+    double test, res_norm, prefs_norm, cpred, wpred, c[3], H[9], G[3], mean_dist, max_dist;
     int n_search, nn_max_ring, status, executed;
 };
 
@@ -846,6 +854,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
         for (int k = 0; k < 3; ++k) { L.c[k] = sol.c[k]; L.G[k] = sol.G[k]; }
         for (int k = 0; k < 9; ++k) L.H[k] = sol.H[k];
         L.mean_dist = sc[SC_NPTS] > 0 ? sc[SC_SUMD] / sc[SC_NPTS] : 0.0;
+        L.max_dist = (double)__int_as_float(st->max_dist_bits);
+        st->max_dist_bits = 0;
         L.n_search = n_search;
         L.nn_max_ring = st->nn_max_ring;
         if (sol.singular) atomicCAS(&st->status, 0, -4 /* NW_ERR_SINGULAR */);

@@ -235,6 +235,7 @@ class ShrinkwrapMeshConjGrad(object):
             self.wpreds = [np.float64(L.wpred)]
             self.nn_max_ring = max(self.nn_max_ring, int(L.nn_max_ring))
             self.mean_dist = float(L.mean_dist)
+            self.max_dist = max(getattr(self, 'max_dist', 0.0), float(L.max_dist))
         if executed:
             self._raw_logs.append((logs, executed))             # expanded on demand (iter_logs): keeps the per-block host time short
 

@@ -67,6 +67,7 @@ typedef struct nw_iter_log {
     double H[9];            /* regularised normal matrix actually solved (float32 values), row-major 3x3 */
     double G[3];
     double mean_dist;       /* mean point -> nearest-centroid distance (lower bound of the grid cell size) */
+    double max_dist;        /* largest point -> nearest-centroid distance (a sharded mesh checks it against its halo radius) */
     int32_t n_search;       /* 2 in the first iteration of a search() call, 3 afterwards               */
     int32_t nn_max_ring;    /* largest ring any point needed in the exact NN query                      */
     int32_t status;         /* NW_OK or the nw_status raised in this iteration                          */
@@ -169,6 +170,11 @@ int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes);
  * NULL) and/or into a strided host array of vertex records -- `rows` points at the first record's position field, consecutive
  * records are `row_stride_bytes` apart (120 for PYME's vertex_t) -- touching only the valid vertices (halfedge != -1). */
 int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes);
+/* Sharded mesh ('halo' mode): owned[M] = 1 for the vertices this rank owns, 0 for the copies of vertices owned by
+ * another rank.  The vertex-side normal-equation sums (S^T S, S.prefs, |prefs|^2) then run over the owned vertices only, so that the
+ * all-reduce over ranks counts every vertex once.  NULL = every vertex is owned (default).  Reset by nw_set_mesh. */
+int nw_set_owned(nw_ctx *ctx, const uint8_t *owned);
+
 /* registers the strided vertex records (mesh._vertices['position'] rows, `row_stride_bytes` apart) that nw_search / nw_search_end
  * fill together with `pos_out` at the end of every search (valid vertices only, mesh_conj_grad.py:288-289); NULL switches it off */
 int nw_set_write_back(nw_ctx *ctx, void *rows, int64_t row_stride_bytes);

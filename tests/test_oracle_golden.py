@@ -132,3 +132,55 @@ def test_live_reference_random_case():
     r = O.search(m2.vertices.copy(), m2.vertex_normals.copy(), m2.neighbor_vertex_table(), m2.faces, pts, [5.0], 7, s)
     assert np.array_equal(r.positions, out)
     assert np.array_equal(np.array(r.tests), np.array(cg.tests))
+
+
+def test_oracle_float64_points_and_wfunc_against_golden():
+    """Round-2 fixture (tests/golden/make_golden.py::golden_f64_and_regulariser): the oracle follows the dtype of `points` like the
+    reference (float64 residual / A f / Gc for float64 localizations) and restates the 'wfunc' regulariser; both bit-identical."""
+    from ch_shrinkwrap_amd.trimesh import TriMesh
+    g = load_golden('f64_and_wfunc')
+    s = 1.0 / np.full(g['points_f32'].size, 10.0, 'f4')
+
+    def mesh():
+        return TriMesh(g['mesh_vertices'], g['mesh_faces'])
+
+    for name, pts in (('f32', g['points_f32']), ('f64_same', g['points_f32'].astype('f8')), ('f64_raw', g['points_f64_raw'])):
+        m = mesh()
+        r = O.search(m.vertices.copy(), m.vertex_normals.copy(), m.neighbor_vertex_table(), m.faces, pts, [10.0], 5, s)
+        assert np.array_equal(r.positions, g[name + '_positions']), name
+        assert np.array_equal(np.array(r.tests, 'f8'), g[name + '_log_tests']), name
+        assert str(r.res.dtype) == str(g[name + '_res_dtype'])
+    m = mesh()
+    r = O.search(m.vertices.copy(), m.vertex_normals.copy(), m.neighbor_vertex_table(), m.faces, g['points_f32'], [float(g['wfunc_lams'][0])], 4, s,
+                 regulariser='wfunc')
+    assert np.array_equal(r.positions, g['wfunc_positions'])
+    assert np.array_equal(r.S, g['wfunc_S_final'])
+    assert np.array_equal(np.array(r.tests, 'f8'), g['wfunc_log_tests'])
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_harness.available(), reason='reference only exists in the build container')
+def test_live_reference_alternate_regularisers_fail_upstream():
+    """Why only ["I"] and ["wfunc"] are offered inside the loop: with the live default `_ncc()` (float64 because of its integer
+    division, mesh_conj_grad.py:782-800) the names that go through conj_grad_utils.c -- "Lfunc", "Lfunc3" -- hand a float64 buffer
+    to C code that reads float32 (conj_grad_utils.c:286-302, no dtype check): the reference raises in its first iteration."""
+    from ch_shrinkwrap_amd.trimesh import TriMesh, icosphere
+    v, f = icosphere(2, 60.0)
+    rng = np.random.default_rng(7)
+    d = rng.normal(size=(800, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    pts = (d * 50 + rng.normal(scale=4, size=d.shape)).astype('f4')
+    s = 1.0 / np.full(pts.size, 4.0, 'f4')
+    for names in (["Lfunc", "Lhfunc"], ["Lfunc3", "Lhfunc3"]):
+        mesh = TriMesh(v, f)
+        cg = ref_harness.new_reference_optimiser(mesh, pts, search_k=200, search_rad=100, shield_sigma=2.0)
+        cg.Lfuncs, cg.Lhfuncs = [names[0]], [names[1]]
+        with np.errstate(all='ignore'), pytest.raises((AssertionError, ValueError, FloatingPointError)):
+            cg.search(pts, lams=[1.0], num_iters=3, sigma_inv=s)
+    mesh = TriMesh(v, f)
+    cg = ref_harness.new_reference_optimiser(mesh, pts, search_k=200, search_rad=100, shield_sigma=2.0)
+    cg.Lfuncs, cg.Lhfuncs = ["wfunc"], ["wfunc"]
+    out = cg.search(pts, lams=[10.0], num_iters=3, sigma_inv=s)
+    m2 = TriMesh(v, f)
+    r = O.search(m2.vertices.copy(), m2.vertex_normals.copy(), m2.neighbor_vertex_table(), m2.faces, pts, [10.0], 3, s, regulariser='wfunc')
+    assert np.array_equal(r.positions, out)

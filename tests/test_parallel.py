@@ -6,6 +6,8 @@ stage functions (test infrastructure), and the sharded result is compared with t
   * mode 'replicated': localizations split by spatial tiles, mesh replicated -> all-reduce of the vertex accumulator + 13 scalars
   * mode 'tiles'     : two disjoint vesicles, one per rank -> all-reduce of all 24 scalars; must equal the single-process run
                        on the union scene (ONE global subspace solve, conj_grad.py:202-219).
+  * mode 'halo'      : ONE mesh sharded by spatial tiles (owned vertices + halo, ghosts); all-reduce of the boundary rows of the
+                       accumulator, of the scalars, and the owners' boundary positions; must equal the single-process run.
 GPU (world_size 1, nccl = RCCL): the split-phase C-ABI path must reproduce nw_search.
 """
 import os
@@ -33,6 +35,34 @@ class OracleExecutor(object):
     def __init__(self, pos, nrm, nbr, faces, points):
         self.pos0, self.nrm, self.nbr, self.faces, self.points = pos, nrm, nbr, faces, points
         self.M = pos.shape[0]
+        self.own3 = np.ones(3 * self.M, bool)
+        self.max_dist = 0.0
+
+    # -- 'halo' mode hooks (same contract as parallel.HipExecutor) ----------------------------------------------------
+    def set_boundary(self, b_local, b_slot, n_boundary, owned_local):
+        self.b_local, self.b_slot, self.n_boundary = np.asarray(b_local), torch.from_numpy(np.asarray(b_slot)), int(n_boundary)
+        self.own3 = np.repeat(np.asarray(owned_local, bool), 3)
+        self.b_owned = np.asarray(owned_local, bool)[self.b_local]
+
+    def pack_boundary_accumulator(self):
+        buf = torch.zeros((self.n_boundary, 4), dtype=torch.float32)
+        buf[self.b_slot] = self.vacc.view(-1, 4)[self.b_local]
+        return buf
+
+    def unpack_boundary_accumulator(self, buf):
+        self.vacc.view(-1, 4)[self.b_local] = buf[self.b_slot]
+
+    def pack_owned_boundary_positions(self):
+        buf = torch.zeros((self.n_boundary, 3), dtype=torch.float32)
+        rows = self.f.reshape(-1, 3)[self.b_local] * self.b_owned[:, None]
+        buf[self.b_slot] = torch.from_numpy(rows.astype('f4'))
+        return buf
+
+    def unpack_boundary_positions(self, buf):
+        f = self.f.reshape(-1, 3)
+        f[self.b_local] = buf[self.b_slot].numpy()
+        self.f = f.ravel()
+        self.cur = self.f.reshape(-1, 3).copy()
 
     def new_tensor(self, values):
         return torch.tensor(values, dtype=torch.float64)
@@ -61,6 +91,7 @@ class OracleExecutor(object):
         d3 = np.repeat(dmean, 3)
         res = (res * (1.0 / (d3 * self.sigma_inv / 2.0 + 1))).astype('f4')
         self.wm, self.res = (v_idx, w), res
+        self.max_dist = max(self.max_dist, float(dmean.max()))
         va = np.zeros((self.M, 4), 'f4')
         va[:, :3] = O.apply_At(res, v_idx, w, self.M).reshape(-1, 3)
         va[:, 3] = O.apply_At(np.ones_like(res), v_idx, w, self.M).reshape(-1, 3)[:, 0]
@@ -82,14 +113,16 @@ class OracleExecutor(object):
         self.S[:, 1] = -1.0 * p64.astype('f4')
         ns = 2 if self.it == 0 else 3
         self.ns = ns
-        S = self.S.astype('f8')
+        own = self.own3                    # vertex-side sums: every vertex once, on the rank that owns it
+        S = self.S.astype('f8')[own]
+        p64o = p64[own]
         idx = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
         for k, (a, b) in enumerate(idx):
             self.sc[13 + k] = float((S[:, a] * S[:, b]).sum()) if max(a, b) < ns else 0.0
         for k in range(3):
-            self.sc[19 + k] = float((S[:, k] * p64).sum()) if k < ns else 0.0
-        self.sc[22] = float((p64 * p64).sum())
-        self.sc[23] = float((p64.astype('f4').astype('f8') ** 2).sum())
+            self.sc[19 + k] = float((S[:, k] * p64o).sum()) if k < ns else 0.0
+        self.sc[22] = float((p64o * p64o).sum())
+        self.sc[23] = float((p64o.astype('f4').astype('f8') ** 2).sum())
         if self.wm is not None:
             v_idx, w = self.wm
             AS = np.stack([O.apply_A(self.S[:, k].copy(), v_idx, w, self.points).astype('f8') if k < ns else np.zeros(self.points.size)
@@ -158,6 +191,20 @@ def _worker(rank, world, port, mode, q):
             mine = parts[rank]
             ex = OracleExecutor(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts[mine])
             out = parallel.run_search(ex, dist, 'replicated', pts[mine], [7.0], 4, 1.0 / sigma[mine].ravel())
+        elif mode == 'halo':
+            (v, f, pts, sigma), = _scene(False)
+            mesh = TriMesh(v, f)
+
+            def make(local_mesh, local_points):
+                lm = local_mesh
+                nb = lm._halfedges['vertex'][lm._vertices['neighbors']]
+                nb[lm._vertices['neighbors'] == -1] = -1
+                return OracleExecutor(lm.vertices.copy(), lm.vertex_normals.copy(), np.ascontiguousarray(nb, np.int32), lm.faces, local_points)
+            scene = parallel.HaloScene(mesh, pts, dist, halo=35.0, make_executor=make)
+            out = scene.search([7.0], 4, 1.0 / sigma.ravel())
+            part = scene.last_partition
+            q.put((rank, (out, part.boundary.size, [int(d['nV']) for d in part.ranks], [int(d['owned'].sum()) for d in part.ranks])))
+            return
         else:
             v, f, pts, sigma = _scene(True)[rank]
             mesh = TriMesh(v, f)
@@ -213,6 +260,49 @@ def test_tiles_two_vesicles_gloo():
     assert rel_rms(res[0], ind.positions) > 1e-5
 
 
+@pytest.mark.timeout(300)
+def test_halo_sharded_mesh_gloo():
+    from oracle import nanowrap_oracle as O
+    res = _run('halo')
+    (v, f, pts, sigma), = _scene(False)
+    mesh = TriMesh(v, f)
+    ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, [7.0], 4, 1.0 / sigma.ravel())
+    (out0, nb, nV, nown), (out1, _, _, _) = res[0], res[1]
+    assert np.array_equal(out0, out1)                             # every rank ends with the same whole mesh
+    assert rel_rms(out0, ref.positions) <= 1e-5
+    M = v.shape[0]
+    assert sum(nown) == M and 0 < nb < M                          # every vertex owned once; a true sharding with a boundary
+    assert max(nV) < M                                            # no rank holds the whole mesh
+
+
+def test_halo_partition_invariants():
+    v, f = icosphere(4, 60.0)
+    mesh = TriMesh(v, f)
+    pts = sphere_cloud(9000, 50.0, 5.0, seed=4)
+    for n in (2, 3, 4, 8):
+        part = parallel.HaloPartition(mesh.vertices, mesh.vertex_normals, mesh.neighbor_vertex_table(), mesh.faces, pts, n, halo=20.0)
+        owned_total = np.zeros(v.shape[0], int)
+        held = np.zeros(v.shape[0], int)
+        for r, d in enumerate(part.ranks):
+            gv = d['gv']
+            assert np.unique(gv).size == gv.size
+            owned_total[gv[d['owned'].astype(bool)]] += 1
+            held[gv] += 1
+            nb = d['nbr']
+            # 1-rings of the computed vertices are complete and local; ghosts carry none
+            assert (nb[:d['nV']] >= -1).all() and (nb[:d['nV']] < gv.size).all() and (nb[d['nV']:] == -1).all()
+            full = mesh.neighbor_vertex_table()[gv[:d['nV']]]
+            assert np.array_equal(np.where(nb[:d['nV']] >= 0, gv[np.maximum(nb[:d['nV']], 0)], -1), full)
+            # every face centroid within the halo of one of the rank's localizations is among its faces
+            cent = mesh.vertices[mesh.faces].mean(1)
+            mine = set(map(tuple, np.sort(gv[d['faces']], 1)))
+            p = pts[d['pidx']]
+            near = np.nonzero((np.abs(cent[:, None, :] - p[None, ::37, :]).max(2) <= 20.0).any(1))[0]
+            assert all(tuple(np.sort(mesh.faces[k])) in mine for k in near)
+        assert (owned_total == 1).all()
+        assert np.array_equal(np.nonzero(held > 1)[0], part.boundary)
+
+
 def test_partition_by_tiles_is_a_partition():
     pts = sphere_cloud(5000, 50.0, 5.0, seed=2)
     for n in (1, 2, 3, 4, 8):
@@ -254,3 +344,81 @@ def test_split_phase_equals_search_on_one_gpu(mode):
     assert rel_rms(b, a) <= 1e-6
     assert cg.loopcount == 3 and len(cg.tests) == 8
     assert np.array_equal(m2.vertices, c)
+
+
+# ---- the HIP executor at world_size 2 (two fresh processes sharing cuda:0, gloo carrying the device tensors) -------------------
+def _gpu_worker(rank, world, port, mode, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+        ts = torch.cuda.Stream()
+        if mode == 'tiles':
+            v, f, pts, sigma = _scene(True)[rank]
+            mesh = TriMesh(v, f)
+            cg = ShrinkwrapMeshConjGrad(mesh, pts, stream=ts.cuda_stream)
+            scene = parallel.TiledScene(cg, dist, mode='tiles', torch_stream=ts)
+            out = scene.search(pts, [7.0], 4, 1.0 / sigma.ravel()).copy()
+            out = scene.search(pts, [7.0], 3, 1.0 / sigma.ravel()).copy()
+        elif mode == 'replicated':
+            (v, f, pts, sigma), = _scene(False)
+            mesh = TriMesh(v, f)
+            mine = parallel.partition_by_tiles(pts, world)[rank]
+            lp = np.ascontiguousarray(pts[mine])
+            cg = ShrinkwrapMeshConjGrad(mesh, lp, stream=ts.cuda_stream)
+            scene = parallel.TiledScene(cg, dist, mode='replicated', torch_stream=ts)
+            s = 1.0 / sigma[mine].ravel()
+            out = scene.search(lp, [7.0], 4, s).copy()
+            out = scene.search(lp, [7.0], 3, s).copy()
+        else:
+            (v, f, pts, sigma), = _scene(False)
+            mesh = TriMesh(v, f)
+            scene = parallel.HaloScene(mesh, pts, dist, halo=35.0, torch_stream=ts)
+            out = scene.search([7.0], 4, 1.0 / sigma.ravel())
+            mesh.update_geometry()
+            out = scene.search([7.0], 3, 1.0 / sigma.ravel())
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('mode', ['tiles', 'replicated', 'halo'])
+def test_hip_executor_two_ranks_share_one_gpu(mode):
+    """The N > 1 HIP path on hardware: two fresh processes, both on cuda:0, run HipExecutor (split-phase C-ABI, device buffers viewed
+    by torch, collectives between the phases) in every mode; the result must equal the single-process nw_search fit of the same
+    scene (two blocks: 4 + 3 iterations; for 'halo' the vertex normals are refreshed between the blocks on both sides)."""
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=400) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    if mode == 'tiles':
+        (v1, f1, p1, s1), (v2, f2, p2, s2) = _scene(True)
+        V = np.concatenate([v1, v2], 0)
+        F = np.concatenate([f1, f2 + v1.shape[0]], 0).astype('i4')
+        P, S = np.concatenate([p1, p2], 0), np.concatenate([s1, s2], 0)
+        got = np.concatenate([res[0], res[1]], 0)
+    else:
+        (V, F, P, S), = _scene(False)
+        assert np.array_equal(res[0], res[1])
+        got = res[0]
+    mesh = TriMesh(V, F)
+    cg = ShrinkwrapMeshConjGrad(mesh, P)
+    cg.search(P, lams=[7.0], num_iters=4, sigma_inv=1.0 / S.ravel())
+    if mode == 'halo':
+        mesh.update_geometry()
+        cg = ShrinkwrapMeshConjGrad(mesh, P)             # a new optimiser per block, as the sharded run builds one
+    ref = cg.search(P, lams=[7.0], num_iters=3, sigma_inv=1.0 / S.ravel())
+    rms = rel_rms(got, ref)
+    print('HIP executor, 2 ranks on one GPU, mode %s: vertex RMS vs single-process nw_search %.3e' % (mode, rms))
+    assert rms <= 1e-5
