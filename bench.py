@@ -184,8 +184,13 @@ def main():
         raise SystemExit('bench: only %d of %d timed iterations executed (stop condition fired): the throughput would be overstated' % (steps_done, args.steps))
     nn_ms, nn_launches = cg.stage_ms_total['nn']
     cg.set_profiling(2)
+    ctimer = None
+    if world > 1:
+        ctimer = parallel.CollectiveTimer()          # device time inside the RCCL collectives of the extra iterations
+        runner.ex.collective_timer = ctimer
     run_steps(2 * BLOCK)
     fence()
+    comm_ms, comm_n = ctimer.total_ms() if ctimer is not None else (0.0, 0)
     stage = dict(cg.stage_ms_total)
     n_extra = max(stage['update'][1], 1)
     if world > 1:
@@ -235,7 +240,8 @@ def main():
                                    % (WORKLOADS[args.config], N, M, F, BLOCK, '' if args.scale == 1.0 else ' [SCALED x%.3g: debug run]' % args.scale),
                        'localizations_per_gpu': N, 'vertices_per_gpu': M, 'faces_per_gpu': F, 'block': BLOCK,
                        'one_off_setup': 'projection re-sort of the localizations (nw_optimize_layout) done after the warm-up, before the timed region',
-                       'parallelism': 'tiles%d (one vesicle per GPU, 24-scalar RCCL all-reduce per iteration)' % world if world > 1 else 'single GPU'},
+                       'parallelism': ('tiles%d (one vesicle per GPU; the scene keeps ONE global subspace solve: one RCCL all-reduce of the 27 normal-equation '
+                                       'sums x 32 ordered parts = 6.9 KB per iteration, no vertex data)' % world) if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'kernel': kern[dom], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': ('profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-measured by this run)' if traffic is not None else None),
@@ -248,6 +254,10 @@ def main():
             'nn_max_ring': cg.nn_max_ring, 'mean_dist_nm': cg.mean_dist,
         }
         out['roofline_iteration']['frac'] = out['roofline_iteration']['achieved'] / HBM_PEAK_GBS
+        if world > 1:
+            out['collectives'] = {'ms_per_iter': comm_ms / n_extra, 'per_iter': comm_n / n_extra,
+                                  'share_of_device_time': (comm_ms / n_extra) / max(stage['total'][0] / n_extra + comm_ms / n_extra, 1e-12),
+                                  'note': 'rank 0, event-bracketed all-reduces of %d extra iterations after the timed region' % n_extra}
         # BASELINE.json north_star: ">= 40 % of the HBM-bandwidth roofline on the curvature+attraction kernel" (SURVEY 8d:
         # <= 0.17 ms/iter for them at C3): the attraction/scatter, curvature-prior, A.S and update kernels together, their
         # SURVEY-8d algorithmic bytes over their HIP-event spans

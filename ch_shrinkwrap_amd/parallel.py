@@ -186,22 +186,60 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ex.quantum(float(t[0]))
     n_red = ex.n_point_scalars if mode == 'replicated' else ex.n_scalars
+    timer = getattr(ex, 'collective_timer', None)        # optional (bench.py): device time spent inside the collectives
+
+    def all_reduce(t):
+        if timer is None:
+            dist.all_reduce(t)
+        else:
+            with timer:
+                dist.all_reduce(t)
+
     for _ in range(int(num_iters)):
         ex.attract()
         if mode == 'replicated':
-            dist.all_reduce(ex.vertex_accumulator())
+            all_reduce(ex.vertex_accumulator())
         elif mode == 'halo':
             buf = ex.pack_boundary_accumulator()             # (|B|, 4): this rank's partial sums of the boundary vertices it holds
-            dist.all_reduce(buf)
+            all_reduce(buf)
             ex.unpack_boundary_accumulator(buf)
         ex.directions()
-        dist.all_reduce(ex.scalars(n_red))
+        all_reduce(ex.scalars(n_red))
         ex.update()
         if mode == 'halo':
             buf = ex.pack_owned_boundary_positions()         # (|B|, 3): rows of the boundary vertices this rank OWNS, zero elsewhere
-            dist.all_reduce(buf)
+            all_reduce(buf)
             ex.unpack_boundary_positions(buf)
     return ex.end()
+
+
+class CollectiveTimer(object):
+    """Context manager that brackets collectives with events on the current torch stream; total_ms() synchronises and sums."""
+
+    def __init__(self):
+        self.pairs = []
+        self.ms = 0.0
+        self.count = 0
+
+    def __enter__(self):
+        import torch
+        self._a = torch.cuda.Event(enable_timing=True)
+        self._a.record()
+
+    def __exit__(self, *exc):
+        import torch
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
+        self.pairs.append((self._a, b))
+
+    def total_ms(self):
+        import torch
+        torch.cuda.synchronize()
+        for a, b in self.pairs:
+            self.ms += a.elapsed_time(b)
+            self.count += 1
+        self.pairs = []
+        return self.ms, self.count
 
 
 class TiledScene(object):
