@@ -1226,16 +1226,17 @@ __global__ __launch_bounds__(128) void k_curvature(int M, int NB, const float *_
     const float Hf = (float)(0.5 * (double)(k0f + k1f));
     const float Kf = (float)(k0f * k1f);
     H[i] = Hf; K[i] = Kf;
-    // pass 3: quadric fit in the (e0,e1) plane displaced by dN -> principal curvatures after the shift
-    double S00 = 0, S01 = 0, S11 = 0, r0 = 0, r1 = 0;
+    // pass 3: quadric fit in the (e0,e1) plane displaced by dN -> principal curvatures after the shift.  Same order of operations as
+    // the reference's matmul chain (membrane_mesh_utils.c:1165-1187): A^T A by rows of A in neighbour order, its 2x2 pseudo-inverse,
+    // then (pinv A^T)[.][j] b[j] summed in neighbour order (second walk over the ring; the unused slots of the fixed 2x20 arrays
+    // contribute exact zeros there).
+    double S00 = 0, S01 = 0, S11 = 0;
     for (int j = 0; j < n; ++j) {
         const int v = row[j];
         const double dx = (double)pos[3 * v] - (double)vix, dy = (double)pos[3 * v + 1] - (double)viy, dz = (double)pos[3 * v + 2] - (double)viz;
         const double t0 = (dx * v1x + dy * v1y) + dz * v1z, t1 = (dx * v2x + dy * v2y) + dz * v2z;
         const double A0 = t0 * t0, A1 = t1 * t1;
-        const double b = A0 * (double)k0f + A1 * (double)k1f - (double)dN;
         S00 += A0 * A0; S01 += A0 * A1; S11 += A1 * A1;
-        r0 += A0 * b; r1 += A1 * b;
     }
     double kp0, kp1;
     {
@@ -1254,8 +1255,16 @@ __global__ __launch_bounds__(128) void k_curvature(int M, int NB, const float *_
         const double si0 = (sig0 < thresh) ? 0.0 : (1.0 / sig0), si1 = (sig1 < thresh) ? 0.0 : (1.0 / sig1);
         const double s0 = sign0 * si0, s1 = sign1 * si1;
         const double i00 = ctcp * s0 + stsp * s1, i01 = ctsp * s0 - stcp * s1, i10 = stcp * s0 - ctsp * s1, i11 = stsp * s0 + ctcp * s1;
-        kp0 = i00 * r0 + i01 * r1;
-        kp1 = i10 * r0 + i11 * r1;
+        kp0 = 0.0; kp1 = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const int v = row[j];
+            const double dx = (double)pos[3 * v] - (double)vix, dy = (double)pos[3 * v + 1] - (double)viy, dz = (double)pos[3 * v + 2] - (double)viz;
+            const double t0 = (dx * v1x + dy * v1y) + dz * v1z, t1 = (dx * v2x + dy * v2y) + dz * v2z;
+            const double A0 = t0 * t0, A1 = t1 * t1;
+            const double b = A0 * (double)k0f + A1 * (double)k1f - (double)dN;
+            kp0 += (i00 * A0 + i01 * A1) * b;
+            kp1 += (i10 * A0 + i11 * A1) * b;
+        }
     }
     const float dHf = (float)(0.5 * (kp0 + kp1)), dKf = (float)(kp0 * kp1);
     dH[i] = dHf; dK[i] = dKf;

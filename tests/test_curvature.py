@@ -76,14 +76,12 @@ def test_hip_curvature_vs_reference_golden():
     m._vertices, m._halfedges, m._faces, m._origin = m2._vertices, m2._halfedges, m2._faces, m2._origin
     dEdN = m.curvature_grad_c(dN=dN, jitter=g['jitter'])
     got = dict(k0=m._k_0, k1=m._k_1, e0=m._e_0, e1=m._e_1, H=m._H, K=m._K, dH=m._dH, dK=m._dK, E=m._E, pE=m._pE, dEn=m._dE_neighbors, dEdN=dEdN)
-    for n in ('k0', 'k1', 'H', 'K', 'E', 'pE', 'e0', 'e1'):
+    # all twelve outputs at ONE tolerance, no exceptions: the kernel follows the reference's order of operations, including the
+    # matmul chain of the least-squares fit (membrane_mesh_utils.c:1165-1187); on MI355X every value is in fact bit-identical to the
+    # golden (tools/curv_diag.py), the tolerance only allows for a different libm (atan2 / sin / cos / exp in float64)
+    for n in ('k0', 'k1', 'H', 'K', 'E', 'pE', 'e0', 'e1', 'dH', 'dK', 'dEn', 'dEdN'):
         a, b = got[n], g['out_' + n]
         assert np.allclose(a, b, rtol=2e-5, atol=1e-7 * max(1.0, np.abs(b).max())), n
-    for n in ('dH', 'dK', 'dEn', 'dEdN'):
-        # least-squares / finite-difference outputs: same formulas, sums reordered (A^T A accumulated on the fly)
-        a, b = got[n], g['out_' + n]
-        bad = ~np.isclose(a, b, rtol=2e-3, atol=1e-5 * max(1.0, np.abs(b).max()))
-        assert bad.mean() < 2e-3, (n, bad.mean())
     # without a supplied rand() stream the deterministic outputs are unchanged and the run is reproducible
     m.curvature_grad_c(dN=dN)
     assert np.allclose(m._H, g['out_H'], rtol=2e-5, atol=1e-8)
