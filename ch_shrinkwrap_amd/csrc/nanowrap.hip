@@ -158,7 +158,6 @@ struct nw_ctx {
     DevBuf<NwItem> items;             // work list of the NN query: runs of <= 64 Morton-consecutive localizations
     int nitems = 0;
     int item_level = -1;              // Morton level (block edge = morton_unit * 2^level) the items were cut at
-    int64_t cent_pad_F = -1;
     DevBuf<unsigned long long> nn_stats;   // developer counters of the NN query (nw_debug_nn_stats); null unless enabled
     DevBuf<unsigned> proj_key;        // projection keys of the last completed query (second sort, see k_projection_keys)
     DevBuf<int> proj_idx;
@@ -452,14 +451,7 @@ int alloc_work(nw_ctx *ctx)
 {
     const int64_t N = ctx->N, M = ctx->M, F = ctx->F;
     NW_HIP(ctx->cent_tmp.ensure(F));
-    NW_HIP(ctx->cent.ensure(F + NW_CENT_PAD));
-    if (ctx->cent_pad_F != F) {
-        // far-away pad entries behind the last centroid: the NN kernel reads candidates four at a time, one batch ahead
-        float pad[4 * NW_CENT_PAD];
-        for (int k = 0; k < 4 * NW_CENT_PAD; ++k) pad[k] = (k & 3) == 3 ? 0.0f : 1e18f;
-        NW_HIP(hipMemcpy(ctx->cent.p + F, pad, sizeof(pad), hipMemcpyHostToDevice));
-        ctx->cent_pad_F = F;
-    }
+    NW_HIP(ctx->cent.ensure(F));
     NW_HIP(ctx->fcell.ensure(F));
     NW_HIP(ctx->frank.ensure(F));
     NW_HIP(ctx->face.ensure(N));
@@ -474,7 +466,7 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->fdef.ensure(3 * M));
     NW_HIP(ctx->pi.ensure(M));
     NW_HIP(ctx->scalars.ensure(NW_N_SCALARS * NW_SPARTS));
-    NW_HIP(ctx->part_a.ensure((size_t)4 * attract_blocks(ctx)));
+    NW_HIP(ctx->part_a.ensure((size_t)5 * attract_blocks(ctx)));
     NW_HIP(ctx->part_s.ensure((size_t)9 * attract_blocks(ctx)));
     NW_HIP(ctx->part_p.ensure((size_t)14 * prior_blocks(ctx)));
     NW_HIP(ctx->wv.ensure(ctx->M));
@@ -486,7 +478,7 @@ int alloc_work(nw_ctx *ctx)
 // =============================================================================================================
 NW_EXPORT int nw_abi_version(void) { return NW_ABI_VERSION; }
 NW_EXPORT int nw_n_point_scalars(void) { return SC_NPOINT; }
-NW_EXPORT int nw_n_scalars(void) { return SC_COUNT; }
+NW_EXPORT int nw_n_scalars(void) { return SC_MAXD; }      // the SUMMED slots (what ranks all-reduce); the max-distance slot behind them stays local
 NW_EXPORT int nw_scalar_stride(void) { return NW_SPARTS; }
 
 NW_EXPORT int nw_create(int device, nw_ctx **out)

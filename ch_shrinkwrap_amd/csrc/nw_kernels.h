@@ -20,7 +20,8 @@ enum {
     SC_PP32 = 23,    // sum prefs32^2 -> prefs log                mesh_conj_grad.py:271
     SC_T = 24,       // 3: S0.S0, S0.S1, S1.S1 of the RAW directions -> test statistic (mesh_conj_grad.py:262-265); equal to SC_SS
                      //    entries 0, 1, 3 unless a regulariser other than the identity scales the directions (wfunc)
-    SC_COUNT = 27
+    SC_MAXD = 27,    // largest NN distance (a MAX, not a sum: k_reduce_scalars / k_solve_update treat this slot accordingly)
+    SC_COUNT = 28
 };
 
 #define NW_SPARTS 32      // ordered partial sums per scalar slot (k_reduce_scalars)
@@ -31,7 +32,7 @@ struct NwDevState {
     float tests[3];       // last three test statistics, oldest first
     int status;           // sticky nw_status raised on the device
     int nn_max_ring;
-    int max_dist_bits;    // float bits of the largest point -> nearest-centroid distance of the current iteration (atomicMax; reset by k_solve_update)
+    int pad;
 };
 
 // ============================================================================================================
@@ -520,11 +521,24 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
         const int key = s_key[t >> 2];                     // four adjacent lanes flush the four components of one vertex
         if (key >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + 4 * (int64_t)key + (t & 3), s_val[(t & 3) * NW_HT + (t >> 2)]);
     }
-    // largest NN distance of the launch (a sharded run checks it against its halo radius): order-independent integer max
+    // per-workgroup partial sums (row of 5: four sums + the largest NN distance of the workgroup, which a sharded run checks against
+    // its halo radius; a same-address atomicMax from every wave serialised: 40 us at 1M localizations, 0.7 ms at 5M)
+    {
+        __shared__ float s_dmax[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
-    if ((threadIdx.x & 63) == 0 && dmax > 0.0f) atomicMax(&st->max_dist_bits, __float_as_int(dmax));
-    nw_block_reduce_store<4>(red, part, s_part);
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+        if ((threadIdx.x & 63) == 0) s_dmax[threadIdx.x >> 6] = dmax;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double sk = nw_wave_sum(red[k]);
+            if (lane == 0) s_part[k * 4 + wv] = sk;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4)
+            part[(int64_t)blockIdx.x * 5 + threadIdx.x] = (s_part[threadIdx.x * 4 + 0] + s_part[threadIdx.x * 4 + 1]) + (s_part[threadIdx.x * 4 + 2] + s_part[threadIdx.x * 4 + 3]);
+        if (threadIdx.x == 4) part[(int64_t)blockIdx.x * 5 + 4] = (double)fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+    }
 }
 
 // K5: curvature prior + search directions S0, S1 + all vertex-side dot products.  One thread per vertex;
@@ -798,8 +812,11 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
     __shared__ double s_sc[SC_COUNT];
     if (threadIdx.x < SC_COUNT) {
         double t = 0.0;
+        if (threadIdx.x == SC_MAXD) { for (int b = 0; b < NW_SPARTS; ++b) t = fmax(t, sc_parts[threadIdx.x * NW_SPARTS + b]); }
+        else {
 #pragma unroll 8
-        for (int b = 0; b < NW_SPARTS; ++b) t += sc_parts[threadIdx.x * NW_SPARTS + b];
+            for (int b = 0; b < NW_SPARTS; ++b) t += sc_parts[threadIdx.x * NW_SPARTS + b];
+        }
         s_sc[threadIdx.x] = t;
     }
     __syncthreads();
@@ -854,8 +871,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
         for (int k = 0; k < 3; ++k) { L.c[k] = sol.c[k]; L.G[k] = sol.G[k]; }
         for (int k = 0; k < 9; ++k) L.H[k] = sol.H[k];
         L.mean_dist = sc[SC_NPTS] > 0 ? sc[SC_SUMD] / sc[SC_NPTS] : 0.0;
-        L.max_dist = (double)__int_as_float(st->max_dist_bits);
-        st->max_dist_bits = 0;
+        L.max_dist = sc[SC_MAXD];
         L.n_search = n_search;
         L.nn_max_ring = st->nn_max_ring;
         if (sol.singular) atomicCAS(&st->status, 0, -4 /* NW_ERR_SINGULAR */);
@@ -876,7 +892,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
 // (one workgroup alone is limited by the ~25 GB/s a single CU pulls: 23 us) into sc[slot * NW_SPARTS + part]; the consumer
 // (k_solve_update, every workgroup for itself) adds the NW_SPARTS values of a slot in order.  Each share is read flat and
 // coalesced by a number of threads that is a multiple of the row length, so a thread stays on one column.
-template <int NV, int NT>
+template <int NV, int NT, int MAXCOL, int MAXSLOT>
 __device__ __forceinline__ void nw_reduce_columns(const double *__restrict__ part, int nblk, double *s_acc /* [NT] */, double *__restrict__ sc, int slot0)
 {
     static_assert(NT % NV == 0 && NT <= NW_BLOCK, "thread count must be a multiple of the row length");
@@ -888,15 +904,21 @@ __device__ __forceinline__ void nw_reduce_columns(const double *__restrict__ par
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;       // four independent chains: loads in flight, fixed association
     if (t < NT) {
         int64_t e = t;
-        for (; e + 3 * NT < total; e += 4 * NT) { a0 += p[e]; a1 += p[e + NT]; a2 += p[e + 2 * NT]; a3 += p[e + 3 * NT]; }
-        for (; e < total; e += NT) a0 += p[e];
-        s_acc[t] = (a0 + a1) + (a2 + a3);
+        if (MAXCOL >= 0 && t % NV == MAXCOL) {           // this thread's column holds maxima (all values >= 0)
+            for (; e < total; e += NT) a0 = fmax(a0, p[e]);
+            s_acc[t] = a0;
+        } else {
+            for (; e + 3 * NT < total; e += 4 * NT) { a0 += p[e]; a1 += p[e + NT]; a2 += p[e + 2 * NT]; a3 += p[e + 3 * NT]; }
+            for (; e < total; e += NT) a0 += p[e];
+            s_acc[t] = (a0 + a1) + (a2 + a3);
+        }
     }
     __syncthreads();
     if (t < NV) {
         double s = 0.0;
-        for (int k = t; k < NT; k += NV) s += s_acc[k];
-        sc[(slot0 + t) * NW_SPARTS + blockIdx.x] = s;
+        if (MAXCOL >= 0 && t == MAXCOL) { for (int k = t; k < NT; k += NV) s = fmax(s, s_acc[k]); }
+        else { for (int k = t; k < NT; k += NV) s += s_acc[k]; }
+        sc[((MAXCOL >= 0 && t == MAXCOL) ? MAXSLOT : slot0 + t) * NW_SPARTS + blockIdx.x] = s;
     }
     __syncthreads();
 }
@@ -907,9 +929,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_reduce_scalars(const double *__res
 {
     if (it >= st->stop_at) return;
     __shared__ double s_acc[NW_BLOCK];
-    nw_reduce_columns<4, 256>(part_a, nblk_a, s_acc, sc, SC_RES2);        // k_attract: res^2, masked res^2, sum d, count
-    nw_reduce_columns<9, 252>(part_s, nblk_s, s_acc, sc, SC_HC);          // k_subspace_point_sums: Hc (6), Gc (3)
-    nw_reduce_columns<14, 252>(part_p, nblk_p, s_acc, sc, SC_SS);         // k_prior_directions: LS^T LS (6), LS.prefs (3), |prefs|^2 (2), raw S.S (3)
+    nw_reduce_columns<5, 255, 4, SC_MAXD>(part_a, nblk_a, s_acc, sc, SC_RES2);   // k_attract: res^2, masked res^2, sum d, count; max d
+    nw_reduce_columns<9, 252, -1, 0>(part_s, nblk_s, s_acc, sc, SC_HC);          // k_subspace_point_sums: Hc (6), Gc (3)
+    nw_reduce_columns<14, 252, -1, 0>(part_p, nblk_p, s_acc, sc, SC_SS);         // k_prior_directions: LS^T LS (6), LS.prefs (3), |prefs|^2 (2), raw S.S (3)
 }
 
 // ============================================================================================================

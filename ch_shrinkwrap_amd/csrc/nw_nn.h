@@ -194,16 +194,19 @@ struct NwLane {
     float ax, ay, az;        // u + eps      } distance (cell units) from u to the slab [k - eps, k + 1 + eps] of cell index k:
     float bx, by, bz;        // u - 1 - eps  }   max(k - a, b - k, 0)
     unsigned b1, b2;         // best / runner-up key
-    int bbase;               // first slot of the chunk the best candidate came from (-1: none yet); slot = bbase + (b1 & 15)
+    int bgi;                 // position (in the list being streamed) of the 16-chunk the best candidate came from, -1: unchanged
+    int bslot;               // slot of the best candidate in the cell-sorted centroid array (-1: none yet)
     unsigned keymask;        // NW_KEY_MASK, pinned in a vector register
 };
 
 __device__ __forceinline__ float nw_best_d2(const NwLane &L) { return __uint_as_float(L.b1); }
 
-// one candidate (wave-uniform: scalar registers) against all lanes; K = its position in the chunk (an inline constant)
+// one candidate (the same for all lanes: an LDS broadcast read) against the lanes' localizations; K = its position in the
+// 16-chunk (an inline constant)
 template <int K>
 __device__ __forceinline__ void nw_eval(NwLane &L, const float4 C)
 {
+    asm volatile("" :: "v"(C.w));              // keeps the read a 16-byte ds_read_b128 (ds_read_b96 takes twice the LDS cycles)
     const float dx = L.px - C.x, dy = L.py - C.y, dz = L.pz - C.z;
     const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     unsigned key, b2;
@@ -213,81 +216,97 @@ __device__ __forceinline__ void nw_eval(NwLane &L, const float4 C)
     L.b1 = min(L.b1, key);
 }
 
-struct alignas(16) NwCand4 { float4 c[4]; };
-template <int K0>
-__device__ __forceinline__ void nw_eval4(NwLane &L, const NwCand4 &A)
-{
-    nw_eval<K0>(L, A.c[0]);
-    nw_eval<K0 + 1>(L, A.c[1]);
-    nw_eval<K0 + 2>(L, A.c[2]);
-    nw_eval<K0 + 3>(L, A.c[3]);
-}
-
-// candidates [s, e) of the cell-sorted array, in chunks of 16; eight candidates (two s_load_dwordx16) are requested per wait.
-// The array is padded by NW_CENT_PAD entries, so reading up to e + 7 is safe, and evaluating a neighbour cell's centroid is
-// harmless (it is a real candidate).
-#define NW_CENT_PAD 8
-__device__ __forceinline__ void nw_eval_range(NwLane &L, const float4 *__restrict__ cent, int s, int e, NwStats &S)
-{
-    S.v[NWS_CAND] += (e - s + 3) & ~3;
-    for (int c = s; c < e; c += 16) {
-        const unsigned before = L.b1;
-        const NwCand4 *__restrict__ q = reinterpret_cast<const NwCand4 *>(cent + c);
-        {
-            const NwCand4 A = q[0], B = q[1];
-            nw_eval4<0>(L, A);
-            if (c + 4 < e) nw_eval4<4>(L, B);
-        }
-        if (c + 8 < e) {
-            const NwCand4 A = q[2], B = q[3];
-            nw_eval4<8>(L, A);
-            if (c + 12 < e) nw_eval4<12>(L, B);
-        }
-        L.bbase = (L.b1 != before) ? c : L.bbase;
-    }
-}
-
 // distance (cell units) from the lane's coordinate to the slab [k - eps, k + 1 + eps] of cell index k (a, b: see NwLane)
 __device__ __forceinline__ float nw_slab_d(float a, float b, float kf)
 {
     return fmaxf(fmaxf(kf - a, b - kf), 0.0f);
 }
 
-// visit the cells [xa, xb] of the row (y, z): candidates [s, e).  dyz2 = per-lane squared (y,z) distance to the row (cell units).
-// lane k fetches the start of cell k's candidates (one round trip for the run); every non-empty cell is then tested against the
-// lanes' CURRENT bests (ball against cell box), and the surviving cells are evaluated run by run.
-__device__ __forceinline__ void nw_visit_run(NwLane &L, const NwGrid &g, const int *__restrict__ cstart, const float4 *__restrict__ cent,
-                                             int rowbase, int xa, int xb, int s, int e, float dyz2, float epsu, float cullk, int lane, NwStats &S)
+// ---- wave-private LDS: the list of candidate ranges collected by the walk, and one batch of 64 staged candidates ---------
+#define NW_SEG 8             // cells per row segment (one lane fetches the 9 cell starts of a segment)
+#define NW_RNG_MAX 48        // ranges collected before they are streamed
+struct NwWaveLds {
+    float4 cand[64];                 // one batch of candidates: lane i stages candidate i, every lane then reads them all (broadcast)
+    int rs[NW_RNG_MAX];              // first slot of range r
+    int pre[NW_RNG_MAX + 1];         // candidates before range r (pre[nr] = total)
+};
+
+// LDS traffic inside ONE wave is in program order; this only stops the compiler from moving accesses across the point
+__device__ __forceinline__ void nw_wave_lds_sync()
 {
-    if (e - s <= 8) { S.v[NWS_SMALL_RUNS] += 1; nw_eval_range(L, cent, s, e, S); return; }       // too few to be worth a per-cell test
-    for (int xc = xa; xc <= xb; xc += 63) {
-        const int n = min(63, xb - xc + 1);
-        const int cs = cstart[rowbase + xc + min(lane, n)];            // lane k: first candidate of cell xc + k (k = n: end)
-        const int nx = __shfl_down(cs, 1, 64);
-        unsigned long long ne = __ballot(lane < n && nx > cs);
-        unsigned long long pass = 0ull;
-        unsigned long long t = ne;
-        const float r2u = nw_best_d2(L) * cullk + epsu;                 // culling radius^2, cell units
-        while (t) {
-            const int k = __builtin_ctzll(t);
-            t &= t - 1ull;
-            const float dx = nw_slab_d(L.ax, L.bx, (float)(xc + k));
-            S.v[NWS_CELLS_TESTED] += 1;
-            if (__any(fmaf(dx, dx, dyz2) <= r2u)) { pass |= 1ull << k; S.v[NWS_CELLS_PASS] += 1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// lane -> slot of the g-th candidate of the collected list (binary search in the prefix counts; nr <= 48 < 64: six steps)
+__device__ __forceinline__ int nw_list_slot(const NwWaveLds *W, int nr, int g)
+{
+    int lo = 0, hi = nr;                      // invariant: pre[lo] <= g < pre[hi]
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+        const int mid = (lo + hi) >> 1;
+        const bool right = W->pre[mid] <= g;
+        lo = right ? mid : lo;
+        hi = right ? hi : mid;
+    }
+    return W->rs[lo] + (g - W->pre[lo]);
+}
+
+// Stream the collected ranges: 64 candidates per batch are fetched by the 64 lanes (one coalesced-ish global load each), staged in
+// LDS and evaluated by every lane against its localization; the fetch of batch b+1 is in flight while batch b is evaluated.
+__device__ __forceinline__ void nw_stream(NwLane &L, NwWaveLds *W, const float4 *__restrict__ cent, int nr, int total, int lane, NwStats &S)
+{
+    if (total <= 0) return;
+    S.v[NWS_CAND] += (total + 3) & ~3;
+    W->pre[nr] = total;
+    nw_wave_lds_sync();
+    // lanes past the end of the list stage a far-away dummy (the last group of four of a batch is evaluated whole)
+    float4 C = cent[nw_list_slot(W, nr, min(lane, total - 1))];
+    if (lane >= total) { C.x = 1e18f; C.y = 1e18f; C.z = 1e18f; }
+    for (int g0 = 0; g0 < total; g0 += 64) {
+        W->cand[lane] = C;
+        nw_wave_lds_sync();
+        const int gn = g0 + 64 + lane;
+        if (g0 + 64 < total) {                                                            // next batch: in flight during the evaluation
+            C = cent[nw_list_slot(W, nr, min(gn, total - 1))];
+            if (gn >= total) { C.x = 1e18f; C.y = 1e18f; C.z = 1e18f; }
         }
-        // runs of surviving cells; empty cells in between join a run for free
-        const unsigned long long joinable = pass | ~ne;
-        while (pass) {
-            const int k0 = __builtin_ctzll(pass);
-            const unsigned long long stop = ~joinable >> k0;            // first cell >= k0 that is non-empty and culled
-            const int len = stop ? __builtin_ctzll(stop) : 64 - k0;
-            const int k1 = min(k0 + len, n);
-            const int c0 = __builtin_amdgcn_readlane(cs, k0), c1 = __builtin_amdgcn_readlane(cs, k1);
-            nw_eval_range(L, cent, c0, c1, S);
-            pass = (k1 >= 64) ? 0ull : (pass >> k1) << k1;
+        const int cnt = min(64, total - g0);
+        for (int c = 0; c < cnt; c += 16) {
+            const unsigned before = L.b1;
+            const float4 *q = W->cand + c;
+            nw_eval<0>(L, q[0]); nw_eval<1>(L, q[1]); nw_eval<2>(L, q[2]); nw_eval<3>(L, q[3]);
+            if (c + 4 < cnt) { nw_eval<4>(L, q[4]); nw_eval<5>(L, q[5]); nw_eval<6>(L, q[6]); nw_eval<7>(L, q[7]); }
+            if (c + 8 < cnt) { nw_eval<8>(L, q[8]); nw_eval<9>(L, q[9]); nw_eval<10>(L, q[10]); nw_eval<11>(L, q[11]); }
+            if (c + 12 < cnt) { nw_eval<12>(L, q[12]); nw_eval<13>(L, q[13]); nw_eval<14>(L, q[14]); nw_eval<15>(L, q[15]); }
+            L.bgi = (L.b1 != before) ? g0 + c : L.bgi;
         }
+        nw_wave_lds_sync();                   // all reads of this batch precede the next staging write
+    }
+    // lanes whose best changed: position in the list -> slot in the centroid array (the list is about to be reused)
+    if (L.bgi >= 0) L.bslot = nw_list_slot(W, nr, L.bgi + (int)(L.b1 & 15u));
+    L.bgi = -1;
+    nw_wave_lds_sync();
+}
+
+// lane j's k-th cell start (k wave-uniform, 0..8): the nine values live in nine registers, picked by a scalar branch
+__device__ __forceinline__ int nw_pick(const int (&cs)[NW_SEG + 1], int k, int j)
+{
+    switch (k) {
+    case 0: return __builtin_amdgcn_readlane(cs[0], j);
+    case 1: return __builtin_amdgcn_readlane(cs[1], j);
+    case 2: return __builtin_amdgcn_readlane(cs[2], j);
+    case 3: return __builtin_amdgcn_readlane(cs[3], j);
+    case 4: return __builtin_amdgcn_readlane(cs[4], j);
+    case 5: return __builtin_amdgcn_readlane(cs[5], j);
+    case 6: return __builtin_amdgcn_readlane(cs[6], j);
+    case 7: return __builtin_amdgcn_readlane(cs[7], j);
+    default: return __builtin_amdgcn_readlane(cs[8], j);
     }
 }
+
+__device__ __forceinline__ float nw_readlane_f(float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); }
 
 __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
                                                  const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,
@@ -295,6 +314,7 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
                                                  NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats)
 {
     if (it >= st->stop_at) return;
+    __shared__ NwWaveLds s_wave[4];
     NwStats S;
 #pragma unroll
     for (int k = 0; k < NWS_COUNT; ++k) S.v[k] = 0;
@@ -305,6 +325,7 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
     const int wb = (warm & 2) ? ((int)blockIdx.x < nwb ? (int)blockIdx.x : -1) : nw_xcd_remap(blockIdx.x, nwb);
     const int wi = __builtin_amdgcn_readfirstlane(wb * wpb + (int)(threadIdx.x >> 6));
     if (wi < 0 || wi >= nitems) return;
+    NwWaveLds *W = &s_wave[threadIdx.x >> 6];
     const NwItem item = items[wi];
     const bool active = lane < item.n;
     const int gi = item.p0 + (active ? lane : 0);                        // idle lanes shadow lane 0 (they never write)
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
     const float epsu = g.eps * g.inv_h;                                  // rounding slack of the cell assignment, cell units
     L.ax = L.ux + epsu; L.ay = L.uy + epsu; L.az = L.uz + epsu;
     L.bx = L.ux - 1.0f - epsu; L.by = L.uy - 1.0f - epsu; L.bz = L.uz - 1.0f - epsu;
-    L.b1 = NW_KEY_INF; L.b2 = NW_KEY_INF; L.bbase = -1;
+    L.b1 = NW_KEY_INF; L.b2 = NW_KEY_INF; L.bgi = -1; L.bslot = -1;
     L.keymask = NW_KEY_MASK;
     asm volatile("" : "+v"(L.keymask));
     int prev = -1;
@@ -364,51 +385,84 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
             }
         }
         ++rounds;
-        // ---- visit N \ E: lane = (z,y) row of N
+        // ---- walk N \ E.  lane = one SEGMENT of NW_SEG cells of one (z,y) row of N: it fetches the segment's nine cell starts (all
+        // requests of 64 segments in flight together: one round trip), and knows which of its cells hold centroids and are new.
         const int ny = Nyh - Nyl + 1, nrows = ny * (Nzh - Nzl + 1);
-        const float inv_ny = 1.0f / (float)ny;
+        const int nchunk = (Nxh - Nxl + NW_SEG) / NW_SEG, nseg = nrows * nchunk;
+        const float inv_ny = 1.0f / (float)ny, inv_nc = 1.0f / (float)nchunk;
+        const float r2u = nw_best_d2(L) * cullk + epsu;                 // culling radius^2 (cell units) for this round
         S.v[NWS_BOX_ROWS] += nrows;
-        for (int rb = 0; rb < nrows; rb += 64) {
-            const int r = rb + lane;
-            const bool ok = r < nrows;
-            const int rz = (int)(((float)r + 0.5f) * inv_ny);             // exact r / ny for the small ints involved
+        int nr = 0, total = 0;                                           // collected ranges (wave-uniform)
+        for (int sb = 0; sb < nseg; sb += 64) {
+            const int sidx = sb + lane;
+            const bool ok = sidx < nseg;
+            const int r = (int)(((float)sidx + 0.5f) * inv_nc);           // exact sidx / nchunk for the small ints involved
+            const int ch = sidx - r * nchunk;
+            const int rz = (int)(((float)r + 0.5f) * inv_ny);
             const int y = Nyl + (r - rz * ny), z = Nzl + rz;
-            const bool inE = Eok && y >= Eyl && y <= Eyh && z >= Ezl && z <= Ezh;
+            const int xa = Nxl + NW_SEG * ch;
+            const int nxh = min(NW_SEG, Nxh - xa + 1);                    // cells of this segment
             const int rowbase = g.gx * (y + g.gy * z);
-            // rows that cross the visited box contribute the two x-runs left and right of it
-            const int xb0 = inE ? Exl - 1 : Nxh;
-            const int xa1 = Exh + 1, xb1 = inE ? Nxh : Exh;
-            int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
-            if (ok && xb0 >= Nxl) { s0 = cstart[rowbase + Nxl]; e0 = cstart[rowbase + xb0 + 1]; }
-            if (ok && xb1 >= xa1) { s1 = cstart[rowbase + xa1]; e1 = cstart[rowbase + xb1 + 1]; }
-            unsigned long long rows = __ballot(e0 > s0 || e1 > s1);
-            S.v[NWS_ROWS_NONEMPTY] += __popcll(rows);
-            while (rows) {
-                const int j = __builtin_ctzll(rows);
-                rows &= rows - 1ull;
-                const int yj = __builtin_amdgcn_readlane(y, j), zj = __builtin_amdgcn_readlane(z, j);
-                const float dy = nw_slab_d(L.ay, L.by, (float)yj), dz = nw_slab_d(L.az, L.bz, (float)zj);
+            int cs[NW_SEG + 1];
+#pragma unroll
+            for (int k = 0; k <= NW_SEG; ++k) cs[k] = ok ? cstart[rowbase + xa + min(k, nxh)] : 0;
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < NW_SEG; ++k) m |= (cs[k + 1] > cs[k]) ? (1u << k) : 0u;
+            if (Eok && y >= Eyl && y <= Eyh && z >= Ezl && z <= Ezh) {
+                // cells of the visited box are done: drop the bits of x in [Exl, Exh]
+                const int k0 = max(Exl - xa, 0), k1 = min(Exh - xa, NW_SEG - 1);
+                if (k1 >= k0) m &= ~(((2u << k1) - 1u) & ~((1u << k0) - 1u));
+            }
+            const float yf = (float)y, zf = (float)z, xaf = (float)xa;
+            unsigned long long segs = __ballot(ok && m != 0u);
+            S.v[NWS_ROWS_NONEMPTY] += __popcll(segs);
+            while (segs) {
+                const int j = __builtin_ctzll(segs);
+                segs &= segs - 1ull;
+                // row test: does any lane's ball reach the (y,z) square of this row?
+                const float dy = nw_slab_d(L.ay, L.by, nw_readlane_f(yf, j)), dz = nw_slab_d(L.az, L.bz, nw_readlane_f(zf, j));
                 const float dyz2 = fmaf(dz, dz, dy * dy);
-                if (!__any(dyz2 <= nw_best_d2(L) * cullk + epsu)) continue;       // no lane's ball reaches this row
+                if (!__any(dyz2 <= r2u)) continue;
                 S.v[NWS_ROWS_PASS] += 1;
-                const int rbj = g.gx * (yj + g.gy * zj);
-                const int a0 = __builtin_amdgcn_readlane(s0, j), b0 = __builtin_amdgcn_readlane(e0, j);
-                const int a1 = __builtin_amdgcn_readlane(s1, j), b1_ = __builtin_amdgcn_readlane(e1, j);
-                const int xb0j = __builtin_amdgcn_readlane(xb0, j), xb1j = __builtin_amdgcn_readlane(xb1, j);
-                if (b0 > a0) nw_visit_run(L, g, cstart, cent, rbj, Nxl, xb0j, a0, b0, dyz2, epsu, cullk, lane, S);
-                if (b1_ > a1) nw_visit_run(L, g, cstart, cent, rbj, xa1, xb1j, a1, b1_, dyz2, epsu, cullk, lane, S);
+                const unsigned mj = (unsigned)__builtin_amdgcn_readlane((int)m, j);
+                const float xj = nw_readlane_f(xaf, j);
+                unsigned pm = 0, t = mj;
+                while (t) {
+                    const int k = __builtin_ctz(t);
+                    t &= t - 1u;
+                    const float dx = nw_slab_d(L.ax, L.bx, xj + (float)k);
+                    S.v[NWS_CELLS_TESTED] += 1;
+                    if (__any(fmaf(dx, dx, dyz2) <= r2u)) { pm |= 1u << k; S.v[NWS_CELLS_PASS] += 1; }
+                }
+                // runs of surviving cells (empty or culled-empty cells in between join for free) -> candidate ranges
+                const unsigned joinable = pm | ~mj;
+                while (pm) {
+                    const int k0 = __builtin_ctz(pm);
+                    const unsigned stop = (~joinable >> k0) & ((1u << (NW_SEG - k0)) - 1u);     // first cell >= k0 that is non-empty and culled
+                    const int k1 = stop ? k0 + __builtin_ctz(stop) : NW_SEG;
+                    const int c0 = nw_pick(cs, k0, j), c1 = nw_pick(cs, k1, j);
+                    if (c1 > c0) {
+                        W->rs[nr] = c0;
+                        W->pre[nr] = total;
+                        ++nr; total += c1 - c0;
+                        if (nr == NW_RNG_MAX) { nw_stream(L, W, cent, nr, total, lane, S); nr = 0; total = 0; }
+                    }
+                    pm = (k1 >= 32) ? 0u : (pm >> k1) << k1;
+                }
             }
         }
+        nw_stream(L, W, cent, nr, total, lane, S);
         Exl = Nxl; Exh = Nxh; Eyl = Nyl; Eyh = Nyh; Ezl = Nzl; Ezh = Nzh;
         if (!any_unseen) break;          // the box was built from every lane's ball and b1 only shrinks: all lanes are final
     }
     if (active) {
         int fid = prev;
-        if (L.bbase >= 0) fid = __float_as_int(cent[L.bbase + (int)(L.b1 & 15u)].w);
+        if (L.bslot >= 0) fid = __float_as_int(cent[L.bslot].w);
         face_io[gi] = fid;
         // runner-up inside the error band (or the walk did not re-find the warm-start face): float64 re-resolution
         const float d1 = __uint_as_float(L.b1), d2 = __uint_as_float(L.b2);
-        if (L.bbase < 0 || d2 - d1 <= NW_NN_BAND * d1) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
+        if (L.bslot < 0 || d2 - d1 <= NW_NN_BAND * d1) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
     }
     if (lane == 0 && rounds > 1) atomicMax(&st->nn_max_ring, rounds);
     if (stats && lane == 0) {
