@@ -28,8 +28,9 @@
 #pragma once
 #include "nw_device.h"
 
-#define NW_NN_BAND 6e-6f          // relative error band of the keys: 16 ulp of truncation (1.9e-6) on both + 4 roundings of 2^-24
-#define NW_NN_CULL 1.2e-5f        // cells are culled against b1 * (1 + NW_NN_CULL)
+#define NW_NN_TOL 6e-6f           // error of a key, relative to ITS magnitude K + d^2: 16 ulp of truncation (1.9e-6) + the roundings of the
+                                  // expanded form (three fused multiply-adds on operands bounded by the magnitude, 2^-24 each) + margin
+#define NW_NN_CULL 4e-6f          // relative slack of the cell-culling test (rounding of the box distance)
 #define NW_ITEM_POINTS 64
 
 struct NwItem { int p0, n; };
@@ -189,7 +190,8 @@ struct NwStats { int v[NWS_COUNT]; };
 #define NW_KEY_INF 0x7f800000u
 
 struct NwLane {
-    float px, py, pz;        // the localization
+    float px, py, pz;        // the localization RELATIVE TO THE WAVE'S ORIGIN (mean of its localizations)
+    float dkp;               // K - |p'|^2: key value = d^2 + dkp (K = the wave's bias, >= every lane's |p'|^2, keeps keys non-negative)
     float ux, uy, uz;        // the same in cell units: (p - origin) * inv_h
     float ax, ay, az;        // u + eps      } distance (cell units) from u to the slab [k - eps, k + 1 + eps] of cell index k:
     float bx, by, bz;        // u - 1 - eps  }   max(k - a, b - k, 0)
@@ -199,21 +201,35 @@ struct NwLane {
     unsigned keymask;        // NW_KEY_MASK, pinned in a vector register
 };
 
-__device__ __forceinline__ float nw_best_d2(const NwLane &L) { return __uint_as_float(L.b1); }
+// conservative (upper) estimate of the lane's best squared distance from its key: key = d^2 + (K - |p'|^2) up to NW_NN_TOL of the
+// key's magnitude
+__device__ __forceinline__ float nw_key_tol(unsigned key) { return NW_NN_TOL * __uint_as_float(key); }
+__device__ __forceinline__ float nw_best_d2(const NwLane &L)
+{
+    const float kf = __uint_as_float(L.b1);
+    return fmaxf(kf - L.dkp, 0.0f) + NW_NN_TOL * kf;
+}
 
-// one candidate (the same for all lanes: an LDS broadcast read) against the lanes' localizations; K = its position in the
-// 16-chunk (an inline constant)
-template <int K>
+// one candidate (the same for all lanes: an LDS broadcast read) against the lanes' localizations; KI = its position in the
+// 16-chunk (an inline constant).  The candidate is staged in EXPANDED form relative to the wave's origin,
+//     C = {-2x', -2y', -2z', |c'|^2 + K},   key value = |p' - c'|^2 - |p'|^2 + K = fma(px', X, fma(py', Y, fma(pz', Z, W))):
+// three fused multiply-adds (the conversion of a candidate is done once, by the lane that stages it).
+template <int KI>
 __device__ __forceinline__ void nw_eval(NwLane &L, const float4 C)
 {
-    asm volatile("" :: "v"(C.w));              // keeps the read a 16-byte ds_read_b128 (ds_read_b96 takes twice the LDS cycles)
-    const float dx = L.px - C.x, dy = L.py - C.y, dz = L.pz - C.z;
-    const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const float d = fmaf(L.px, C.x, fmaf(L.py, C.y, fmaf(L.pz, C.z, C.w)));
     unsigned key, b2;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(d), "v"(L.keymask), "n"(K));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(d), "v"(L.keymask), "n"(KI));
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(b2) : "v"(L.b1), "v"(L.b2), "v"(key));      // b1 <= b2: the runner-up is the median of {b1, b2, key}
     L.b2 = b2;
     L.b1 = min(L.b1, key);
+}
+
+// candidate as stored -> staged (expanded) form; O = the wave's origin, K = its bias
+__device__ __forceinline__ float4 nw_expand(const float4 C, float Ox, float Oy, float Oz, float K)
+{
+    const float x = C.x - Ox, y = C.y - Oy, z = C.z - Oz;
+    return make_float4(-2.0f * x, -2.0f * y, -2.0f * z, fmaf(z, z, fmaf(y, y, x * x)) + K);
 }
 
 // distance (cell units) from the lane's coordinate to the slab [k - eps, k + 1 + eps] of cell index k (a, b: see NwLane)
@@ -255,22 +271,24 @@ __device__ __forceinline__ int nw_list_slot(const NwWaveLds *W, int nr, int g)
 
 // Stream the collected ranges: 64 candidates per batch are fetched by the 64 lanes (one coalesced-ish global load each), staged in
 // LDS and evaluated by every lane against its localization; the fetch of batch b+1 is in flight while batch b is evaluated.
-__device__ __forceinline__ void nw_stream(NwLane &L, NwWaveLds *W, const float4 *__restrict__ cent, int nr, int total, int lane, NwStats &S)
+__device__ __forceinline__ void nw_stream(NwLane &L, NwWaveLds *W, const float4 *__restrict__ cent, int nr, int total, int lane, NwStats &S,
+                                          float Ox, float Oy, float Oz, float K)
 {
     if (total <= 0) return;
     S.v[NWS_CAND] += (total + 3) & ~3;
     W->pre[nr] = total;
     nw_wave_lds_sync();
     // lanes past the end of the list stage a far-away dummy (the last group of four of a batch is evaluated whole)
-    float4 C = cent[nw_list_slot(W, nr, min(lane, total - 1))];
-    if (lane >= total) { C.x = 1e18f; C.y = 1e18f; C.z = 1e18f; }
+    const float4 far = make_float4(0.0f, 0.0f, 0.0f, 1e30f);
+    float4 C = nw_expand(cent[nw_list_slot(W, nr, min(lane, total - 1))], Ox, Oy, Oz, K);
+    if (lane >= total) C = far;
     for (int g0 = 0; g0 < total; g0 += 64) {
         W->cand[lane] = C;
         nw_wave_lds_sync();
         const int gn = g0 + 64 + lane;
         if (g0 + 64 < total) {                                                            // next batch: in flight during the evaluation
-            C = cent[nw_list_slot(W, nr, min(gn, total - 1))];
-            if (gn >= total) { C.x = 1e18f; C.y = 1e18f; C.z = 1e18f; }
+            C = nw_expand(cent[nw_list_slot(W, nr, min(gn, total - 1))], Ox, Oy, Oz, K);
+            if (gn >= total) C = far;
         }
         const int cnt = min(64, total - g0);
         for (int c = 0; c < cnt; c += 16) {
@@ -330,14 +348,24 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
     const bool active = lane < item.n;
     const int gi = item.p0 + (active ? lane : 0);                        // idle lanes shadow lane 0 (they never write)
     NwLane L;
-    {
-        const float4 P = pts[gi];
-        L.px = P.x; L.py = P.y; L.pz = P.z;
-        L.ux = (P.x - g.ox) * g.inv_h; L.uy = (P.y - g.oy) * g.inv_h; L.uz = (P.z - g.oz) * g.inv_h;
-    }
+    const float4 P = pts[gi];
+    L.ux = (P.x - g.ox) * g.inv_h; L.uy = (P.y - g.oy) * g.inv_h; L.uz = (P.z - g.oz) * g.inv_h;
     const float epsu = g.eps * g.inv_h;                                  // rounding slack of the cell assignment, cell units
     L.ax = L.ux + epsu; L.ay = L.uy + epsu; L.az = L.uz + epsu;
     L.bx = L.ux - 1.0f - epsu; L.by = L.uy - 1.0f - epsu; L.bz = L.uz - 1.0f - epsu;
+    // wave origin = mean of the wave's localizations (idle lanes shadow lane 0), bias K = largest |p'|^2: the distances are evaluated
+    // in the expanded form on LOCAL coordinates, so their float32 error scales with the wave's size, not with the coordinate offset
+    float Ox = P.x, Oy = P.y, Oz = P.z;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { Ox += __shfl_xor(Ox, off, 64); Oy += __shfl_xor(Oy, off, 64); Oz += __shfl_xor(Oz, off, 64); }
+    Ox = nw_readlane_f(Ox * (1.0f / 64.0f), 0); Oy = nw_readlane_f(Oy * (1.0f / 64.0f), 0); Oz = nw_readlane_f(Oz * (1.0f / 64.0f), 0);
+    L.px = P.x - Ox; L.py = P.y - Oy; L.pz = P.z - Oz;
+    const float pn = fmaf(L.pz, L.pz, fmaf(L.py, L.py, L.px * L.px));
+    float Kb = pn;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) Kb = fmaxf(Kb, __shfl_xor(Kb, off, 64));
+    Kb = nw_readlane_f(Kb, 0) * (1.0f + 1e-5f) + 1e-6f;
+    L.dkp = Kb - pn;
     L.b1 = NW_KEY_INF; L.b2 = NW_KEY_INF; L.bgi = -1; L.bslot = -1;
     L.keymask = NW_KEY_MASK;
     asm volatile("" : "+v"(L.keymask));
@@ -345,10 +373,11 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
     if (warm & 1) {
         prev = face_io[gi];
         if ((unsigned)prev < (unsigned)F) {
-            const float4 C = cent_by_face[prev];
-            const float dx = L.px - C.x, dy = L.py - C.y, dz = L.pz - C.z;
-            // strictly above the value the walk will compute for this very centroid, so the walk re-finds it (and its slot)
-            L.b1 = __float_as_uint(fmaf(dz, dz, fmaf(dy, dy, dx * dx)) * (1.0f + 1e-5f) + 1e-30f) | 15u;
+            const float4 C = nw_expand(cent_by_face[prev], Ox, Oy, Oz, Kb);
+            const float d = fmaf(L.px, C.x, fmaf(L.py, C.y, fmaf(L.pz, C.z, C.w)));
+            // strictly above the key the walk will compute for this very centroid, so the walk re-finds it (and its slot); the bump
+            // also becomes the runner-up until a real one is seen, so it must lie outside the ambiguity band (2 NW_NN_TOL)
+            L.b1 = __float_as_uint(d * (1.0f + 8.0f * NW_NN_TOL) + 1e-30f) | 15u;
         } else prev = -1;
     }
     const float cullk = g.inv_h * g.inv_h * (1.0f + NW_NN_CULL);
@@ -446,13 +475,13 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
                         W->rs[nr] = c0;
                         W->pre[nr] = total;
                         ++nr; total += c1 - c0;
-                        if (nr == NW_RNG_MAX) { nw_stream(L, W, cent, nr, total, lane, S); nr = 0; total = 0; }
+                        if (nr == NW_RNG_MAX) { nw_stream(L, W, cent, nr, total, lane, S, Ox, Oy, Oz, Kb); nr = 0; total = 0; }
                     }
                     pm = (k1 >= 32) ? 0u : (pm >> k1) << k1;
                 }
             }
         }
-        nw_stream(L, W, cent, nr, total, lane, S);
+        nw_stream(L, W, cent, nr, total, lane, S, Ox, Oy, Oz, Kb);
         Exl = Nxl; Exh = Nxh; Eyl = Nyl; Eyh = Nyh; Ezl = Nzl; Ezh = Nzh;
         if (!any_unseen) break;          // the box was built from every lane's ball and b1 only shrinks: all lanes are final
     }
@@ -461,8 +490,10 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
         if (L.bslot >= 0) fid = __float_as_int(cent[L.bslot].w);
         face_io[gi] = fid;
         // runner-up inside the error band (or the walk did not re-find the warm-start face): float64 re-resolution
+        // both keys carry the same offset K - |p'|^2: their difference is a difference of squared distances, each known to NW_NN_TOL
+        // of the key's magnitude
         const float d1 = __uint_as_float(L.b1), d2 = __uint_as_float(L.b2);
-        if (L.bslot < 0 || d2 - d1 <= NW_NN_BAND * d1) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
+        if (L.bslot < 0 || d2 - d1 <= 2.0f * NW_NN_TOL * d2) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
     }
     if (lane == 0 && rounds > 1) atomicMax(&st->nn_max_ring, rounds);
     if (stats && lane == 0) {
