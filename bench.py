@@ -239,7 +239,7 @@ def main():
             'config': {'workload': '%s, %d localizations sigma=10 nm, %d vertices / %d faces, lams=[10], blocks of %d iterations, fixed topology%s'
                                    % (WORKLOADS[args.config], N, M, F, BLOCK, '' if args.scale == 1.0 else ' [SCALED x%.3g: debug run]' % args.scale),
                        'localizations_per_gpu': N, 'vertices_per_gpu': M, 'faces_per_gpu': F, 'block': BLOCK,
-                       'one_off_setup': 'projection re-sort of the localizations (nw_optimize_layout) done after the warm-up, before the timed region',
+                       'one_off_setup': 'nw_optimize_layout after the warm-up, before the timed region: projection re-sort of the localizations + cell-size tuner (a few timed probe queries)',
                        'parallelism': ('tiles%d (one vesicle per GPU; the scene keeps ONE global subspace solve: one RCCL all-reduce of the 27 normal-equation '
                                        'sums x 32 ordered parts = 6.9 KB per iteration, no vertex data)' % world) if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'kernel': kern[dom], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

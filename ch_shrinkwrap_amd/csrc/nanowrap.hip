@@ -152,7 +152,9 @@ struct nw_ctx {
     double scene_ext = 1.0;           // extent of localizations + mesh at the last grid build
     double quantum_override = 0.0;    // > 0: nw_accumulator_quantum fixed it (multi-GPU: every rank must use the same)
     double acc_quantum = 1.0;         // fixed-point quantum of the LDS scatter accumulators (k_attract): 2^-36 of the cloud extent
-    double cell_tune = 1.0;           // multiplier on the cell-size rule (nw_tune_grid)
+    double cell_tune = 1.0;           // multiplier on the cell-size rule (tune_grid)
+    bool tuned = false;
+    int blocks_done = 0;              // completed search() calls since the localizations were set
     double force_h = 0.0;             // > 0: build_grid uses exactly this cell (nw_tune_grid probes)
     DevBuf<int> ccount, cstart, scan_tmp;
     DevBuf<NwItem> items;             // work list of the NN query: runs of <= 64 Morton-consecutive localizations
@@ -198,6 +200,8 @@ struct nw_ctx {
 
     void *wb_rows = nullptr;          // strided write-back target registered with nw_set_write_back
     int64_t wb_stride = 0;
+    void *pin_log = nullptr;          // pinned staging for the per-iteration logs + device state
+    size_t pin_log_bytes = 0;
     void *pin = nullptr;              // pinned staging for the write-back
     size_t pin_bytes = 0;
     NwHostPool *pool = nullptr;       // host threads of the write-back (created on first use)
@@ -516,6 +520,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->wv.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
     if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->pin_log) (void)hipHostFree(ctx->pin_log);
     for (hipEvent_t e : ctx->wb_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -642,6 +647,7 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
     ctx->nitems = 0;
     ctx->face_warm = false;
     ctx->proj_ready = false; ctx->proj_sorted = false;
+    ctx->tuned = false; ctx->cell_tune = 1.0; ctx->blocks_done = 0;
     ctx->last_mean_dist = -1.0;
     ctx->searched = false;
     return NW_OK;
@@ -810,6 +816,61 @@ static int resort_by_projection(nw_ctx *ctx)
     return NW_OK;
 }
 
+static int launch_query(nw_ctx *ctx, int it);
+// Cell-size tuner, once per localization cloud.  The query is exact for every cell size, and its cost depends on more than the rule
+// (desired_cell) can see -- a 200k-localization tube leaves half of the GPU's wave slots empty and prefers smaller cells (fewer
+// candidates per wave) than the 1M-localization vesicle, for which the cost is flat between 9 and 13 nm -- so the query is simply
+// timed on a few cells around the rule's (x0.65 / x0.8 / x1 / x1.25; a probe = new cell table + work list + two warm queries) and the
+// fastest is kept as a multiplier on the rule for all later meshes of this cloud.  Runs from nw_optimize_layout (a caller can keep it
+// out of a timed region), else at the start of the third block; needs a warm query (the first block ran).  NW_AUTOTUNE=0 disables it.
+static int tune_grid(nw_ctx *ctx)
+{
+    if (ctx->tuned) return NW_OK;
+    const char *at = getenv("NW_AUTOTUNE");
+    if ((at && atoi(at) == 0) || getenv("NW_CELL_SIZE") || getenv("NW_CELL_FACTOR") || ctx->N < 20000 || !ctx->face_warm) {
+        if (ctx->face_warm || (at && atoi(at) == 0)) ctx->tuned = true;
+        return NW_OK;
+    }
+    ctx->tuned = true;
+    const int verbose = getenv("NW_VERBOSE") != nullptr;
+    const int it = ctx->global_iter;
+    const int prof = ctx->profiling;
+    ctx->profiling = 0;
+    NW_TRY(alloc_work(ctx));
+    hipEvent_t e0, e1;
+    NW_HIP(hipEventCreate(&e0)); NW_HIP(hipEventCreate(&e1));
+    const double md = ctx->last_mean_dist > 0 ? ctx->last_mean_dist : ctx->est_mean_dist;
+    if (!ctx->grid_valid) { const int r = build_grid(ctx, md); if (r != NW_OK) return r; }
+    const double h_rule = desired_cell(ctx, 0.0, ctx->spacing) / ctx->cell_tune;
+    const double factors[4] = {1.0, 0.8, 0.65, 1.25};
+    double best_f = 1.0, best_t = 1e30;
+    int rc = NW_OK;
+    for (int k = 0; k < 4 && rc == NW_OK; ++k) {
+        ctx->force_h = std::max(h_rule * factors[k], 0.6 * md);
+        rc = build_grid(ctx, md);
+        ctx->force_h = 0.0;
+        if (rc != NW_OK) break;
+        float t = 0;
+        for (int rep = 0; rep < 2 && rc == NW_OK; ++rep) {                     // the first repetition warms the caches of the new table
+            if (hipEventRecord(e0, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+            rc = launch_query(ctx, it);
+            if (rc != NW_OK) break;
+            if (hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = NW_ERR_HIP;
+        }
+        if (verbose) fprintf(stderr, "[nanowrap] autotune: cell %.3f -> query %.4f ms\n", ctx->grid.h, t);
+        if (rc == NW_OK && t < best_t) { best_t = t; best_f = factors[k]; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ctx->profiling = prof;
+    if (rc != NW_OK) return rc;
+    ctx->cell_tune = best_f;
+    ctx->force_h = std::max(h_rule * best_f, 0.6 * md);
+    rc = build_grid(ctx, md);
+    ctx->force_h = 0.0;
+    if (verbose) fprintf(stderr, "[nanowrap] autotune: rule %.3f -> cell %.3f (x%.2f)\n", h_rule, ctx->grid.h, ctx->cell_tune);
+    return rc;
+}
+
 // One-off set-up that would otherwise run at the start of the next block (the projection re-sort of the localizations and the
 // work list cut from it): lets a caller (bench.py) take it out of a timed region.  No-op when there is nothing to do.
 NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
@@ -821,6 +882,7 @@ NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
     if (ctx->proj_ready && !ctx->proj_sorted && !getenv("NW_NO_PROJ_SORT")) NW_TRY(resort_by_projection(ctx));
     NW_TRY(alloc_work(ctx));
     NW_TRY(ensure_grid(ctx));
+    NW_TRY(tune_grid(ctx));
     return NW_OK;
 }
 
@@ -837,6 +899,7 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     NW_HIP(hipMemcpyAsync(ctx->pos.p, ctx->meshpos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->proj_ready && !ctx->proj_sorted && num_iters > 0 && !getenv("NW_NO_PROJ_SORT")) NW_TRY(resort_by_projection(ctx));
     NW_TRY(ensure_grid(ctx));
+    if (ctx->blocks_done >= 2 && num_iters > 0) NW_TRY(tune_grid(ctx));      // (nw_optimize_layout does it earlier if the caller asks)
     // fixed-point quanta of the scatter (k_attract): 2^-36 of a bound on |w res| <= largest weight x scene extent; 2^-40 for sum w
     ctx->acc_quantum = ctx->quantum_override > 0 ? ctx->quantum_override
                                                  : std::ldexp(1.0, (int)std::ceil(std::log2(std::max(ctx->scene_ext * ctx->w_bound, 1e-300))) - 36);
@@ -952,11 +1015,20 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_search_end outside a search");
     ctx->in_search = false;
-    std::vector<nw_iter_log> host((size_t)std::max(ctx->search_done, 1));
+    // logs + device state land in PINNED memory: a device-to-host copy into pageable memory blocks the host until everything queued
+    // before it has run, which would serialise "wait for the kernels", the two small copies and the position slices below
+    const size_t log_bytes = (size_t)std::max(ctx->search_done, 1) * sizeof(nw_iter_log);
+    if (ctx->pin_log_bytes < log_bytes + sizeof(NwDevState)) {
+        if (ctx->pin_log) (void)hipHostFree(ctx->pin_log);
+        ctx->pin_log = nullptr; ctx->pin_log_bytes = 0;
+        NW_HIP(hipHostMalloc(&ctx->pin_log, 2 * log_bytes + sizeof(NwDevState), hipHostMallocDefault));
+        ctx->pin_log_bytes = 2 * log_bytes + sizeof(NwDevState);
+    }
+    nw_iter_log *host = (nw_iter_log *)ctx->pin_log;
+    NwDevState *stp = (NwDevState *)((char *)ctx->pin_log + ctx->pin_log_bytes - sizeof(NwDevState));
     if (ctx->search_done > 0)
-        NW_HIP(hipMemcpyAsync(host.data(), ctx->logs.p, (size_t)ctx->search_done * sizeof(nw_iter_log), hipMemcpyDeviceToHost, ctx->stream));
-    NwDevState st;
-    NW_HIP(hipMemcpyAsync(&st, ctx->state.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+        NW_HIP(hipMemcpyAsync(host, ctx->logs.p, (size_t)ctx->search_done * sizeof(nw_iter_log), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipMemcpyAsync(stp, ctx->state.p, sizeof(NwDevState), hipMemcpyDeviceToHost, ctx->stream));
     if (pos_out) {
         // the positions come back in slices that host threads copy out (contiguous result + the registered strided vertex records)
         // while the later slices are still in flight; a device pointer gets a plain copy
@@ -967,12 +1039,14 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
         else NW_TRY(write_back_impl(ctx, pos_out, ctx->wb_rows, ctx->wb_stride));
     }
     NW_HIP(hipStreamSynchronize(ctx->stream));
+    const NwDevState st = *stp;
     int executed = 0;
     for (int i = 0; i < ctx->search_done; ++i) executed += host[i].executed ? 1 : 0;
     if (loopcount) *loopcount = executed;
     if (log) for (int i = 0; i < ctx->search_done; ++i) log[i] = host[i];
     if (executed > 0) ctx->last_mean_dist = host[executed - 1].mean_dist;
     ctx->searched = ctx->searched || executed > 0;
+    if (executed > 0) ctx->blocks_done += 1;
     if (executed > 0 && !ctx->proj_sorted && !ctx->proj_ready && ctx->face_warm) {
         // foot points of this block's last query -> keys of the second sort (applied at the start of the next block)
         const NwGrid &g = ctx->grid;
@@ -1146,7 +1220,7 @@ static int write_back_impl(nw_ctx *ctx, float *contiguous, void *rows, int64_t r
     static const int64_t rows_per_thread = getenv("NW_WB_ROWS_PER_THREAD") ? std::max(1000, atoi(getenv("NW_WB_ROWS_PER_THREAD"))) : 50000;   // measured: more, smaller slices lose to thread wake-up latency
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, M / rows_per_thread));
     std::vector<int64_t> cut(T + 1);
-    for (int t = 0; t <= T; ++t) cut[t] = M * t / T;
+    for (int t = 0; t <= T; ++t) cut[t] = (t == T) ? M : ((M * t / T) & ~(int64_t)3);      // slice starts on 16-byte boundaries (4 vertices = 48 B)
     for (int t = 0; t < T; ++t) {
         NW_HIP(hipMemcpyAsync(stage + 3 * cut[t], ctx->pos.p + 3 * cut[t], (size_t)(cut[t + 1] - cut[t]) * 12, hipMemcpyDeviceToHost, ctx->stream));
         NW_HIP(hipEventRecord(ctx->wb_events[t], ctx->stream));
