@@ -267,9 +267,11 @@ def main():
         out['roofline_attraction_curvature'] = {'kernels': [kern[k] for k in ca], 'algorithmic_bytes': ca_bytes, 'device_ms': ca_ms,
                                                 'achieved': ca_bytes / (ca_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                                 'frac': ca_bytes / (ca_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        # The dominant kernel is not an HBM kernel (25 MB algorithmic, 37 MB measured per launch): it is bound by instruction
-        # issue.  VALU wave-instructions per launch from the SQ_INSTS_VALU pass (tools/pmc.sh) against the issue peak of
-        # 256 CUs x 4 SIMD-32 x 2.4 GHz x 1 wave64 instruction per 2 cycles (MI355X_MICROARCH.md).
+        # The dominant kernel is not an HBM kernel (25 MB algorithmic per launch): it is bound by VALU instruction issue.  VALU
+        # wave-instructions per launch from the committed SQ_INSTS_VALU pass (tools/profile_round.sh; file-sourced like `traffic`),
+        # against two peaks: the guide's 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction, and the ~4.1 cycles per
+        # instruction this kernel's mix actually retires at (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of the same pass; a micro-benchmark,
+        # tools/micro/valu_rate.hip, gives 2.6 cycles for pure-VGPR VOP2, 4.3 with an SGPR operand or VCC, 7.0 for v_pk_fma_f32).
         if traffic is not None and dom == 'nn':
             try:
                 vi = json.load(open(tfile)).get('k_nn_wave_valu_wave_instructions')
@@ -277,8 +279,9 @@ def main():
                 vi = None
             if vi:
                 peak = 256 * 4 * 2.4e9 * 0.5
-                out['roofline']['valu_issue'] = {'wave_instructions_per_launch': vi, 'achieved': vi / (avg_ms * 1e-3), 'peak': peak,
-                                                 'unit': 'wave-instructions/s', 'frac': vi / (avg_ms * 1e-3) / peak}
+                out['roofline']['valu_issue'] = {'wave_instructions_per_launch': vi, 'source': 'profiles/r02_pmc_traffic.json (not re-measured by this run)',
+                                                 'achieved': vi / (avg_ms * 1e-3), 'peak': peak, 'unit': 'wave-instructions/s',
+                                                 'frac': vi / (avg_ms * 1e-3) / peak, 'frac_of_measured_issue_rate': vi / (avg_ms * 1e-3) / (256 * 4 * 2.4e9 / 4.1)}
         # a shared box is occasionally throttled (every kernel 5-50x slower for a whole call, seen twice this round): flag it
         cp = out['roofline'].get('measured_copy_peak', 0.0)
         out['device_health'] = 'ok' if cp >= 3000.0 else 'degraded: device-to-device copy ran at %.0f GB/s (normally ~5100)' % cp

@@ -84,7 +84,7 @@ def load():
     for s in SYMBOLS:
         if s not in ('nw_destroy', 'nw_last_error'):
             getattr(L, s).restype = i32
-    if L.nw_abi_version() != 1:
+    if L.nw_abi_version() != 2:
         raise RuntimeError('libnanowrap_hip.so ABI version mismatch')
     _lib = L
     return L

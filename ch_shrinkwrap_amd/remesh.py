@@ -29,8 +29,9 @@ def load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            from . import build
-            build.build_host_library()
+            # never compile lazily: the first caller may run under rocprofv3 (a compiler child started from a process whose GPU is
+            # initialised is the exec hop the GPU pool forbids), and a silent g++ run hides a missing build step
+            raise ImportError('%s not found: build it with `python -m ch_shrinkwrap_amd.build` (or __graft_entry__.build())' % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
         L.nwr_abi_version.restype = ctypes.c_int
         L.nwr_remesh.restype = ctypes.c_int

@@ -144,8 +144,8 @@ def _build_halfedges(faces, n_vertices):
         from .remesh import halfedge_twins
         he['twin'] = halfedge_twins(faces, n_vertices)
         return he, origin.astype('i4')
-    except Exception:                                 # library unavailable or input it rejects: NumPy definition below
-        pass
+    except (RuntimeError, ValueError):                # an input the library rejects (non-manifold edge): NumPy definition below.
+        pass                                          # (a missing library raises ImportError and is NOT hidden)
     nv = np.int64(n_vertices)
     key = origin.astype('i8') * nv + dest
     rkey = dest.astype('i8') * nv + origin
@@ -232,7 +232,7 @@ class TriMesh(object):
                 if vertex_normals:
                     self._vertices['normal'] = vn
                 return
-            except Exception:                                 # library unavailable or input it rejects: NumPy definition below
+            except (RuntimeError, ValueError):                # an input the library rejects: NumPy definition below
                 pass
         v0, v1, v2 = pos[f[:, 0]], pos[f[:, 1]], pos[f[:, 2]]
         cr = np.cross(v1 - v0, v2 - v0)                      # f32, |cr| = 2*area

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NW_ABI_VERSION 1
+#define NW_ABI_VERSION 2
 
 typedef struct nw_ctx nw_ctx;
 

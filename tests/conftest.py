@@ -18,6 +18,9 @@ def pytest_configure(config):
     src = os.path.join(ROOT, 'oracle', 'nw_oracle.c')
     if (not os.path.exists(lib)) or os.path.getmtime(lib) < os.path.getmtime(src):
         subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libnw_oracle.so'])
+    # the host-side remesher / half-edge helper is product code but plain C++: make sure a fresh checkout has it before the first TriMesh
+    from ch_shrinkwrap_amd import build as _b
+    _b.build_host_library()
 
 
 def load_golden(name):

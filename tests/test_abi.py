@@ -23,14 +23,14 @@ def test_library_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), 'libnanowrap_hip.so does not export %s' % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.load().nw_abi_version() == 1
+    assert _lib.load().nw_abi_version() == 2
     assert _lib.load().nw_n_point_scalars() == 13
 
 
 def test_log_struct_layout_matches_header():
     from ch_shrinkwrap_amd import _lib
-    # 5 + 3 + 9 + 3 + 1 doubles, 4 int32
-    assert ctypes.sizeof(_lib.IterLog) == 21 * 8 + 4 * 4
+    # 5 + 3 + 9 + 3 + 2 doubles (mean_dist, max_dist), 4 int32
+    assert ctypes.sizeof(_lib.IterLog) == 22 * 8 + 4 * 4
 
 
 def test_product_path_never_imports_the_oracle():

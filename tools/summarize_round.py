@@ -3,7 +3,7 @@
   <tag>_bench.json                       the bench line of the same round (no profiler attached)
   <tag>_pmc_and_trace_summary.json       per-kernel HBM traffic from the FETCH_SIZE / WRITE_SIZE passes + average durations
   <tag>_sq_counters.json                 per-kernel SQ counters (mean per dispatch)
-  r01_pmc_traffic.json                   what bench.py reports as roofline.traffic
+  r02_pmc_traffic.json                   what bench.py reports as roofline.traffic (tagged there as file-sourced)
 HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB and gfx950's FETCH_SIZE counts half of
 the wide coalesced reads (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).
 usage: python tools/summarize_round.py <tag>"""
@@ -51,7 +51,7 @@ for r in csv.DictReader(open(trace)):
 WARM, STEPS = 10, 50
 for k, v in per.items():
     v.sort()
-    if k in dur and len(v) >= WARM + STEPS + 10:         # (the autotuner adds a few probe launches during the warm-up)
+    if k in dur and len(v) >= WARM + STEPS + 10:         # (nw_optimize_layout adds a few probe launches after the warm-up)
         t = [d for _, d in v[len(v) - 10 - STEPS:len(v) - 10]]
         dur[k]['avg_us_timed_region'] = sum(t) / len(t) / 1e3
 bench = json.loads(open(os.path.join(src, 'bench.log')).read().strip().splitlines()[-1])
@@ -79,7 +79,7 @@ sq = counters('sq')
 json.dump({k: dict({c: sum(v) / len(v) for c, v in d.items()}, dispatches=max(len(v) for v in d.values())) for k, d in sorted(sq.items())},
           open(os.path.join(dst, tag + '_sq_counters.json'), 'w'), indent=1)
 
-out = {k: traffic[k]['hbm_bytes_per_launch'] for k in ('k_nn_wave', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update')
+out = {k: traffic[k]['hbm_bytes_per_launch'] for k in ('k_nn_wave', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update', 'k_reduce_scalars')
        if k in traffic}
 out['grid_build'] = sum(traffic[k]['hbm_bytes_per_launch'] * (3 if k.startswith('k_scan') and False else 1) for k in grid if k in traffic)
 if 'k_nn_wave' in sq and 'SQ_INSTS_VALU' in sq['k_nn_wave']:
@@ -87,9 +87,10 @@ if 'k_nn_wave' in sq and 'SQ_INSTS_VALU' in sq['k_nn_wave']:
 out['_note'] = ('HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts half of '
                 'wide coalesced reads, MI355X_MICROARCH.md section HBM); mean of the timed iterations of bench.py --steps 10 --warmup 10; '
                 'profiles/' + tag + '_*')
-json.dump(out, open(os.path.join(dst, 'r01_pmc_traffic.json'), 'w'), indent=1)
+out['_source_tag'] = tag
+json.dump(out, open(os.path.join(dst, 'r02_pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
-for k in ('k_nn_wave', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update', 'k_face_centroids', 'k_centroid_scatter'):
+for k in ('k_nn_wave', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_reduce_scalars', 'k_prior_directions', 'k_solve_update', 'k_face_centroids', 'k_scan_tile_sums', 'k_scan_final', 'k_centroid_scatter'):
     if k in dur:
         print('%-24s calls %5d avg %8.1f us (timed region %8.1f us)  %5.1f %%' % (k, dur[k]['calls'], dur[k]['avg_us'], dur[k].get('avg_us_timed_region', float('nan')), dur[k]['pct']))
 print('bench', bench['ms_per_step'], bench['value'], bench['roofline'])
