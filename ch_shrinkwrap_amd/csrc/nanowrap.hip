@@ -124,6 +124,11 @@ struct nw_ctx {
     // sizes
     int64_t N = 0, M = 0, F = 0;
     int NB = 0;
+    // captured search() blocks (hipGraph): replayed while nothing they bake in has changed
+    struct BlockGraph { hipGraphExec_t exec = nullptr; uint64_t key = 0; };
+    BlockGraph graphs[4];
+    int graph_next = 0;
+    uint64_t grid_generation = 0;
     bool have_points = false, have_mesh = false;
 
     // localizations as given (caller order) -- kept so the grid can be rebuilt when the cell size changes
@@ -196,6 +201,7 @@ struct nw_ctx {
     uint32_t search_flags = 0;
     float lam0 = 0.0f;
     bool in_search = false;
+    bool begin_ops_pending = false;
     bool searched = false;
 
     void *wb_rows = nullptr;          // strided write-back target registered with nw_set_write_back
@@ -347,14 +353,14 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     // mesh bbox + area
     float mlo[3], mhi[3];
     bool bad = false;
-    NW_TRY(minmax3(ctx, ctx->pos.p, ctx->M, mlo, mhi, &bad));
+    NW_TRY(minmax3(ctx, ctx->meshpos.p, ctx->M, mlo, mhi, &bad));
     if (bad) return fail(ctx, NW_ERR_NONFINITE, "non-finite vertex coordinate");
     NW_HIP(ctx->wsum.ensure(4));
     NW_HIP(hipMemsetAsync(ctx->wsum.p + 1, 0, 2 * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(k_mesh_area, dim3(std::min(1024, nblk(F))), dim3(NW_BLOCK), 0, ctx->stream, ctx->pos.p, ctx->faces.p, (int)F, ctx->wsum.p + 1);
+    hipLaunchKernelGGL(k_mesh_area, dim3(std::min(1024, nblk(F))), dim3(NW_BLOCK), 0, ctx->stream, ctx->meshpos.p, ctx->faces.p, (int)F, ctx->wsum.p + 1);
     const int nsample = (int)std::min<int64_t>(N, 256);
     if (mean_dist <= 0.0)
-        hipLaunchKernelGGL(k_sample_nn, dim3(nsample), dim3(NW_BLOCK), 0, ctx->stream, ctx->pts_in.p, N, nsample, ctx->pos.p, ctx->faces.p, (int)F, ctx->wsum.p + 2);
+        hipLaunchKernelGGL(k_sample_nn, dim3(nsample), dim3(NW_BLOCK), 0, ctx->stream, ctx->pts_in.p, N, nsample, ctx->meshpos.p, ctx->faces.p, (int)F, ctx->wsum.p + 2);
     NW_HIP(hipGetLastError());
     double h2[2];
     NW_HIP(hipMemcpyAsync(h2, ctx->wsum.p + 1, sizeof(h2), hipMemcpyDeviceToHost, ctx->stream));
@@ -395,10 +401,12 @@ int build_grid(nw_ctx *ctx, double mean_dist)
                                   std::fabs(g.ox + g.gx * h), std::fabs(g.oy + g.gy * h), std::fabs(g.oz + g.gz * h)});
     g.eps = (float)(1e-3 * h + 2e-6 * maxc);
     ctx->grid = g;
+    ctx->grid_generation += 1;
 
     const size_t nc = (size_t)g.ncell;
     NW_HIP(ctx->ccount.ensure(nc));
     NW_HIP(ctx->cstart.ensure(nc + 1));
+    NW_HIP(ctx->scan_tmp.ensure(nc / NW_SCAN_TILE + 2));      // (no allocation inside a captured block)
     NW_HIP(hipMemsetAsync(ctx->ccount.p, 0, nc * sizeof(int), ctx->stream));
     // work list: Morton blocks of about NW_ITEM_BLOCK_CELLS cells per edge
     const double block_cells = getenv("NW_ITEM_BLOCK_CELLS") ? atof(getenv("NW_ITEM_BLOCK_CELLS")) : 4.0;
@@ -518,6 +526,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->wv.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
+    for (auto &gph : ctx->graphs) if (gph.exec) (void)hipGraphExecDestroy(gph.exec);
     if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin_log) (void)hipHostFree(ctx->pin_log);
@@ -833,7 +842,8 @@ static int tune_grid(nw_ctx *ctx)
     }
     ctx->tuned = true;
     const int verbose = getenv("NW_VERBOSE") != nullptr;
-    const int it = ctx->global_iter;
+    const int it = 0;
+    hipLaunchKernelGGL(k_set_iter_base, dim3(1), dim3(1), 0, ctx->stream, ctx->state.p, ctx->global_iter);
     const int prof = ctx->profiling;
     ctx->profiling = 0;
     NW_TRY(alloc_work(ctx));
@@ -895,8 +905,6 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_search_begin: previous search not ended");
     NW_HIP(hipSetDevice(ctx->device));
     NW_TRY(alloc_work(ctx));
-    // start_guess: fs = vertices.copy() -> f restarts from the mesh positions (mesh_conj_grad.py:170, :1002-1007)
-    NW_HIP(hipMemcpyAsync(ctx->pos.p, ctx->meshpos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->proj_ready && !ctx->proj_sorted && num_iters > 0 && !getenv("NW_NO_PROJ_SORT")) NW_TRY(resort_by_projection(ctx));
     NW_TRY(ensure_grid(ctx));
     if (ctx->blocks_done >= 2 && num_iters > 0) NW_TRY(tune_grid(ctx));      // (nw_optimize_layout does it earlier if the caller asks)
@@ -909,12 +917,24 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     ctx->search_iters = num_iters;
     ctx->search_done = 0;
     NW_HIP(ctx->logs.ensure((size_t)std::max(num_iters, 1)));
-    NW_HIP(hipMemsetAsync(ctx->logs.p, 0, (size_t)std::max(num_iters, 1) * sizeof(NwIterLogDev), ctx->stream));
+    hipLaunchKernelGGL(k_set_iter_base, dim3(1), dim3(1), 0, ctx->stream, ctx->state.p, ctx->global_iter);
+    if (ctx->profiling) { ctx->ev_used = 0; g_marks.spans.clear(); for (int k = 0; k < ST_COUNT; ++k) { ctx->stage_ms[k] = 0; ctx->stage_launches[k] = 0; } }
+    ctx->in_search = true;
+    ctx->begin_ops_pending = true;         // the stream operations of the block's start are issued with its first iteration (or captured)
+    return NW_OK;
+}
+
+// stream operations at the start of a block (capturable: no host synchronisation)
+static int enqueue_begin_ops(nw_ctx *ctx)
+{
+    ctx->begin_ops_pending = false;
+    const int n = std::max(ctx->search_iters, 1);
+    // start_guess: fs = vertices.copy() -> f restarts from the mesh positions (mesh_conj_grad.py:170, :1002-1007)
+    NW_HIP(hipMemcpyAsync(ctx->pos.p, ctx->meshpos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    NW_HIP(hipMemsetAsync(ctx->logs.p, 0, (size_t)n * sizeof(NwIterLogDev), ctx->stream));
     NW_HIP(hipMemsetAsync(ctx->S.p, 0, 9 * ctx->M * sizeof(float), ctx->stream));         // S = zeros (:207)
     NW_HIP(hipMemsetAsync(ctx->res.p, 0, 3 * ctx->N * sizeof(float), ctx->stream));       // res = 0*data (:181)
     NW_HIP(hipMemsetAsync(ctx->vacc.p, 0, 4 * ctx->M * sizeof(long long), ctx->stream));
-    if (ctx->profiling) { ctx->ev_used = 0; g_marks.spans.clear(); for (int k = 0; k < ST_COUNT; ++k) { ctx->stage_ms[k] = 0; ctx->stage_launches[k] = 0; } }
-    ctx->in_search = true;
     return NW_OK;
 }
 
@@ -952,7 +972,8 @@ static int launch_query(nw_ctx *ctx, int it)
 NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_attract outside a search");
-    const int it = ctx->global_iter;
+    if (ctx->begin_ops_pending) NW_TRY(enqueue_begin_ops(ctx));
+    const int it = ctx->search_done;
     const int64_t N = ctx->N, F = ctx->F;
     NW_TRY(launch_query(ctx, it));
     {
@@ -968,7 +989,7 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
 NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_directions outside a search");
-    const int it = ctx->global_iter;
+    const int it = ctx->search_done;
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
     {
         StageScope s(ctx, ST_PRIOR);
@@ -995,7 +1016,7 @@ NW_EXPORT int nw_iter_update(nw_ctx *ctx)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_update outside a search");
     if (ctx->search_done >= ctx->search_iters) return fail(ctx, NW_ERR_BADARG, "nw_iter_update: more iterations than announced");
-    const int it = ctx->global_iter;
+    const int it = ctx->search_done;
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
     {
         StageScope s(ctx, ST_UPDATE);
@@ -1014,6 +1035,7 @@ static int write_back_impl(nw_ctx *ctx, float *contiguous, void *rows, int64_t r
 NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *loopcount)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_search_end outside a search");
+    if (ctx->begin_ops_pending) NW_TRY(enqueue_begin_ops(ctx));
     ctx->in_search = false;
     // logs + device state land in PINNED memory: a device-to-host copy into pageable memory blocks the host until everything queued
     // before it has run, which would serialise "wait for the kernels", the two small copies and the position slices below
@@ -1079,13 +1101,77 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
     return NW_OK;
 }
 
+// everything a captured block bakes into its launches
+static uint64_t block_graph_key(const nw_ctx *ctx)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; };
+    auto mixp = [&](const void *p) { mix((uint64_t)(uintptr_t)p); };
+    mix((uint64_t)ctx->search_iters); mix(ctx->search_flags); mix(ctx->face_warm ? 1 : 0); mix(ctx->grid_generation); mix((uint64_t)ctx->nitems);
+    mix((uint64_t)ctx->N); mix((uint64_t)ctx->M); mix((uint64_t)ctx->F); mix((uint64_t)ctx->NB); mix((uint64_t)ctx->maxdeg);
+    uint32_t lb; memcpy(&lb, &ctx->lam0, 4); mix(lb);
+    uint64_t qb; memcpy(&qb, &ctx->acc_quantum, 8); mix(qb);
+    uint32_t sb; memcpy(&sb, &ctx->sinv_scalar, 4); mix(sb); memcpy(&sb, &ctx->w_scalar, 4); mix(sb);
+    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0));
+    const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
+                          ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
+                          ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
+                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p};
+    for (const void *p : ptrs) mixp(p);
+    return h;
+}
+
 NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags, float *pos_out, nw_iter_log *log, int *loopcount)
 {
     const bool verbose = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 2;
     const auto t0 = std::chrono::steady_clock::now();
     NW_TRY(nw_search_begin(ctx, lams, n_lams, num_iters, flags));
     const auto t1 = std::chrono::steady_clock::now();
-    for (int i = 0; i < num_iters; ++i) {
+    // A block is a fixed launch sequence (begin ops + num_iters x 11 launches) with block-relative arguments: captured once as a
+    // hipGraph and replayed for later blocks while nothing it bakes in has changed (sizes, buffers, grid, flags, lambda, quantum,
+    // warm/cold start).  Host-side enqueue drops from ~3.5 us per launch to one graph launch: what small meshes are bound by.
+    // Not with profiling on: events recorded by graph nodes do not give elapsed times on ROCm 7.2 (they read 0).
+    static const bool graphs_on = !(getenv("NW_GRAPH") && atoi(getenv("NW_GRAPH")) == 0);
+    bool replayed = false;
+    if (graphs_on && ctx->own_stream && ctx->profiling == 0 && num_iters > 0) {
+        const uint64_t key = block_graph_key(ctx);
+        nw_ctx::BlockGraph *slot = nullptr;
+        for (auto &gph : ctx->graphs) if (gph.exec && gph.key == key) slot = &gph;
+        if (!slot) {
+            // capture this block (the launches below are recorded, not run), then instantiate
+            if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                const bool warm0 = ctx->face_warm;
+                int r = enqueue_begin_ops(ctx);
+                for (int i = 0; i < num_iters && r == NW_OK; ++i) {
+                    r = nw_iter_attract(ctx);
+                    if (r == NW_OK) r = nw_iter_directions(ctx);
+                    if (r == NW_OK) r = nw_iter_update(ctx);
+                }
+                hipGraph_t graph = nullptr;
+                const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+                // rewind the host-side bookkeeping the recorded calls advanced
+                ctx->global_iter -= ctx->search_done; ctx->search_done = 0; ctx->face_warm = warm0;
+                ctx->begin_ops_pending = true;          // recorded, not run
+                if (r == NW_OK && ce == hipSuccess && graph) {
+                    nw_ctx::BlockGraph &dst = ctx->graphs[ctx->graph_next];
+                    ctx->graph_next = (ctx->graph_next + 1) % 4;
+                    if (dst.exec) (void)hipGraphExecDestroy(dst.exec);
+                    dst.exec = nullptr;
+                    if (hipGraphInstantiate(&dst.exec, graph, nullptr, nullptr, 0) == hipSuccess) { dst.key = key; slot = &dst; }
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipGetLastError();
+            }
+        }
+        if (slot) {
+            if (hipGraphLaunch(slot->exec, ctx->stream) == hipSuccess) {
+                ctx->begin_ops_pending = false;
+                ctx->global_iter += num_iters; ctx->search_done = num_iters; ctx->face_warm = true;
+                replayed = true;
+            } else (void)hipGetLastError();
+        }
+    }
+    for (int i = 0; !replayed && i < num_iters; ++i) {
         int r = nw_iter_attract(ctx);
         if (r == NW_OK) r = nw_iter_directions(ctx);
         if (r == NW_OK) r = nw_iter_update(ctx);

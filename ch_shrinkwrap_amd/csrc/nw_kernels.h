@@ -32,8 +32,11 @@ struct NwDevState {
     float tests[3];       // last three test statistics, oldest first
     int status;           // sticky nw_status raised on the device
     int nn_max_ring;
-    int pad;
+    int iter_base;        // global index of the current block's first iteration (k_set_iter_base): kernels get the block-relative index,
+                          // so a captured block (hipGraph) can be replayed for later blocks
 };
+
+__global__ void k_set_iter_base(NwDevState *st, int base) { st->iter_base = base; }
 
 // ============================================================================================================
 // generic exclusive scan of int32 counts (3 launches): out[0..n] with out[n] = total
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const flo
                                                             float4 *__restrict__ cent_tmp, int *__restrict__ fcell, int *__restrict__ frank, int *__restrict__ count,
                                                             int *__restrict__ ambig_count, const NwDevState *__restrict__ st, int it)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ int s_key[NW_FC_HT], s_cnt[NW_FC_HT];
     for (int t = threadIdx.x; t < NW_FC_HT; t += NW_BLOCK) { s_key[t] = -1; s_cnt[t] = 0; }
     __syncthreads();
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const floa
                                                               const int *__restrict__ start, float4 *__restrict__ cent,
                                                               const NwDevState *__restrict__ st, int it)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     cent[start[fcell[f]] + frank[f]] = cent_tmp[f];
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
                                                       const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face,
                                                       int *__restrict__ face_out, const NwDevState *__restrict__ st, int it)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     const int na = *ambig_count;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
                                                      int *__restrict__ vidx, float *__restrict__ wout, float *__restrict__ res, long long *__restrict__ vacc,
                                                      double *__restrict__ part, NwDevState *__restrict__ st, int it, double inv_q, double inv_qw)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ double s_part[4 * 4];
     __shared__ int s_key[NW_HT];
     __shared__ unsigned long long s_val[NW_HT * 4];        // component-major [4][NW_HT], two's-complement fixed point
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
                                                               float *__restrict__ pi_out, double *__restrict__ part, NwDevState *__restrict__ st, int it, int n_search,
                                                               double q, double qw, const float *__restrict__ wv, const unsigned char *__restrict__ owned)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ double s_part[14 * 4];
     double red[14];
 #pragma unroll
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
 __global__ __launch_bounds__(NW_BLOCK) void k_vertex_area_weights(int M, int NB, const int *__restrict__ nbr, const float *__restrict__ f, float *__restrict__ wv,
                                                                  const NwDevState *__restrict__ st, int it)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const int *row = nbr + (int64_t)i * NB;
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
                                                                  const unsigned char *__restrict__ mask, const float *__restrict__ S, double *__restrict__ part,
                                                                  const NwDevState *__restrict__ st, int it, int n_search)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ double s_part[9 * 4];
     const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK - 1) / NW_BLOCK);      // see k_attract
     const int i = blk < 0 ? N : blk * blockDim.x + threadIdx.x;
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
                                                           const double *__restrict__ sc_parts, NwDevState *__restrict__ st,
                                                           NwIterLogDev *__restrict__ logrec, int it)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ NwSolve s_sol;
     __shared__ double s_sc[SC_COUNT];
     if (threadIdx.x < SC_COUNT) {
@@ -882,8 +885,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
         float a = st->tests[1], b = st->tests[2];
         st->tests[0] = a; st->tests[1] = b; st->tests[2] = test;
         st->ntests += 1;
-        if (st->ntests >= 3 && (test < b) && (b < a) && (a < 1e-6f)) st->stop_at = it + 1;
-        if (st->status != 0) st->stop_at = it + 1;
+        if (st->ntests >= 3 && (test < b) && (b < a) && (a < 1e-6f)) st->stop_at = st->iter_base + it + 1;
+        if (st->status != 0) st->stop_at = st->iter_base + it + 1;
     }
 }
 
@@ -927,7 +930,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_reduce_scalars(const double *__res
                                                             const double *__restrict__ part_s, int nblk_s, double *__restrict__ sc,
                                                             const NwDevState *__restrict__ st, int it)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ double s_acc[NW_BLOCK];
     nw_reduce_columns<5, 255, 4, SC_MAXD>(part_a, nblk_a, s_acc, sc, SC_RES2);   // k_attract: res^2, masked res^2, sum d, count; max d
     nw_reduce_columns<9, 252, -1, 0>(part_s, nblk_s, s_acc, sc, SC_HC);          // k_subspace_point_sums: Hc (6), Gc (3)

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
                                                  int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
                                                  NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats)
 {
-    if (it >= st->stop_at) return;
+    if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ NwWaveLds s_wave[4];
     NwStats S;
 #pragma unroll
