@@ -183,6 +183,17 @@ def main():
     if steps_done != args.steps:
         raise SystemExit('bench: only %d of %d timed iterations executed (stop condition fired): the throughput would be overstated' % (steps_done, args.steps))
     nn_ms, nn_launches = cg.stage_ms_total['nn']
+    # the same K steps once more WITHOUT the HIP events of the timed region: blocks are then replayed from a captured hipGraph (the
+    # library does not capture while events are recorded).  Reported beside the official number, never instead of it.
+    dt_graph = None
+    if world == 1:
+        cg.set_profiling(0)
+        run_steps(BLOCK)                       # captures (first un-instrumented block)
+        fence()
+        tg = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        dt_graph = time.perf_counter() - tg
     cg.set_profiling(2)
     ctimer = None
     if world > 1:
@@ -231,6 +242,7 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3,
+            'ms_per_step_graph_replay': (dt_graph / args.steps * 1e3) if dt_graph is not None else None,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
