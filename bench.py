@@ -103,6 +103,7 @@ def main():
     ap.add_argument('--config', default='c3')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the workload (debug only; the reported config says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph-pass', action='store_true', help='skip the extra un-instrumented (graph-replay) pass (profiling runs)')
     ap.add_argument('--cpu-iters', type=int, default=0, help='oracle iterations for cpu_baseline (0 = about 10-20 s of CPU work: 10 up to 2M localizations, else 3)')
     args = ap.parse_args()
 
@@ -186,7 +187,7 @@ def main():
     # the same K steps once more WITHOUT the HIP events of the timed region: blocks are then replayed from a captured hipGraph (the
     # library does not capture while events are recorded).  Reported beside the official number, never instead of it.
     dt_graph = None
-    if world == 1:
+    if world == 1 and not args.no_graph_pass:
         cg.set_profiling(0)
         run_steps(BLOCK)                       # captures (first un-instrumented block)
         fence()

@@ -953,10 +953,12 @@ static int launch_query(nw_ctx *ctx, int it)
     }
     {
         StageScope s(ctx, ST_NN);
+        static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;   // 0 slabs, 1 round-robin, 2 interleaved runs (default)
         static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
         const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;   // one wave = one work item
-        hipLaunchKernelGGL(k_nn_wave, dim3(8 * ((nb + 7) / 8)), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | (getenv("NW_NN_XCD_SLABS") ? 0 : 2), ctx->ambig_list.p, ctx->ambig_count.p,
+        const int nbp = nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
+        hipLaunchKernelGGL(k_nn_wave, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map, ctx->ambig_list.p, ctx->ambig_count.p,
                            ctx->state.p, it, ctx->nn_stats.p);
         ctx->face_warm = true;
     }

@@ -239,6 +239,7 @@ __device__ __forceinline__ float nw_slab_d(float a, float b, float kf)
 }
 
 // ---- wave-private LDS: the list of candidate ranges collected by the walk, and one batch of 64 staged candidates ---------
+#define NW_XCD_RUN 16         // consecutive workgroups of the work list per XCD turn (interleaved-runs mapping)
 #define NW_SEG 8             // cells per row segment (one lane fetches the 9 cell starts of a segment)
 #define NW_RNG_MAX 48        // ranges collected before they are streamed
 struct NwWaveLds {
@@ -337,10 +338,20 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
 #pragma unroll
     for (int k = 0; k < NWS_COUNT; ++k) S.v[k] = 0;
     const int lane = threadIdx.x & 63;
-    // (warm & 2): plain round-robin of the workgroups over the XCDs (default; measured 5 % faster here than one contiguous slab of
-    // the work list per XCD, nw_xcd_remap: the slabs' work differs and the launch waits for the slowest XCD)
+    // Workgroup -> work-list position.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the L2 they share).
+    //   (warm & 2) plain: consecutive list positions land on different XCDs: every L2 pulls the whole centroid / cell tables;
+    //   (warm & 4) interleaved runs: XCD x takes runs of NW_XCD_RUN consecutive positions, the runs of the 8 XCDs interleaved along
+    //              the list: neighbours in space (= in the list) share an L2, and all XCDs advance through the list together;
+    //   else       one contiguous slab of the list per XCD (nw_xcd_remap): best locality, but the slabs' work differs and the
+    //              launch waits for the slowest XCD.
     const int wpb = (int)blockDim.x >> 6, nwb = (nitems + wpb - 1) / wpb;       // waves (= work items) per workgroup, workgroups with work
-    const int wb = (warm & 2) ? ((int)blockIdx.x < nwb ? (int)blockIdx.x : -1) : nw_xcd_remap(blockIdx.x, nwb);
+    int wb;
+    if (warm & 4) {
+        const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+        wb = ((l / NW_XCD_RUN) * 8 + x) * NW_XCD_RUN + (l % NW_XCD_RUN);
+        if (wb >= nwb) wb = -1;
+    } else if (warm & 2) wb = (int)blockIdx.x < nwb ? (int)blockIdx.x : -1;
+    else wb = nw_xcd_remap(blockIdx.x, nwb);
     const int wi = __builtin_amdgcn_readfirstlane(wb * wpb + (int)(threadIdx.x >> 6));
     if (wi < 0 || wi >= nitems) return;
     NwWaveLds *W = &s_wave[threadIdx.x >> 6];
