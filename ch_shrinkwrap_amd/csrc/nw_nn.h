@@ -28,8 +28,14 @@
 #pragma once
 #include "nw_device.h"
 
-#define NW_NN_TOL 6e-6f           // error of a key, relative to ITS magnitude K + d^2: 16 ulp of truncation (1.9e-6) + the roundings of the
-                                  // expanded form (three fused multiply-adds on operands bounded by the magnitude, 2^-24 each) + margin
+// Error bound of a key (expanded form on wave-local coordinates, |p'|^2 <= K, candidate within d of p): every intermediate of
+//   fma(px', X, fma(py', Y, fma(pz', Z, W))),  W = |c'|^2 + K,   is bounded by |c'|^2 + K + 2 |p'| |c'| <= 5 K + 4 d^2 <= 5 K + 4 key,
+// three fused roundings + the roundings of the staged operands (2^-24 each, ~8 in all) give < 2.4e-6 K + 1.9e-6 key, the index bits
+// another 16 ulp = 1.9e-6 key.  With margin:   tol(key) = NW_NN_TOLK * K + NW_NN_TOL * key   (absolute, in units of d^2).
+// NB the K term: a lane at the edge of its wave has key ~ d^2 << K, so a tolerance relative to the key alone is NOT a bound
+// (seen as a few hundred float64 ties resolved to the wrong face id at 5M localizations).
+#define NW_NN_TOL 6e-6f
+#define NW_NN_TOLK 4e-6f
 #define NW_NN_CULL 4e-6f          // relative slack of the cell-culling test (rounding of the box distance)
 #define NW_ITEM_POINTS 64
 
@@ -192,6 +198,7 @@ struct NwStats { int v[NWS_COUNT]; };
 struct NwLane {
     float px, py, pz;        // the localization RELATIVE TO THE WAVE'S ORIGIN (mean of its localizations)
     float dkp;               // K - |p'|^2: key value = d^2 + dkp (K = the wave's bias, >= every lane's |p'|^2, keeps keys non-negative)
+    float tolk;              // NW_NN_TOLK * K: the part of a key's error bound that does not shrink with the key
     float ux, uy, uz;        // the same in cell units: (p - origin) * inv_h
     float ax, ay, az;        // u + eps      } distance (cell units) from u to the slab [k - eps, k + 1 + eps] of cell index k:
     float bx, by, bz;        // u - 1 - eps  }   max(k - a, b - k, 0)
@@ -203,11 +210,10 @@ struct NwLane {
 
 // conservative (upper) estimate of the lane's best squared distance from its key: key = d^2 + (K - |p'|^2) up to NW_NN_TOL of the
 // key's magnitude
-__device__ __forceinline__ float nw_key_tol(unsigned key) { return NW_NN_TOL * __uint_as_float(key); }
 __device__ __forceinline__ float nw_best_d2(const NwLane &L)
 {
     const float kf = __uint_as_float(L.b1);
-    return fmaxf(kf - L.dkp, 0.0f) + NW_NN_TOL * kf;
+    return fmaxf(kf - L.dkp, 0.0f) + (NW_NN_TOL * kf + L.tolk);
 }
 
 // one candidate (the same for all lanes: an LDS broadcast read) against the lanes' localizations; KI = its position in the
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
     for (int off = 32; off > 0; off >>= 1) Kb = fmaxf(Kb, __shfl_xor(Kb, off, 64));
     Kb = nw_readlane_f(Kb, 0) * (1.0f + 1e-5f) + 1e-6f;
     L.dkp = Kb - pn;
+    L.tolk = NW_NN_TOLK * Kb;
     L.b1 = NW_KEY_INF; L.b2 = NW_KEY_INF; L.bgi = -1; L.bslot = -1;
     L.keymask = NW_KEY_MASK;
     asm volatile("" : "+v"(L.keymask));
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
             const float d = fmaf(L.px, C.x, fmaf(L.py, C.y, fmaf(L.pz, C.z, C.w)));
             // strictly above the key the walk will compute for this very centroid, so the walk re-finds it (and its slot); the bump
             // also becomes the runner-up until a real one is seen, so it must lie outside the ambiguity band (2 NW_NN_TOL)
-            L.b1 = __float_as_uint(d * (1.0f + 8.0f * NW_NN_TOL) + 1e-30f) | 15u;
+            L.b1 = __float_as_uint(d * (1.0f + 8.0f * NW_NN_TOL) + 8.0f * L.tolk + 1e-30f) | 15u;
         } else prev = -1;
     }
     const float cullk = g.inv_h * g.inv_h * (1.0f + NW_NN_CULL);
@@ -501,10 +508,9 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
         if (L.bslot >= 0) fid = __float_as_int(cent[L.bslot].w);
         face_io[gi] = fid;
         // runner-up inside the error band (or the walk did not re-find the warm-start face): float64 re-resolution
-        // both keys carry the same offset K - |p'|^2: their difference is a difference of squared distances, each known to NW_NN_TOL
-        // of the key's magnitude
+        // both keys carry the same offset K - |p'|^2: their difference is a difference of squared distances, each known to tol(key)
         const float d1 = __uint_as_float(L.b1), d2 = __uint_as_float(L.b2);
-        if (L.bslot < 0 || d2 - d1 <= 2.0f * NW_NN_TOL * d2) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
+        if (L.bslot < 0 || d2 - d1 <= 2.0f * (NW_NN_TOL * d2 + L.tolk)) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
     }
     if (lane == 0 && rounds > 1) atomicMax(&st->nn_max_ring, rounds);
     if (stats && lane == 0) {
