@@ -1,30 +1,35 @@
 // Exact nearest-face-centroid query, wave-autonomous form (replaces cKDTree build + query, mesh_conj_grad.py:451-454:
-// exact Euclidean 1-NN in float64).  MI355X (gfx950), wave64.  No LDS, no workgroup barriers, no MFMA.
+// exact Euclidean 1-NN in float64).  MI355X (gfx950), wave64.  Wave-private LDS only, no workgroup barriers, no MFMA.
 //
 // Layout.  Localizations are sorted ONCE (nw_set_points) by the 30-bit Morton code of their position inside the cloud's
-// bounding box, so every contiguous run of the sorted list is spatially compact at every scale.  A work item is a run of
+// bounding cube, and once more after the first block by the Morton code of their FOOT POINT (centroid of the nearest face):
+// every contiguous run of the list is then compact along the surface whatever the height above it.  A work item is a run of
 // <= 64 consecutive localizations that does not leave one aligned Morton block (edge ~4 fine cells); one WAVE owns one item,
 // lane = localization.  Face centroids are binned per iteration into the fine cells of the uniform grid (cell-sorted float4
 // {x, y, z, face id}, x fastest: a (z,y) row of cells is one contiguous candidate range, `cstart` = dense cell table).
 //
-// Walk.  Every lane keeps its best squared distance b1 (and runner-up b2).  The ball of radius sqrt(b1) around the
-// localization bounds where a closer centroid can be; the wave visits the bounding box (in cells) of its lanes' balls:
-//   * lane = (z,y) ROW of the box: two gathers from `cstart` give the row's candidate range; a ballot keeps the non-empty rows;
-//   * lane = LOCALIZATION again: a non-empty row is visited only if some lane's ball reaches its (y,z) square, and inside the
-//     row a non-empty CELL only if some lane's ball reaches the cell (exact box-distance tests against the lane's CURRENT b1);
-//   * the candidates of the surviving cells are streamed through the SCALAR cache (s_load: the candidate is wave-uniform, it
-//     sits in SGPRs and costs no vector-memory or LDS traffic) and evaluated by all 64 lanes at once in float32.
+// Walk.  Every lane keeps its best key b1 (and runner-up b2).  The ball of radius sqrt(d1) around the localization bounds
+// where a closer centroid can be; the wave visits the bounding box (in cells) of its lanes' balls:
+//   * lane = SEGMENT of NW_SEG cells of one (z,y) row: nine gathers from `cstart` (all in flight together) tell which of the
+//     segment's cells hold centroids that have not been visited yet;
+//   * lane = LOCALIZATION again: a non-empty segment is kept only if some lane's ball reaches the row's (y,z) square, and a
+//     non-empty CELL only if some lane's ball reaches the cell box (exact box-distance tests against the lane's CURRENT best);
+//     surviving cells join into runs and their candidate ranges are COLLECTED in a wave-private LDS list (NwWaveLds::rs/pre);
+//   * nw_stream evaluates the list in batches of 64: lane = i-th candidate of the list (binary search in the prefix counts,
+//     one independent load per lane, the next batch's loads in flight during the current batch), staged in LDS in expanded
+//     form, then lane = localization reads every staged candidate (broadcast ds_read_b128) and evaluates it.
 // Warm start: the previous iteration's nearest face (the sorted order never changes) gives every lane a tight starting radius,
 // so one visit of the box settles the wave.  Cold start (first iteration, new topology): own cell +- 1, then the ball box of
 // what that found; lanes that have seen no candidate yet double their margin until the box covers the grid.
-// A lane is final once its ball lies inside the visited box; the visited region only grows and b1 only shrinks.
+// A lane is final once its ball lies inside the visited box; the visited region only grows and the radii only shrink.
 //
-// Arithmetic.  d^2 = (px-cx)^2 + (py-cy)^2 + (pz-cz)^2 in float32 straight from the stored coordinates: each difference
-// is correctly rounded (relative error 2^-24 whatever the coordinate offset), so the value is within 4 ulp of the float64 one.
-// Cells are culled against b1 * (1 + 4e-6) (+ the rounding slack of the cell assignment), so every centroid whose float32
-// distance is within the error band of the winner IS evaluated and is seen by the runner-up; a lane whose runner-up lies
-// within NW_NN_BAND of its best is re-resolved in float64 by k_nn_fixup (a few dozen per million).  The result is the float64
-// argmin for every localization (lowest face id on exact ties; SciPy's tie order is unspecified).
+// Arithmetic.  Wave-local coordinates p' = p - O, c' = c - O (O = mean of the wave's localizations), K = max |p'|^2.  The staged
+// candidate is {-2x', -2y', -2z', |c'|^2 + K}:  key = fma(px', X, fma(py', Y, fma(pz', Z, W))) = |p - c|^2 + (K - |p'|^2) >= 0,
+// kept as an unsigned integer (float bits, low 4 mantissa bits = position in the 16-chunk): v_and_or_b32, v_med3_u32, v_min_u32.
+// Cells are culled against the best + tol (+ the rounding slack of the cell assignment), so every centroid whose key is
+// within the error band of the winner IS evaluated and is seen by the runner-up; a lane whose runner-up lies within 2 tol of
+// its best is re-resolved in float64 by k_nn_fixup (< 1 % of the lanes).  The result is the float64 argmin for every
+// localization (lowest face id on exact ties; SciPy's tie order is unspecified).
 #pragma once
 #include "nw_device.h"
 

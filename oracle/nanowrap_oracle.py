@@ -17,7 +17,7 @@ of the reference's live per-iteration path:
 
 Parity pinning: the reference holds NO golden vectors or tests for this path, so the
 oracle is pinned against outputs of the reference itself run in the build container (oracle/ref_harness.py):
-tests/test_oracle_vs_reference.py (live, when /root/reference is present) and the committed fixtures under
+tests/test_oracle_golden.py::test_live_reference_* (live, when /root/reference is present) and the committed fixtures under
 tests/golden/ produced by tests/golden/make_golden.py (checked everywhere, including the GPU box).
 
 Float-width notes (the restatement keeps the reference's mixed precision because it is observable):

@@ -5,7 +5,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * Each function cites the reference lines whose arithmetic (order of operations, float width) it follows.
  * Parity of this file against the compiled reference (oracle/_ref/conj_grad_utils*.so, built in place from
- * /root/reference by oracle/Makefile) is checked by tests/test_oracle_vs_reference.py in the build container.
+ * /root/reference by oracle/Makefile) is checked by tests/test_oracle_golden.py (test_live_reference_*) in the build container.
  */
 #include <stdint.h>
 #include <stdlib.h>

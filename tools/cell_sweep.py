@@ -42,13 +42,7 @@ for h in hs:
     cg.set_profiling(2)
     cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
     st = cg.stage_ms_total
-    lo = np.minimum(pts.min(0), mesh.vertices.min(0))
-    hh = h if h > 0 else 0
     line = 'h=%5.1f  wall %.4f ms/iter  nn %.4f  attract %.4f  grid %.4f fixup %.4f  md %.2f' % (
         h, wall * 1e3, nn[0] / nn[1], st['attract'][0] / st['attract'][1], st['grid'][0] / st['grid'][1], st['fixup'][0] / st['fixup'][1], cg.mean_dist)
-    if hh:
-        b = np.floor((pts - lo) / (2 * hh)).astype(np.int64)
-        occ = np.unique(b[:, 0] + 4096 * (b[:, 1] + 4096 * b[:, 2])).size
-        line += '  points/occupied brick %.1f' % (pts.shape[0] / occ)
     print(line, flush=True)
     del cg

@@ -1,5 +1,5 @@
 """Developer tool: steady-state cost of the NN query against the cell size and the Morton block of the work list.
-usage: python tools/nn_sweep.py <config> h[:block_cells] ...      (runs on the GPU box; h = 0: the built-in rule)"""
+usage: python tools/nn_sweep.py <config> h[:block_cells[:nn_map]] ...      (runs on the GPU box; h = 0: the built-in rule)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,10 +24,10 @@ for spec in sys.argv[2:]:
         os.environ['NW_ITEM_BLOCK_CELLS'] = parts[1]
     else:
         os.environ.pop('NW_ITEM_BLOCK_CELLS', None)
-    if len(parts) > 2 and parts[2] == 'rr':
-        os.environ['NW_NN_ROUNDROBIN'] = '1'
+    if len(parts) > 2 and parts[2]:
+        os.environ['NW_NN_MAP'] = parts[2]               # bit 1 warm start, 2 round-robin over XCDs, 4 interleaved runs
     else:
-        os.environ.pop('NW_NN_ROUNDROBIN', None)
+        os.environ.pop('NW_NN_MAP', None)
     mesh = TriMesh(v0.copy(), f)
     cg = ShrinkwrapMeshConjGrad(mesh, pts)
     cg.set_profiling(1)
