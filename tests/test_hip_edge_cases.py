@@ -179,3 +179,58 @@ def test_randomized_clouds_nearest_face_is_exact(seed):
     assert np.allclose(cg.d[:, 0], d_ref, rtol=2e-6, atol=0)
     v_idx, w = cg.w
     assert np.array_equal(v_idx, f[cg.nearest_face]) and np.allclose(w.sum(1), 1.0, atol=1e-5)
+
+
+def _union_jack_sheet(n, origin=3000.0):
+    """Open planar sheet, vertices on the lattice 3*(i, j) + origin, squares split along alternating diagonals: every
+    centroid has integer coordinates (exact in float32) and centroids of neighbouring squares are mirror images of each other
+    about the lattice lines x = 3k and y = 3k."""
+    ii, jj = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing='ij')
+    v = np.stack([3.0 * ii + origin, 3.0 * jj + origin, np.zeros_like(ii, dtype='f8')], -1).reshape(-1, 3).astype('f4')
+    vid = lambda i, j: i * (n + 1) + j
+    faces = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = vid(i, j), vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)
+            faces += [[a, b, c], [a, c, d]] if (i + j) % 2 == 0 else [[a, b, d], [b, c, d]]
+    return v, np.array(faces, 'i4')
+
+
+def test_tens_of_thousands_of_exact_ties_take_the_lowest_face_id():
+    """A scene built so that a large share of the localizations is EXACTLY equidistant (in float64) from its two nearest
+    centroids: the nearest face must be the float64 argmin with the lowest face id among the tied ones, for every
+    localization, whatever its place in its wave (the tie policy the fix-up kernel promises; cKDTree's is unspecified)."""
+    from scipy.spatial import cKDTree
+    from ch_shrinkwrap_amd.trimesh import TriMesh
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    from oracle import nanowrap_oracle as O
+    n = 120
+    v, f = _union_jack_sheet(n)
+    rng = np.random.default_rng(11)
+    N = 200000
+    pts = np.empty((N, 3), 'f4')
+    pts[:, 0] = rng.uniform(3000.0 + 3.0, 3000.0 + 3.0 * (n - 1), N)
+    pts[:, 1] = rng.uniform(3000.0 + 3.0, 3000.0 + 3.0 * (n - 1), N)
+    pts[:, 2] = rng.uniform(0.5, 25.0, N) * rng.choice([-1.0, 1.0], N)
+    on_line = rng.integers(0, 3, N)                              # a third each: x on a lattice line, y on one, neither
+    pts[on_line == 0, 0] = 3.0 * np.round((pts[on_line == 0, 0] - 3000.0) / 3.0) + 3000.0
+    pts[on_line == 1, 1] = 3.0 * np.round((pts[on_line == 1, 1] - 3000.0) / 3.0) + 3000.0
+    cent = O.face_centroids(v, f)
+    assert np.array_equal(cent, np.round(cent))                  # integer centroids: mirror pairs are exact
+    c8 = cent.astype('f8')
+    _, cand = cKDTree(c8).query(pts.astype('f8'), k=16)
+    diff = pts.astype('f8')[:, None, :] - c8[cand]
+    d2 = diff[..., 0] ** 2 + diff[..., 1] ** 2 + diff[..., 2] ** 2
+    tied = d2 == d2.min(1, keepdims=True)
+    want = np.where(tied, cand, np.iinfo(np.int64).max).min(1)
+    n_ties = int((tied.sum(1) > 1).sum())
+    assert tied.sum(1).max() < 16                              # every tied candidate is among the 16 looked at
+    assert n_ties > 20000, n_ties
+    mesh = TriMesh(v, f)
+    cg = ShrinkwrapMeshConjGrad(mesh, pts)
+    s = 1.0 / np.full(pts.size, 10.0, 'f4')
+    cg.search(pts, lams=[10.0], num_iters=1, sigma_inv=s)
+    got = cg.nearest_face
+    wrong = np.nonzero(got != want)[0]
+    print('%d exact ties among %d localizations, %d resolved differently' % (n_ties, N, wrong.size))
+    assert wrong.size == 0, (wrong[:10], got[wrong[:10]], want[wrong[:10]])

