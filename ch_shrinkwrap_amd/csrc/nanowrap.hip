@@ -125,7 +125,8 @@ struct nw_ctx {
     int64_t N = 0, M = 0, F = 0;
     int NB = 0;
     // captured search() blocks (hipGraph): replayed while nothing they bake in has changed
-    struct BlockGraph { hipGraphExec_t exec = nullptr; uint64_t key = 0; };
+    struct BlockGraph { hipGraphExec_t exec = nullptr, exec_b = nullptr; uint64_t key = 0; };      // exec_b: second half of a block split for sampled profiling
+    bool capturing = false;
     BlockGraph graphs[4];
     int graph_next = 0;
     uint64_t grid_generation = 0;
@@ -452,7 +453,7 @@ thread_local StageMarks g_marks;
 struct StageScope {
     nw_ctx *c; int stage; hipEvent_t a;
     bool on;
-    StageScope(nw_ctx *ctx, int s) : c(ctx), stage(s), a(nullptr), on(ctx->profiling >= 2 || (ctx->profiling == 1 && s == ST_NN)) { if (on) a = next_event(c); }
+    StageScope(nw_ctx *ctx, int s) : c(ctx), stage(s), a(nullptr), on(!ctx->capturing && (ctx->profiling == 2 || ((ctx->profiling == 1 || ctx->profiling == 3) && s == ST_NN))) { if (on) a = next_event(c); }
     ~StageScope() { if (on) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
 };
 
@@ -526,7 +527,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->wv.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
-    for (auto &gph : ctx->graphs) if (gph.exec) (void)hipGraphExecDestroy(gph.exec);
+    for (auto &gph : ctx->graphs) { if (gph.exec) (void)hipGraphExecDestroy(gph.exec); if (gph.exec_b) (void)hipGraphExecDestroy(gph.exec_b); }
     if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin_log) (void)hipHostFree(ctx->pin_log);
@@ -825,7 +826,9 @@ static int resort_by_projection(nw_ctx *ctx)
     return NW_OK;
 }
 
-static int launch_query(nw_ctx *ctx, int it);
+enum { QP_GRID = 1, QP_NN = 2, QP_FIXUP = 4, QP_ATTRACT = 8, QP_ALL = 15 };     // parts of the first half of an iteration
+static int launch_query(nw_ctx *ctx, int it, int parts = QP_GRID | QP_NN | QP_FIXUP);
+static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters);
 // Cell-size tuner, once per localization cloud.  The query is exact for every cell size, and its cost depends on more than the rule
 // (desired_cell) can see -- a 200k-localization tube leaves half of the GPU's wave slots empty and prefers smaller cells (fewer
 // candidates per wave) than the 1M-localization vesicle, for which the cost is flat between 9 and 13 nm -- so the query is simply
@@ -884,8 +887,9 @@ static int tune_grid(nw_ctx *ctx)
     return rc;
 }
 
-// One-off set-up that would otherwise run at the start of the next block (the projection re-sort of the localizations and the
-// work list cut from it): lets a caller (bench.py) take it out of a timed region.  No-op when there is nothing to do.
+// One-off set-up that would otherwise run at the start of the next block (the projection re-sort of the localizations, the
+// work list cut from it, the cell-size tuner and the capture of the block's hipGraph): lets a caller (bench.py) take it out of a
+// timed region.  No-op when there is nothing to do.
 NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
 {
     if (!ctx) return NW_ERR_BADARG;
@@ -896,6 +900,15 @@ NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
     NW_TRY(alloc_work(ctx));
     NW_TRY(ensure_grid(ctx));
     NW_TRY(tune_grid(ctx));
+    // pre-record the next block as a hipGraph, assuming it repeats the last one (iterations, lambda, flags): the capture
+    // (a fraction of a millisecond) then does not fall into the caller's next block either.  A different next block just captures again.
+    if (ctx->searched && ctx->search_iters > 0 && ctx->face_warm) {
+        const float lam = ctx->lam0;
+        NW_TRY(nw_search_begin(ctx, &lam, 1, ctx->search_iters, ctx->search_flags));
+        (void)block_graph(ctx, ctx->search_iters);
+        ctx->in_search = false;
+        ctx->begin_ops_pending = false;
+    }
     return NW_OK;
 }
 
@@ -941,12 +954,14 @@ static int enqueue_begin_ops(nw_ctx *ctx)
     return NW_OK;
 }
 
-// centroid binning + staged nearest-face query + float64 fix-up of the ambiguous points, for the current positions
-static int launch_query(nw_ctx *ctx, int it)
+// centroid binning + exact nearest-face query + float64 fix-up of the ambiguous points, for the current positions
+// (`parts`: 1 grid build, 2 the query kernel, 4 fix-up -- a block captured for sampled profiling launches part 2 of its first
+// iteration outside the graphs, between two events)
+static int launch_query(nw_ctx *ctx, int it, int parts)
 {
     const int64_t F = ctx->F;
     const NwGrid g = ctx->grid;
-    {
+    if (parts & QP_GRID) {
         StageScope s(ctx, ST_GRID);
         hipLaunchKernelGGL(k_face_centroids, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pos.p, ctx->faces.p, (int)F,
                            ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->ccount.p, ctx->ambig_count.p, ctx->state.p, it);
@@ -954,7 +969,7 @@ static int launch_query(nw_ctx *ctx, int it)
         hipLaunchKernelGGL(k_centroid_scatter, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, (int)F, ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->cstart.p,
                            ctx->cent.p, ctx->state.p, it);
     }
-    {
+    if (parts & QP_NN) {
         StageScope s(ctx, ST_NN);
         static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;   // 0 slabs, 1 round-robin, 2 interleaved runs (default)
         static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
@@ -965,7 +980,7 @@ static int launch_query(nw_ctx *ctx, int it)
                            ctx->state.p, it, ctx->nn_stats.p);
         ctx->face_warm = true;
     }
-    {
+    if (parts & QP_FIXUP) {
         StageScope s(ctx, ST_FIXUP);
         hipLaunchKernelGGL(k_nn_fixup, dim3(512), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->ambig_list.p, ctx->ambig_count.p, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, ctx->face.p, ctx->state.p, it);
@@ -974,14 +989,13 @@ static int launch_query(nw_ctx *ctx, int it)
     return NW_OK;
 }
 
-NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
+static int iter_attract_parts(nw_ctx *ctx, int parts)
 {
-    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_attract outside a search");
     if (ctx->begin_ops_pending) NW_TRY(enqueue_begin_ops(ctx));
     const int it = ctx->search_done;
     const int64_t N = ctx->N, F = ctx->F;
-    NW_TRY(launch_query(ctx, it));
-    {
+    if (parts & (QP_GRID | QP_NN | QP_FIXUP)) NW_TRY(launch_query(ctx, it, parts & (QP_GRID | QP_NN | QP_FIXUP)));
+    if (parts & QP_ATTRACT) {
         StageScope s(ctx, ST_ATTRACT);
         hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
                            ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->sinv_scalar, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->w_scalar, ctx->mask.p,
@@ -989,6 +1003,12 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
     }
     NW_HIP(hipGetLastError());
     return NW_OK;
+}
+
+NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
+{
+    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_attract outside a search");
+    return iter_attract_parts(ctx, QP_ALL);
 }
 
 NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
@@ -1063,9 +1083,17 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
         const bool on_device = hipPointerGetAttributes(&attr, pos_out) == hipSuccess && attr.type == hipMemoryTypeDevice;
         (void)hipGetLastError();
         if (on_device) NW_HIP(hipMemcpyAsync(pos_out, ctx->pos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-        else NW_TRY(write_back_impl(ctx, pos_out, ctx->wb_rows, ctx->wb_stride));
+        else {
+            const auto tw0 = std::chrono::steady_clock::now();
+            NW_TRY(write_back_impl(ctx, pos_out, ctx->wb_rows, ctx->wb_stride));
+            if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
+                fprintf(stderr, "[nanowrap] search_end: wait + sliced write-back %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw0).count());
+        }
     }
+    const auto ts0 = std::chrono::steady_clock::now();
     NW_HIP(hipStreamSynchronize(ctx->stream));
+    if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
+        fprintf(stderr, "[nanowrap] search_end: final synchronize %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - ts0).count());
     const NwDevState st = *stp;
     int executed = 0;
     for (int i = 0; i < ctx->search_done; ++i) executed += host[i].executed ? 1 : 0;
@@ -1117,13 +1145,65 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     uint32_t lb; memcpy(&lb, &ctx->lam0, 4); mix(lb);
     uint64_t qb; memcpy(&qb, &ctx->acc_quantum, 8); mix(qb);
     uint32_t sb; memcpy(&sb, &ctx->sinv_scalar, 4); mix(sb); memcpy(&sb, &ctx->w_scalar, 4); mix(sb);
-    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0));
+    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 3 ? 32 : 0));
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
                           ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p};
     for (const void *p : ptrs) mixp(p);
     return h;
+}
+
+// The captured form of the block the ctx is about to run (nw_search_begin done): found among the cached ones or captured now
+// (the launches are recorded, not run).  nullptr: not eligible, or the capture failed -> the caller launches directly.
+// Profiling level 3 ("sampled") keeps the graphs: the block is captured in two halves around the query kernel of its first
+// iteration, which is launched directly between two events -- one live sample of the dominant kernel per block.
+static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters)
+{
+    static const bool graphs_on = !(getenv("NW_GRAPH") && atoi(getenv("NW_GRAPH")) == 0);
+    if (!(graphs_on && ctx->own_stream && (ctx->profiling == 0 || ctx->profiling == 3) && num_iters > 0)) return nullptr;
+    const bool split = ctx->profiling == 3;
+    const uint64_t key = block_graph_key(ctx);
+    for (auto &gph : ctx->graphs) if (gph.exec && gph.key == key) return &gph;
+    if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] capturing a block of %d (%s, key %016llx, warm %d, grid generation %llu)\n", num_iters, split ? "two halves" : "one graph",
+                                      (unsigned long long)key, ctx->face_warm ? 1 : 0, (unsigned long long)ctx->grid_generation);
+    const bool warm0 = ctx->face_warm;
+    auto capture = [&](int half) -> hipGraphExec_t {
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        ctx->capturing = true;
+        int r = NW_OK;
+        if (half != 2) r = enqueue_begin_ops(ctx);
+        if (half == 1 && r == NW_OK) r = iter_attract_parts(ctx, QP_GRID);
+        for (int i = 0; i < num_iters && r == NW_OK && half != 1; ++i) {
+            r = (half == 2 && i == 0) ? iter_attract_parts(ctx, QP_FIXUP | QP_ATTRACT) : iter_attract_parts(ctx, QP_ALL);
+            if (r == NW_OK) r = nw_iter_directions(ctx);
+            if (r == NW_OK) r = nw_iter_update(ctx);
+        }
+        ctx->capturing = false;
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (r == NW_OK && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return exec;
+    };
+    hipGraphExec_t ea = capture(split ? 1 : 0), eb = nullptr;
+    if (ea && split) {
+        ctx->begin_ops_pending = false; ctx->face_warm = true;      // the state the second half is recorded in
+        eb = capture(2);
+        if (!eb) { (void)hipGraphExecDestroy(ea); ea = nullptr; }
+    }
+    // rewind the host-side bookkeeping the recorded calls advanced
+    ctx->global_iter -= ctx->search_done; ctx->search_done = 0; ctx->face_warm = warm0;
+    ctx->begin_ops_pending = true;          // recorded, not run
+    if (!ea) return nullptr;
+    nw_ctx::BlockGraph &dst = ctx->graphs[ctx->graph_next];
+    ctx->graph_next = (ctx->graph_next + 1) % 4;
+    if (dst.exec) (void)hipGraphExecDestroy(dst.exec);
+    if (dst.exec_b) (void)hipGraphExecDestroy(dst.exec_b);
+    dst.exec = ea; dst.exec_b = eb; dst.key = key;
+    return &dst;
 }
 
 NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags, float *pos_out, nw_iter_log *log, int *loopcount)
@@ -1135,46 +1215,23 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     // A block is a fixed launch sequence (begin ops + num_iters x 11 launches) with block-relative arguments: captured once as a
     // hipGraph and replayed for later blocks while nothing it bakes in has changed (sizes, buffers, grid, flags, lambda, quantum,
     // warm/cold start).  Host-side enqueue drops from ~3.5 us per launch to one graph launch: what small meshes are bound by.
-    // Not with profiling on: events recorded by graph nodes do not give elapsed times on ROCm 7.2 (they read 0).
-    static const bool graphs_on = !(getenv("NW_GRAPH") && atoi(getenv("NW_GRAPH")) == 0);
+    // Not with per-launch profiling (levels 1, 2): events recorded by graph nodes do not give elapsed times on ROCm 7.2 (they read 0).
     bool replayed = false;
-    if (graphs_on && ctx->own_stream && ctx->profiling == 0 && num_iters > 0) {
-        const uint64_t key = block_graph_key(ctx);
-        nw_ctx::BlockGraph *slot = nullptr;
-        for (auto &gph : ctx->graphs) if (gph.exec && gph.key == key) slot = &gph;
-        if (!slot) {
-            // capture this block (the launches below are recorded, not run), then instantiate
-            if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                const bool warm0 = ctx->face_warm;
-                int r = enqueue_begin_ops(ctx);
-                for (int i = 0; i < num_iters && r == NW_OK; ++i) {
-                    r = nw_iter_attract(ctx);
-                    if (r == NW_OK) r = nw_iter_directions(ctx);
-                    if (r == NW_OK) r = nw_iter_update(ctx);
-                }
-                hipGraph_t graph = nullptr;
-                const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
-                // rewind the host-side bookkeeping the recorded calls advanced
-                ctx->global_iter -= ctx->search_done; ctx->search_done = 0; ctx->face_warm = warm0;
-                ctx->begin_ops_pending = true;          // recorded, not run
-                if (r == NW_OK && ce == hipSuccess && graph) {
-                    nw_ctx::BlockGraph &dst = ctx->graphs[ctx->graph_next];
-                    ctx->graph_next = (ctx->graph_next + 1) % 4;
-                    if (dst.exec) (void)hipGraphExecDestroy(dst.exec);
-                    dst.exec = nullptr;
-                    if (hipGraphInstantiate(&dst.exec, graph, nullptr, nullptr, 0) == hipSuccess) { dst.key = key; slot = &dst; }
-                }
-                if (graph) (void)hipGraphDestroy(graph);
-                (void)hipGetLastError();
+    static const bool trace_blocks = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 3;
+    static hipEvent_t tb0 = nullptr, tb1 = nullptr;
+    if (trace_blocks) { if (!tb0) { (void)hipEventCreate(&tb0); (void)hipEventCreate(&tb1); } (void)hipEventRecord(tb0, ctx->stream); }
+    nw_ctx::BlockGraph *slot = block_graph(ctx, num_iters);
+    if (slot) {
+        if (hipGraphLaunch(slot->exec, ctx->stream) == hipSuccess) {
+            ctx->begin_ops_pending = false;
+            if (slot->exec_b) {
+                int r = iter_attract_parts(ctx, QP_NN);                      // the sampled launch, between two events
+                if (r == NW_OK && hipGraphLaunch(slot->exec_b, ctx->stream) != hipSuccess) r = NW_ERR_HIP;
+                if (r != NW_OK) { ctx->in_search = false; return fail(ctx, r, "replay of a captured block failed half-way"); }
             }
-        }
-        if (slot) {
-            if (hipGraphLaunch(slot->exec, ctx->stream) == hipSuccess) {
-                ctx->begin_ops_pending = false;
-                ctx->global_iter += num_iters; ctx->search_done = num_iters; ctx->face_warm = true;
-                replayed = true;
-            } else (void)hipGetLastError();
-        }
+            ctx->global_iter += num_iters; ctx->search_done = num_iters; ctx->face_warm = true;
+            replayed = true;
+        } else (void)hipGetLastError();
     }
     for (int i = 0; !replayed && i < num_iters; ++i) {
         int r = nw_iter_attract(ctx);
@@ -1183,11 +1240,13 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         if (r != NW_OK) { ctx->in_search = false; return r; }
     }
     const auto t2 = std::chrono::steady_clock::now();
+    if (trace_blocks) (void)hipEventRecord(tb1, ctx->stream);
     const int rc = nw_search_end(ctx, pos_out, log, loopcount);
+    if (trace_blocks) { float ms = 0; (void)hipEventElapsedTime(&ms, tb0, tb1); fprintf(stderr, "[nanowrap] block device time (first to last launch) %.3f ms\n", ms); }
     if (verbose) {
         const auto t3 = std::chrono::steady_clock::now();
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-        fprintf(stderr, "[nanowrap] search(%d): begin %ld us, enqueue %ld us, end(sync+D2H) %ld us\n", num_iters, us(t0, t1), us(t1, t2), us(t2, t3));
+        fprintf(stderr, "[nanowrap] search(%d): begin %ld us, enqueue %ld us (%s), end(sync+D2H) %ld us\n", num_iters, us(t0, t1), us(t1, t2), replayed ? "graph" : "direct", us(t2, t3));
     }
     return rc;
 }
@@ -1459,7 +1518,7 @@ NW_EXPORT int nw_accumulator_quantum(nw_ctx *ctx, double *q)
 NW_EXPORT int nw_set_profiling(nw_ctx *ctx, int enable)
 {
     if (!ctx) return NW_ERR_BADARG;
-    ctx->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    ctx->profiling = enable < 0 ? 0 : (enable > 3 ? 3 : enable);
     return NW_OK;
 }
 

@@ -388,8 +388,9 @@ class ShrinkwrapMeshConjGrad(object):
 
     # -- timing hooks for bench.py ------------------------------------------------------------------
     def set_profiling(self, level=2):
-        """0/False off; 1 = HIP events around the NN query only (cheap: what bench.py keeps on in its timed region);
-        2/True = around every stage (each event pair serialises the stream for a few microseconds)."""
+        """0/False off; 1 = HIP events around every NN query launch; 2/True = around every stage (each event pair serialises the
+        stream for a few microseconds; 1 and 2 launch every kernel from the host); 3 = sampled: blocks stay captured hipGraphs and
+        only the NN query of each block's first iteration is bracketed (what bench.py keeps on in its timed region)."""
         level = 2 if level is True else int(level)
         self._native.check(self._L.nw_set_profiling(self._h, level))
         self._profiling = level > 0

@@ -206,7 +206,9 @@ int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, co
 /* device timing of the last nw_search (ms), split by stage; for bench.py's roofline object.
  * stage: 0 total, 1 grid build, 2 NN query, 3 attraction (weights/residual/scatter), 4 prior+directions,
  * 5 A.S + dots, 6 solve+update, 7 float64 NN fix-up.  nw_set_profiling level: 0 off; 1 = HIP events around the NN query only (the dominant kernel;
- * each event pair costs a few microseconds of stream serialisation); 2 = around every stage. */
+ * each event pair costs a few microseconds of stream serialisation); 2 = around every stage; 3 = sampled: nw_search keeps replaying
+ * the block as a hipGraph (levels 1 and 2 launch every kernel from the host: events inside graph nodes read 0 on ROCm 7.2) and brackets
+ * only the NN query of the block's FIRST iteration, launched directly between the two halves of the graph. */
 int nw_set_profiling(nw_ctx *ctx, int enable);
 int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
 
