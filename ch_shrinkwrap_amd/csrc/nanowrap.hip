@@ -1486,7 +1486,7 @@ NW_EXPORT int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out)
     if (!ctx->nn_stats.p) {
         NW_HIP(ctx->nn_stats.ensure(NWS_COUNT));
         NW_HIP(hipMemset(ctx->nn_stats.p, 0, NWS_COUNT * sizeof(unsigned long long)));
-        for (int k = 0; k < 9; ++k) out[k] = 0;
+        for (int k = 0; k <= NWS_COUNT; ++k) out[k] = 0;
         return NW_OK;
     }
     unsigned long long h[NWS_COUNT];
@@ -1494,7 +1494,7 @@ NW_EXPORT int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out)
     NW_HIP(hipMemcpy(h, ctx->nn_stats.p, sizeof(h), hipMemcpyDeviceToHost));
     NW_HIP(hipMemset(ctx->nn_stats.p, 0, sizeof(h)));
     for (int k = 0; k < NWS_COUNT; ++k) out[k] = (int64_t)h[k];
-    out[8] = ctx->nitems;
+    out[NWS_COUNT] = ctx->nitems;
     return NW_OK;
 }
 
