@@ -40,14 +40,24 @@ int match_twins(const int32_t *faces, int64_t nf, int64_t nv, int *twin)
         std::vector<int> fill(first.begin(), first.end() - 1);
         for (int64_t h = 0; h < nh; ++h) out[fill[faces[h]]++] = (int)h;
     }
-    auto target = [&](int h) { const int f = h / 3, k = h - 3 * f; return faces[3 * f + (k + 1) % 3]; };
+    // target vertex of every half-edge, laid out next to the bucket entries (one sequential read per candidate)
+    std::vector<int> tgt(nh), out_tgt(nh);
+    for (int64_t f = 0; f < nf; ++f) { tgt[3 * f] = faces[3 * f + 1]; tgt[3 * f + 1] = faces[3 * f + 2]; tgt[3 * f + 2] = faces[3 * f]; }
+    for (int64_t i = 0; i < nh; ++i) out_tgt[i] = tgt[out[i]];
     for (int64_t h = 0; h < nh; ++h) {
-        const int a = faces[h], b = target((int)h);
-        int t = -1, same = 0;
-        for (int i = first[b]; i < first[b + 1]; ++i) if (target(out[i]) == a) { if (t >= 0) return NWR_ERR_NONMANIFOLD; t = out[i]; }
-        for (int i = first[a]; i < first[a + 1]; ++i) same += (target(out[i]) == b);
-        if (same != 1) return NWR_ERR_NONMANIFOLD;             // the same directed edge twice
+        const int a = faces[h], b = tgt[h];
+        int t = -1;
+        for (int i = first[b]; i < first[b + 1]; ++i) if (out_tgt[i] == a) { if (t >= 0) return NWR_ERR_NONMANIFOLD; t = out[i]; }
         twin[h] = t;
+    }
+    // the same directed edge twice: both copies found the same twin, which can point back at only one of them; an unmatched
+    // duplicate pair shows up among the half-edges leaving their origin
+    for (int64_t h = 0; h < nh; ++h) {
+        if (twin[h] >= 0) { if (twin[twin[h]] != (int)h) return NWR_ERR_NONMANIFOLD; continue; }
+        const int a = faces[h], b = tgt[h];
+        int same = 0;
+        for (int i = first[a]; i < first[a + 1]; ++i) same += (out_tgt[i] == b);
+        if (same != 1) return NWR_ERR_NONMANIFOLD;
     }
     return NWR_OK;
 }
@@ -326,7 +336,7 @@ struct HalfEdgeMesh {
 
 }  // namespace
 
-NWR_EXPORT int nwr_abi_version(void) { return 1; }
+NWR_EXPORT int nwr_abi_version(void) { return 2; }
 
 NWR_EXPORT void nwr_free(void *p) { std::free(p); }
 
@@ -401,6 +411,89 @@ NWR_EXPORT int nwr_mesh_geometry(const void *positions, int64_t pos_stride_bytes
     } catch (const std::bad_alloc &) {
         return NWR_ERR_NOMEM;
     }
+}
+
+// Half-edge tables + 1-rings of an oriented triangle mesh, written straight into the caller's records (PYME-style structured
+// arrays: trimesh.HALFEDGE_DTYPE / VERTEX_DTYPE): what trimesh._build_halfedges + TriMesh._build_rings define in NumPy, same
+// conventions -- half-edge 3f+k runs faces[f][k] -> faces[f][(k+1)%3]; a vertex starts its ring at its lowest-numbered outgoing
+// half-edge, a boundary vertex at its (highest-numbered) outgoing half-edge without a twin; the ring is walked counter-clockwise
+// (cur -> twin[prev[cur]]) for at most `neighbor_size` steps.
+NWR_EXPORT int nwr_build_topology(const int32_t *faces, int64_t n_faces, int64_t n_vertex_slots,
+                                  void *halfedges, int64_t he_stride, int64_t off_vertex, int64_t off_face, int64_t off_twin, int64_t off_next, int64_t off_prev,
+                                  int32_t *origin, void *vertices, int64_t v_stride, int64_t off_halfedge, int64_t off_valence, int64_t off_neighbors,
+                                  int32_t neighbor_size)
+{
+    if (!faces || !halfedges || !origin || !vertices || n_faces < 1 || n_vertex_slots < 1 || n_faces > (1ll << 29) || neighbor_size < 1 || neighbor_size > 64)
+        return NWR_ERR_BADARG;
+    const int64_t nh = 3 * n_faces;
+    for (int64_t i = 0; i < nh; ++i) if (faces[i] < 0 || faces[i] >= n_vertex_slots) return NWR_ERR_BADARG;
+    try {
+        std::vector<int> twin(nh);
+        const int rc = match_twins(faces, n_faces, n_vertex_slots, twin.data());
+        if (rc != NWR_OK) return rc;
+        char *hb = (char *)halfedges, *vb = (char *)vertices;
+        auto H = [&](int64_t h, int64_t off) -> int32_t & { return *(int32_t *)(hb + h * he_stride + off); };
+        for (int64_t f = 0; f < n_faces; ++f)
+            for (int k = 0; k < 3; ++k) {
+                const int64_t h = 3 * f + k;
+                H(h, off_vertex) = faces[3 * f + (k + 1) % 3];
+                H(h, off_face) = (int32_t)f;
+                H(h, off_twin) = twin[h];
+                H(h, off_next) = (int32_t)(3 * f + (k + 1) % 3);
+                H(h, off_prev) = (int32_t)(3 * f + (k + 2) % 3);
+                origin[h] = faces[h];
+            }
+        std::vector<int> start(n_vertex_slots, -1);
+        for (int64_t h = nh - 1; h >= 0; --h) start[faces[h]] = (int)h;                  // lowest index wins
+        for (int64_t h = 0; h < nh; ++h) if (twin[h] < 0) start[faces[h]] = (int)h;       // boundary: the last one wins
+        for (int64_t v = 0; v < n_vertex_slots; ++v) {
+            int32_t *nb = (int32_t *)(vb + v * v_stride + off_neighbors);
+            for (int s = 0; s < neighbor_size; ++s) nb[s] = -1;
+            const int s0 = start[v];
+            *(int32_t *)(vb + v * v_stride + off_halfedge) = s0;
+            int n = 0, cur = s0;
+            while (cur >= 0 && n < neighbor_size) {
+                nb[n++] = cur;
+                const int k = cur % 3, p = cur - k + (k + 2) % 3;
+                const int nx = twin[p];
+                if (nx < 0 || nx == s0) break;
+                cur = nx;
+            }
+            *(int32_t *)(vb + v * v_stride + off_valence) = n;
+        }
+        return NWR_OK;
+    } catch (const std::bad_alloc &) {
+        return NWR_ERR_NOMEM;
+    }
+}
+
+// Per-slot tables of the 1-rings (slot s of vertex v = half-edge nb[v][s], -1 padded): the vertex it points to (the table the
+// optimiser caches, mesh_conj_grad.py:50-54), the vertex its NEXT half-edge points to and the area of its face (what
+// c_curvature_grad reads through the half-edge records, membrane_mesh_utils.c:1099-1104).  Any output may be NULL.
+NWR_EXPORT int nwr_ring_tables(const void *halfedges, int64_t he_stride, int64_t off_vertex, int64_t off_face, int64_t off_next, int64_t n_halfedges,
+                               const void *vertices, int64_t v_stride, int64_t off_neighbors, int32_t neighbor_size, int64_t n_vertex_slots,
+                               const void *face_area, int64_t fa_stride, int32_t *ring_vertex, int32_t *ring_next_vertex, float *ring_area)
+{
+    if (!halfedges || !vertices || n_halfedges < 3 || n_vertex_slots < 1 || neighbor_size < 1 || (ring_area && !face_area)) return NWR_ERR_BADARG;
+    const char *hb = (const char *)halfedges, *vb = (const char *)vertices, *fb = (const char *)face_area;
+    auto H = [&](int64_t h, int64_t off) { return *(const int32_t *)(hb + h * he_stride + off); };
+    for (int64_t v = 0; v < n_vertex_slots; ++v) {
+        const int32_t *nb = (const int32_t *)(vb + v * v_stride + off_neighbors);
+        for (int s = 0; s < neighbor_size; ++s) {
+            const int h = nb[s];
+            const int64_t o = v * neighbor_size + s;
+            if (h < 0 || h >= n_halfedges) {
+                if (ring_vertex) ring_vertex[o] = -1;
+                if (ring_next_vertex) ring_next_vertex[o] = -1;
+                if (ring_area) ring_area[o] = 0.0f;
+                continue;
+            }
+            if (ring_vertex) ring_vertex[o] = H(h, off_vertex);
+            if (ring_next_vertex) ring_next_vertex[o] = H(H(h, off_next), off_vertex);
+            if (ring_area) ring_area[o] = *(const float *)(fb + (int64_t)H(h, off_face) * fa_stride);
+        }
+    }
+    return NWR_OK;
 }
 
 NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces,

@@ -116,6 +116,10 @@ class MembraneMesh(TriMesh):
     def _neighbor_tables(self):
         """Flat per-slot tables the curvature kernel needs besides the 1-ring vertex ids: the vertex the NEXT half-edge
         points to and the area of the half-edge's face (membrane_mesh_utils.c:1099-1104)."""
+        if not getattr(TriMesh, '_numpy_topology', False):
+            from .remesh import ring_tables
+            _, nxt, area = ring_tables(self._halfedges, self._vertices, self._faces, ring_vertex=False, ring_next=True, ring_area=True)
+            return nxt, area
         he = self._halfedges
         nb = self._vertices['neighbors']
         ok = nb != -1

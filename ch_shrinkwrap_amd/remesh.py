@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libnw_remesh.so')
-SYMBOLS = ['nwr_abi_version', 'nwr_remesh', 'nwr_free', 'nwr_halfedge_twins', 'nwr_mesh_geometry']
+SYMBOLS = ['nwr_abi_version', 'nwr_remesh', 'nwr_free', 'nwr_halfedge_twins', 'nwr_mesh_geometry', 'nwr_build_topology', 'nwr_ring_tables']
 ERRORS = {-1: 'bad argument', -2: 'the mesh is not an oriented 2-manifold', -3: 'out of memory'}
 
 _lib = None
@@ -45,7 +45,13 @@ def load():
         L.nwr_mesh_geometry.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4
         L.nwr_free.restype = None
         L.nwr_free.argtypes = [ctypes.c_void_p]
-        if L.nwr_abi_version() != 1:
+        L.nwr_build_topology.restype = ctypes.c_int
+        L.nwr_build_topology.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int64] * 6 + \
+                                         [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int64] * 4 + [ctypes.c_int32]
+        L.nwr_ring_tables.restype = ctypes.c_int
+        L.nwr_ring_tables.argtypes = [ctypes.c_void_p] + [ctypes.c_int64] * 5 + [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
+                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        if L.nwr_abi_version() != 2:
             raise RuntimeError('libnw_remesh.so ABI version mismatch')
         _lib = L
     return _lib
@@ -86,6 +92,45 @@ def halfedge_twins(faces, n_vertices):
     if rc != 0:
         raise RuntimeError('nwr_halfedge_twins: %s' % ERRORS.get(rc, 'error %d' % rc))
     return twin
+
+
+def build_topology(faces, halfedges, vertices):
+    """Fill the half-edge records (vertex, face, twin, next, prev) and the vertex records (halfedge, valence, neighbors) of a
+    TriMesh from its face array; returns the origin vertex of every half-edge.  Raises RuntimeError on a non-manifold edge."""
+    L = load()
+    f = np.ascontiguousarray(faces, np.int32)
+    origin = np.empty(3 * f.shape[0], np.int32)
+    ho = lambda name: halfedges.dtype.fields[name][1]
+    vo = lambda name: vertices.dtype.fields[name][1]
+    nbsize = vertices.dtype.fields['neighbors'][0].shape[0]
+    rc = L.nwr_build_topology(f.ctypes.data, f.shape[0], vertices.shape[0], halfedges.ctypes.data, halfedges.strides[0], ho('vertex'), ho('face'),
+                              ho('twin'), ho('next'), ho('prev'), origin.ctypes.data, vertices.ctypes.data, vertices.strides[0], vo('halfedge'),
+                              vo('valence'), vo('neighbors'), nbsize)
+    if rc != 0:
+        raise RuntimeError('nwr_build_topology: %s' % ERRORS.get(rc, 'error %d' % rc))
+    return origin
+
+
+def ring_tables(halfedges, vertices, faces_rec=None, ring_vertex=True, ring_next=False, ring_area=False):
+    """(ring vertex ids, vertex after each ring half-edge, area of each ring half-edge's face) as (M, NEIGHBORSIZE) tables; entries
+    not asked for are None."""
+    L = load()
+    ho = lambda name: halfedges.dtype.fields[name][1]
+    nbsize = vertices.dtype.fields['neighbors'][0].shape[0]
+    M = vertices.shape[0]
+    rv = np.empty((M, nbsize), np.int32) if ring_vertex else None
+    rn = np.empty((M, nbsize), np.int32) if ring_next else None
+    ra = np.empty((M, nbsize), np.float32) if ring_area else None
+    fa_ptr, fa_stride = (None, 0)
+    if ring_area:
+        fa_ptr, fa_stride = faces_rec.ctypes.data + faces_rec.dtype.fields['area'][1], faces_rec.strides[0]
+    ptr = lambda a: a.ctypes.data if a is not None else None
+    rc = L.nwr_ring_tables(halfedges.ctypes.data, halfedges.strides[0], ho('vertex'), ho('face'), ho('next'), halfedges.shape[0],
+                           vertices.ctypes.data, vertices.strides[0], vertices.dtype.fields['neighbors'][1], nbsize, M,
+                           fa_ptr, fa_stride, ptr(rv), ptr(rn), ptr(ra))
+    if rc != 0:
+        raise RuntimeError('nwr_ring_tables: %s' % ERRORS.get(rc, 'error %d' % rc))
+    return rv, rn, ra
 
 
 def mesh_geometry(positions, faces, vertex_normals=True):

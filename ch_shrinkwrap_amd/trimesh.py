@@ -171,16 +171,36 @@ class TriMesh(object):
         self._vertices['position'][:vertices.shape[0]] = vertices
         self._nv = vertices.shape[0]
         self._faces_arr = faces
-        self._halfedges, self._origin = _build_halfedges(faces, M)
         self._faces = np.zeros(faces.shape[0], FACE_DTYPE)
         self._faces['halfedge'] = 3 * np.arange(faces.shape[0], dtype='i4')
-        self._build_rings()
+        if not self._build_topology_native(faces):
+            self._halfedges, self._origin = _build_halfedges(faces, M)
+            self._build_rings()
         self.update_geometry()
         self.cg = None
         self.vertex_properties = []
         self.vertex_vector_properties = []
 
     # -- topology ---------------------------------------------------------------------------
+    def _build_topology_native(self, faces):
+        """Half-edge records and 1-rings in one native pass (include/nw_remesh.h: nwr_build_topology, the same conventions as the
+        NumPy definitions below, which stay the fallback for inputs the library rejects -- non-manifold edges)."""
+        if getattr(TriMesh, '_numpy_topology', False) or faces.shape[0] < 1:
+            return False
+        from .remesh import build_topology
+        he = np.zeros(3 * faces.shape[0], HALFEDGE_DTYPE)
+        try:
+            origin = build_topology(faces, he, self._vertices)
+        except (RuntimeError, ValueError):                # (a missing library raises ImportError and is NOT hidden)
+            self._vertices['halfedge'] = -1
+            self._vertices['neighbors'] = -1
+            self._vertices['valence'] = 0
+            return False
+        self._halfedges, self._origin = he, origin
+        self._vertices['locally_manifold'] = 1
+        self._vertices['component'] = 0
+        return True
+
     def _build_rings(self):
         he = self._halfedges
         M = self._vertices.shape[0]
@@ -289,6 +309,9 @@ class TriMesh(object):
     def neighbor_vertex_table(self):
         """(M, NEIGHBORSIZE) i4 table of 1-ring VERTEX ids, -1 padded -- what the reference caches
         at mesh_conj_grad.py:50-54."""
+        if not getattr(TriMesh, '_numpy_topology', False):
+            from .remesh import ring_tables
+            return ring_tables(self._halfedges, self._vertices)[0]
         n = self._halfedges['vertex'][self._vertices['neighbors']]
         n[self._vertices['neighbors'] == -1] = -1
         return np.ascontiguousarray(n, dtype='i4')

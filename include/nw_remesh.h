@@ -65,6 +65,22 @@ int nwr_halfedge_twins(const int32_t *faces, int64_t n_faces, int64_t n_vertices
 int nwr_mesh_geometry(const void *positions, int64_t pos_stride_bytes, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
                       float *face_normal, float *face_area, float *halfedge_length, float *vertex_normal /* may be NULL */);
 
+/* Half-edge tables and 1-rings written straight into the caller's records (structured arrays in PYME's layout: half-edge records
+ * he_stride bytes apart with int32 fields at the given byte offsets, vertex records likewise): what a half-edge substrate
+ * rebuilds after every topology change (trimesh._build_halfedges + TriMesh._build_rings, same conventions).  origin[3F]
+ * receives the origin vertex of every half-edge.  NWR_ERR_NONMANIFOLD as for nwr_halfedge_twins. */
+int nwr_build_topology(const int32_t *faces, int64_t n_faces, int64_t n_vertex_slots,
+                       void *halfedges, int64_t he_stride, int64_t off_vertex, int64_t off_face, int64_t off_twin, int64_t off_next, int64_t off_prev,
+                       int32_t *origin, void *vertices, int64_t v_stride, int64_t off_halfedge, int64_t off_valence, int64_t off_neighbors,
+                       int32_t neighbor_size);
+
+/* Per-slot tables of the 1-rings: vertex each ring half-edge points to (the optimiser's neighbour table,
+ * /root/reference/ch_shrinkwrap/mesh_conj_grad.py:50-54), vertex its next half-edge points to and area of its face
+ * (read by c_curvature_grad, membrane_mesh_utils.c:1099-1104); -1 / 0 in empty slots.  Any output may be NULL. */
+int nwr_ring_tables(const void *halfedges, int64_t he_stride, int64_t off_vertex, int64_t off_face, int64_t off_next, int64_t n_halfedges,
+                    const void *vertices, int64_t v_stride, int64_t off_neighbors, int32_t neighbor_size, int64_t n_vertex_slots,
+                    const void *face_area, int64_t fa_stride, int32_t *ring_vertex, int32_t *ring_next_vertex, float *ring_area);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,7 +37,7 @@ def test_library_exports_header_symbols():
     assert names == sorted(R.SYMBOLS)
     for n in names:
         assert hasattr(L, n)
-    assert R.load().nwr_abi_version() == 1
+    assert R.load().nwr_abi_version() == 2
     assert ctypes.sizeof(R.Stats) == 3 * 8 + 8 + 2 * 4
 
 
@@ -135,3 +135,41 @@ def test_native_geometry_refresh_is_bit_identical_to_the_numpy_definition(case):
     posn = np.minimum(np.searchsorted(key[order], rkey), key.shape[0] - 1)
     cand = order[posn]
     assert np.array_equal(a._halfedges['twin'], np.where(key[cand] == rkey, cand, -1))
+
+
+@pytest.mark.parametrize('case', ['icosphere', 'network', 'open_with_spare_slots', 'remeshed'])
+def test_native_topology_is_identical_to_the_numpy_definition(case):
+    """nwr_build_topology / nwr_ring_tables against the NumPy code they replace (trimesh._build_halfedges, TriMesh._build_rings,
+    neighbor_vertex_table, MembraneMesh._neighbor_tables): every half-edge field, ring start, ring order, valence, and the per-slot
+    tables -- closed, open (boundary fans) and freshly remeshed (ids in creation order) meshes, with unused vertex slots."""
+    from ch_shrinkwrap_amd.membrane_mesh import MembraneMesh
+    extra = 0
+    if case == 'network':
+        from ch_shrinkwrap_amd import synth
+        c = synth.make_config('c4', scale=0.02, seed=5)
+        v, f = c['vertices'], c['faces']
+    else:
+        v, f = icosphere(3, 73.0)
+        v = (v * np.array([1.0, 0.6, 1.7], 'f4')).astype('f4')
+        if case == 'open_with_spare_slots':
+            f = f[v[f].mean(1)[:, 2] > 0]
+            extra = 11
+        if case == 'remeshed':
+            v, f = R.remesh(v, f, 3, 6.0, 0.5, 2)
+    a = MembraneMesh(vertices=v, faces=f) if extra == 0 else TriMesh(v, f, max_vertices=v.shape[0] + extra)
+    TriMesh._numpy_topology = True
+    try:
+        b = MembraneMesh(vertices=v, faces=f) if extra == 0 else TriMesh(v, f, max_vertices=v.shape[0] + extra)
+        nvt_b = b.neighbor_vertex_table()
+        tabs_b = b._neighbor_tables() if extra == 0 else None
+    finally:
+        TriMesh._numpy_topology = False
+    for name in ('vertex', 'face', 'twin', 'next', 'prev', 'length', 'component'):
+        assert np.array_equal(a._halfedges[name], b._halfedges[name]), name
+    assert np.array_equal(a._origin, b._origin)
+    for name in ('halfedge', 'valence', 'neighbors', 'component', 'locally_manifold', 'normal'):
+        assert np.array_equal(a._vertices[name], b._vertices[name]), name
+    assert np.array_equal(a.neighbor_vertex_table(), nvt_b)
+    if tabs_b is not None:
+        nxt, area = a._neighbor_tables()
+        assert np.array_equal(nxt, tabs_b[0]) and np.array_equal(area, tabs_b[1])
