@@ -11,6 +11,8 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <chrono>
+#include <cstdio>
 
 #include "../../include/nw_remesh.h"
 
@@ -72,9 +74,41 @@ struct HalfEdgeMesh {
     int max_valence = 16;
     int64_t n_split = 0, n_collapse = 0, n_flip = 0;
     bool corrupt = false;
+    // Without relaxation no vertex moves, so a collapse or flip that was refused is refused again until an operation changes the
+    // ring of one of the edge's quad vertices (its end points and the two opposite vertices).  Every operation stamps the half-edges
+    // that have a vertex it touched in their quad (`mark`), and the collapse / flip passes skip the edges without a stamp from this or
+    // the previous iteration: same order, same decisions as the full scans (checked: identical output), without re-running the
+    // refused tests every iteration.  (With relaxation every vertex moves in every iteration: `all_dirty`.)
+    std::vector<int> estamp;
+    int cur_it = 1;
+    bool all_dirty = false;
+    bool fresh_edge(int h) const { return all_dirty || estamp[h] >= cur_it - 1; }
+    void mark(int v)
+    {
+        if (vhe[v] < 0 || boundary[v]) return;
+        ring(v, [&](int o) {
+            estamp[o] = cur_it;
+            const int n = next[o];
+            estamp[n] = cur_it;
+            if (twin[o] >= 0) estamp[twin[o]] = cur_it;
+            if (twin[n] >= 0) estamp[twin[n]] = cur_it;
+        });
+    }
+
+    // squared length of every half-edge, kept current by the operations: no vertex moves between relaxations, so the split and
+    // collapse passes -- most of which look at an edge only to find it neither long nor short -- read one sequential array instead
+    // of two vertex records per edge
+    std::vector<double> l2;
 
     int from(int h) const { return vert[prev[h]]; }
     double len2(int h) const { return norm2(pos[vert[h]] - pos[from(h)]); }
+    void set_len(int h)
+    {
+        const double v = len2(h);
+        l2[h] = v;
+        if (twin[h] >= 0) l2[twin[h]] = v;
+    }
+    void refresh_lengths() { for (size_t h = 0; h < vert.size(); ++h) if (vert[h] >= 0) l2[h] = len2((int)h); }
 
     // outgoing half-edges of an interior vertex, counter-clockwise
     template <class F>
@@ -98,7 +132,7 @@ struct HalfEdgeMesh {
 
     int add_halfedge()
     {
-        vert.push_back(-1); next.push_back(-1); prev.push_back(-1); twin.push_back(-1); face.push_back(-1);
+        vert.push_back(-1); next.push_back(-1); prev.push_back(-1); twin.push_back(-1); face.push_back(-1); l2.push_back(0.0); estamp.push_back(cur_it);
         return (int)vert.size() - 1;
     }
 
@@ -134,6 +168,9 @@ struct HalfEdgeMesh {
             ring((int)v, [&](int) { ++n; });
             if (n != val[v]) boundary[v] = 1;
         }
+        l2.assign(nh, 0.0);
+        estamp.assign(nh, 0);
+        refresh_lengths();
         corrupt = false;
         return NWR_OK;
     }
@@ -171,6 +208,8 @@ struct HalfEdgeMesh {
         twin[h] = t2; twin[t2] = h; twin[h2] = t; twin[t] = h2; twin[e0] = e1; twin[e1] = e0; twin[e2] = e3; twin[e3] = e2;
         vhe[m] = h2;
         val[c] += 1; val[d] += 1;
+        set_len(h); set_len(h2); set_len(e0); set_len(e2);
+        mark(a); mark(b); mark(c); mark(d); mark(m);
         ++n_split;
     }
 
@@ -220,6 +259,10 @@ struct HalfEdgeMesh {
         fhe[face[h]] = -1; fhe[face[t]] = -1;
         val[b] = val[a] + val[b] - 4; val[c] -= 1; val[d] -= 1;
         val[a] = 0; vhe[a] = -1;
+        for (int i = 0; i < na; ++i) if (alive(rh[i])) set_len(rh[i]);      // the edges that ended at a now end at b
+        set_len(tn_t); set_len(hp_t);                                       // (d->a whose partner a->d died; the re-paired c-b edge)
+        mark(b);
+        for (int i = 0; i < na; ++i) if (ra[i] != b) mark(ra[i]);
         ++n_collapse;
         return true;
     }
@@ -255,6 +298,8 @@ struct HalfEdgeMesh {
         if (vhe[a] == h) vhe[a] = tn;
         if (vhe[b] == t) vhe[b] = hn;
         val[a] -= 1; val[b] -= 1; val[c] += 1; val[d] += 1;
+        set_len(h);
+        mark(a); mark(b); mark(c); mark(d);
         ++n_flip;
         return true;
     }
@@ -267,11 +312,11 @@ struct HalfEdgeMesh {
             const int64_t before = n_split;
             const size_t nh = vert.size();                 // edges created by this pass are looked at in the next one
             for (size_t h = 0; h < nh; ++h) {
-                if (!alive((int)h)) continue;
+                if (!(l2[h] > high2) || !alive((int)h)) continue;
                 const int t = twin[h];
                 if (t < 0 || (int)h > t) continue;         // each interior edge once
                 if (boundary[from((int)h)] && boundary[vert[h]]) continue;
-                if (len2((int)h) > high2) split((int)h);
+                split((int)h);
             }
             if (n_split == before) break;
         }
@@ -281,10 +326,9 @@ struct HalfEdgeMesh {
     {
         const size_t nh = vert.size();
         for (size_t h = 0; h < nh; ++h) {
-            if (!alive((int)h)) continue;
+            if (l2[h] >= low2 || !fresh_edge((int)h) || !alive((int)h)) continue;
             const int t = twin[h];
             if (t < 0 || (int)h > t) continue;
-            if (len2((int)h) >= low2) continue;
             if (!collapse((int)h, high2)) collapse(t, high2);
             if (corrupt) return;
         }
@@ -294,7 +338,7 @@ struct HalfEdgeMesh {
     {
         const size_t nh = vert.size();
         for (size_t h = 0; h < nh; ++h) {
-            if (!alive((int)h)) continue;
+            if (!fresh_edge((int)h) || !alive((int)h)) continue;
             const int t = twin[h];
             if (t < 0 || (int)h > t) continue;
             flip((int)h);
@@ -331,6 +375,7 @@ struct HalfEdgeMesh {
             }
             pos.swap(upd);
         }
+        refresh_lengths();
     }
 };
 
@@ -506,10 +551,15 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
         return NWR_ERR_BADARG;
     *out_vertices = nullptr; *out_faces = nullptr; *out_n_vertices = 0; *out_n_faces = 0;
     try {
+        const bool verbose = std::getenv("NWR_VERBOSE") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t_start = now();
         HalfEdgeMesh m;
         m.max_valence = max_valence > 0 ? std::min(max_valence, 60) : 16;
         int rc = m.build(vertices, n_vertices, faces, n_faces);
         if (rc != NWR_OK) return rc;
+        if (verbose) std::fprintf(stderr, "[nw_remesh] build %.1f ms\n", ms(t_start, now()));
         double L = target_edge_length;
         if (!(L > 0)) {
             double s = 0; int64_t n = 0;
@@ -517,17 +567,25 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
             L = n ? s / n : 1.0;
         }
         const double high = 4.0 / 3.0 * L, low = 4.0 / 5.0 * L;
+        m.all_dirty = n_relax > 0;
         for (int it = 0; it < n_iterations; ++it) {
+            m.cur_it = it + 1;
             const int64_t ops_before = m.n_split + m.n_collapse + m.n_flip;
+            const auto t0 = now();
             m.split_long_edges(high * high);
+            const auto t1 = now();
             m.collapse_short_edges(low * low, high * high);
+            const auto t2 = now();
             m.equalize_valences();
+            if (verbose) std::fprintf(stderr, "[nw_remesh] iteration %d: split %.1f ms, collapse %.1f ms, flip %.1f ms (%lld / %lld / %lld operations so far)\n", it, ms(t0, t1), ms(t1, t2),
+                                      ms(t2, now()), (long long)m.n_split, (long long)m.n_collapse, (long long)m.n_flip);
             if (n_relax > 0) m.relax(relax_lambda, n_relax);
             if (m.corrupt) return NWR_ERR_NONMANIFOLD;
             // a pass that changed nothing would be repeated unchanged by every later iteration (no relaxation to move vertices)
             if (n_relax == 0 && m.n_split + m.n_collapse + m.n_flip == ops_before) break;
         }
         // splits can pile degree onto a vertex faster than one flip pass removes it: keep flipping while it helps
+        m.all_dirty = true;
         for (int extra = 0; extra < 6 && n_iterations > 0; ++extra) {
             int mv = 0;
             for (size_t v = 0; v < m.pos.size(); ++v) if (m.vhe[v] >= 0) mv = std::max(mv, m.val[v]);
@@ -570,6 +628,7 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
             stats->mean_edge_length = n ? s / n : 0.0; stats->max_valence = mv; stats->reserved = 0;
         }
         *out_vertices = ov; *out_n_vertices = nv; *out_faces = of; *out_n_faces = nf;
+        if (verbose) std::fprintf(stderr, "[nw_remesh] total %.1f ms\n", ms(t_start, now()));
         return NWR_OK;
     } catch (const std::bad_alloc &) {
         return NWR_ERR_NOMEM;

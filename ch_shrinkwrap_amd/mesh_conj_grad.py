@@ -91,9 +91,12 @@ class ShrinkwrapMeshConjGrad(object):
         self.dims = self._vertices.shape[1]
         self.shape = self._vertices.shape
         self.faces = mesh.faces                                                        # :47
-        n = mesh._halfedges['vertex'][mesh._vertices['neighbors']]                     # :50-54
-        n[mesh._vertices['neighbors'] == -1] = -1
-        self.vertex_neighbors = np.ascontiguousarray(n, dtype=np.int32)
+        if hasattr(mesh, 'neighbor_vertex_table'):                                     # :50-54 (native table builder of the substrate)
+            self.vertex_neighbors = mesh.neighbor_vertex_table()
+        else:
+            n = mesh._halfedges['vertex'][mesh._vertices['neighbors']]
+            n[mesh._vertices['neighbors'] == -1] = -1
+            self.vertex_neighbors = np.ascontiguousarray(n, dtype=np.int32)
         self.N = self.vertex_neighbors.shape[1]
 
         self._native = native if native is not None else NativeContext(device, stream)
