@@ -171,6 +171,7 @@ class TriMesh(object):
         self._vertices['position'][:vertices.shape[0]] = vertices
         self._nv = vertices.shape[0]
         self._faces_arr = faces
+        self._ring_vertex_table = None
         self._faces = np.zeros(faces.shape[0], FACE_DTYPE)
         self._faces['halfedge'] = 3 * np.arange(faces.shape[0], dtype='i4')
         if not self._build_topology_native(faces):
@@ -310,8 +311,11 @@ class TriMesh(object):
         """(M, NEIGHBORSIZE) i4 table of 1-ring VERTEX ids, -1 padded -- what the reference caches
         at mesh_conj_grad.py:50-54."""
         if not getattr(TriMesh, '_numpy_topology', False):
-            from .remesh import ring_tables
-            return ring_tables(self._halfedges, self._vertices)[0]
+            # built once per topology (TriMesh.__init__ drops it); callers treat the table as read-only
+            if getattr(self, '_ring_vertex_table', None) is None:
+                from .remesh import ring_tables
+                self._ring_vertex_table = ring_tables(self._halfedges, self._vertices)[0]
+            return self._ring_vertex_table
         n = self._halfedges['vertex'][self._vertices['neighbors']]
         n[self._vertices['neighbors'] == -1] = -1
         return np.ascontiguousarray(n, dtype='i4')
