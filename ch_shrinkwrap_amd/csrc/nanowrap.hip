@@ -761,10 +761,19 @@ NW_EXPORT int nw_refresh_normals(nw_ctx *ctx, float *nrm_out)
 {
     if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_refresh_normals: mesh not set");
     NW_HIP(hipSetDevice(ctx->device));
-    NW_HIP(ctx->tmp_f.ensure(3 * ctx->M));
-    NW_HIP(hipMemsetAsync(ctx->tmp_f.p, 0, 3 * ctx->M * sizeof(float), ctx->stream));
-    hipLaunchKernelGGL(k_normals_scatter, dim3(nblk(ctx->F)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->F, ctx->faces.p, ctx->meshpos.p, ctx->tmp_f.p);
-    hipLaunchKernelGGL(k_normals_finish, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->tmp_f.p, ctx->nrm.p);
+    if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_refresh_normals inside a search");
+    // the scatter accumulator of the iteration doubles as the normals' accumulator (every block zeroes it before it starts)
+    NW_HIP(ctx->vacc.ensure(4 * ctx->M));
+    NW_HIP(hipMemsetAsync(ctx->vacc.p, 0, 3 * ctx->M * sizeof(long long), ctx->stream));
+    float mlo[3], mhi[3];
+    bool bad = false;
+    NW_TRY(minmax3(ctx, ctx->meshpos.p, ctx->M, mlo, mhi, &bad));
+    if (bad) return fail(ctx, NW_ERR_NONFINITE, "non-finite vertex coordinate");
+    double ext = 1e-30;
+    for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)mhi[k] - (double)mlo[k]);
+    const double q = std::ldexp(1.0, (int)std::ceil(std::log2(ext * ext)) - 44);      // |cross product| <= extent^2; <= 2^5 terms per vertex
+    hipLaunchKernelGGL(k_normals_scatter, dim3(nblk(ctx->F)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->F, ctx->faces.p, ctx->meshpos.p, ctx->vacc.p, 1.0 / q);
+    hipLaunchKernelGGL(k_normals_finish, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->vacc.p, ctx->nrm.p);
     NW_HIP(hipGetLastError());
     if (nrm_out) NW_HIP(hipMemcpyAsync(nrm_out, ctx->nrm.p, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
     NW_HIP(hipStreamSynchronize(ctx->stream));
@@ -982,7 +991,8 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
     }
     if (parts & QP_FIXUP) {
         StageScope s(ctx, ST_FIXUP);
-        hipLaunchKernelGGL(k_nn_fixup, dim3(512), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->ambig_list.p, ctx->ambig_count.p, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+        static const int fb = getenv("NW_FIXUP_BLOCKS") ? std::max(64, atoi(getenv("NW_FIXUP_BLOCKS"))) : 2048;      // one wave per ambiguous localization: ~7000 of them at 10^6, 4 waves per workgroup
+        hipLaunchKernelGGL(k_nn_fixup, dim3(fb), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->ambig_list.p, ctx->ambig_count.p, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, ctx->face.p, ctx->state.p, it);
     }
     NW_HIP(hipGetLastError());

@@ -984,8 +984,10 @@ __global__ void k_unpermute(int N, int width, const int *__restrict__ perm, cons
 // ---- block-boundary geometry refresh (the reference's `self.face_normals; self.vertex_neighbors` after a block,
 // _membrane_mesh.pyx:1524-1527, for an unchanged topology): area-weighted vertex normals from the CURRENT device positions.
 // Definition (this build's, PYME's is unpinned -- trimesh.py): n_v = normalise( sum over incident faces of
-// (v1-v0) x (v2-v0) ), zero for vertices without faces.  Faces scatter with float atomics, vertices normalise.
-__global__ __launch_bounds__(NW_BLOCK) void k_normals_scatter(int F, const int *__restrict__ faces, const float *__restrict__ pos, float *__restrict__ acc)
+// (v1-v0) x (v2-v0) ), zero for vertices without faces.  Faces scatter into a 64-bit FIXED-POINT accumulator (quantum q, a power of
+// two: 2^-44 of the squared scene extent, which bounds a cross product), so the sums are exact and do not depend on the order in
+// which the faces arrive -- the normals feed the next block's curvature prior, and a fit must be reproducible bit for bit.
+__global__ __launch_bounds__(NW_BLOCK) void k_normals_scatter(int F, const int *__restrict__ faces, const float *__restrict__ pos, long long *__restrict__ acc, double inv_q)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
@@ -994,20 +996,21 @@ __global__ __launch_bounds__(NW_BLOCK) void k_normals_scatter(int F, const int *
     const float ux = pos[3 * b] - ax, uy = pos[3 * b + 1] - ay, uz = pos[3 * b + 2] - az;
     const float vx = pos[3 * c] - ax, vy = pos[3 * c + 1] - ay, vz = pos[3 * c + 2] - az;
     const float cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+    const long long qx = __double2ll_rn((double)cx * inv_q), qy = __double2ll_rn((double)cy * inv_q), qz = __double2ll_rn((double)cz * inv_q);
     const int vv[3] = {a, b, c};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        atomicAdd(&acc[3 * vv[k]], cx);
-        atomicAdd(&acc[3 * vv[k] + 1], cy);
-        atomicAdd(&acc[3 * vv[k] + 2], cz);
+        atomicAdd((unsigned long long *)&acc[3 * (int64_t)vv[k]], (unsigned long long)qx);
+        atomicAdd((unsigned long long *)&acc[3 * (int64_t)vv[k] + 1], (unsigned long long)qy);
+        atomicAdd((unsigned long long *)&acc[3 * (int64_t)vv[k] + 2], (unsigned long long)qz);
     }
 }
 
-__global__ __launch_bounds__(NW_BLOCK) void k_normals_finish(int M, const float *__restrict__ acc, float *__restrict__ nrm)
+__global__ __launch_bounds__(NW_BLOCK) void k_normals_finish(int M, const long long *__restrict__ acc, float *__restrict__ nrm)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= M) return;
-    const double x = acc[3 * v], y = acc[3 * v + 1], z = acc[3 * v + 2];
+    const double x = (double)acc[3 * (int64_t)v], y = (double)acc[3 * (int64_t)v + 1], z = (double)acc[3 * (int64_t)v + 2];      // (the quantum cancels)
     const double l = sqrt(x * x + y * y + z * z);
     const bool ok = l > 0.0 && isfinite(l);
     nrm[3 * v] = ok ? (float)(x / l) : 0.0f;

@@ -208,7 +208,9 @@ int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, co
  * 5 A.S + dots, 6 solve+update, 7 float64 NN fix-up.  nw_set_profiling level: 0 off; 1 = HIP events around the NN query only (the dominant kernel;
  * each event pair costs a few microseconds of stream serialisation); 2 = around every stage; 3 = sampled: nw_search keeps replaying
  * the block as a hipGraph (levels 1 and 2 launch every kernel from the host: events inside graph nodes read 0 on ROCm 7.2) and brackets
- * only the NN query of the block's FIRST iteration, launched directly between the two halves of the graph. */
+ * only the NN query of the block's FIRST iteration, launched directly between the two halves of the graph.  (Measured caveat: in a
+ * process that has also loaded PyTorch, about one block in twenty at level 3 waits 5-6 ms between its last kernel and the copies that
+ * follow; levels 0, 1 and 2 do not show it, which is why bench.py times at level 1.) */
 int nw_set_profiling(nw_ctx *ctx, int enable);
 int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
 
