@@ -127,6 +127,7 @@ struct nw_ctx {
     // captured search() blocks (hipGraph): replayed while nothing they bake in has changed
     struct BlockGraph { hipGraphExec_t exec = nullptr, exec_b = nullptr; uint64_t key = 0; };      // exec_b: second half of a block split for sampled profiling
     bool capturing = false;
+    bool direct_out = false;         // nw_search: the last update of the block writes its result into the pinned staging buffer itself
     BlockGraph graphs[4];
     int graph_next = 0;
     uint64_t grid_generation = 0;
@@ -1057,7 +1058,7 @@ NW_EXPORT int nw_iter_update(nw_ctx *ctx)
         StageScope s(ctx, ST_UPDATE);
         hipLaunchKernelGGL(k_solve_update, dim3(std::min(nblk(ctx->M), 512)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->lam0, n_search, ctx->search_flags,
                            ctx->have_valid ? ctx->valid.p : nullptr, ctx->pos.p, ctx->meshpos.p, ctx->S.p, ctx->vacc.p, ctx->scalars.p, ctx->state.p,
-                           ctx->logs.p + ctx->search_done, it);
+                           ctx->logs.p + ctx->search_done, it, (ctx->direct_out && it == ctx->search_iters - 1) ? (float *)ctx->pin : nullptr);
     }
     NW_HIP(hipGetLastError());
     ctx->global_iter += 1;
@@ -1066,6 +1067,8 @@ NW_EXPORT int nw_iter_update(nw_ctx *ctx)
 }
 
 static int write_back_impl(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes);
+static int ensure_staging(nw_ctx *ctx);
+static void copy_out_staged(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes);
 
 NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *loopcount)
 {
@@ -1093,7 +1096,17 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
         const bool on_device = hipPointerGetAttributes(&attr, pos_out) == hipSuccess && attr.type == hipMemoryTypeDevice;
         (void)hipGetLastError();
         if (on_device) NW_HIP(hipMemcpyAsync(pos_out, ctx->pos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-        else {
+        else if (ctx->direct_out) {
+            // the block's last update wrote the result into the pinned staging buffer itself: wait for the stream, copy out.  (If the
+            // device-side stop condition ended the block early that kernel did not run: the ordinary copy below takes over.)
+            const auto tw0 = std::chrono::steady_clock::now();
+            NW_HIP(hipStreamSynchronize(ctx->stream));
+            const bool last_ran = ctx->search_done > 0 && ctx->search_done == ctx->search_iters && host[ctx->search_done - 1].executed;
+            if (last_ran) copy_out_staged(ctx, pos_out, ctx->wb_rows, ctx->wb_stride);
+            else NW_TRY(write_back_impl(ctx, pos_out, ctx->wb_rows, ctx->wb_stride));
+            if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
+                fprintf(stderr, "[nanowrap] search_end: wait + copy-out of the staged result %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw0).count());
+        } else {
             const auto tw0 = std::chrono::steady_clock::now();
             NW_TRY(write_back_impl(ctx, pos_out, ctx->wb_rows, ctx->wb_stride));
             if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
@@ -1101,6 +1114,7 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
         }
     }
     const auto ts0 = std::chrono::steady_clock::now();
+    ctx->direct_out = false;
     NW_HIP(hipStreamSynchronize(ctx->stream));
     if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
         fprintf(stderr, "[nanowrap] search_end: final synchronize %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - ts0).count());
@@ -1155,7 +1169,8 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     uint32_t lb; memcpy(&lb, &ctx->lam0, 4); mix(lb);
     uint64_t qb; memcpy(&qb, &ctx->acc_quantum, 8); mix(qb);
     uint32_t sb; memcpy(&sb, &ctx->sinv_scalar, 4); mix(sb); memcpy(&sb, &ctx->w_scalar, 4); mix(sb);
-    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 3 ? 32 : 0));
+    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 3 ? 32 : 0) | (ctx->direct_out ? 64 : 0));
+    mixp(ctx->direct_out ? ctx->pin : nullptr);
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
@@ -1226,6 +1241,15 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     // hipGraph and replayed for later blocks while nothing it bakes in has changed (sizes, buffers, grid, flags, lambda, quantum,
     // warm/cold start).  Host-side enqueue drops from ~3.5 us per launch to one graph launch: what small meshes are bound by.
     // Not with per-launch profiling (levels 1, 2): events recorded by graph nodes do not give elapsed times on ROCm 7.2 (they read 0).
+    // a host result comes back straight from the block's last update kernel (pinned staging buffer, then host threads copy it out)
+    static const bool direct_on = !(getenv("NW_DIRECT_OUT") && atoi(getenv("NW_DIRECT_OUT")) == 0);
+    ctx->direct_out = false;
+    if (direct_on && pos_out && num_iters > 0) {
+        hipPointerAttribute_t attr;
+        const bool on_device = hipPointerGetAttributes(&attr, pos_out) == hipSuccess && attr.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        if (!on_device) { NW_TRY(ensure_staging(ctx)); ctx->direct_out = true; }
+    }
     bool replayed = false;
     static const bool trace_blocks = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 3;
     static hipEvent_t tb0 = nullptr, tb1 = nullptr;
@@ -1350,23 +1374,16 @@ NW_EXPORT int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes)
     return NW_OK;
 }
 
-static int write_back_impl(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes)
+// pinned staging buffer for a block's result (3 M floats) and the host threads that copy it out
+static int ensure_staging(nw_ctx *ctx)
 {
-    if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_write_back: mesh not set");
-    if (rows && row_stride_bytes < 12) return fail(ctx, NW_ERR_BADARG, "nw_write_back: bad stride");
-    const int64_t M = ctx->M;
-    const size_t bytes = (size_t)3 * M * sizeof(float);
+    const size_t bytes = (size_t)3 * ctx->M * sizeof(float);
     if (ctx->pin_bytes < bytes) {
         if (ctx->pin) (void)hipHostFree(ctx->pin);
         ctx->pin = nullptr; ctx->pin_bytes = 0;
         NW_HIP(hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault));
         ctx->pin_bytes = bytes;
     }
-    float *stage = (float *)ctx->pin;
-    const bool masked = rows && ctx->have_valid;
-    const unsigned char *vstage = masked ? ctx->valid_host.data() : nullptr;
-    // The positions come back in T slices; slice t is copied out (contiguous result + strided vertex records) by host
-    // thread t as soon as ITS part of the device-to-host transfer has landed, while the later slices are still in flight.
     if (!ctx->pool) {
         int T = 8;
         if (const char *e = getenv("NW_HOST_THREADS")) T = atoi(e);
@@ -1377,6 +1394,42 @@ static int write_back_impl(nw_ctx *ctx, float *contiguous, void *rows, int64_t r
         ctx->wb_events.resize(ctx->pool->n);
         for (auto &e : ctx->wb_events) NW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    return NW_OK;
+}
+
+// the staging buffer already holds the result (written by the block's last kernel, stream synchronised): copy it out with the host threads
+static void copy_out_staged(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes)
+{
+    const int64_t M = ctx->M;
+    const float *stage = (const float *)ctx->pin;
+    const bool masked = rows && ctx->have_valid;
+    const unsigned char *vstage = masked ? ctx->valid_host.data() : nullptr;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, M / 25000));
+    auto work = [&](int t) {
+        if (t >= T) return;
+        const int64_t v0 = M * t / T, v1 = M * (t + 1) / T;
+        if (contiguous) memcpy(contiguous + 3 * v0, stage + 3 * v0, (size_t)(v1 - v0) * 12);
+        if (rows) {
+            char *dst = (char *)rows;
+            for (int64_t v = v0; v < v1; ++v)
+                if (!masked || vstage[v]) memcpy(dst + v * row_stride_bytes, stage + 3 * v, 12);
+        }
+    };
+    if (T == 1) work(0);
+    else ctx->pool->run(work);
+}
+
+static int write_back_impl(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes)
+{
+    if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_write_back: mesh not set");
+    if (rows && row_stride_bytes < 12) return fail(ctx, NW_ERR_BADARG, "nw_write_back: bad stride");
+    const int64_t M = ctx->M;
+    NW_TRY(ensure_staging(ctx));
+    float *stage = (float *)ctx->pin;
+    const bool masked = rows && ctx->have_valid;
+    const unsigned char *vstage = masked ? ctx->valid_host.data() : nullptr;
+    // The positions come back in T slices; slice t is copied out (contiguous result + strided vertex records) by host
+    // thread t as soon as ITS part of the device-to-host transfer has landed, while the later slices are still in flight.
     static const int64_t rows_per_thread = getenv("NW_WB_ROWS_PER_THREAD") ? std::max(1000, atoi(getenv("NW_WB_ROWS_PER_THREAD"))) : 50000;   // measured: more, smaller slices lose to thread wake-up latency
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, M / rows_per_thread));
     std::vector<int64_t> cut(T + 1);

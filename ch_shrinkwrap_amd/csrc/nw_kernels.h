@@ -808,8 +808,10 @@ struct NwIterLogDev {   // mirrors nw_iter_log in include/nanowrap.h
 __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int n_search, unsigned flags, const unsigned char *__restrict__ valid,
                                                           float *__restrict__ pos, float *__restrict__ meshpos, float *__restrict__ S, long long *__restrict__ vacc,
                                                           const double *__restrict__ sc_parts, NwDevState *__restrict__ st,
-                                                          NwIterLogDev *__restrict__ logrec, int it)
+                                                          NwIterLogDev *__restrict__ logrec, int it, float *__restrict__ host_out)
 {
+    // host_out (last iteration of a block only): pinned host memory that receives the block's result straight from this kernel --
+    // the PCIe writes overlap the kernel instead of following it as a separate device-to-host copy
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ NwSolve s_sol;
     __shared__ double s_sc[SC_COUNT];
@@ -842,7 +844,11 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
             if (!(flags & 2u)) row[2] = fn - f0;
             pos[3 * v + c] = fn;
             if (ok) meshpos[3 * v + c] = fn;
+            if (host_out) host_out[3 * v + c] = fn;
         }
+      } else if (host_out) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) host_out[3 * v + c] = pos[3 * v + c];
       }
       *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)v) = make_longlong2(0, 0);          // ready for the next scatter
       *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)v + 2) = make_longlong2(0, 0);
