@@ -131,6 +131,7 @@ struct nw_ctx {
     BlockGraph graphs[4];
     int graph_next = 0;
     uint64_t grid_generation = 0;
+    int item_points = 64;
     bool have_points = false, have_mesh = false;
 
     // localizations as given (caller order) -- kept so the grid can be rebuilt when the cell size changes
@@ -318,8 +319,13 @@ double desired_cell(const nw_ctx *ctx, double mean_dist, double spacing)
 // morton_unit * 2^level (about four cells): a dense block is cut into equal runs, a sparse one is a single under-filled wave.
 int build_items(nw_ctx *ctx, int level)
 {
-    if (level == ctx->item_level && ctx->nitems > 0) return NW_OK;
     const int64_t N = ctx->N;
+    // localizations per wave: 64 when that still gives every SIMD several waves; a small cloud is cut finer (more, lighter waves: the
+    // launch then ends with its slowest wave, and a wave's candidate set shrinks with its patch)
+    int ipts = (N >= 64 * 9216) ? NW_ITEM_POINTS : NW_ITEM_POINTS / 2;       // 9216 = 1.5 waves for each of the 256 x 4 x 6 wave slots
+    if (const char *e = getenv("NW_ITEM_PTS")) ipts = std::max(8, std::min(NW_ITEM_POINTS, atoi(e)));
+    if (level == ctx->item_level && ctx->nitems > 0 && ipts == ctx->item_points) return NW_OK;
+    ctx->item_points = ipts;
     DevBuf<int> head, hscan, bstart, icount, istart;
     NW_HIP(head.ensure(N)); NW_HIP(hscan.ensure(N + 1));
     hipLaunchKernelGGL(k_block_heads, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, ctx->mkey.p, (int)N, 3 * level, head.p);
@@ -329,13 +335,13 @@ int build_items(nw_ctx *ctx, int level)
     NW_HIP(hipStreamSynchronize(ctx->stream));
     NW_HIP(bstart.ensure((size_t)nblocks + 1)); NW_HIP(icount.ensure((size_t)nblocks)); NW_HIP(istart.ensure((size_t)nblocks + 1));
     hipLaunchKernelGGL(k_block_starts, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, head.p, hscan.p, (int)N, bstart.p);
-    hipLaunchKernelGGL(k_block_item_counts, dim3(nblk(nblocks)), dim3(NW_BLOCK), 0, ctx->stream, bstart.p, nblocks, icount.p);
+    hipLaunchKernelGGL(k_block_item_counts, dim3(nblk(nblocks)), dim3(NW_BLOCK), 0, ctx->stream, bstart.p, nblocks, icount.p, ctx->item_points);
     NW_TRY(scan_exclusive(ctx, icount.p, nblocks, istart.p));
     int nitems = 0;
     NW_HIP(hipMemcpyAsync(&nitems, istart.p + nblocks, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     NW_HIP(hipStreamSynchronize(ctx->stream));
     NW_HIP(ctx->items.ensure((size_t)nitems));
-    hipLaunchKernelGGL(k_block_fill_items, dim3(nblk(nblocks)), dim3(NW_BLOCK), 0, ctx->stream, bstart.p, istart.p, nblocks, ctx->items.p);
+    hipLaunchKernelGGL(k_block_fill_items, dim3(nblk(nblocks)), dim3(NW_BLOCK), 0, ctx->stream, bstart.p, istart.p, nblocks, ctx->items.p, ctx->item_points);
     NW_HIP(hipGetLastError());
     NW_HIP(hipStreamSynchronize(ctx->stream));          // the temporaries die with this scope
     ctx->nitems = nitems;
@@ -1248,7 +1254,8 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         hipPointerAttribute_t attr;
         const bool on_device = hipPointerGetAttributes(&attr, pos_out) == hipSuccess && attr.type == hipMemoryTypeDevice;
         (void)hipGetLastError();
-        if (!on_device) { NW_TRY(ensure_staging(ctx)); ctx->direct_out = true; }
+        // (above ~4 MB the sliced copy, which overlaps the transfer with the host-side copy-out, is the faster one: measured at 810k vertices)
+        if (!on_device && 3 * ctx->M * sizeof(float) <= (4u << 20)) { NW_TRY(ensure_staging(ctx)); ctx->direct_out = true; }
     }
     bool replayed = false;
     static const bool trace_blocks = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 3;

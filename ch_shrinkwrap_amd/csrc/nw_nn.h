@@ -150,19 +150,19 @@ __global__ void k_block_starts(const int *__restrict__ head, const int *__restri
     if (i == N - 1) bstart[scan[i] + head[i]] = N;
 }
 
-__global__ void k_block_item_counts(const int *__restrict__ bstart, int nblocks, int *__restrict__ nitems)
+__global__ void k_block_item_counts(const int *__restrict__ bstart, int nblocks, int *__restrict__ nitems, int item_points)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
-    nitems[b] = (bstart[b + 1] - bstart[b] + NW_ITEM_POINTS - 1) / NW_ITEM_POINTS;
+    nitems[b] = (bstart[b + 1] - bstart[b] + item_points - 1) / item_points;
 }
 
-__global__ void k_block_fill_items(const int *__restrict__ bstart, const int *__restrict__ istart, int nblocks, NwItem *__restrict__ items)
+__global__ void k_block_fill_items(const int *__restrict__ bstart, const int *__restrict__ istart, int nblocks, NwItem *__restrict__ items, int item_points)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
     const int p0 = bstart[b], p1 = bstart[b + 1];
-    const int n = (p1 - p0 + NW_ITEM_POINTS - 1) / NW_ITEM_POINTS;        // a crowded block is cut into n EQUAL runs
+    const int n = (p1 - p0 + item_points - 1) / item_points;        // a crowded block is cut into n EQUAL runs
     if (n <= 0) return;
     const int per = (p1 - p0 + n - 1) / n;
     int o = istart[b];
@@ -188,7 +188,7 @@ __device__ __forceinline__ int nw_wave_max_i(int v)
 }
 
 // developer counters of one launch (nw_debug_nn_stats): candidates evaluated, rows listed / visited, cells tested / visited, ...
-enum { NWS_CAND = 0, NWS_ROWS_NONEMPTY, NWS_ROWS_PASS, NWS_CELLS_TESTED, NWS_CELLS_PASS, NWS_BOX_ROWS, NWS_ROUNDS, NWS_SMALL_RUNS, NWS_T_STREAM, NWS_T_WAVE, NWS_COUNT };   // T_*: s_memtime ticks / 16
+enum { NWS_CAND = 0, NWS_ROWS_NONEMPTY, NWS_ROWS_PASS, NWS_CELLS_TESTED, NWS_CELLS_PASS, NWS_BOX_ROWS, NWS_ROUNDS, NWS_T_WAVE_MAX, NWS_T_STREAM, NWS_T_WAVE, NWS_COUNT };   // T_*: s_memtime ticks / 16
 struct NwStats { int v[NWS_COUNT]; bool timed; };
 
 // Best / runner-up are kept as integer KEYS: the float32 bits of d^2 (non-negative, so they order like unsigned integers)
@@ -527,5 +527,6 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
         S.v[NWS_T_WAVE] = (int)((__builtin_amdgcn_s_memtime() - t_wave) >> 4);
 #pragma unroll
         for (int k = 0; k < NWS_COUNT; ++k) atomicAdd(stats + k, (unsigned long long)S.v[k]);
+        atomicMax(stats + NWS_T_WAVE_MAX, (unsigned long long)S.v[NWS_T_WAVE]);
     }
 }

@@ -415,7 +415,7 @@ class ShrinkwrapMeshConjGrad(object):
         """developer counters of the nearest-face query since the previous call (first call: switches them on)"""
         out = (ctypes.c_int64 * 11)()
         self._native.check(self._L.nw_debug_nn_stats(self._h, out))
-        names = ['candidates', 'rows_nonempty', 'rows_visited', 'cells_tested', 'cells_visited', 'box_rows', 'rounds', 'small_runs', 'stream_cycles_16', 'wave_cycles_16', 'items']
+        names = ['candidates', 'rows_nonempty', 'rows_visited', 'cells_tested', 'cells_visited', 'box_rows', 'rounds', 'max_wave_cycles_16', 'stream_cycles_16', 'wave_cycles_16', 'items']
         return dict(zip(names, [int(v) for v in out]))
 
     def stage_ms(self):

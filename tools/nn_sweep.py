@@ -49,10 +49,10 @@ for spec in sys.argv[2:]:
     cg.search(pts, lams=c['lams'], num_iters=1, sigma_inv=s)
     ns = cg.nn_stats()
     w = float(max(ns['items'], 1))
-    print('   per wave: %.0f candidates, box rows %.0f, rows listed %.1f visited %.1f, cells tested %.1f visited %.1f, small runs %.1f, rounds %.2f; %d waves'
+    print('   per wave: %.0f candidates, box rows %.0f, rows listed %.1f visited %.1f, cells tested %.1f visited %.1f, rounds %.2f; %d waves'
           % (ns['candidates'] / w, ns['box_rows'] / w, ns['rows_nonempty'] / w, ns['rows_visited'] / w, ns['cells_tested'] / w, ns['cells_visited'] / w,
-             ns['small_runs'] / w, ns['rounds'] / w, ns['items']))
-    print('   per wave: %.0f cycles in all, %.0f in the stream stage' % (16 * ns['wave_cycles_16'] / w, 16 * ns['stream_cycles_16'] / w))
+             ns['rounds'] / w, ns['items']))
+    print('   per wave: %.0f ticks in all (slowest wave %.0f), %.0f in the stream stage' % (16 * ns['wave_cycles_16'] / w, 16.0 * ns['max_wave_cycles_16'], 16 * ns['stream_cycles_16'] / w))
     print('%-10s wall %.4f ms/iter  nn %.4f (cold first query %.4f)  grid %.4f fixup %.4f attract %.4f  md %.2f' % (
         spec, wall * 1e3, nn[0] / nn[1], cold[0] / max(cold[1], 1), st['grid'][0] / st['grid'][1], st['fixup'][0] / st['fixup'][1],
         st['attract'][0] / st['attract'][1], cg.mean_dist), flush=True)
