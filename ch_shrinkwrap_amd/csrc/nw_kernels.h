@@ -419,7 +419,16 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
 // product, 2^27 such terms of headroom; for {w} 2^-40 (w <= 1).  Integer addition is associative, so the sums are EXACT and
 // independent of the order in which lanes, waves and workgroups arrive: the scatter is bitwise reproducible (the reference's is a
 // serial, deterministic loop, conj_grad_utils.c:153-162); k_prior_directions rounds each sum once to float32.
-#define NW_HT 1024
+// round-to-nearest-even of |x| < 2^51 to a 64-bit integer: adding 1.5 * 2^52 leaves the integer in the low mantissa bits (one f64 add
+// and a 64-bit subtract instead of the dozen instructions of the f64 -> i64 conversion sequence)
+__device__ __forceinline__ long long nw_round_to_i64(double x)
+{
+    return __double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000LL;
+}
+
+#define NW_HT 512          // slots of the per-workgroup table: 18 KB of LDS, 8 workgroups per CU (1024 slots: 36 KB, 4 per CU, 10 us slower)
+#define NW_HT_BITS 9
+#define NW_HT_PROBES 48    // a contribution that finds no slot within this many probes goes to HBM directly (unsorted input only)
 
 __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4 *__restrict__ pts, const int *__restrict__ face, const float4 *__restrict__ cent_by_face, float *__restrict__ dist,
                                                      const int *__restrict__ faces, const float *__restrict__ pos,
@@ -502,10 +511,11 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
         __builtin_memcpy(wout + 3 * (int64_t)i, w, 12);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            unsigned hsh = ((unsigned)v[j] * 2654435761u) >> 22;      // 10 bits
-            for (;;) {
+            unsigned hsh = ((unsigned)v[j] * 2654435761u) >> (32 - NW_HT_BITS);
+            bool slot = false;
+            for (int probe = 0; probe < NW_HT_PROBES; ++probe) {
                 const int old = atomicCAS(&s_key[hsh], -1, v[j]);
-                if (old == -1 || old == v[j]) break;
+                if (old == -1 || old == v[j]) { slot = true; break; }
                 hsh = (hsh + 1) & (NW_HT - 1);
             }
             unsigned long long *a = s_val + hsh;
@@ -514,7 +524,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
             for (int k = 0; k < 4; ++k) {
                 const double x = (double)c[k] * (k < 3 ? inv_q : inv_qw);           // exact scaling (powers of two)
                 bad |= !(fabs(x) < 7.0e13);                                         // far beyond the bound behind the quantum / inf / NaN: raise the NaN status
-                atomicAdd(a + k * NW_HT, (unsigned long long)__double2ll_rn(x));
+                const unsigned long long q = (unsigned long long)nw_round_to_i64(x);
+                if (slot) atomicAdd(a + k * NW_HT, q);
+                else atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + 4 * (int64_t)v[j] + k, q);      // (integer sums: the path taken does not change the result)
             }
         }
         if (bad) atomicCAS(&st->status, 0, -3 /* NW_ERR_NAN */);
