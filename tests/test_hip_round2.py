@@ -220,3 +220,32 @@ def test_profiling_levels_do_not_change_the_result_and_sampled_keeps_the_graph()
         results[level] = out.copy()
     for level in (1, 2, 3):
         assert np.array_equal(results[0], results[level]), 'profiling level %d changed the result' % level
+
+
+@pytest.mark.parametrize('name,scale,n_before', [('c3', 0.2, 1), ('c3', 0.2, 4), ('c4', 0.04, 4)])
+def test_query_is_exact_in_later_iterations_of_a_block(name, scale, n_before):
+    """The exactness checks elsewhere look at the first (cold) query of a fit.  This one checks a WARM query deep inside a block --
+    warm start from the previous nearest faces, centroids that moved by several nm since the block began (the fit starts 20 nm off
+    the cloud): iteration n of a block of n+1 must return the exact float64 argmin over the centroids of the positions it started
+    from, which a second, bit-identical fit of n iterations provides."""
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    from oracle import nanowrap_oracle as O
+    c = synth.make_config(name, scale=scale, seed=17)
+    pts, s = c['points'], 1.0 / c['sigma'].ravel()
+    mesh_a = TriMesh(c['vertices'].copy(), c['faces'])
+    p_n = CG(mesh_a, pts).search(pts, lams=c['lams'], num_iters=n_before, sigma_inv=s).copy()
+    moved = np.linalg.norm(p_n - c['vertices'], axis=1).max()
+    mesh_b = TriMesh(c['vertices'].copy(), c['faces'])
+    cg = CG(mesh_b, pts)
+    cg.search(pts, lams=c['lams'], num_iters=n_before + 1, sigma_inv=s)
+    cent = O.face_centroids(p_n, mesh_b.faces)
+    d_all, f_all = O.nearest_faces(cent, pts)
+    got = cg.nearest_face
+    diff = np.nonzero(got != f_all)[0]
+    print('%s x%.2f: vertices moved up to %.2f nm since the block began; %d of %d nearest faces differ from cKDTree' % (name, scale, moved, diff.size, pts.shape[0]))
+    assert moved > 1.0
+    if diff.size:                                      # only exact float64 ties may differ (cKDTree's tie order is unspecified)
+        dd = np.linalg.norm(pts[diff].astype('f8') - cent[got[diff]].astype('f8'), axis=1)
+        assert np.allclose(dd, d_all[diff], rtol=1e-15, atol=0), 'nearest face differs from cKDTree at %d points' % diff.size
+    assert np.allclose(cg.d[:, 0], d_all, rtol=1e-6)
