@@ -973,6 +973,9 @@ static int enqueue_begin_ops(nw_ctx *ctx)
 // centroid binning + exact nearest-face query + float64 fix-up of the ambiguous points, for the current positions
 // (`parts`: 1 grid build, 2 the query kernel, 4 fix-up -- a block captured for sampled profiling launches part 2 of its first
 // iteration outside the graphs, between two events)
+// the query kernel resolves its ambiguous localizations itself (default); NW_FUSE_FIXUP=0 brings back the separate fix-up launch
+static bool fuse_fixup() { static const bool on = !(getenv("NW_FUSE_FIXUP") && atoi(getenv("NW_FUSE_FIXUP")) == 0); return on; }
+
 static int launch_query(nw_ctx *ctx, int it, int parts)
 {
     const int64_t F = ctx->F;
@@ -992,11 +995,11 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
         const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;   // one wave = one work item
         const int nbp = nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
         hipLaunchKernelGGL(k_nn_wave, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map, ctx->ambig_list.p, ctx->ambig_count.p,
+                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
                            ctx->state.p, it, ctx->nn_stats.p);
         ctx->face_warm = true;
     }
-    if (parts & QP_FIXUP) {
+    if ((parts & QP_FIXUP) && !fuse_fixup()) {
         StageScope s(ctx, ST_FIXUP);
         static const int fb = getenv("NW_FIXUP_BLOCKS") ? std::max(64, atoi(getenv("NW_FIXUP_BLOCKS"))) : 2048;      // one wave per ambiguous localization: ~7000 of them at 10^6, 4 waves per workgroup
         hipLaunchKernelGGL(k_nn_fixup, dim3(fb), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->ambig_list.p, ctx->ambig_count.p, ctx->pts.p, ctx->cstart.p, ctx->cent.p,

@@ -336,10 +336,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const floa
 // K4a: the exact nearest-face query (k_nn_wave) and the set-up kernels of its work list
 #include "nw_nn.h"
 
-// exact float64 re-resolution of the ambiguous points (runner-up inside the float32 error band of the best): one wave
-// per point.  Phase 1: every (z,y) row of fine cells of the box around the ball of radius dist*(1+1e-4)+eps gets a lane that
-// fetches its candidate range; a wave scan lays the ranges end to end.  Phase 2: the candidates are spread over the
-// lanes (binary search in the scanned offsets through shuffles), evaluated in float64, and reduced (lowest face id on exact ties).
+// exact float64 re-resolution of the ambiguous points (runner-up inside the float32 error band of the best) as its own launch: one
+// wave per point, nw_fixup_point (nw_nn.h).  Only used when the query kernel does not resolve them itself (NW_FUSE_FIXUP=0).
 __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__restrict__ ambig_list, const int *__restrict__ ambig_count, const float4 *__restrict__ pts,
                                                       const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face,
                                                       int *__restrict__ face_out, const NwDevState *__restrict__ st, int it)
@@ -348,54 +346,10 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
     const int na = *ambig_count;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    // one WAVE per ambiguous point: the box around its ball is a few dozen (z,y) rows, one lane each; no workgroup barrier
     for (int a = wave; a < na; a += nwaves) {
         const int gi = ambig_list[a];
         const float4 P = pts[gi];
-        const float4 C0 = cent_by_face[face_out[gi]];
-        const float r = sqrtf((P.x - C0.x) * (P.x - C0.x) + (P.y - C0.y) * (P.y - C0.y) + (P.z - C0.z) * (P.z - C0.z)) * (1.0f + 1e-4f) + g.eps;
-        int lx, ly, lz, hx, hy, hz;
-        nw_cell_coords(g, P.x - r, P.y - r, P.z - r, lx, ly, lz);
-        nw_cell_coords(g, P.x + r, P.y + r, P.z + r, hx, hy, hz);
-        const int ny = hy - ly + 1, nrow = ny * (hz - lz + 1);
-        double best = INFINITY;
-        int bf = 0x7fffffff;
-        for (int rb = 0; rb < nrow; rb += 64) {
-            int start = 0, len = 0;
-            const int rr = rb + lane;
-            if (rr < nrow) {
-                const int z = lz + rr / ny, y = ly + rr % ny;
-                const int c0 = nw_cell_index(g, lx, y, z);
-                start = cstart[c0];
-                len = cstart[c0 + (hx - lx) + 1] - start;
-            }
-            const int inc = nw_wave_incl_scan(len, lane);           // candidates up to and including this lane's row
-            const int total = __shfl(inc, 63, 64);
-            for (int base = 0; base < total; base += 64) {           // uniform trip count: every lane takes part in the shuffles
-                const int e = min(base + lane, total - 1);
-                int lo = 0;                                          // first row whose inclusive count exceeds e
-#pragma unroll
-                for (int step = 32; step > 0; step >>= 1) {
-                    const int probe = __shfl(inc, lo + step - 1, 64);
-                    if (probe <= e) lo += step;
-                }
-                const int row_start = __shfl(start, lo, 64);
-                const int row_excl = __shfl(inc, lo, 64) - __shfl(len, lo, 64);
-                if (base + lane < total) {
-                    const float4 C = cent[row_start + (e - row_excl)];
-                    const double dx = (double)P.x - (double)C.x, dy = (double)P.y - (double)C.y, dz = (double)P.z - (double)C.z;
-                    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-                    const int fid = __float_as_int(C.w);
-                    if (d2 < best || (d2 == best && fid < bf)) { best = d2; bf = fid; }
-                }
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double od = __shfl_xor(best, off, 64);
-            const int of = __shfl_xor(bf, off, 64);
-            if (od < best || (od == best && of < bf)) { best = od; bf = of; }
-        }
+        const int bf = nw_fixup_point(g, P.x, P.y, P.z, cent_by_face[face_out[gi]], cstart, cent, lane);
         if (lane == 0) face_out[gi] = bf;
     }
 }

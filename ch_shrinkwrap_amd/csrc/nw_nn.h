@@ -340,7 +340,61 @@ __device__ __forceinline__ int nw_pick(const int (&cs)[NW_SEG + 1], int k, int j
 
 __device__ __forceinline__ float nw_readlane_f(float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); }
 
-__global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
+// Exact float64 re-resolution of ONE localization P by a whole wave: C0 = a centroid known to be at most tol further than the nearest
+// (the float32 winner).  Phase 1: every (z,y) row of fine cells of the box around the ball of radius |P - C0| (1 + 1e-4) + eps gets a
+// lane that fetches its candidate range; a wave scan lays the ranges end to end.  Phase 2: the candidates are spread over the lanes
+// (binary search in the scanned offsets through shuffles), evaluated in float64, and reduced (lowest face id on exact ties).
+// Every lane returns the face id.
+__device__ __forceinline__ int nw_fixup_point(const NwGrid &g, float Px, float Py, float Pz, const float4 C0, const int *__restrict__ cstart,
+                                           const float4 *__restrict__ cent, int lane)
+{
+    const float r = sqrtf((Px - C0.x) * (Px - C0.x) + (Py - C0.y) * (Py - C0.y) + (Pz - C0.z) * (Pz - C0.z)) * (1.0f + 1e-4f) + g.eps;
+    int lx, ly, lz, hx, hy, hz;
+    nw_cell_coords(g, Px - r, Py - r, Pz - r, lx, ly, lz);
+    nw_cell_coords(g, Px + r, Py + r, Pz + r, hx, hy, hz);
+    const int ny = hy - ly + 1, nrow = ny * (hz - lz + 1);
+    double best = INFINITY;
+    int bf = 0x7fffffff;
+    for (int rb = 0; rb < nrow; rb += 64) {
+        int start = 0, len = 0;
+        const int rr = rb + lane;
+        if (rr < nrow) {
+            const int z = lz + rr / ny, y = ly + rr % ny;
+            const int c0 = nw_cell_index(g, lx, y, z);
+            start = cstart[c0];
+            len = cstart[c0 + (hx - lx) + 1] - start;
+        }
+        const int inc = nw_wave_incl_scan(len, lane);           // candidates up to and including this lane's row
+        const int total = __shfl(inc, 63, 64);
+        for (int base = 0; base < total; base += 64) {           // uniform trip count: every lane takes part in the shuffles
+            const int e = min(base + lane, total - 1);
+            int lo = 0;                                          // first row whose inclusive count exceeds e
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                const int probe = __shfl(inc, lo + step - 1, 64);
+                if (probe <= e) lo += step;
+            }
+            const int row_start = __shfl(start, lo, 64);
+            const int row_excl = __shfl(inc, lo, 64) - __shfl(len, lo, 64);
+            if (base + lane < total) {
+                const float4 C = cent[row_start + (e - row_excl)];
+                const double dx = (double)Px - (double)C.x, dy = (double)Py - (double)C.y, dz = (double)Pz - (double)C.z;
+                const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                const int fid = __float_as_int(C.w);
+                if (d2 < best || (d2 == best && fid < bf)) { best = d2; bf = fid; }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(best, off, 64);
+        const int of = __shfl_xor(bf, off, 64);
+        if (od < best || (od == best && of < bf)) { best = od; bf = of; }
+    }
+    return bf;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_nn_wave(NwGrid g, const NwItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
                                                  const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,
                                                  int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
                                                  NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats)
@@ -512,14 +566,30 @@ __global__ __launch_bounds__(256) void k_nn_wave(NwGrid g, const NwItem *__restr
         Exl = Nxl; Exh = Nxh; Eyl = Nyl; Eyh = Nyh; Ezl = Nzl; Ezh = Nzh;
         if (!any_unseen) break;          // the box was built from every lane's ball and b1 only shrinks: all lanes are final
     }
-    if (active) {
+    {
         int fid = prev;
-        if (L.bslot >= 0) fid = __float_as_int(cent[L.bslot].w);
-        face_io[gi] = fid;
+        if (active && L.bslot >= 0) fid = __float_as_int(cent[L.bslot].w);
         // runner-up inside the error band (or the walk did not re-find the warm-start face): float64 re-resolution
         // both keys carry the same offset K - |p'|^2: their difference is a difference of squared distances, each known to tol(key)
         const float d1 = __uint_as_float(L.b1), d2 = __uint_as_float(L.b2);
-        if (L.bslot < 0 || d2 - d1 <= 2.0f * (NW_NN_TOL * d2 + L.tolk)) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
+        const bool amb = active && (L.bslot < 0 || d2 - d1 <= 2.0f * (NW_NN_TOL * d2 + L.tolk));
+        if (warm & 8) {
+            // resolved here, by the whole wave, one ambiguous localization after the other (0.4 per wave on average): their cells are
+            // in this CU's caches, and the iteration has one launch and one list less
+            unsigned long long todo = __ballot(amb && (unsigned)fid < (unsigned)F);
+            const float4 Pw = pts[gi];
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const float4 C0 = cent_by_face[__builtin_amdgcn_readlane(fid, j)];
+                const int res = nw_fixup_point(g, nw_readlane_f(Pw.x, j), nw_readlane_f(Pw.y, j), nw_readlane_f(Pw.z, j), C0, cstart, cent, lane);
+                if (lane == j) fid = res;
+            }
+            if (active) face_io[gi] = fid;
+        } else if (active) {
+            face_io[gi] = fid;
+            if (amb) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
+        }
     }
     if (lane == 0 && rounds > 1) atomicMax(&st->nn_max_ring, rounds);
     if (stats && lane == 0) {
