@@ -168,6 +168,11 @@ struct nw_ctx {
     DevBuf<NwItem> items;             // work list of the NN query: runs of <= 64 Morton-consecutive localizations
     int nitems = 0;
     int item_level = -1;              // Morton level (block edge = morton_unit * 2^level) the items were cut at
+    // scratch of the block-boundary / diagnostic entry points (nw_curvature, nw_lfunc): kept, so that a call per block does not
+    // allocate and free tens of megabytes
+    DevBuf<int> aux_i;
+    DevBuf<float> aux_f, aux_f2, aux_f3;
+    DevBuf<double> aux_d;
     DevBuf<unsigned long long> nn_stats;   // developer counters of the NN query (nw_debug_nn_stats); null unless enabled
     DevBuf<unsigned> proj_key;        // projection keys of the last completed query (second sort, see k_projection_keys)
     DevBuf<int> proj_idx;
@@ -528,7 +533,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pts_in.release(); ctx->sinv_in.release(); ctx->w_in.release(); ctx->wsum.release();
     ctx->pts.release(); ctx->perm.release(); ctx->mkey.release(); ctx->proj_key.release(); ctx->proj_idx.release(); ctx->sinv.release(); ctx->wnorm.release(); ctx->mask.release();
-    ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_stats.release();
+    ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->owned.release(); ctx->d_small.release();
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
@@ -1489,7 +1494,7 @@ NW_EXPORT int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, f
     if (!ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_lfunc: mesh not set");
     if ((kind == 2 || kind == 3) && !f0) return fail(ctx, NW_ERR_BADARG, "nw_lfunc: f0 required");
     const int64_t M = ctx->M;
-    DevBuf<float> dx, df, dout;
+    DevBuf<float> &dx = ctx->aux_f, &df = ctx->aux_f2, &dout = ctx->aux_f3;
     NW_HIP(dx.ensure(3 * M)); NW_HIP(df.ensure(3 * M)); NW_HIP(dout.ensure(3 * M));
     int rc = NW_OK;
     do {
@@ -1504,7 +1509,6 @@ NW_EXPORT int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, f
         if (hipMemcpyAsync(out, dout.p, 3 * M * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
     } while (0);
-    dx.release(); df.release(); dout.release();
     if (rc != NW_OK) return fail(ctx, rc, "nw_lfunc: HIP failure");
     return NW_OK;
 }
@@ -1518,9 +1522,9 @@ NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nb
     NW_HIP(hipSetDevice(ctx->device));
     const int64_t M = ctx->M;
     const int NB = ctx->NB;
-    DevBuf<int> d_next;
-    DevBuf<float> d_area, d_out;
-    DevBuf<double> d_jit;
+    DevBuf<int> &d_next = ctx->aux_i;
+    DevBuf<float> &d_area = ctx->aux_f, &d_out = ctx->aux_f2;
+    DevBuf<double> &d_jit = ctx->aux_d;
     int rc = NW_OK;
     std::string msg;
     do {
@@ -1545,7 +1549,6 @@ NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nb
         if (rc != NW_OK) break;
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
     } while (0);
-    d_next.release(); d_area.release(); d_out.release(); d_jit.release();
     if (rc != NW_OK) return fail(ctx, rc, "nw_curvature: HIP failure");
     return NW_OK;
 }
