@@ -463,24 +463,31 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
         __builtin_memcpy(res + 3 * (int64_t)i, r, 12);           // three 12-byte stores instead of nine dword stores
         __builtin_memcpy(vidx + 3 * (int64_t)i, v, 12);
         __builtin_memcpy(wout + 3 * (int64_t)i, w, 12);
+        // Neighbouring lanes mostly share their face (the localizations are sorted by foot point), i.e. all three vertices: corner
+        // (j + lane) % 3 in turn j makes them hit three different accumulators at the same time instead of serialising on one
+        // (integer sums: the order of the additions does not matter)
+        const int rot = (int)(threadIdx.x % 3u);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            unsigned hsh = ((unsigned)v[j] * 2654435761u) >> (32 - NW_HT_BITS);
+        for (int j0 = 0; j0 < 3; ++j0) {
+            const int jr = j0 + rot, j = jr >= 3 ? jr - 3 : jr;
+            const int vj = j == 0 ? v[0] : (j == 1 ? v[1] : v[2]);
+            const float wj = j == 0 ? w[0] : (j == 1 ? w[1] : w[2]);
+            unsigned hsh = ((unsigned)vj * 2654435761u) >> (32 - NW_HT_BITS);
             bool slot = false;
             for (int probe = 0; probe < NW_HT_PROBES; ++probe) {
-                const int old = atomicCAS(&s_key[hsh], -1, v[j]);
-                if (old == -1 || old == v[j]) { slot = true; break; }
+                const int old = atomicCAS(&s_key[hsh], -1, vj);
+                if (old == -1 || old == vj) { slot = true; break; }
                 hsh = (hsh + 1) & (NW_HT - 1);
             }
             unsigned long long *a = s_val + hsh;
-            const float c[4] = {w[j] * r[0], w[j] * r[1], w[j] * r[2], w[j]};     // float32 products, as the reference forms them
+            const float c[4] = {wj * r[0], wj * r[1], wj * r[2], wj};     // float32 products, as the reference forms them
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double x = (double)c[k] * (k < 3 ? inv_q : inv_qw);           // exact scaling (powers of two)
                 bad |= !(fabs(x) < 7.0e13);                                         // far beyond the bound behind the quantum / inf / NaN: raise the NaN status
                 const unsigned long long q = (unsigned long long)nw_round_to_i64(x);
                 if (slot) atomicAdd(a + k * NW_HT, q);
-                else atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + 4 * (int64_t)v[j] + k, q);      // (integer sums: the path taken does not change the result)
+                else atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + 4 * (int64_t)vj + k, q);      // (integer sums: the path taken does not change the result)
             }
         }
         if (bad) atomicCAS(&st->status, 0, -3 /* NW_ERR_NAN */);
