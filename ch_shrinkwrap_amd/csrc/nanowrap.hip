@@ -469,7 +469,8 @@ struct StageScope {
     ~StageScope() { if (on) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
 };
 
-inline int attract_blocks(const nw_ctx *ctx) { return 8 * ((nblk(ctx->N) + 7) / 8); }      // k_attract / k_subspace_point_sums (XCD-remapped grids)
+inline int attract_blocks(const nw_ctx *ctx) { return 8 * ((nblk(ctx->N) + 7) / 8); }      // k_attract (XCD-remapped grid)
+inline int subspace_blocks(const nw_ctx *ctx) { const int nb = (int)((ctx->N + NW_BLOCK * NW_SUBSPACE_PPT - 1) / (NW_BLOCK * NW_SUBSPACE_PPT)); return 8 * ((nb + 7) / 8); }
 inline int prior_blocks(const nw_ctx *ctx) { return std::min(nblk(ctx->M), 512); }
 
 int alloc_work(nw_ctx *ctx)
@@ -1052,11 +1053,11 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
     }
     {
         StageScope s(ctx, ST_AS);
-        hipLaunchKernelGGL(k_subspace_point_sums, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
+        hipLaunchKernelGGL(k_subspace_point_sums, dim3(subspace_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
                            ctx->mask.p, ctx->S.p, ctx->part_s.p, ctx->state.p, it, n_search);
         // the 24 sums of this iteration, added in a fixed order (deterministic); multi-GPU runs all-reduce them after this call
         hipLaunchKernelGGL(k_reduce_scalars, dim3(NW_SPARTS), dim3(NW_BLOCK), 0, ctx->stream, ctx->part_a.p, attract_blocks(ctx), ctx->part_p.p, prior_blocks(ctx),
-                           ctx->part_s.p, attract_blocks(ctx), ctx->scalars.p, ctx->state.p, it);
+                           ctx->part_s.p, subspace_blocks(ctx), ctx->scalars.p, ctx->state.p, it);
     }
     NW_HIP(hipGetLastError());
     return NW_OK;

@@ -659,6 +659,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_vertex_area_weights(int M, int NB,
     wv[i] = (w > 0) ? (float)(1.0 / (double)sqrtf(w + 1)) : 0.0f;
 }
 
+#define NW_SUBSPACE_PPT 4
+
 // K6: A.S_k for the n_search directions and the point-side normal-equation sums, never materialising AS:
 //   AS_k[i] = sum_j w_ij S_k[v_ij] (f32, corner order, mesh_conj_grad.py:544-545 via conj_grad.py:198)
 //   Hc = AS^T AS, Gc = AS^T res over the masked entries (conj_grad.py:198-203)
@@ -669,12 +671,16 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ double s_part[9 * 4];
-    const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK - 1) / NW_BLOCK);      // see k_attract
-    const int i = blk < 0 ? N : blk * blockDim.x + threadIdx.x;
+    // NW_SUBSPACE_PPT localizations per thread (consecutive tiles of 256): the nine sums are reduced over the workgroup once per
+    // 1024 localizations -- the shuffles of that reduction go through the CU's LDS pipe, which bounded the kernel at one per thread
+    const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK * NW_SUBSPACE_PPT - 1) / (NW_BLOCK * NW_SUBSPACE_PPT));      // see k_attract
     double red[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) red[k] = 0.0;
-    if (i < N) {
+#pragma unroll
+    for (int p = 0; p < NW_SUBSPACE_PPT; ++p) {
+      const int64_t i = blk < 0 ? (int64_t)N : ((int64_t)blk * NW_SUBSPACE_PPT + p) * NW_BLOCK + threadIdx.x;
+      if (i < N) {
         const unsigned m = mask[i];
         float as[3][3];   // [direction][component]
 #pragma unroll
@@ -704,6 +710,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
                 red[6] += a0 * r;  red[7] += a1 * r;  red[8] += a2 * r;
             }
         }
+      }
     }
     nw_block_reduce_store<9>(red, part, s_part);
 }
