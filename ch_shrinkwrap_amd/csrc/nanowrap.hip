@@ -469,7 +469,7 @@ struct StageScope {
     ~StageScope() { if (on) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
 };
 
-inline int attract_blocks(const nw_ctx *ctx) { return 8 * ((nblk(ctx->N) + 7) / 8); }      // k_attract (XCD-remapped grid)
+inline int attract_blocks(const nw_ctx *ctx) { const int nb = (int)((ctx->N + NW_BLOCK * NW_ATTRACT_PPT - 1) / (NW_BLOCK * NW_ATTRACT_PPT)); return 8 * ((nb + 7) / 8); }      // k_attract (XCD-remapped grid)
 inline int subspace_blocks(const nw_ctx *ctx) { const int nb = (int)((ctx->N + NW_BLOCK * NW_SUBSPACE_PPT - 1) / (NW_BLOCK * NW_SUBSPACE_PPT)); return 8 * ((nb + 7) / 8); }
 inline int prior_blocks(const nw_ctx *ctx) { return std::min(nblk(ctx->M), 512); }
 
@@ -493,7 +493,7 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->pi.ensure(M));
     NW_HIP(ctx->scalars.ensure(NW_N_SCALARS * NW_SPARTS));
     NW_HIP(ctx->part_a.ensure((size_t)5 * attract_blocks(ctx)));
-    NW_HIP(ctx->part_s.ensure((size_t)9 * attract_blocks(ctx)));
+    NW_HIP(ctx->part_s.ensure((size_t)9 * subspace_blocks(ctx)));
     NW_HIP(ctx->part_p.ensure((size_t)14 * prior_blocks(ctx)));
     NW_HIP(ctx->wv.ensure(ctx->M));
     return NW_OK;

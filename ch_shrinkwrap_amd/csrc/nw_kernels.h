@@ -382,6 +382,7 @@ __device__ __forceinline__ long long nw_round_to_i64(double x)
 
 #define NW_HT 512          // slots of the per-workgroup table: 18 KB of LDS, 8 workgroups per CU (1024 slots: 36 KB, 4 per CU, 10 us slower)
 #define NW_HT_BITS 9
+#define NW_ATTRACT_PPT 1      // (2: 39.7 us against 36.5 -- the two dependent load chains of a thread do not overlap)
 #define NW_HT_PROBES 48    // a contribution that finds no slot within this many probes goes to HBM directly (unsorted input only)
 
 __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4 *__restrict__ pts, const int *__restrict__ face, const float4 *__restrict__ cent_by_face, float *__restrict__ dist,
@@ -400,10 +401,14 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
     __syncthreads();
     // each XCD takes one contiguous range of the brick-sorted localizations: the vertices its workgroups gather and the
     // accumulator lines their atomics touch then live in ONE L2 instead of being spread round-robin over all eight
-    const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK - 1) / NW_BLOCK);
-    const int i = blk < 0 ? N : blk * blockDim.x + threadIdx.x;
+    // NW_ATTRACT_PPT localizations per thread (consecutive tiles of 256): the table's set-up and flush and the workgroup reduction
+    // are paid once per 512 localizations
+    const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK * NW_ATTRACT_PPT - 1) / (NW_BLOCK * NW_ATTRACT_PPT));
     double red[4] = {0.0, 0.0, 0.0, 0.0};
     float dmax = 0.0f;
+#pragma unroll 1
+    for (int pp = 0; pp < NW_ATTRACT_PPT; ++pp) {
+    const int i = blk < 0 ? N : (blk * NW_ATTRACT_PPT + pp) * (int)blockDim.x + (int)threadIdx.x;
     const int f_raw = i < N ? face[i] : 0;
     // a face id outside [0, F) can only come from a bug in the NN query: never dereference it (a faulting kernel can
     // take the whole node down), raise the internal-error status instead
@@ -457,9 +462,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
             red[0] += r2;
             if (m & (1u << k)) red[1] += r2;
         }
-        red[2] = (double)d;
-        red[3] = 1.0;
-        dmax = d;
+        red[2] += (double)d;
+        red[3] += 1.0;
+        dmax = fmaxf(dmax, d);
         __builtin_memcpy(res + 3 * (int64_t)i, r, 12);           // three 12-byte stores instead of nine dword stores
         __builtin_memcpy(vidx + 3 * (int64_t)i, v, 12);
         __builtin_memcpy(wout + 3 * (int64_t)i, w, 12);
@@ -491,6 +496,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
             }
         }
         if (bad) atomicCAS(&st->status, 0, -3 /* NW_ERR_NAN */);
+    }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < NW_HT * 4; t += NW_BLOCK) {
