@@ -567,7 +567,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (!any_unseen) break;          // the box was built from every lane's ball and b1 only shrinks: all lanes are final
     }
     {
-        int fid = prev;
+        // (the item, the lane's localization index and its previous face are re-derived here rather than kept alive across the walk:
+        // with them in registers the kernel does not fit the 80 VGPRs of six waves per SIMD and spills 20 bytes per lane)
+        const NwItem item_t = items[wi];
+        const bool active = lane < item_t.n;
+        const int gi = item_t.p0 + (active ? lane : 0);
+        int fid = (warm & 1) ? face_io[gi] : -1;
+        if ((unsigned)fid >= (unsigned)F) fid = -1;
         if (active && L.bslot >= 0) fid = __float_as_int(cent[L.bslot].w);
         // runner-up inside the error band (or the walk did not re-find the warm-start face): float64 re-resolution
         // both keys carry the same offset K - |p'|^2: their difference is a difference of squared distances, each known to tol(key)

@@ -24,7 +24,7 @@ def short(name):
 
 def counters(sub):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for fn in glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True):
+    for fn in [max(glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)]:
         for r in csv.DictReader(open(fn)):
             acc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
     return acc
@@ -36,7 +36,8 @@ def mean_tail(v, k):
     return sum(v) / len(v)
 
 
-stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)[0]
+newest = lambda pattern: max(glob.glob(pattern, recursive=True), key=os.path.getmtime)      # (a re-run into the same directory leaves the older files behind)
+stats = newest(os.path.join(src, 'trace', '**', '*kernel_stats.csv'))
 shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats.csv'))
 dur = {}
 for r in csv.DictReader(open(stats)):
@@ -44,7 +45,7 @@ for r in csv.DictReader(open(stats)):
 # the same kernels restricted to the bench's TIMED region: the `steps` launches before the 10 extra (per-stage) ones
 # (the first launches run on the far-from-converged start state and are slower; bench.py's live HIP-event average covers
 # exactly the timed launches, so this is the number it must agree with)
-trace = glob.glob(os.path.join(src, 'trace', '**', '*kernel_trace.csv'), recursive=True)[0]
+trace = newest(os.path.join(src, 'trace', '**', '*kernel_trace.csv'))
 per = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     per[short(r['Kernel_Name'])].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
