@@ -67,6 +67,26 @@ __device__ __forceinline__ void nw_block_reduce_store(double (&v)[NV], double *_
         part[(int64_t)blockIdx.x * NV + threadIdx.x] = (s_part[threadIdx.x * 4 + 0] + s_part[threadIdx.x * 4 + 1]) + (s_part[threadIdx.x * 4 + 2] + s_part[threadIdx.x * 4 + 3]);
 }
 
+// The same sums through LDS MEMORY: every thread parks its NV values, wave 0 adds the four values of each lane position (one per
+// wave, fixed order) and does the only wave reduction.  The shuffles of a wave reduction are LDS-pipe instructions (12 per double),
+// and that pipe is shared by the CU's four SIMDs: a quarter of them is what is left.  s_red: NV * 256 doubles.
+template <int NV>
+__device__ __forceinline__ void nw_block_reduce_store_lds(double (&v)[NV], double *__restrict__ part, double *s_red)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s_red[k * NW_BLOCK + tid] = v[k];
+    __syncthreads();
+    if (tid < 64) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const double *c = s_red + k * NW_BLOCK + tid;
+            const double s = nw_wave_sum((c[0] + c[64]) + (c[128] + c[192]));
+            if (tid == 0) part[(int64_t)blockIdx.x * NV + k] = s;
+        }
+    }
+}
+
 // plain (non-replicated) variant with float64 atomics for the set-up reductions (mesh area, weight sums): not on the iteration path
 template <int NV>
 __device__ __forceinline__ void nw_block_reduce_atomic(double (&v)[NV], double *out, double *s_part /* [NV*4] */)

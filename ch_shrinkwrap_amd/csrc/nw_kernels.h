@@ -393,7 +393,6 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
                                                      double *__restrict__ part, NwDevState *__restrict__ st, int it, double inv_q, double inv_qw)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
-    __shared__ double s_part[4 * 4];
     __shared__ int s_key[NW_HT];
     __shared__ unsigned long long s_val[NW_HT * 4];        // component-major [4][NW_HT], two's-complement fixed point
     for (int t = threadIdx.x; t < NW_HT; t += NW_BLOCK) s_key[t] = -1;
@@ -504,22 +503,28 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
         if (key >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + 4 * (int64_t)key + (t & 3), s_val[(t & 3) * NW_HT + (t >> 2)]);
     }
     // per-workgroup partial sums (row of 5: four sums + the largest NN distance of the workgroup, which a sharded run checks against
-    // its halo radius; a same-address atomicMax from every wave serialised: 40 us at 1M localizations, 0.7 ms at 5M)
+    // its halo radius; a same-address atomicMax from every wave serialised: 40 us at 1M localizations, 0.7 ms at 5M).  The four sums
+    // go through LDS memory (the flushed table's) so that only one wave does wave reductions: see nw_block_reduce_store_lds.
     {
         __shared__ float s_dmax[4];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
         if ((threadIdx.x & 63) == 0) s_dmax[threadIdx.x >> 6] = dmax;
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        __syncthreads();                                      // the table has been flushed: its memory is free
+        double *s_red = reinterpret_cast<double *>(s_val);    // 4 * 256 doubles of the 4 * NW_HT the table holds
+        const int tid = threadIdx.x;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            double sk = nw_wave_sum(red[k]);
-            if (lane == 0) s_part[k * 4 + wv] = sk;
-        }
+        for (int k = 0; k < 4; ++k) s_red[k * NW_BLOCK + tid] = red[k];
         __syncthreads();
-        if (threadIdx.x < 4)
-            part[(int64_t)blockIdx.x * 5 + threadIdx.x] = (s_part[threadIdx.x * 4 + 0] + s_part[threadIdx.x * 4 + 1]) + (s_part[threadIdx.x * 4 + 2] + s_part[threadIdx.x * 4 + 3]);
-        if (threadIdx.x == 4) part[(int64_t)blockIdx.x * 5 + 4] = (double)fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+        if (tid < 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double *c = s_red + k * NW_BLOCK + tid;
+                const double sk = nw_wave_sum((c[0] + c[64]) + (c[128] + c[192]));
+                if (tid == 0) part[(int64_t)blockIdx.x * 5 + k] = sk;
+            }
+            if (tid == 0) part[(int64_t)blockIdx.x * 5 + 4] = (double)fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+        }
     }
 }
 
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
                                                                  const NwDevState *__restrict__ st, int it, int n_search)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
-    __shared__ double s_part[9 * 4];
+    __shared__ double s_red[9 * NW_BLOCK];
     // NW_SUBSPACE_PPT localizations per thread (consecutive tiles of 256): the nine sums are reduced over the workgroup once per
     // 1024 localizations -- the shuffles of that reduction go through the CU's LDS pipe, which bounded the kernel at one per thread
     const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK * NW_SUBSPACE_PPT - 1) / (NW_BLOCK * NW_SUBSPACE_PPT));      // see k_attract
@@ -718,7 +723,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
         }
       }
     }
-    nw_block_reduce_store<9>(red, part, s_part);
+    nw_block_reduce_store_lds<9>(red, part, s_red);
 }
 
 // K7: <=3x3 regularised normal equations (every workgroup solves them redundantly from the reduced sums),
