@@ -1056,7 +1056,7 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
         hipLaunchKernelGGL(k_subspace_point_sums, dim3(subspace_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
                            ctx->mask.p, ctx->S.p, ctx->part_s.p, ctx->state.p, it, n_search);
         // the 24 sums of this iteration, added in a fixed order (deterministic); multi-GPU runs all-reduce them after this call
-        hipLaunchKernelGGL(k_reduce_scalars, dim3(NW_SPARTS), dim3(NW_BLOCK), 0, ctx->stream, ctx->part_a.p, attract_blocks(ctx), ctx->part_p.p, prior_blocks(ctx),
+        hipLaunchKernelGGL(k_reduce_scalars, dim3(3 * NW_SPARTS), dim3(NW_BLOCK), 0, ctx->stream, ctx->part_a.p, attract_blocks(ctx), ctx->part_p.p, prior_blocks(ctx),
                            ctx->part_s.p, subspace_blocks(ctx), ctx->scalars.p, ctx->state.p, it);
     }
     NW_HIP(hipGetLastError());
