@@ -21,7 +21,7 @@ NW_N_SCALARS = 32
 SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set_stream', 'nw_synchronize',
            'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_refresh_normals', 'nw_reset_history', 'nw_search', 'nw_search_begin',
            'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
-           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned']
+           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_debug_items', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned']
 
 
 class IterLog(ctypes.Structure):
@@ -79,6 +79,7 @@ def load():
     L.nw_set_profiling.argtypes = [vp, i32]
     L.nw_stage_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     L.nw_debug_nn_stats.argtypes = [vp, ctypes.POINTER(i64)]
+    L.nw_debug_items.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.nw_optimize_layout.argtypes = [vp]
     L.nw_accumulator_quantum.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     for s in SYMBOLS:

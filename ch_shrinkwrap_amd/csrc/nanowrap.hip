@@ -166,6 +166,9 @@ struct nw_ctx {
     double force_h = 0.0;             // > 0: build_grid uses exactly this cell (nw_tune_grid probes)
     DevBuf<int> ccount, cstart, scan_tmp;
     DevBuf<NwItem> items;             // work list of the NN query: runs of <= 64 Morton-consecutive localizations
+    DevBuf<unsigned> item_cost;       // measured duration of every item in the last query (until the list has been ordered by it)
+    bool items_by_cost = false;       // the list has been ordered longest-first (once per work list)
+    bool item_cost_valid = false;     // a warm query has filled item_cost for the current list
     int nitems = 0;
     int item_level = -1;              // Morton level (block edge = morton_unit * 2^level) the items were cut at
     // scratch of the block-boundary / diagnostic entry points (nw_curvature, nw_lfunc): kept, so that a call per block does not
@@ -351,6 +354,9 @@ int build_items(nw_ctx *ctx, int level)
     NW_HIP(hipStreamSynchronize(ctx->stream));          // the temporaries die with this scope
     ctx->nitems = nitems;
     ctx->item_level = level;
+    NW_HIP(ctx->item_cost.ensure((size_t)nitems));
+    NW_HIP(hipMemsetAsync(ctx->item_cost.p, 0, (size_t)nitems * sizeof(unsigned), ctx->stream));
+    ctx->items_by_cost = false; ctx->item_cost_valid = false;
     if (getenv("NW_VERBOSE"))
         fprintf(stderr, "[nanowrap] work list: Morton level %d (block %.2f), %d blocks, %d items (%.1f localizations per wave)\n", level,
                 ctx->morton_unit * (float)(1 << level), nblocks, nitems, (double)N / std::max(nitems, 1));
@@ -909,6 +915,29 @@ static int tune_grid(nw_ctx *ctx)
     return rc;
 }
 
+// Longest-first order of the work list (once per list, from the durations the last warm query measured): a launch ends with its
+// slowest waves, and a cloud of a few hundred thousand localizations is a single round of waves -- the heavy ones must not start last.
+static int order_items_by_cost(nw_ctx *ctx)
+{
+    static const bool on = !(getenv("NW_ITEM_ORDER") && atoi(getenv("NW_ITEM_ORDER")) == 0);
+    if (!on || ctx->items_by_cost || !ctx->item_cost_valid || ctx->nitems < 2) return NW_OK;
+    const int n = ctx->nitems;
+    DevBuf<unsigned> key, key2;
+    DevBuf<int> idx, order;
+    DevBuf<NwItem> items2;
+    NW_HIP(key.ensure(n)); NW_HIP(key2.ensure(n)); NW_HIP(idx.ensure(n)); NW_HIP(order.ensure(n)); NW_HIP(items2.ensure(n));
+    hipLaunchKernelGGL(k_item_cost_keys, dim3(nblk(n)), dim3(NW_BLOCK), 0, ctx->stream, ctx->item_cost.p, n, key.p, idx.p);
+    NW_HIP(hipGetLastError());
+    if (nw_sort_pairs_u32(key.p, key2.p, idx.p, order.p, n, 32, ctx->stream) != 0) return fail(ctx, NW_ERR_HIP, "work-list sort failed");
+    hipLaunchKernelGGL(k_items_gather, dim3(nblk(n)), dim3(NW_BLOCK), 0, ctx->stream, ctx->items.p, order.p, n, items2.p);
+    NW_HIP(hipGetLastError());
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->items.swap(items2);
+    ctx->items_by_cost = true;
+    if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] work list ordered by measured cost (longest first)\n");
+    return NW_OK;
+}
+
 // One-off set-up that would otherwise run at the start of the next block (the projection re-sort of the localizations, the
 // work list cut from it, the cell-size tuner and the capture of the block's hipGraph): lets a caller (bench.py) take it out of a
 // timed region.  No-op when there is nothing to do.
@@ -922,6 +951,17 @@ NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
     NW_TRY(alloc_work(ctx));
     NW_TRY(ensure_grid(ctx));
     NW_TRY(tune_grid(ctx));
+    if (!ctx->items_by_cost && ctx->face_warm) {
+        if (!ctx->item_cost_valid) {            // (the tuner ends on a fresh work list: one query to time its items)
+            hipLaunchKernelGGL(k_set_iter_base, dim3(1), dim3(1), 0, ctx->stream, ctx->state.p, ctx->global_iter);
+            const int prof = ctx->profiling;
+            ctx->profiling = 0;
+            const int rq = launch_query(ctx, 0);
+            ctx->profiling = prof;
+            if (rq != NW_OK) return rq;
+        }
+        NW_TRY(order_items_by_cost(ctx));
+    }
     // pre-record the next block as a hipGraph, assuming it repeats the last one (iterations, lambda, flags): the capture
     // (a fraction of a millisecond) then does not fall into the caller's next block either.  A different next block just captures again.
     if (ctx->searched && ctx->search_iters > 0 && ctx->face_warm) {
@@ -946,6 +986,7 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     if (ctx->proj_ready && !ctx->proj_sorted && num_iters > 0 && !getenv("NW_NO_PROJ_SORT")) NW_TRY(resort_by_projection(ctx));
     NW_TRY(ensure_grid(ctx));
     if (ctx->blocks_done >= 2 && num_iters > 0) NW_TRY(tune_grid(ctx));      // (nw_optimize_layout does it earlier if the caller asks)
+    if (ctx->blocks_done >= 3 && num_iters > 0) NW_TRY(order_items_by_cost(ctx));
     // fixed-point quanta of the scatter (k_attract): 2^-36 of a bound on |w res| <= largest weight x scene extent; 2^-40 for sum w
     ctx->acc_quantum = ctx->quantum_override > 0 ? ctx->quantum_override
                                                  : std::ldexp(1.0, (int)std::ceil(std::log2(std::max(ctx->scene_ext * ctx->w_bound, 1e-300))) - 36);
@@ -997,12 +1038,14 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
     if (parts & QP_NN) {
         StageScope s(ctx, ST_NN);
         static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;   // 0 slabs, 1 round-robin, 2 interleaved runs (default)
+        static const bool no_outliers = getenv("NW_NO_OUTLIERS") != nullptr;      // developer knob
         static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
         const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;   // one wave = one work item
         const int nbp = nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
         hipLaunchKernelGGL(k_nn_wave, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p);
+                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
+                           ctx->state.p, it, ctx->nn_stats.p, ctx->items_by_cost ? nullptr : ctx->item_cost.p);
+        if (ctx->face_warm && !ctx->items_by_cost) ctx->item_cost_valid = true;      // (a cold query's costs say little about the warm ones)
         ctx->face_warm = true;
     }
     if ((parts & QP_FIXUP) && !fuse_fixup()) {
@@ -1551,6 +1594,20 @@ NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nb
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
     } while (0);
     if (rc != NW_OK) return fail(ctx, rc, "nw_curvature: HIP failure");
+    return NW_OK;
+}
+
+// developer aid: the work list of the NN query and the duration the last query measured for every item (s_memtime ticks / 16;
+// zeros once the list has been ordered).  out_items: int32[2 * cap] = {first localization (sorted order), count}; returns the number
+// of items through *n.
+NW_EXPORT int nw_debug_items(nw_ctx *ctx, int32_t *out_items, uint32_t *out_cost, int cap, int *n)
+{
+    if (!ctx || !n) return NW_ERR_BADARG;
+    *n = ctx->nitems;
+    const int m = std::min(cap, ctx->nitems);
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    if (out_items && m > 0) NW_HIP(hipMemcpy(out_items, ctx->items.p, (size_t)m * sizeof(NwItem), hipMemcpyDeviceToHost));
+    if (out_cost && m > 0) NW_HIP(hipMemcpy(out_cost, ctx->item_cost.p, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToHost));
     return NW_OK;
 }
 

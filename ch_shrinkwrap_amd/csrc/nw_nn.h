@@ -43,6 +43,7 @@
 #define NW_NN_TOLK 4e-6f
 #define NW_NN_CULL 4e-6f          // relative slack of the cell-culling test (rounding of the box distance)
 #define NW_ITEM_POINTS 64
+#define NW_OUTLIERS 8               // lanes per wave that may be resolved on their own (k_nn_wave)
 
 struct NwItem { int p0, n; };
 
@@ -171,6 +172,21 @@ __global__ void k_block_fill_items(const int *__restrict__ bstart, const int *__
         w.p0 = p; w.n = min(per, p1 - p);
         items[o++] = w;
     }
+}
+
+// work list ordered by measured cost, longest first: sort keys (descending cost = ascending key), then the gather
+__global__ void k_item_cost_keys(const unsigned *__restrict__ cost, int n, unsigned *__restrict__ key, int *__restrict__ idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = 0xffffffffu - cost[i];
+    idx[i] = i;
+}
+
+__global__ void k_items_gather(const NwItem *__restrict__ in, const int *__restrict__ order, int n, NwItem *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[order[i]];
 }
 
 // ---- the query ------------------------------------------------------------------------------------------------
@@ -353,6 +369,11 @@ __device__ __forceinline__ int nw_fixup_point(const NwGrid &g, float Px, float P
     nw_cell_coords(g, Px - r, Py - r, Pz - r, lx, ly, lz);
     nw_cell_coords(g, Px + r, Py + r, Pz + r, hx, hy, hz);
     const int ny = hy - ly + 1, nrow = ny * (hz - lz + 1);
+    // a row contributes the cells its chord of the ball covers, not the whole width of the box (cell units; the slack of the cell
+    // assignment widens every cell; the outermost cells of the grid also hold what lies beyond it)
+    const float epsu = g.eps * g.inv_h;
+    const float ux = (Px - g.ox) * g.inv_h, uy = (Py - g.oy) * g.inv_h, uz = (Pz - g.oz) * g.inv_h;
+    const float ru = r * g.inv_h * (1.0f + 1e-5f) + epsu, ru2 = ru * ru;
     double best = INFINITY;
     int bf = 0x7fffffff;
     for (int rb = 0; rb < nrow; rb += 64) {
@@ -360,9 +381,17 @@ __device__ __forceinline__ int nw_fixup_point(const NwGrid &g, float Px, float P
         const int rr = rb + lane;
         if (rr < nrow) {
             const int z = lz + rr / ny, y = ly + rr % ny;
-            const int c0 = nw_cell_index(g, lx, y, z);
-            start = cstart[c0];
-            len = cstart[c0 + (hx - lx) + 1] - start;
+            const float dyl = y == 0 ? 0.0f : (float)y - (uy + epsu), dyh = y == g.gy - 1 ? 0.0f : (uy - 1.0f - epsu) - (float)y;
+            const float dzl = z == 0 ? 0.0f : (float)z - (uz + epsu), dzh = z == g.gz - 1 ? 0.0f : (uz - 1.0f - epsu) - (float)z;
+            const float dy = fmaxf(fmaxf(dyl, dyh), 0.0f), dz = fmaxf(fmaxf(dzl, dzh), 0.0f);
+            const float rem = ru2 - fmaf(dz, dz, dy * dy);
+            if (rem >= 0.0f) {
+                const float sx = sqrtf(rem) * (1.0f + 1e-5f) + epsu + 1e-3f;
+                const int xl = nw_clampi((int)floorf(ux - sx), lx, hx), xh = nw_clampi((int)floorf(ux + sx), lx, hx);
+                const int c0 = nw_cell_index(g, xl, y, z);
+                start = cstart[c0];
+                len = cstart[c0 + (xh - xl) + 1] - start;
+            }
         }
         const int inc = nw_wave_incl_scan(len, lane);           // candidates up to and including this lane's row
         const int total = __shfl(inc, 63, 64);
@@ -397,7 +426,8 @@ __device__ __forceinline__ int nw_fixup_point(const NwGrid &g, float Px, float P
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_nn_wave(NwGrid g, const NwItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
                                                  const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,
                                                  int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
-                                                 NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats)
+                                                 NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats,
+                                                 unsigned *__restrict__ item_cost)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ NwWaveLds s_wave[4];
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #pragma unroll
     for (int k = 0; k < NWS_COUNT; ++k) S.v[k] = 0;
     S.timed = stats != nullptr;
-    const unsigned long long t_wave = S.timed ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_wave = (S.timed || item_cost) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int lane = threadIdx.x & 63;
     // Workgroup -> work-list position.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the L2 they share).
     //   (warm & 2) plain: consecutive list positions land on different XCDs: every L2 pulls the whole centroid / cell tables;
@@ -462,6 +492,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         } else prev = -1;
     }
     const float cullk = g.inv_h * g.inv_h * (1.0f + NW_NN_CULL);
+    // Outliers.  A localization far from the surface has a ball many cells wide, and every candidate in it would be evaluated by all
+    // 64 lanes.  Up to NW_OUTLIERS lanes whose warm-start radius is far above the wave's (2.5 x its rms, and more than 1.5 cells) are
+    // taken out of the walk -- no share in the box, no say in the culling -- and resolved at the end like the ambiguous ones: the whole
+    // wave over that one ball, float64, exact (nw_fixup_point needs only a centroid that bounds the distance: the warm-start face).
+    unsigned long long outl_mask = 0ull;
+    if ((warm & 25) == 9) {                                          // warm start, in-kernel fix-up, not switched off (16)
+        const float r2 = (active && prev >= 0) ? nw_best_d2(L) : 0.0f;
+        float sum = r2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float mean = nw_readlane_f(sum, 0) / (float)item.n;
+        const unsigned long long m = __ballot(active && prev >= 0 && r2 > 6.25f * mean && r2 * cullk > 2.25f);
+        if (__popcll(m) <= NW_OUTLIERS) outl_mask = m;
+    }
+    const bool wact = active && !((outl_mask >> lane) & 1ull);         // takes part in the walk
     // own cell (clamped like nw_cell_coords)
     const int cx = nw_clampi((int)floorf(L.ux), 0, g.gx - 1), cy = nw_clampi((int)floorf(L.uy), 0, g.gy - 1), cz = nw_clampi((int)floorf(L.uz), 0, g.gz - 1);
     int Exl = 0, Exh = -1, Eyl = 0, Eyh = -1, Ezl = 0, Ezh = -1;         // visited box (cells), empty
@@ -469,7 +514,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     for (;;) {
         // ---- the box this round must cover: the lanes' balls (finite b1) or their own cell +- margin (nothing seen yet)
         const bool seen = L.b1 < NW_KEY_INF;
-        const bool any_unseen = __any(active && !seen);
+        const bool any_unseen = __any(wact && !seen);
         int lxl, lxh, lyl, lyh, lzl, lzh;
         if (seen) {
             const float ru = fminf(sqrtf(nw_best_d2(L) * cullk) + 2.0f * epsu + 1e-3f, 4096.0f);     // (a lane that has only seen pad entries)
@@ -479,7 +524,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         } else {
             lxl = cx - margin; lxh = cx + margin; lyl = cy - margin; lyh = cy + margin; lzl = cz - margin; lzh = cz + margin;
         }
-        if (!active) { lxl = lyl = lzl = 0x7fffffff; lxh = lyh = lzh = -0x7fffffff; }
+        if (!wact) { lxl = lyl = lzl = 0x7fffffff; lxh = lyh = lzh = -0x7fffffff; }
         int Nxl = max(nw_wave_min_i(lxl), 0), Nxh = min(nw_wave_max_i(lxh), g.gx - 1);
         int Nyl = max(nw_wave_min_i(lyl), 0), Nyh = min(nw_wave_max_i(lyh), g.gy - 1);
         int Nzl = max(nw_wave_min_i(lzl), 0), Nzh = min(nw_wave_max_i(lzh), g.gz - 1);
@@ -500,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const int ny = Nyh - Nyl + 1, nrows = ny * (Nzh - Nzl + 1);
         const int nchunk = (Nxh - Nxl + NW_SEG) / NW_SEG, nseg = nrows * nchunk;
         const float inv_ny = 1.0f / (float)ny, inv_nc = 1.0f / (float)nchunk;
-        const float r2u = nw_best_d2(L) * cullk + epsu;                 // culling radius^2 (cell units) for this round
+        const float r2u = wact ? nw_best_d2(L) * cullk + epsu : -1.0f;   // culling radius^2 (cell units) for this round; idle and outlier lanes reach nothing
         S.v[NWS_BOX_ROWS] += nrows;
         int nr = 0, total = 0;                                           // collected ranges (wave-uniform)
         for (int sb = 0; sb < nseg; sb += 64) {
@@ -578,7 +623,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         // runner-up inside the error band (or the walk did not re-find the warm-start face): float64 re-resolution
         // both keys carry the same offset K - |p'|^2: their difference is a difference of squared distances, each known to tol(key)
         const float d1 = __uint_as_float(L.b1), d2 = __uint_as_float(L.b2);
-        const bool amb = active && (L.bslot < 0 || d2 - d1 <= 2.0f * (NW_NN_TOL * d2 + L.tolk));
+        const bool amb = active && (((outl_mask >> lane) & 1ull) || L.bslot < 0 || d2 - d1 <= 2.0f * (NW_NN_TOL * d2 + L.tolk));
         if (warm & 8) {
             // resolved here, by the whole wave, one ambiguous localization after the other (0.4 per wave on average): their cells are
             // in this CU's caches, and the iteration has one launch and one list less
@@ -598,6 +643,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
     }
     if (lane == 0 && rounds > 1) atomicMax(&st->nn_max_ring, rounds);
+    // how long this item took: the work list is ordered by it once (longest first), so that the launch does not end on its heaviest waves
+    if (item_cost && lane == 0) item_cost[wi] = (unsigned)min((unsigned long long)0xffffffffu, (__builtin_amdgcn_s_memtime() - t_wave) >> 4);
     if (stats && lane == 0) {
         S.v[NWS_ROUNDS] = rounds;
         S.v[NWS_T_WAVE] = (int)((__builtin_amdgcn_s_memtime() - t_wave) >> 4);

@@ -227,6 +227,9 @@ int nw_accumulator_quantum(nw_ctx *ctx, double *q);
  * call switches the counting on).  out[9]: candidate evaluations per wave summed, non-empty rows listed, rows visited, cells
  * tested, cells visited, rows of the boxes, rounds, small runs, work items. */
 int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out);
+/* developer aid: work list of the NN query ({first localization in sorted order, count} per item) and the duration (s_memtime ticks / 16)
+ * the last query measured for each item; zeros once the list has been ordered longest-first. */
+int nw_debug_items(nw_ctx *ctx, int32_t *out_items, uint32_t *out_cost, int cap, int *n);
 
 #ifdef __cplusplus
 }
