@@ -1042,9 +1042,15 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
         static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
         const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;   // one wave = one work item
         const int nbp = nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
-        hipLaunchKernelGGL(k_nn_wave, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+if (ctx->nn_stats.p) {
+            hipLaunchKernelGGL(k_nn_wave<true>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
                            ctx->state.p, it, ctx->nn_stats.p, ctx->items_by_cost ? nullptr : ctx->item_cost.p);
+        } else {
+            hipLaunchKernelGGL(k_nn_wave<false>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
+                           ctx->state.p, it, ctx->nn_stats.p, ctx->items_by_cost ? nullptr : ctx->item_cost.p);
+        }
         if (ctx->face_warm && !ctx->items_by_cost) ctx->item_cost_valid = true;      // (a cold query's costs say little about the warm ones)
         ctx->face_warm = true;
     }

@@ -219,7 +219,7 @@ struct NwStats { int v[NWS_COUNT]; bool timed; };
 struct NwLane {
     float px, py, pz;        // the localization RELATIVE TO THE WAVE'S ORIGIN (mean of its localizations)
     float dkp;               // K - |p'|^2: key value = d^2 + dkp (K = the wave's bias, >= every lane's |p'|^2, keeps keys non-negative)
-    float tolk;              // NW_NN_TOLK * K: the part of a key's error bound that does not shrink with the key
+    int kbits;               // bits of the wave's bias K (uniform): NW_NN_TOLK * K is the part of a key's error bound that does not shrink with the key
     float ux, uy, uz;        // the same in cell units: (p - origin) * inv_h
     float ax, ay, az;        // u + eps      } distance (cell units) from u to the slab [k - eps, k + 1 + eps] of cell index k:
     float bx, by, bz;        // u - 1 - eps  }   max(k - a, b - k, 0)
@@ -234,7 +234,7 @@ struct NwLane {
 __device__ __forceinline__ float nw_best_d2(const NwLane &L)
 {
     const float kf = __uint_as_float(L.b1);
-    return fmaxf(kf - L.dkp, 0.0f) + (NW_NN_TOL * kf + L.tolk);
+    return fmaxf(kf - L.dkp, 0.0f) + (NW_NN_TOL * kf + NW_NN_TOLK * __int_as_float(L.kbits));
 }
 
 // one candidate (the same for all lanes: an LDS broadcast read) against the lanes' localizations; KI = its position in the
@@ -299,12 +299,13 @@ __device__ __forceinline__ int nw_list_slot(const NwWaveLds *W, int nr, int g)
 
 // Stream the collected ranges: 64 candidates per batch are fetched by the 64 lanes (one coalesced-ish global load each), staged in
 // LDS and evaluated by every lane against its localization; the fetch of batch b+1 is in flight while batch b is evaluated.
+template <bool STATS>
 __device__ __forceinline__ void nw_stream(NwLane &L, NwWaveLds *W, const float4 *__restrict__ cent, int nr, int total, int lane, NwStats &S,
                                           float Ox, float Oy, float Oz, float K)
 {
     if (total <= 0) return;
-    const unsigned long long t_in = S.timed ? __builtin_amdgcn_s_memtime() : 0ull;
-    S.v[NWS_CAND] += (total + 3) & ~3;
+    const unsigned long long t_in = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (STATS) S.v[NWS_CAND] += (total + 3) & ~3;
     W->pre[nr] = total;
     nw_wave_lds_sync();
     // lanes past the end of the list stage a far-away dummy (the last group of four of a batch is evaluated whole)
@@ -335,7 +336,7 @@ __device__ __forceinline__ void nw_stream(NwLane &L, NwWaveLds *W, const float4 
     if (L.bgi >= 0) L.bslot = nw_list_slot(W, nr, L.bgi + (int)(L.b1 & 15u));
     L.bgi = -1;
     nw_wave_lds_sync();
-    if (S.timed) S.v[NWS_T_STREAM] += (int)((__builtin_amdgcn_s_memtime() - t_in) >> 4);
+    if (STATS) S.v[NWS_T_STREAM] += (int)((__builtin_amdgcn_s_memtime() - t_in) >> 4);
 }
 
 // lane j's k-th cell start (k wave-uniform, 0..8): the nine values live in nine registers, picked by a scalar branch
@@ -423,6 +424,8 @@ __device__ __forceinline__ int nw_fixup_point(const NwGrid &g, float Px, float P
     return bf;
 }
 
+// STATS: the developer counters of nw_debug_nn_stats (compiled out of the production variant: they cost registers)
+template <bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_nn_wave(NwGrid g, const NwItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
                                                  const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,
                                                  int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
@@ -434,8 +437,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     NwStats S;
 #pragma unroll
     for (int k = 0; k < NWS_COUNT; ++k) S.v[k] = 0;
-    S.timed = stats != nullptr;
-    const unsigned long long t_wave = (S.timed || item_cost) ? __builtin_amdgcn_s_memtime() : 0ull;
+    S.timed = STATS;
+    const unsigned long long t_wave = (STATS || item_cost) ? __builtin_amdgcn_s_memtime() : 0ull;
     const int lane = threadIdx.x & 63;
     // Workgroup -> work-list position.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the L2 they share).
     //   (warm & 2) plain: consecutive list positions land on different XCDs: every L2 pulls the whole centroid / cell tables;
@@ -463,42 +466,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const float epsu = g.eps * g.inv_h;                                  // rounding slack of the cell assignment, cell units
     L.ax = L.ux + epsu; L.ay = L.uy + epsu; L.az = L.uz + epsu;
     L.bx = L.ux - 1.0f - epsu; L.by = L.uy - 1.0f - epsu; L.bz = L.uz - 1.0f - epsu;
-    // wave origin = mean of the wave's localizations (idle lanes shadow lane 0), bias K = largest |p'|^2: the distances are evaluated
-    // in the expanded form on LOCAL coordinates, so their float32 error scales with the wave's size, not with the coordinate offset
-    float Ox = P.x, Oy = P.y, Oz = P.z;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { Ox += __shfl_xor(Ox, off, 64); Oy += __shfl_xor(Oy, off, 64); Oz += __shfl_xor(Oz, off, 64); }
-    Ox = nw_readlane_f(Ox * (1.0f / 64.0f), 0); Oy = nw_readlane_f(Oy * (1.0f / 64.0f), 0); Oz = nw_readlane_f(Oz * (1.0f / 64.0f), 0);
-    L.px = P.x - Ox; L.py = P.y - Oy; L.pz = P.z - Oz;
-    const float pn = fmaf(L.pz, L.pz, fmaf(L.py, L.py, L.px * L.px));
-    float Kb = pn;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) Kb = fmaxf(Kb, __shfl_xor(Kb, off, 64));
-    Kb = nw_readlane_f(Kb, 0) * (1.0f + 1e-5f) + 1e-6f;
-    L.dkp = Kb - pn;
-    L.tolk = NW_NN_TOLK * Kb;
-    L.b1 = NW_KEY_INF; L.b2 = NW_KEY_INF; L.bgi = -1; L.bslot = -1;
-    L.keymask = NW_KEY_MASK;
-    asm volatile("" : "+v"(L.keymask));
+    // warm start: the previous nearest face, and its centroid
     int prev = -1;
     if (warm & 1) {
         prev = face_io[gi];
-        if ((unsigned)prev < (unsigned)F) {
-            const float4 C = nw_expand(cent_by_face[prev], Ox, Oy, Oz, Kb);
-            const float d = fmaf(L.px, C.x, fmaf(L.py, C.y, fmaf(L.pz, C.z, C.w)));
-            // strictly above the key the walk will compute for this very centroid, so the walk re-finds it (and its slot); the bump
-            // also becomes the runner-up until a real one is seen, so it must lie outside the ambiguity band (2 NW_NN_TOL)
-            L.b1 = __float_as_uint(d * (1.0f + 8.0f * NW_NN_TOL) + 8.0f * L.tolk + 1e-30f) | 15u;
-        } else prev = -1;
+        if ((unsigned)prev >= (unsigned)F) prev = -1;
     }
     const float cullk = g.inv_h * g.inv_h * (1.0f + NW_NN_CULL);
     // Outliers.  A localization far from the surface has a ball many cells wide, and every candidate in it would be evaluated by all
-    // 64 lanes.  Up to NW_OUTLIERS lanes whose warm-start radius is far above the wave's (2.5 x its rms, and more than 1.5 cells) are
-    // taken out of the walk -- no share in the box, no say in the culling -- and resolved at the end like the ambiguous ones: the whole
-    // wave over that one ball, float64, exact (nw_fixup_point needs only a centroid that bounds the distance: the warm-start face).
+    // 64 lanes; it also stretches the wave's local frame (origin, bias K) and with it every lane's error band.  Up to NW_OUTLIERS
+    // lanes whose warm-start radius is far above the wave's (2.5 x its rms, and more than 1.5 cells) are taken out of the walk -- no
+    // share in the box, the frame or the culling -- and resolved at the end like the ambiguous ones: the whole wave over that one
+    // ball, float64, exact (nw_fixup_point needs only a centroid that bounds the distance: the warm-start face).
     unsigned long long outl_mask = 0ull;
     if ((warm & 25) == 9) {                                          // warm start, in-kernel fix-up, not switched off (16)
-        const float r2 = (active && prev >= 0) ? nw_best_d2(L) : 0.0f;
+        float r2 = 0.0f;
+        if (active && prev >= 0) {                                   // (the centroid is fetched again for the warm start below: four registers less across the reductions)
+            const float4 Cw = cent_by_face[prev];
+            const float wx = P.x - Cw.x, wy = P.y - Cw.y, wz = P.z - Cw.z;
+            r2 = fmaf(wz, wz, fmaf(wy, wy, wx * wx));
+        }
         float sum = r2;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
@@ -507,6 +494,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (__popcll(m) <= NW_OUTLIERS) outl_mask = m;
     }
     const bool wact = active && !((outl_mask >> lane) & 1ull);         // takes part in the walk
+    // wave origin = mean of the walk's localizations (idle and outlier lanes stand in for the first of them), bias K = largest
+    // |p'|^2: the distances are evaluated in the expanded form on LOCAL coordinates, so their float32 error scales with the
+    // wave's size, not with the coordinate offset
+    const int first = __builtin_ctzll(__ballot(wact));
+    const float Qx = wact ? P.x : nw_readlane_f(P.x, first), Qy = wact ? P.y : nw_readlane_f(P.y, first), Qz = wact ? P.z : nw_readlane_f(P.z, first);
+    float Ox = Qx, Oy = Qy, Oz = Qz;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { Ox += __shfl_xor(Ox, off, 64); Oy += __shfl_xor(Oy, off, 64); Oz += __shfl_xor(Oz, off, 64); }
+    Ox = nw_readlane_f(Ox * (1.0f / 64.0f), 0); Oy = nw_readlane_f(Oy * (1.0f / 64.0f), 0); Oz = nw_readlane_f(Oz * (1.0f / 64.0f), 0);
+    L.px = P.x - Ox; L.py = P.y - Oy; L.pz = P.z - Oz;
+    const float pn = fmaf(L.pz, L.pz, fmaf(L.py, L.py, L.px * L.px));
+    const float qx = Qx - Ox, qy = Qy - Oy, qz = Qz - Oz;
+    float Kb = fmaf(qz, qz, fmaf(qy, qy, qx * qx));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) Kb = fmaxf(Kb, __shfl_xor(Kb, off, 64));
+    Kb = nw_readlane_f(Kb, 0) * (1.0f + 1e-5f) + 1e-6f;
+    L.dkp = Kb - pn;                                                   // (negative for an outlier: its keys are never used)
+    L.kbits = __builtin_amdgcn_readfirstlane(__float_as_int(Kb));          // (a scalar register: nothing to keep alive per lane)
+    const float tolk = NW_NN_TOLK * __int_as_float(L.kbits);
+    L.b1 = NW_KEY_INF; L.b2 = NW_KEY_INF; L.bgi = -1; L.bslot = -1;
+    L.keymask = NW_KEY_MASK;
+    asm volatile("" : "+v"(L.keymask));
+    if (prev >= 0) {
+        const float4 C = nw_expand(cent_by_face[prev], Ox, Oy, Oz, Kb);
+        const float d = fmaf(L.px, C.x, fmaf(L.py, C.y, fmaf(L.pz, C.z, C.w)));
+        // strictly above the key the walk will compute for this very centroid, so the walk re-finds it (and its slot); the bump
+        // also becomes the runner-up until a real one is seen, so it must lie outside the ambiguity band (2 NW_NN_TOL)
+        L.b1 = __float_as_uint(d * (1.0f + 8.0f * NW_NN_TOL) + 8.0f * tolk + 1e-30f) | 15u;
+    }
     // own cell (clamped like nw_cell_coords)
     const int cx = nw_clampi((int)floorf(L.ux), 0, g.gx - 1), cy = nw_clampi((int)floorf(L.uy), 0, g.gy - 1), cz = nw_clampi((int)floorf(L.uz), 0, g.gz - 1);
     int Exl = 0, Exh = -1, Eyl = 0, Eyh = -1, Ezl = 0, Ezh = -1;         // visited box (cells), empty
@@ -546,7 +562,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const int nchunk = (Nxh - Nxl + NW_SEG) / NW_SEG, nseg = nrows * nchunk;
         const float inv_ny = 1.0f / (float)ny, inv_nc = 1.0f / (float)nchunk;
         const float r2u = wact ? nw_best_d2(L) * cullk + epsu : -1.0f;   // culling radius^2 (cell units) for this round; idle and outlier lanes reach nothing
-        S.v[NWS_BOX_ROWS] += nrows;
+        if (STATS) S.v[NWS_BOX_ROWS] += nrows;
         int nr = 0, total = 0;                                           // collected ranges (wave-uniform)
         for (int sb = 0; sb < nseg; sb += 64) {
             const int sidx = sb + lane;
@@ -571,7 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             }
             const float yf = (float)y, zf = (float)z, xaf = (float)xa;
             unsigned long long segs = __ballot(ok && m != 0u);
-            S.v[NWS_ROWS_NONEMPTY] += __popcll(segs);
+            if (STATS) S.v[NWS_ROWS_NONEMPTY] += __popcll(segs);
             while (segs) {
                 const int j = __builtin_ctzll(segs);
                 segs &= segs - 1ull;
@@ -579,7 +595,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 const float dy = nw_slab_d(L.ay, L.by, nw_readlane_f(yf, j)), dz = nw_slab_d(L.az, L.bz, nw_readlane_f(zf, j));
                 const float dyz2 = fmaf(dz, dz, dy * dy);
                 if (!__any(dyz2 <= r2u)) continue;
-                S.v[NWS_ROWS_PASS] += 1;
+                if (STATS) S.v[NWS_ROWS_PASS] += 1;
                 const unsigned mj = (unsigned)__builtin_amdgcn_readlane((int)m, j);
                 const float xj = nw_readlane_f(xaf, j);
                 unsigned pm = 0, t = mj;
@@ -587,8 +603,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     const int k = __builtin_ctz(t);
                     t &= t - 1u;
                     const float dx = nw_slab_d(L.ax, L.bx, xj + (float)k);
-                    S.v[NWS_CELLS_TESTED] += 1;
-                    if (__any(fmaf(dx, dx, dyz2) <= r2u)) { pm |= 1u << k; S.v[NWS_CELLS_PASS] += 1; }
+                    if (STATS) S.v[NWS_CELLS_TESTED] += 1;
+                    if (__any(fmaf(dx, dx, dyz2) <= r2u)) { pm |= 1u << k; if (STATS) S.v[NWS_CELLS_PASS] += 1; }
                 }
                 // runs of surviving cells (empty or culled-empty cells in between join for free) -> candidate ranges
                 const unsigned joinable = pm | ~mj;
@@ -601,13 +617,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                         W->rs[nr] = c0;
                         W->pre[nr] = total;
                         ++nr; total += c1 - c0;
-                        if (nr == NW_RNG_MAX) { nw_stream(L, W, cent, nr, total, lane, S, Ox, Oy, Oz, Kb); nr = 0; total = 0; }
+                        if (nr == NW_RNG_MAX) { nw_stream<STATS>(L, W, cent, nr, total, lane, S, Ox, Oy, Oz, Kb); nr = 0; total = 0; }
                     }
                     pm = (k1 >= 32) ? 0u : (pm >> k1) << k1;
                 }
             }
         }
-        nw_stream(L, W, cent, nr, total, lane, S, Ox, Oy, Oz, Kb);
+        nw_stream<STATS>(L, W, cent, nr, total, lane, S, Ox, Oy, Oz, Kb);
         Exl = Nxl; Exh = Nxh; Eyl = Nyl; Eyh = Nyh; Ezl = Nzl; Ezh = Nzh;
         if (!any_unseen) break;          // the box was built from every lane's ball and b1 only shrinks: all lanes are final
     }
@@ -619,11 +635,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const int gi = item_t.p0 + (active ? lane : 0);
         int fid = (warm & 1) ? face_io[gi] : -1;
         if ((unsigned)fid >= (unsigned)F) fid = -1;
-        if (active && L.bslot >= 0) fid = __float_as_int(cent[L.bslot].w);
+        unsigned long long om0 = outl_mask;
+        asm volatile("" : "+s"(om0));
+        if (active && L.bslot >= 0 && !((om0 >> lane) & 1ull)) fid = __float_as_int(cent[L.bslot].w);      // (an outlier's keys mean nothing: its bound stays the warm-start face)
         // runner-up inside the error band (or the walk did not re-find the warm-start face): float64 re-resolution
         // both keys carry the same offset K - |p'|^2: their difference is a difference of squared distances, each known to tol(key)
         const float d1 = __uint_as_float(L.b1), d2 = __uint_as_float(L.b2);
-        const bool amb = active && (((outl_mask >> lane) & 1ull) || L.bslot < 0 || d2 - d1 <= 2.0f * (NW_NN_TOL * d2 + L.tolk));
+        unsigned long long om = outl_mask;
+        asm volatile("" : "+s"(om));                               // (re-derive the lane's bit here instead of keeping it alive across the walk)
+        const bool outl = (om >> lane) & 1ull;
+        const bool amb = active && (outl || L.bslot < 0 || d2 - d1 <= 2.0f * (NW_NN_TOL * d2 + NW_NN_TOLK * __int_as_float(L.kbits)));
         if (warm & 8) {
             // resolved here, by the whole wave, one ambiguous localization after the other (0.4 per wave on average): their cells are
             // in this CU's caches, and the iteration has one launch and one list less
@@ -645,7 +666,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (lane == 0 && rounds > 1) atomicMax(&st->nn_max_ring, rounds);
     // how long this item took: the work list is ordered by it once (longest first), so that the launch does not end on its heaviest waves
     if (item_cost && lane == 0) item_cost[wi] = (unsigned)min((unsigned long long)0xffffffffu, (__builtin_amdgcn_s_memtime() - t_wave) >> 4);
-    if (stats && lane == 0) {
+    if (STATS && stats && lane == 0) {
         S.v[NWS_ROUNDS] = rounds;
         S.v[NWS_T_WAVE] = (int)((__builtin_amdgcn_s_memtime() - t_wave) >> 4);
 #pragma unroll
