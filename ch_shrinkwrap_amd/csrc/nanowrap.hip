@@ -922,19 +922,44 @@ static int order_items_by_cost(nw_ctx *ctx)
     static const bool on = !(getenv("NW_ITEM_ORDER") && atoi(getenv("NW_ITEM_ORDER")) == 0);
     if (!on || ctx->items_by_cost || !ctx->item_cost_valid || ctx->nitems < 2) return NW_OK;
     const int n = ctx->nitems;
-    DevBuf<unsigned> key, key2;
-    DevBuf<int> idx, order;
-    DevBuf<NwItem> items2;
-    NW_HIP(key.ensure(n)); NW_HIP(key2.ensure(n)); NW_HIP(idx.ensure(n)); NW_HIP(order.ensure(n)); NW_HIP(items2.ensure(n));
-    hipLaunchKernelGGL(k_item_cost_keys, dim3(nblk(n)), dim3(NW_BLOCK), 0, ctx->stream, ctx->item_cost.p, n, key.p, idx.p);
-    NW_HIP(hipGetLastError());
-    if (nw_sort_pairs_u32(key.p, key2.p, idx.p, order.p, n, 32, ctx->stream) != 0) return fail(ctx, NW_ERR_HIP, "work-list sort failed");
-    hipLaunchKernelGGL(k_items_gather, dim3(nblk(n)), dim3(NW_BLOCK), 0, ctx->stream, ctx->items.p, order.p, n, items2.p);
-    NW_HIP(hipGetLastError());
+    // a few thousand items: done on the host
+    std::vector<NwItem> items(n);
+    std::vector<unsigned> cost(n);
+    NW_HIP(hipMemcpyAsync(items.data(), ctx->items.p, (size_t)n * sizeof(NwItem), hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipMemcpyAsync(cost.data(), ctx->item_cost.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     NW_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->items.swap(items2);
+    std::vector<unsigned> tmp(cost);
+    std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+    const double median = std::max(1.0, (double)tmp[n / 2]);
+    // While the list is shorter than two rounds of waves the launch ends on its heaviest items: those are cut into pieces of about the
+    // median cost (a piece repeats the item's walk over fewer localizations -- more work in all, shorter waves).
+    static const bool split_on = !(getenv("NW_ITEM_SPLIT") && atoi(getenv("NW_ITEM_SPLIT")) == 0);
+    const bool split = split_on && n < 2 * 256 * 4 * 6;
+    struct Piece { NwItem it; double est; };
+    std::vector<Piece> out;
+    out.reserve(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        int k = 1;
+        if (split) k = std::max(1, std::min((int)std::lround(cost[i] / (1.25 * median)), items[i].n / 4));
+        const int per = (items[i].n + k - 1) / k;
+        for (int p = 0; p < items[i].n; p += per) {
+            Piece pc;
+            pc.it.p0 = items[i].p0 + p; pc.it.n = std::min(per, items[i].n - p);
+            pc.est = (double)cost[i] / k;
+            out.push_back(pc);
+        }
+    }
+    std::stable_sort(out.begin(), out.end(), [](const Piece &a, const Piece &b) { return a.est > b.est; });
+    const int m = (int)out.size();
+    std::vector<NwItem> flat(m);
+    for (int i = 0; i < m; ++i) flat[i] = out[i].it;
+    NW_HIP(ctx->items.ensure((size_t)m));
+    NW_HIP(hipMemcpyAsync(ctx->items.p, flat.data(), (size_t)m * sizeof(NwItem), hipMemcpyHostToDevice, ctx->stream));
+    NW_HIP(ctx->item_cost.ensure((size_t)m));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->nitems = m;
     ctx->items_by_cost = true;
-    if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] work list ordered by measured cost (longest first)\n");
+    if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] work list ordered by measured cost (longest first)%s: %d -> %d items\n", split ? ", heavy items cut" : "", n, m);
     return NW_OK;
 }
 
