@@ -915,7 +915,7 @@ static int tune_grid(nw_ctx *ctx)
     return rc;
 }
 
-// Longest-first order of the work list (once per list, from the durations the last warm query measured): a launch ends with its
+// Heavy-first order of the work list (once per list, from the durations the last warm query measured): a launch ends with its
 // slowest waves, and a cloud of a few hundred thousand localizations is a single round of waves -- the heavy ones must not start last.
 static int order_items_by_cost(nw_ctx *ctx)
 {
@@ -949,7 +949,9 @@ static int order_items_by_cost(nw_ctx *ctx)
             out.push_back(pc);
         }
     }
-    std::stable_sort(out.begin(), out.end(), [](const Piece &a, const Piece &b) { return a.est > b.est; });
+    // heavy pieces first -- but in two classes only, each in the list's own (spatial) order: neighbours in the list share centroid
+    // cells, and the XCD mapping of the launch keeps them on one L2 (fully sorted by cost the query fetched 148 MB instead of 64)
+    std::stable_partition(out.begin(), out.end(), [&](const Piece &a) { return a.est > 1.5 * median; });
     const int m = (int)out.size();
     std::vector<NwItem> flat(m);
     for (int i = 0; i < m; ++i) flat[i] = out[i].it;
@@ -959,7 +961,7 @@ static int order_items_by_cost(nw_ctx *ctx)
     NW_HIP(hipStreamSynchronize(ctx->stream));
     ctx->nitems = m;
     ctx->items_by_cost = true;
-    if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] work list ordered by measured cost (longest first)%s: %d -> %d items\n", split ? ", heavy items cut" : "", n, m);
+    if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] work list: heavy items first%s: %d -> %d items\n", split ? ", heavy items cut" : "", n, m);
     return NW_OK;
 }
 
