@@ -21,7 +21,7 @@ NW_N_SCALARS = 32
 SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set_stream', 'nw_synchronize',
            'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_refresh_normals', 'nw_reset_history', 'nw_search', 'nw_search_begin',
            'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
-           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_debug_items', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned']
+           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_debug_items', 'nw_set_data', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned']
 
 
 class IterLog(ctypes.Structure):
@@ -73,6 +73,7 @@ def load():
     L.nw_write_back.argtypes = [vp, vp, vp, i64]
     L.nw_set_write_back.argtypes = [vp, vp, i64]
     L.nw_set_owned.argtypes = [vp, vp]
+    L.nw_set_data.argtypes = [vp, vp]
     L.nw_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     L.nw_lfunc.argtypes = [vp, i32, vp, vp, vp]
     L.nw_curvature.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32] + [vp] * 12

@@ -165,6 +165,8 @@ struct nw_ctx {
     int blocks_done = 0;              // completed search() calls since the localizations were set
     double force_h = 0.0;             // > 0: build_grid uses exactly this cell (nw_tune_grid probes)
     DevBuf<int> ccount, cstart, scan_tmp;
+    DevBuf<float> data_in, dat;       // search(data != points): the residual's target in the caller's / the sorted order (nw_set_data)
+    bool have_data = false;
     DevBuf<NwItem> items;             // work list of the NN query: runs of <= 64 Morton-consecutive localizations
     DevBuf<unsigned> item_cost;       // measured duration of every item in the last query (until the list has been ordered by it)
     bool items_by_cost = false;       // the list has been ordered longest-first (once per work list)
@@ -671,6 +673,7 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
         NW_HIP(hipStreamSynchronize(ctx->stream));      // key_in / idx_in die with this scope
     }
     ctx->have_points = true;
+    ctx->have_data = false;                  // (a residual target given with nw_set_data belonged to the previous localizations)
     ctx->grid_valid = false;
     ctx->item_level = -1;
     ctx->nitems = 0;
@@ -679,6 +682,36 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
     ctx->tuned = false; ctx->cell_tune = 1.0; ctx->blocks_done = 0;
     ctx->last_mean_dist = -1.0;
     ctx->searched = false;
+    return NW_OK;
+}
+
+// search(data, ...) with `data` other than the localizations of nw_set_points (mesh_conj_grad.py:150, :164, :180-181, :222): the residual
+// is taken against `data` ((N,3) float32, the caller's point order) while the weight matrix keeps coming from the localizations.
+// NULL: back to the localizations (what nw_set_points leaves).
+static int gather_data(nw_ctx *ctx)
+{
+    const int64_t N = ctx->N;
+    if (ctx->have_data) NW_HIP(ctx->dat.ensure(3 * N));
+    hipLaunchKernelGGL(k_data_gather, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->perm.p, ctx->have_data ? ctx->data_in.p : nullptr, ctx->pts.p,
+                       ctx->have_data ? ctx->dat.p : nullptr, ctx->w_array ? nullptr : ctx->mask.p);
+    NW_HIP(hipGetLastError());
+    return NW_OK;
+}
+
+NW_EXPORT int nw_set_data(nw_ctx *ctx, const float *data)
+{
+    if (!ctx) return NW_ERR_BADARG;
+    if (!ctx->have_points) return fail(ctx, NW_ERR_BADARG, "nw_set_data: set the localizations first");
+    if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_set_data inside a search");
+    NW_HIP(hipSetDevice(ctx->device));
+    if (!data && !ctx->have_data) return NW_OK;
+    ctx->have_data = data != nullptr;
+    if (data) {
+        NW_HIP(ctx->data_in.ensure(3 * ctx->N));
+        NW_HIP(hipMemcpyAsync(ctx->data_in.p, data, 3 * ctx->N * sizeof(float), hipMemcpyDefault, ctx->stream));
+    }
+    NW_TRY(gather_data(ctx));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
     return NW_OK;
 }
 
@@ -850,6 +883,7 @@ static int resort_by_projection(nw_ctx *ctx)
     ctx->proj_sorted = true; ctx->proj_ready = false;
     ctx->searched = false;                   // cached per-localization results are in the old order
     ctx->proj_key.release(); ctx->proj_idx.release();
+    if (ctx->have_data) NW_TRY(gather_data(ctx));
     if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] localizations re-sorted by their foot point on the surface\n");
     return NW_OK;
 }
@@ -1101,7 +1135,8 @@ static int iter_attract_parts(nw_ctx *ctx, int parts)
         StageScope s(ctx, ST_ATTRACT);
         hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
                            ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->sinv_scalar, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->w_scalar, ctx->mask.p,
-                           ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, ctx->part_a.p, ctx->state.p, it, 1.0 / ctx->acc_quantum, 1.0 / ctx->w_quantum);
+                           ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, ctx->part_a.p, ctx->state.p, it, 1.0 / ctx->acc_quantum, 1.0 / ctx->w_quantum,
+                           ctx->have_data ? ctx->dat.p : nullptr);
     }
     NW_HIP(hipGetLastError());
     return NW_OK;
@@ -1260,8 +1295,9 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     uint32_t lb; memcpy(&lb, &ctx->lam0, 4); mix(lb);
     uint64_t qb; memcpy(&qb, &ctx->acc_quantum, 8); mix(qb);
     uint32_t sb; memcpy(&sb, &ctx->sinv_scalar, 4); mix(sb); memcpy(&sb, &ctx->w_scalar, 4); mix(sb);
-    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 3 ? 32 : 0) | (ctx->direct_out ? 64 : 0));
+    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 3 ? 32 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0));
     mixp(ctx->direct_out ? ctx->pin : nullptr);
+    mixp(ctx->have_data ? ctx->dat.p : nullptr);
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
                                                      const float *__restrict__ sinv, float sinv_scalar, const float *__restrict__ wnorm, float w_scalar,
                                                      const unsigned char *__restrict__ mask,
                                                      int *__restrict__ vidx, float *__restrict__ wout, float *__restrict__ res, long long *__restrict__ vacc,
-                                                     double *__restrict__ part, NwDevState *__restrict__ st, int it, double inv_q, double inv_qw)
+                                                     double *__restrict__ part, NwDevState *__restrict__ st, int it, double inv_q, double inv_qw,
+                                                     const float *__restrict__ dat /* target of the residual if it is not the localizations (nw_set_data), else NULL */)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ int s_key[NW_HT];
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
             af = af + fv[2][k] * w[2];
             bad |= isnan(af);
             const float wt = wnorm ? wnorm[3 * i + k] : w_scalar;
-            const float r0 = wt * (p[k] - af);
+            const float r0 = wt * ((dat ? dat[3 * i + k] : p[k]) - af);
             const double si = sinv ? (double)sinv[3 * i + k] : (double)sinv_scalar;
             const double wd = 1.0 / ((double)d * si / 2.0 + 1.0);
             r[k] = (float)((double)r0 * wd);

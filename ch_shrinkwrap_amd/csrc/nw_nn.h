@@ -134,6 +134,20 @@ __global__ void k_point_regather(int N, const int *__restrict__ order, const flo
         for (int k = 0; k < 3; ++k) wnorm[3 * s + k] = wnorm_o[3 * o + k];
 }
 
+// search(data, ...) with `data` other than the localizations (mesh_conj_grad.py:164, 180-181, 222): the residual's target in sorted
+// order, and -- for scalar weights -- the mask isfinite(data) (:164).  data_in == NULL restores the mask of the localizations.
+__global__ void k_data_gather(int N, const int *__restrict__ perm, const float *__restrict__ data_in, const float4 *__restrict__ pts, float *__restrict__ dat,
+                              unsigned char *__restrict__ mask /* NULL: weights array decides */)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int o = perm[s];
+    float d[3];
+    if (data_in) { d[0] = data_in[3 * o]; d[1] = data_in[3 * o + 1]; d[2] = data_in[3 * o + 2]; dat[3 * s] = d[0]; dat[3 * s + 1] = d[1]; dat[3 * s + 2] = d[2]; }
+    else { const float4 P = pts[s]; d[0] = P.x; d[1] = P.y; d[2] = P.z; }
+    if (mask) mask[s] = (unsigned char)((isfinite(d[0]) ? 1u : 0u) | (isfinite(d[1]) ? 2u : 0u) | (isfinite(d[2]) ? 4u : 0u));
+}
+
 // block heads of the sorted key list: head[i] = 1 where the aligned Morton block (key >> shift) changes
 __global__ void k_block_heads(const unsigned *__restrict__ key, int N, int shift, int *__restrict__ head)
 {

@@ -172,6 +172,7 @@ class ShrinkwrapMeshConjGrad(object):
         self._native.check(self._L.nw_set_points(self._h, nw.ptr(self._points_f32), self._points_f32.shape[0], nw.ptr(s_arr), s_sc,
                                                  mode, nw.ptr(w_arr), w_sc))
         self._native.points_key = key
+        self._native.data_key = None            # (nw_set_points drops a residual target set for the previous upload)
         self._native._keep = [self._points, sigma_inv, weights]      # keep ids alive while they key the cache
         # host view of the mask for API parity (`cg.mask`)
         if mode in (nw.NW_WEIGHTS_ARRAY, nw.NW_WEIGHTS_PRENORMALIZED):
@@ -196,14 +197,23 @@ class ShrinkwrapMeshConjGrad(object):
     # -- the hot path ---------------------------------------------------------------------------
     def search(self, data, lams, defaults=None, num_iters=10, weights=None, sigma_inv=1.0, pos=False, last_step=True):
         """mesh_conj_grad.py:150-292.  Returns the (M,3) float32 vertex estimate."""
+        # `data` is the target of the residual (mesh_conj_grad.py:164, 180-181, 222); the weight matrix always comes from the
+        # localizations the optimiser was built with (:222 -> :433).  Upstream passes the same array for both (_membrane_mesh.pyx:1516).
+        target = None
         if data is not self._points:
             d = np.asarray(data)
+            if d.size != self._points_f32.size:
+                raise ValueError('data must have as many entries as the localizations (%d)' % self._points_f32.size)
             if d.shape != np.asarray(self._points).shape or not np.array_equal(d, self._points):
-                raise NotImplementedError('search(data=...) must be the localizations the optimiser was built with')
+                target = _as_f32(d.reshape(-1, 3))
         if type(lams) is float or np.isscalar(lams):
             lams = [float(lams)]
         lams_a = np.ascontiguousarray(lams, dtype=np.float32)
         self._upload_points(sigma_inv, weights)
+        dkey = None if target is None else (id(data), self._native.points_key)
+        if getattr(self._native, 'data_key', None) != dkey or (target is not None and not getattr(self, '_data_is_static', False)):
+            self._native.check(self._L.nw_set_data(self._h, nw.ptr(target)))
+            self._native.data_key = dkey
         num_iters = int(num_iters)
         flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP) | self._regulariser_flag()
         logs = (nw.IterLog * max(num_iters, 1))()

@@ -112,6 +112,11 @@ int nw_synchronize(nw_ctx *ctx);
 int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points,
                   const float *sigma_inv, float sigma_inv_scalar,
                   int weights_mode, const float *weights, float weights_scalar);
+/* `data` of search(data, lams, ...) when it is NOT the localizations the optimiser was built with (mesh_conj_grad.py:150): the
+ * residual targets `data` ((N,3) float32, the order of nw_set_points; :180-181, :222) and, with scalar weights, the mask is
+ * isfinite(data) (:164), while the weight matrix keeps coming from the localizations (:222 -> :433).  NULL: the localizations
+ * themselves (the state nw_set_points leaves; what every upstream caller passes, _membrane_mesh.pyx:1516). */
+int nw_set_data(nw_ctx *ctx, const float *data);
 
 /* mesh arrays the optimiser reads: positions `mesh._vertices['position']` (M,3), block-stale vertex normals
  * `mesh.vertex_normals` (M,3), 1-ring VERTEX ids (M,NB), -1 padded (= mesh._halfedges['vertex'][mesh._vertices

@@ -213,21 +213,24 @@ class OracleResult(object):
 
 
 def search(pos, nrm, nbr, faces, points, lams, num_iters=10, sigma_inv=1.0, weights=None, valid=None,
-           pos_constraint=False, last_step=True, tests=None, trace=None, workers=-1, brute_nn=False, regulariser='I'):
+           pos_constraint=False, last_step=True, tests=None, trace=None, workers=-1, brute_nn=False, regulariser='I', data=None):
     """mesh_conj_grad.py:150-292 for one fixed-topology block.
 
     pos (M,3) f4 vertex positions at block start, nrm (M,3) f4 block-stale vertex normals, nbr (M,NB) i4 1-ring
     vertex ids, faces (F,3) i4, points (N,3) f4.  `tests` = history list carried by the optimiser object
     (the stop condition looks at it before the first iteration).  If `trace` is a list, one dict of
     intermediates is appended per iteration.  regulariser: 'I' (mesh_conj_grad.py:38, the live setting) or 'wfunc' (:724-735; the
-    other names hand float64 data to float32 C code upstream and fail in the first iteration).  Returns an OracleResult with the final positions and logs."""
+    other names hand float64 data to float32 C code upstream and fail in the first iteration).  `data`: the first argument of the
+    reference's search() -- the target of the residual (:164, :180-181, :222), by default the localizations the weight matrix is built
+    from (`self.points`, :222 -> :433), which is what every upstream caller passes.  Returns an OracleResult with the final positions and logs."""
     M = pos.shape[0]
     N = points.shape[0]
     if valid is None:
         valid = np.ones(M, bool)
     if weights is None:
         weights = sigma_inv
-    data = points.ravel()
+    data = (points if data is None else np.asarray(data)).ravel()
+    assert data.size == points.size
     if not np.isscalar(weights):
         mask = weights > 0
         weights = weights / weights.mean()

@@ -205,6 +205,25 @@ def golden_f64_and_regulariser():
     save('f64_and_wfunc', **arrays)
 
 
+
+def golden_data_target():
+    """search(data, ...) with `data` different from the localizations the optimiser was built with: the weight matrix comes from
+    `self.points` (mesh_conj_grad.py:222 -> :433), the residual targets `data` (:180-181, :222).  No upstream caller does this
+    (_membrane_mesh.pyx:1516 passes the same array), but the reference's signature allows it."""
+    v, f = icosphere(3, 120.0)
+    N = 4000
+    pts = sphere_cloud(N, 100.0, 10.0, seed=8)
+    rng = np.random.default_rng(9)
+    data = (pts + rng.normal(scale=3.0, size=pts.shape)).astype('f4')           # e.g. a drift-corrected copy of the table
+    s = 1.0 / np.full(3 * N, 10.0, 'f4')
+    mesh = TriMesh(v, f)
+    arrays = {'mesh_' + k: a for k, a in mesh_inputs(mesh).items()}
+    cg = ref_harness.new_reference_optimiser(mesh, pts, search_k=200, search_rad=100, shield_sigma=float(mesh._mean_edge_length) / 2.0)
+    out = np.array(cg.search(data, lams=[10.0], num_iters=5, sigma_inv=s))
+    arrays.update(points=pts, data=data, positions=out, res=np.array(cg.res).copy())
+    arrays.update({'log_' + k: a for k, a in logs(cg).items()})
+    save('data_target', **arrays)
+
 def golden_lfuncs():
     """Outputs of the reference's compiled C helpers (conj_grad_utils.c) on a small sphere."""
     _, _, cgu = ref_harness.load()
@@ -296,6 +315,7 @@ if __name__ == '__main__':
     golden_c1()
     golden_variants()
     golden_f64_and_regulariser()
+    golden_data_target()
     golden_lfuncs()
     golden_curvature()
     golden_sdf_shapes()

@@ -118,7 +118,7 @@ def test_zero_iterations_and_argument_errors():
     assert np.all(cg.res == 0)                                       # res = 0*data (mesh_conj_grad.py:181)
     with pytest.raises(ValueError):
         cg.search(pts, lams=[5.0], num_iters=1, sigma_inv=np.ones(7, 'f4'))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                                  # data of another length: the reference's `data - Afunc(f)` cannot broadcast either
         cg.search(pts[:10], lams=[5.0], num_iters=1, sigma_inv=0.1)
     bad = pts.copy()
     bad[3, 1] = np.nan

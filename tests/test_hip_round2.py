@@ -256,3 +256,31 @@ def test_query_is_exact_in_later_iterations_of_a_block(name, scale, n_before, ba
         dd = np.linalg.norm(pts[diff].astype('f8') - cent[got[diff]].astype('f8'), axis=1)
         assert np.allclose(dd, d_all[diff], rtol=1e-15, atol=0), 'nearest face differs from cKDTree at %d points' % diff.size
     assert np.allclose(cg.d[:, 0], d_all, rtol=1e-6)
+
+
+def test_search_with_data_other_than_the_localizations():
+    """search(data, ...) where `data` is not the array the optimiser was built with (mesh_conj_grad.py:150): the weight matrix comes
+    from the localizations, the residual targets `data` (nw_set_data).  Against the reference's own run of that call; a later
+    search with the localizations themselves must not see the old target."""
+    TriMesh, CG = _imports()
+    g = load_golden('data_target')
+    s = 1.0 / np.full(g['points'].size, 10.0, 'f4')
+    mesh = _golden_mesh(g)
+    cg = CG(mesh, g['points'])
+    out = cg.search(g['data'], lams=[10.0], num_iters=5, sigma_inv=s)
+    assert rel_rms(out, g['positions']) <= 1e-5
+    assert np.allclose(np.array(cg.ress, 'f8'), g['log_ress'], rtol=2e-5)
+    assert np.allclose(cg.res, g['res'], rtol=2e-4, atol=2e-4 * np.abs(g['res']).max())
+    # the same optimiser, now with its own localizations as data (the upstream call pattern): equals a fresh optimiser doing that
+    mesh.vertices[:] = g['mesh_vertices']
+    cg2 = CG(mesh, g['points'])
+    a = cg2.search(g['points'], lams=[10.0], num_iters=3, sigma_inv=s).copy()
+    mesh_b = _golden_mesh(g)
+    b = CG(mesh_b, g['points']).search(g['points'], lams=[10.0], num_iters=3, sigma_inv=s)
+    assert np.array_equal(a, b)
+    mesh.vertices[:] = g['mesh_vertices']
+    cg3 = CG(mesh, g['points'])
+    cg3.search(g['data'], lams=[10.0], num_iters=1, sigma_inv=s)
+    mesh.vertices[:] = g['mesh_vertices']
+    c = CG(mesh, g['points'], native=cg3._native).search(g['points'], lams=[10.0], num_iters=3, sigma_inv=s)
+    assert np.array_equal(c, b), 'the residual target of an earlier search leaked into a search with the localizations'

@@ -184,3 +184,18 @@ def test_live_reference_alternate_regularisers_fail_upstream():
     m2 = TriMesh(v, f)
     r = O.search(m2.vertices.copy(), m2.vertex_normals.copy(), m2.neighbor_vertex_table(), m2.faces, pts, [10.0], 3, s, regulariser='wfunc')
     assert np.array_equal(r.positions, out)
+
+
+def test_oracle_data_other_than_the_localizations_against_golden():
+    """search(data, ...) with `data` different from the optimiser's localizations (mesh_conj_grad.py:150: weight matrix from
+    `self.points`, residual against `data`): fixture from the reference (tests/golden/make_golden.py::golden_data_target)."""
+    g = load_golden('data_target')
+    pos, nrm, nbr, faces, _ = _mesh(g, 'mesh_')
+    s = 1.0 / np.full(g['points'].size, 10.0, 'f4')
+    r = O.search(pos.copy(), nrm.copy(), nbr, faces, g['points'], [10.0], 5, s, data=g['data'])
+    assert np.array_equal(r.positions.astype('f4'), g['positions'])
+    assert np.array_equal(np.array(r.ress, 'f8'), g['log_ress'])
+    assert np.array_equal(np.array(r.tests, 'f8'), g['log_tests'])
+    # and it is not the fit to the localizations themselves
+    r0 = O.search(pos.copy(), nrm.copy(), nbr, faces, g['points'], [10.0], 5, s)
+    assert rel_rms(r0.positions, g['positions']) > 1e-5
