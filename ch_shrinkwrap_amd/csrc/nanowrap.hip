@@ -1651,6 +1651,14 @@ NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nb
         float *o = d_out.p;
         float *p_k0 = o, *p_k1 = o + M, *p_H = o + 2 * M, *p_K = o + 3 * M, *p_dH = o + 4 * M, *p_dK = o + 5 * M, *p_E = o + 6 * M, *p_pE = o + 7 * M,
               *p_dEn = o + 8 * M, *p_e0 = o + 9 * M, *p_e1 = o + 12 * M, *p_dEdN = o + 15 * M;
+        // unused (or stochastically skipped, membrane_mesh_utils.c:962) vertices keep what the caller's k0 / k1 / e0 / e1 hold: the reference
+        // does not touch those rows
+        if (ctx->have_valid) {
+            struct { const float *src; float *dst; int64_t n; } ins[4] = {{k0, p_k0, M}, {k1, p_k1, M}, {e0, p_e0, 3 * M}, {e1, p_e1, 3 * M}};
+            for (auto &t : ins)
+                if (t.src && hipMemcpyAsync(t.dst, t.src, (size_t)t.n * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+            if (rc != NW_OK) break;
+        }
         hipLaunchKernelGGL(k_curvature, dim3(nblk(M, 128)), dim3(128), 0, ctx->stream, (int)M, NB, ctx->meshpos.p, ctx->nrm.p,
                            ctx->have_valid ? ctx->valid.p : nullptr, ctx->nbr.p, d_next.p, d_area.p, jitter ? d_jit.p : nullptr, dN, kc, kg, c0,
                            p_k0, p_k1, p_e0, p_e1, p_H, p_K, p_dH, p_dK, p_E, p_pE, p_dEn, p_dEdN);

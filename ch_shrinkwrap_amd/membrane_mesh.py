@@ -130,14 +130,13 @@ class MembraneMesh(TriMesh):
         area[~ok] = 0
         return np.ascontiguousarray(nxt, 'i4'), np.ascontiguousarray(area, 'f4')
 
-    def curvature_grad_c(self, dN=0.1, skip_prob=0.0, jitter=None):
+    def curvature_grad_c(self, dN=0.1, skip_prob=0.0, jitter=None, skip_u=None):
         """_membrane_mesh.pyx:323-347 -> c_curvature_grad (membrane_mesh_utils.c:915-1250) on the GPU.  Fills the
         per-vertex curvature arrays and returns dEdN (M,3).  `jitter`: optional (M,3) float64 array in [0,1) replacing the
-        reference's rand() stream; None = deterministic hash."""
+        reference's rand() stream; None = deterministic hash.  `skip_prob` > 0 (:962, never used on the live path): a vertex whose
+        uniform draw -- `skip_u` (M,), default a seeded generator -- is below it is treated like an unused slot (outputs zeroed)."""
         import ctypes
         from . import _lib as nw
-        if skip_prob != 0.0:
-            raise NotImplementedError('skip_prob != 0 is never used on the live path (_membrane_mesh.pyx:323)')
         if self._native is None:
             self._native = NativeContext(self._device)
         nat = self._native
@@ -146,6 +145,9 @@ class MembraneMesh(TriMesh):
         nrm = np.ascontiguousarray(self.vertex_normals, 'f4')
         nbr = self.neighbor_vertex_table()
         valid = np.ascontiguousarray(self._vertices['halfedge'] != -1, 'u1')
+        if skip_prob > 0:                                   # `(halfedge == -1) || (r2() < skip_prob)`: float32 draw against the float32 argument
+            u = np.random.default_rng(0).random(M) if skip_u is None else np.asarray(skip_u)
+            valid = np.ascontiguousarray(valid & ~(u.astype(np.float32) < np.float32(skip_prob)), 'u1')
         faces = np.ascontiguousarray(self.faces, 'i4')
         nat.check(nat.L.nw_set_mesh(nat.h, nw.ptr(pos), nw.ptr(nrm), nw.ptr(nbr), nw.ptr(valid), nw.ptr(faces), M, faces.shape[0], nbr.shape[1]))
         nat.mesh_key = None                                 # uploaded outside an optimiser: do not assume it is reusable

@@ -284,8 +284,24 @@ def golden_curvature():
         if valid[i]:
             for k in range(3):
                 jit[i, k] = libc.rand() / 2147483648.0
+    # the same call with skip_prob > 0 (membrane_mesh_utils.c:962): `(halfedge == -1) || (r2() < skip_prob)` draws one float32 uniform per
+    # used vertex, and only the vertices that are kept go on to draw their three jitter values
+    skip_prob = 0.3
+    rs = {n: np.zeros(shp.get(n, (M,)), 'f4') for n in names}
+    ref.ref_c_curvature_grad(P(m._vertices), P(m._faces), P(m._halfedges), dN, skip_prob, M, P(rs['k0']), P(rs['k1']), P(rs['e0']), P(rs['e1']), P(rs['H']), P(rs['K']),
+                             P(rs['dH']), P(rs['dK']), P(rs['E']), P(rs['pE']), P(rs['dEn']), kc, kg, c0, P(rs['dEdN']), seed)
+    libc.srand(seed)
+    skip_u = np.ones(M, 'f4')
+    jit_s = np.zeros((M, 3))
+    for i in range(M):
+        if valid[i]:
+            skip_u[i] = np.float32(libc.rand()) / np.float32(2147483648.0)
+            if not (skip_u[i] < np.float32(skip_prob)):
+                for k in range(3):
+                    jit_s[i, k] = libc.rand() / 2147483648.0
     save('curvature_geo9', vertices=m.vertices.copy(), faces=m.faces.copy(), normals=m.vertex_normals.copy(), face_area=m._faces['area'].copy(),
-         params=np.array([dN, kc, kg, c0]), jitter=jit, **{'out_' + n: a for n, a in r.items()})
+         params=np.array([dN, kc, kg, c0]), jitter=jit, skip_prob=np.float32(skip_prob), skip_u=skip_u, skip_jitter=jit_s,
+         **{'out_' + n: a for n, a in r.items()}, **{'skip_out_' + n: a for n, a in rs.items()})
 
 
 def golden_sdf_shapes():

@@ -56,6 +56,14 @@ def test_oracle_curvature_bit_exact_vs_reference_golden():
     for n in NAMES:
         assert np.array_equal(o[n], g['out_' + n], equal_nan=True), n
     assert valid[-1] == 0 and o['H'][-1] == 0
+    # skip_prob > 0 (membrane_mesh_utils.c:962): a vertex whose float32 draw is below it is treated like an unused slot; the kept ones
+    # draw their jitter afterwards (the recorded stream of that run)
+    keep = (valid != 0) & ~(g['skip_u'] < g['skip_prob'])
+    o2 = {n: np.zeros(shp.get(n, (M,)), 'f4') for n in NAMES}
+    jit2 = np.ascontiguousarray(g['skip_jitter'])
+    L.nwo_curvature_grad(P(pos), P(nrm), P(keep.astype('u1')), P(nbr), P(nxt), P(area), P(jit2), M, nbr.shape[1], dN, kc, kg, c0, *[P(o2[n]) for n in NAMES])
+    for n in NAMES:
+        assert np.array_equal(o2[n], g['skip_out_' + n], equal_nan=True), 'skip_prob: ' + n
 
 
 def _gpu_mesh(v, f, **kw):
@@ -82,6 +90,12 @@ def test_hip_curvature_vs_reference_golden():
     for n in ('k0', 'k1', 'H', 'K', 'E', 'pE', 'e0', 'e1', 'dH', 'dK', 'dEn', 'dEdN'):
         a, b = got[n], g['out_' + n]
         assert np.allclose(a, b, rtol=2e-5, atol=1e-7 * max(1.0, np.abs(b).max())), n
+    # skip_prob > 0 with the reference's own draws (:962): skipped vertices read as unused slots
+    dEdN_s = m.curvature_grad_c(dN=dN, skip_prob=float(g['skip_prob']), jitter=g['skip_jitter'], skip_u=g['skip_u'])
+    got_s = dict(k0=m._k_0, k1=m._k_1, e0=m._e_0, e1=m._e_1, H=m._H, K=m._K, dH=m._dH, dK=m._dK, E=m._E, pE=m._pE, dEn=m._dE_neighbors, dEdN=dEdN_s)
+    for n in ('k0', 'k1', 'H', 'K', 'E', 'pE', 'e0', 'e1', 'dH', 'dK', 'dEn', 'dEdN'):
+        a, b = got_s[n], g['skip_out_' + n]
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-7 * max(1.0, np.abs(b).max())), 'skip_prob: ' + n
     # without a supplied rand() stream the deterministic outputs are unchanged and the run is reproducible
     m.curvature_grad_c(dN=dN)
     assert np.allclose(m._H, g['out_H'], rtol=2e-5, atol=1e-8)
