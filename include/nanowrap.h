@@ -197,7 +197,9 @@ int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, float *out)
 
 /* Block-boundary kernel: per-vertex curvature tensor and Canham-Helfrich energy, replaces c_curvature_grad
  * (membrane_mesh_utils.c:915-1250, reached through MembraneMesh.curvature_grad_c, _membrane_mesh.pyx:323-347), with
- * skip_prob = 0 (the only value the live path uses).  Works on the ctx's CURRENT device-resident mesh positions, the
+ * skip_prob folded into the valid flags of nw_set_mesh: a vertex the reference would skip (:962, `r2() < skip_prob`; never > 0 on the
+ * live path) is an unused slot for this call -- its H, K, dH, dK, dE_neighbors, E, pE, dEdN read 0 and its k0, k1, e0, e1 rows keep
+ * what the caller's arrays held.  Works on the ctx's CURRENT device-resident mesh positions, the
  * normals of nw_set_mesh / nw_set_normals and the neighbour table of nw_set_mesh (walk stops at the first -1, as the
  * reference's does).  nbr_next (M,NB) i32 = halfedges[halfedges[neighbors[j]].next].vertex, nbr_area (M,NB) f32 =
  * faces[halfedges[neighbors[j]].face].area.  jitter: (M,3) float64 in [0,1) standing for the reference's rand() stream
