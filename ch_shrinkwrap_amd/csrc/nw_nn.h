@@ -28,8 +28,15 @@
 // kept as an unsigned integer (float bits, low 4 mantissa bits = position in the 16-chunk): v_and_or_b32, v_med3_u32, v_min_u32.
 // Cells are culled against the best + tol (+ the rounding slack of the cell assignment), so every centroid whose key is
 // within the error band of the winner IS evaluated and is seen by the runner-up; a lane whose runner-up lies within 2 tol of
-// its best is re-resolved in float64 by k_nn_fixup (< 1 % of the lanes).  The result is the float64 argmin for every
-// localization (lowest face id on exact ties; SciPy's tie order is unspecified).
+// its best is re-resolved in float64 (< 1 % of the lanes) at the end of the kernel: the whole wave over that one ball, lane =
+// candidate (nw_fixup_point).  The result is the float64 argmin for every localization (lowest face id on exact ties; SciPy's tie
+// order is unspecified).
+//
+// Outliers.  Up to NW_OUTLIERS lanes of a wave whose warm radius is far above the wave's (background noise far from the surface)
+// are taken out of the walk and out of the local frame and resolved like the ambiguous ones.
+//
+// Work list.  The kernel times every item once; the host then puts the heavy items first (two classes, each in spatial order) and,
+// for clouds too small to fill the GPU twice, cuts them into pieces (order_items_by_cost, nanowrap.hip).
 #pragma once
 #include "nw_device.h"
 
