@@ -473,7 +473,8 @@ thread_local StageMarks g_marks;
 struct StageScope {
     nw_ctx *c; int stage; hipEvent_t a;
     bool on;
-    StageScope(nw_ctx *ctx, int s) : c(ctx), stage(s), a(nullptr), on(!ctx->capturing && (ctx->profiling == 2 || ((ctx->profiling == 1 || ctx->profiling == 3) && s == ST_NN))) { if (on) a = next_event(c); }
+    StageScope(nw_ctx *ctx, int s, bool first_of_block = true) : c(ctx), stage(s), a(nullptr),
+        on(!ctx->capturing && (ctx->profiling == 2 || ((ctx->profiling == 1 || ctx->profiling == 3 || (ctx->profiling == 4 && first_of_block)) && s == ST_NN))) { if (on) a = next_event(c); }
     ~StageScope() { if (on) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
 };
 
@@ -1097,7 +1098,7 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
                            ctx->cent.p, ctx->state.p, it);
     }
     if (parts & QP_NN) {
-        StageScope s(ctx, ST_NN);
+        StageScope s(ctx, ST_NN, it == 0);
         static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;   // 0 slabs, 1 round-robin, 2 interleaved runs (default)
         static const bool no_outliers = getenv("NW_NO_OUTLIERS") != nullptr;      // developer knob
         static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
@@ -1729,7 +1730,7 @@ NW_EXPORT int nw_accumulator_quantum(nw_ctx *ctx, double *q)
 NW_EXPORT int nw_set_profiling(nw_ctx *ctx, int enable)
 {
     if (!ctx) return NW_ERR_BADARG;
-    ctx->profiling = enable < 0 ? 0 : (enable > 3 ? 3 : enable);
+    ctx->profiling = enable < 0 ? 0 : (enable > 4 ? 4 : enable);
     return NW_OK;
 }
 

@@ -197,13 +197,14 @@ def test_profiling_levels_do_not_change_the_result_and_sampled_keeps_the_graph()
     """Four identical fits (6 blocks of 5) with profiling off (blocks replayed as hipGraphs), with every query launch
     bracketed (every kernel launched from the host), with every stage bracketed, and 'sampled' (level 3: two half-block graphs around
     one directly launched, event-bracketed query per block; the next block pre-recorded by optimize_layout): bit-identical positions;
-    level 3 yields one sample per block, level 1 one per iteration."""
+    levels 3 and 4 (4: direct launches, one bracketed query per block -- what bench.py times at) yield one sample per block, level 1
+    one per iteration."""
     TriMesh, CG = _imports()
     from ch_shrinkwrap_amd import synth
     c = synth.make_config('c3', scale=0.05, seed=9)
     pts, s = c['points'], 1.0 / c['sigma'].ravel()
     results = {}
-    for level in (0, 1, 2, 3):
+    for level in (0, 1, 2, 3, 4):
         mesh = TriMesh(c['vertices'].copy(), c['faces'])
         cg = CG(mesh, pts)
         cg.set_profiling(level)
@@ -216,9 +217,9 @@ def test_profiling_levels_do_not_change_the_result_and_sampled_keeps_the_graph()
         if level:
             ms, samples = cg.stage_ms_total['nn']
             assert ms > 0
-            assert samples == (4 if level == 3 else 20), (level, samples)      # blocks 2..5 since the last set_profiling
+            assert samples == (4 if level in (3, 4) else 20), (level, samples)      # blocks 2..5 since the last set_profiling
         results[level] = out.copy()
-    for level in (1, 2, 3):
+    for level in (1, 2, 3, 4):
         assert np.array_equal(results[0], results[level]), 'profiling level %d changed the result' % level
 
 
