@@ -406,7 +406,12 @@ def make_config(name, scale=1.0, seed=0):
         # surface nets leave slivers where neighbouring cell vertices project to almost the same point: three passes of the
         # isotropic remesher at the mesh's own mean edge length (what the real pipeline does to its isosurface as well)
         from . import remesh as _remesh
-        v, f = _remesh.remesh(v, f, 3, -1, 0.5, 0)
+        e = np.concatenate([v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 1]], v[f[:, 0]] - v[f[:, 2]]]).astype('f8')
+        target = float(np.sqrt((e * e).sum(1)).mean())                # the mean edge length, stated (not left to the remesher's default)
+        nf_in = f.shape[0]
+        v, f = _remesh.remesh(v, f, 3, target, 0.5, 0)
+        if not (0.5 * nf_in < f.shape[0] < 2 * nf_in):                # a remesh at the mesh's own edge length changes the face count by ~20 %
+            raise RuntimeError('synth c4: remeshing at the mean edge length %.3f turned %d faces into %d' % (target, nf_in, f.shape[0]))
         v = project_to_level(sdf, v, 20.0, iters=2).astype('f4')
         pts = sample_surface(sdf, v, f, n, 10.0, seed, iters=6)
         return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5)

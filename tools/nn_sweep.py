@@ -54,6 +54,6 @@ for spec in sys.argv[2:]:
              ns['rounds'] / w, ns['items']))
     print('   per wave: %.0f ticks in all (slowest wave %.0f), %.0f in the stream stage' % (16 * ns['wave_cycles_16'] / w, 16.0 * ns['max_wave_cycles_16'], 16 * ns['stream_cycles_16'] / w))
     print('%-10s wall %.4f ms/iter  nn %.4f (cold first query %.4f)  grid %.4f fixup %.4f attract %.4f  md %.2f' % (
-        spec, wall * 1e3, nn[0] / nn[1], cold[0] / max(cold[1], 1), st['grid'][0] / st['grid'][1], st['fixup'][0] / st['fixup'][1],
+        spec, wall * 1e3, nn[0] / nn[1], cold[0] / max(cold[1], 1), st['grid'][0] / st['grid'][1], st['fixup'][0] / max(st['fixup'][1], 1),
         st['attract'][0] / st['attract'][1], cg.mean_dist), flush=True)
     del cg
