@@ -306,19 +306,20 @@ struct HalfEdgeMesh {
 
     bool alive(int h) const { return vert[h] >= 0; }
 
+    int64_t split_cap = INT64_MAX;
     void split_long_edges(double high2)
     {
         for (int pass = 0; pass < 8; ++pass) {
             const int64_t before = n_split;
             const size_t nh = vert.size();                 // edges created by this pass are looked at in the next one
             for (size_t h = 0; h < nh; ++h) {
-                if (!(l2[h] > high2) || !alive((int)h)) continue;
+                if (!(l2[h] > high2) || !std::isfinite(l2[h]) || !alive((int)h)) continue;     // (an edge of non-finite length would be split for ever)
                 const int t = twin[h];
                 if (t < 0 || (int)h > t) continue;         // each interior edge once
                 if (boundary[from((int)h)] && boundary[vert[h]]) continue;
                 split((int)h);
             }
-            if (n_split == before) break;
+            if (n_split == before || n_split > split_cap) break;
         }
     }
 
@@ -557,17 +558,24 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
         const auto t_start = now();
         HalfEdgeMesh m;
         m.max_valence = max_valence > 0 ? std::min(max_valence, 60) : 16;
+        for (int64_t i = 0; i < 3 * n_vertices; ++i) if (!std::isfinite(vertices[i])) return NWR_ERR_BADARG;      // a non-finite vertex: its edges would be split for ever
         int rc = m.build(vertices, n_vertices, faces, n_faces);
         if (rc != NWR_OK) return rc;
         if (verbose) std::fprintf(stderr, "[nw_remesh] build %.1f ms\n", ms(t_start, now()));
-        double L = target_edge_length;
-        if (!(L > 0)) {
+        double L = target_edge_length, L_in = 1.0, L_med = 1.0;
+        {
             double s = 0; int64_t n = 0;
-            for (size_t h = 0; h < m.vert.size(); ++h) { s += std::sqrt(m.len2((int)h)); ++n; }
-            L = n ? s / n : 1.0;
+            std::vector<double> len(m.vert.size());
+            for (size_t h = 0; h < m.vert.size(); ++h) { len[h] = std::sqrt(m.len2((int)h)); s += len[h]; ++n; }
+            L_in = n ? s / n : 1.0;                 // mean edge length of the input (PYME's default target)
+            if (n) { std::nth_element(len.begin(), len.begin() + n / 2, len.end()); L_med = len[n / 2]; }      // (robust against a few wild edges)
         }
+        if (!(L > 0)) L = L_in;
         const double high = 4.0 / 3.0 * L, low = 4.0 / 5.0 * L;
         m.all_dirty = n_relax > 0;
+        // splitting towards L multiplies the face count by about (typical edge / L)^2: four times that many splits and something feeds on itself
+        const double growth = std::max(1.0, (L_med / L) * (L_med / L));
+        m.split_cap = (int64_t)(4.0 * growth * (double)n_faces) + 100000;
         for (int it = 0; it < n_iterations; ++it) {
             m.cur_it = it + 1;
             const int64_t ops_before = m.n_split + m.n_collapse + m.n_flip;
@@ -581,6 +589,7 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
                                       ms(t2, now()), (long long)m.n_split, (long long)m.n_collapse, (long long)m.n_flip);
             if (n_relax > 0) m.relax(relax_lambda, n_relax);
             if (m.corrupt) return NWR_ERR_NONMANIFOLD;
+            if (m.n_split > m.split_cap) return NWR_ERR_RUNAWAY;
             // a pass that changed nothing would be repeated unchanged by every later iteration (no relaxation to move vertices)
             if (n_relax == 0 && m.n_split + m.n_collapse + m.n_flip == ops_before) break;
         }

@@ -15,7 +15,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libnw_remesh.so')
 SYMBOLS = ['nwr_abi_version', 'nwr_remesh', 'nwr_free', 'nwr_halfedge_twins', 'nwr_mesh_geometry', 'nwr_build_topology', 'nwr_ring_tables']
-ERRORS = {-1: 'bad argument', -2: 'the mesh is not an oriented 2-manifold', -3: 'out of memory'}
+ERRORS = {-1: 'bad argument (sizes, indices or a non-finite vertex)', -2: 'the mesh is not an oriented 2-manifold', -3: 'out of memory',
+          -4: 'runaway: far more splits than the target length can explain (degenerate input)'}
 
 _lib = None
 

@@ -297,7 +297,14 @@ def isosurface_mesh(sdf, lo, hi, cell, level=0.0, block=32, lipschitz=1.5, slack
     if (qi >= vid.shape[0]).any() or (vid[np.minimum(qi, vid.shape[0] - 1)] != q).any():
         raise RuntimeError('isosurface_mesh: a surface cell was not evaluated (raise `lipschitz` / `slack`)')
     if project:
+        pos0 = pos
         pos = project_to_level(sdf, pos, level, iters=project)
+        # a vertex already sits inside a crossed cell: a projection that carries it further than two cells (or to a non-finite place --
+        # seen once in a few dozen runs on a 256-thread host, where the last bits of the BLAS products vary from run to run) is undone
+        off = np.abs(pos - pos0).max(1)
+        bad = ~(off < 2.0 * cell)
+        if bad.any():
+            pos = np.where(bad[:, None], pos0, pos)
     d02 = np.linalg.norm(pos[qi[:, 0]] - pos[qi[:, 2]], axis=1)
     d13 = np.linalg.norm(pos[qi[:, 1]] - pos[qi[:, 3]], axis=1)
     s_ = (d02 <= d13)[:, None]
@@ -375,6 +382,29 @@ def sample_surface(sdf, verts, faces, n, sigma, seed, dtype='f4', iters=4):
     return p.astype(dtype)
 
 
+def _c4_start_mesh(sdf, cell):
+    """Start mesh of config C4: sparse surface nets at +20 nm, then three passes of the isotropic remesher at the mesh's own mean
+    edge length (surface nets leave slivers where neighbouring cell vertices project to almost the same point; the real pipeline
+    remeshes its isosurface as well).  The result is checked -- a remesh at the mean edge length changes the face count by ~20 % --
+    and the construction repeated if it is not sane: on a many-core host the last bits of the threaded BLAS products differ from
+    run to run, and one run in a few dozen came back with a mesh several times too dense."""
+    from . import remesh as _remesh
+    last = None
+    for attempt in range(3):
+        v, f = isosurface_mesh(sdf, (-1500, -1500, -420), (1400, 900, 420), cell, level=20.0, slack=60.0)
+        e = np.concatenate([v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 1]], v[f[:, 0]] - v[f[:, 2]]]).astype('f8')
+        target = float(np.sqrt((e * e).sum(1)).mean())
+        try:
+            v2, f2 = _remesh.remesh(v, f, 3, target, 0.5, 0)
+        except RuntimeError as err:
+            last = str(err)
+            continue
+        if 0.5 * f.shape[0] < f2.shape[0] < 2 * f.shape[0]:
+            return v2, f2
+        last = 'remeshing at the mean edge length %.3f turned %d faces into %d' % (target, f.shape[0], f2.shape[0])
+    raise RuntimeError('synth c4: no sane start mesh in three attempts (%s)' % last)
+
+
 def make_config(name, scale=1.0, seed=0):
     """BASELINE.json configs -> dict(points, sigma, mesh vertices, faces, lams, block, iters).
     `scale` < 1 shrinks N and the mesh resolution together (parity-test sizes)."""
@@ -402,16 +432,7 @@ def make_config(name, scale=1.0, seed=0):
         sdf = lambda p: 2.0 * sdf_er_sim2(np.asarray(p, 'f8') * 0.5)
         n = int(5000000 * scale)
         cell = 2.96 / np.sqrt(scale)
-        v, f = isosurface_mesh(sdf, (-1500, -1500, -420), (1400, 900, 420), cell, level=20.0, slack=60.0)
-        # surface nets leave slivers where neighbouring cell vertices project to almost the same point: three passes of the
-        # isotropic remesher at the mesh's own mean edge length (what the real pipeline does to its isosurface as well)
-        from . import remesh as _remesh
-        e = np.concatenate([v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 1]], v[f[:, 0]] - v[f[:, 2]]]).astype('f8')
-        target = float(np.sqrt((e * e).sum(1)).mean())                # the mean edge length, stated (not left to the remesher's default)
-        nf_in = f.shape[0]
-        v, f = _remesh.remesh(v, f, 3, target, 0.5, 0)
-        if not (0.5 * nf_in < f.shape[0] < 2 * nf_in):                # a remesh at the mesh's own edge length changes the face count by ~20 %
-            raise RuntimeError('synth c4: remeshing at the mean edge length %.3f turned %d faces into %d' % (target, nf_in, f.shape[0]))
+        v, f = _c4_start_mesh(sdf, cell)
         v = project_to_level(sdf, v, 20.0, iters=2).astype('f4')
         pts = sample_surface(sdf, v, f, n, 10.0, seed, iters=6)
         return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5)

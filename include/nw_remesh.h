@@ -26,9 +26,10 @@ extern "C" {
 #endif
 
 #define NWR_OK 0
-#define NWR_ERR_BADARG (-1)
+#define NWR_ERR_BADARG (-1)      /* bad sizes / indices, or a non-finite vertex coordinate */
 #define NWR_ERR_NONMANIFOLD (-2) /* an edge is used by more than two faces, or twice in the same direction */
 #define NWR_ERR_NOMEM (-3)
+#define NWR_ERR_RUNAWAY (-4)     /* far more splits than the target length can explain (> 4 (median edge / L)^2 per input face): degenerate input */
 
 typedef struct nwr_stats {
     int64_t n_split, n_collapse, n_flip; /* operations performed over all iterations */

@@ -173,3 +173,20 @@ def test_native_topology_is_identical_to_the_numpy_definition(case):
     if tabs_b is not None:
         nxt, area = a._neighbor_tables()
         assert np.array_equal(nxt, tabs_b[0]) and np.array_equal(area, tabs_b[1])
+
+
+def test_degenerate_input_is_refused_not_refined_for_ever():
+    """A non-finite vertex (or one flung far away) has edges that stay too long however often they are split: the remesher must say
+    so instead of doubling the mesh in every pass (seen as a ten-fold face count / a generator that did not come back)."""
+    import time
+    v, f = icosphere(3, 50.0)
+    bad = v.copy()
+    bad[7, 1] = np.inf
+    with pytest.raises(RuntimeError):
+        R.remesh(bad, f, 5, -1, 0.5, 0)
+    far = v.copy()
+    far[7] *= 1e7
+    t0 = time.time()
+    with pytest.raises(RuntimeError):
+        R.remesh(far, f, 5, float(np.median(np.linalg.norm(v[f[:, 0]] - v[f[:, 1]], axis=1))), 0.5, 0)
+    assert time.time() - t0 < 20.0
