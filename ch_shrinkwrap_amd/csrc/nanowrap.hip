@@ -391,18 +391,25 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     double spacing = std::sqrt(std::max(area, 1e-30) / (double)F);
     float lo[3], hi[3];
     double ext = 0;
-    for (int k = 0; k < 3; ++k) {
-        lo[k] = std::min(mlo[k], ctx->pmin[k]);
-        hi[k] = std::max(mhi[k], ctx->pmax[k]);
-        ext = std::max(ext, (double)hi[k] - lo[k]);
-    }
+    for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)std::max(mhi[k], ctx->pmax[k]) - (double)std::min(mlo[k], ctx->pmin[k]));
     if (!(ext > 0)) ext = 1.0;
-    ctx->scene_ext = ext;
+    ctx->scene_ext = ext;                                // extent of everything (bounds the residuals: quantum of the scatter)
     ctx->spacing = spacing;
     double h = ctx->force_h > 0 ? ctx->force_h : desired_cell(ctx, mean_dist, spacing);
     if (!(h > 0) || !std::isfinite(h)) h = ext / 16;
     ctx->est_mean_dist = mean_dist;
-    h = std::max(h, ext / 1024.0);                       // at most ~1024 cells per axis
+    // The grid bins CENTROIDS: its box is the mesh's, widened to the localizations only where they are near (what the vertices can
+    // reach while the grid is kept).  A localization far away -- background, a fiducial -- lies outside the grid and is handled by the
+    // clamped cell coordinates; it must not decide the cell size (one such point used to blow the box, and with it the cells, up).
+    double gext = 0;
+    const double reach = 4.0 * h + 3.0 * std::max(mean_dist, 0.0);
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = std::min(mlo[k], std::max(ctx->pmin[k], (float)(mlo[k] - reach)));
+        hi[k] = std::max(mhi[k], std::min(ctx->pmax[k], (float)(mhi[k] + reach)));
+        gext = std::max(gext, (double)hi[k] - lo[k]);
+    }
+    if (!(gext > 0)) gext = 1.0;
+    h = std::max(h, gext / 1024.0);                      // at most ~1024 cells per axis
     const char *env_h = getenv("NW_CELL_SIZE");
     if (env_h && atof(env_h) > 0 && !(ctx->force_h > 0)) h = atof(env_h);
     NwGrid g;
@@ -650,14 +657,49 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
     double ext = 0;
     for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)ctx->pmax[k] - (double)ctx->pmin[k]);
     if (!(ext > 0) || !std::isfinite(ext)) ext = 1.0;
-    // Morton order, once: 30-bit code of the position inside the cloud's bounding cube, stable radix sort (deterministic order)
+    // Morton order, once: 30-bit code of the position inside the cloud's bounding cube, stable radix sort (deterministic order).
+    // A few localizations far from the rest (a fiducial, hot pixels) must not stretch that cube -- the structure would fall into a
+    // handful of its 1024^3 quanta and a wave's 64 localizations would be scattered all over it until the second sort: the cube is
+    // cut to mean +- 4 sd per axis of the bulk (three trimming passes) when that is less than half the extent; what lies outside gets
+    // the keys of the cube's faces.  An ordinary cloud keeps its bounding cube.
+    float mlo3[3] = {ctx->pmin[0], ctx->pmin[1], ctx->pmin[2]};
+    {
+        float blo[3] = {ctx->pmin[0], ctx->pmin[1], ctx->pmin[2]}, bhi[3] = {ctx->pmax[0], ctx->pmax[1], ctx->pmax[2]};
+        DevBuf<unsigned long long> mom;
+        NW_HIP(mom.ensure(7));
+        const double q = ext / 65535.0;
+        bool ok = true;
+        for (int pass = 0; pass < 3 && ok; ++pass) {
+            unsigned long long m[7];
+            NW_HIP(hipMemsetAsync(mom.p, 0, sizeof(m), ctx->stream));
+            hipLaunchKernelGGL(k_box_moments, dim3((unsigned)std::min<int64_t>(1024, nblk(N))), dim3(NW_BLOCK), 0, ctx->stream, ctx->pts_in.p, N, ctx->pmin[0], ctx->pmin[1],
+                               ctx->pmin[2], (float)(1.0 / q), blo[0], blo[1], blo[2], bhi[0], bhi[1], bhi[2], mom.p);
+            NW_HIP(hipGetLastError());
+            NW_HIP(hipMemcpyAsync(m, mom.p, sizeof(m), hipMemcpyDeviceToHost, ctx->stream));
+            NW_HIP(hipStreamSynchronize(ctx->stream));
+            if (m[0] < 2) { ok = false; break; }
+            for (int k = 0; k < 3; ++k) {
+                const double mean = (double)m[1 + k] / (double)m[0];
+                const double sd = std::sqrt(std::max((double)m[4 + k] / (double)m[0] - mean * mean, 0.0));
+                blo[k] = std::max(ctx->pmin[k], (float)(ctx->pmin[k] + (mean - 4.0 * sd - 1.0) * q));
+                bhi[k] = std::min(ctx->pmax[k], (float)(ctx->pmin[k] + (mean + 4.0 * sd + 2.0) * q));
+            }
+        }
+        double bext = 0;
+        for (int k = 0; k < 3; ++k) bext = std::max(bext, (double)bhi[k] - (double)blo[k]);
+        if (ok && bext > 0 && bext < 0.5 * ext) {
+            ext = bext;
+            for (int k = 0; k < 3; ++k) mlo3[k] = blo[k];
+            if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] Morton cube cut to the bulk of the cloud: edge %.1f\n", bext);
+        }
+    }
     {
         ctx->morton_unit = (float)(ext / 1024.0);
         DevBuf<unsigned> key_in;
         DevBuf<int> idx_in;
         NW_HIP(key_in.ensure(N)); NW_HIP(idx_in.ensure(N));
         NW_HIP(ctx->mkey.ensure(N)); NW_HIP(ctx->perm.ensure(N));
-        hipLaunchKernelGGL(k_morton_keys, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pts_in.p, (int)N, ctx->pmin[0], ctx->pmin[1], ctx->pmin[2],
+        hipLaunchKernelGGL(k_morton_keys, dim3(nblk(N)), dim3(NW_BLOCK), 0, ctx->stream, ctx->pts_in.p, (int)N, mlo3[0], mlo3[1], mlo3[2],
                            1.0f / ctx->morton_unit, key_in.p, idx_in.p);
         NW_HIP(hipGetLastError());
         const int se = nw_sort_pairs_u32(key_in.p, ctx->mkey.p, idx_in.p, ctx->perm.p, (int)N, 30, ctx->stream);
@@ -1253,6 +1295,7 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
     if (executed > 0) ctx->last_mean_dist = host[executed - 1].mean_dist;
     ctx->searched = ctx->searched || executed > 0;
     if (executed > 0) ctx->blocks_done += 1;
+    if (st.grid_escape) ctx->grid_valid = false;            // the mesh left the cell grid during this block: lay a new one before the next
     if (executed > 0 && !ctx->proj_sorted && !ctx->proj_ready && ctx->face_warm) {
         // foot points of this block's last query -> keys of the second sort (applied at the start of the next block)
         const NwGrid &g = ctx->grid;

@@ -34,9 +34,11 @@ struct NwDevState {
     int nn_max_ring;
     int iter_base;        // global index of the current block's first iteration (k_set_iter_base): kernels get the block-relative index,
                           // so a captured block (hipGraph) can be replayed for later blocks
+    int grid_escape;      // a centroid lay more than a cell outside the cell grid in this block (the query stays exact -- the outermost
+                          // cells hold what lies beyond them -- but gets slower: the host lays a new grid before the next block)
 };
 
-__global__ void k_set_iter_base(NwDevState *st, int base) { st->iter_base = base; }
+__global__ void k_set_iter_base(NwDevState *st, int base) { st->iter_base = base; st->grid_escape = 0; }
 
 // ============================================================================================================
 // generic exclusive scan of int32 counts (3 launches): out[0..n] with out[n] = total
@@ -150,6 +152,31 @@ __global__ __launch_bounds__(NW_BLOCK) void k_minmax3(const float *__restrict__ 
         atomicMax((int *)&mm[3 + k], h >= 0 ? __float_as_int(h) : (int)(0x80000000u - (unsigned)__float_as_int(h)));
     }
     if (bad) atomicOr(nonfinite, 1);
+}
+
+// count / sum / sum of squares per axis of the points inside a box, on coordinates quantised to 16 bits of the cloud's extent and
+// accumulated in integers: the result does not depend on the order of the atomics (it decides the localizations' sort order, and with
+// it the order of every ordered sum downstream -- it has to be the same in every run).  out[7]: n, sx sy sz, sxx syy szz.
+__global__ __launch_bounds__(NW_BLOCK) void k_box_moments(const float *__restrict__ xyz, int64_t n, float ox, float oy, float oz, float inv_q,
+                                                         float lx, float ly, float lz, float hx, float hy, float hz, unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long s_part[7][4];
+    unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (x < lx || x > hx || y < ly || y > hy || z < lz || z > hz) continue;
+        const unsigned long long qx = (unsigned)nw_clampi((int)((x - ox) * inv_q), 0, 65535), qy = (unsigned)nw_clampi((int)((y - oy) * inv_q), 0, 65535),
+                                 qz = (unsigned)nw_clampi((int)((z - oz) * inv_q), 0, 65535);
+        v[0] += 1; v[1] += qx; v[2] += qy; v[3] += qz; v[4] += qx * qx; v[5] += qy * qy; v[6] += qz * qz;
+    }
+    for (int k = 0; k < 7; ++k) {
+        unsigned long long t = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if ((threadIdx.x & 63) == 0) s_part[k][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) atomicAdd(out + threadIdx.x, s_part[threadIdx.x][0] + s_part[threadIdx.x][1] + s_part[threadIdx.x][2] + s_part[threadIdx.x][3]);
 }
 
 // sum of a float array in float64 (weights.mean(), mesh_conj_grad.py:162)
@@ -286,7 +313,7 @@ __global__ void k_nbr_transpose(const int *__restrict__ nbr, int M, int NB, int 
 #define NW_FC_HT 512
 __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const float *__restrict__ pos, const int *__restrict__ faces, int F,
                                                             float4 *__restrict__ cent_tmp, int *__restrict__ fcell, int *__restrict__ frank, int *__restrict__ count,
-                                                            int *__restrict__ ambig_count, const NwDevState *__restrict__ st, int it)
+                                                            int *__restrict__ ambig_count, NwDevState *__restrict__ st, int it)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ int s_key[NW_FC_HT], s_cnt[NW_FC_HT];
@@ -303,6 +330,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const flo
         int ix, iy, iz;
         nw_cell_coords(g, x, y, z, ix, iy, iz);
         const int cell = nw_cell_index(g, ix, iy, iz);
+        const float fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
+        if (fx < -1.0f || fy < -1.0f || fz < -1.0f || fx > (float)g.gx + 1.0f || fy > (float)g.gy + 1.0f || fz > (float)g.gz + 1.0f) st->grid_escape = 1;
         cent_tmp[f] = make_float4(x, y, z, __int_as_float(f));
         fcell[f] = cell;
         slot = (int)(((unsigned)cell * 2654435761u) >> 23);            // 9 bits

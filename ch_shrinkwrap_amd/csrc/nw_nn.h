@@ -483,7 +483,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const int gi = item.p0 + (active ? lane : 0);                        // idle lanes shadow lane 0 (they never write)
     NwLane L;
     const float4 P = pts[gi];
-    L.ux = (P.x - g.ox) * g.inv_h; L.uy = (P.y - g.oy) * g.inv_h; L.uz = (P.z - g.oz) * g.inv_h;
+    // Cell-unit coordinates for the WALK (own cell, ball box, slab distances): those of the localization's projection onto the grid's
+    // box.  The outermost cells hold whatever lies beyond them (nw_cell_coords clamps), so the distance from P to a centroid filed
+    // in a cell is at least the distance between their projections (projection onto a convex box does not expand distances), hence
+    // at least the projection's distance to the cell: the culling stays a valid lower bound for a localization outside the grid
+    // (background far from the structure) and for a centroid that left it since the grid was laid.  The keys use P itself.
+    L.ux = fminf(fmaxf((P.x - g.ox) * g.inv_h, 0.0f), (float)g.gx);
+    L.uy = fminf(fmaxf((P.y - g.oy) * g.inv_h, 0.0f), (float)g.gy);
+    L.uz = fminf(fmaxf((P.z - g.oz) * g.inv_h, 0.0f), (float)g.gz);
     const float epsu = g.eps * g.inv_h;                                  // rounding slack of the cell assignment, cell units
     L.ax = L.ux + epsu; L.ay = L.uy + epsu; L.az = L.uz + epsu;
     L.bx = L.ux - 1.0f - epsu; L.by = L.uy - 1.0f - epsu; L.bz = L.uz - 1.0f - epsu;
@@ -562,9 +569,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             lxl = cx - margin; lxh = cx + margin; lyl = cy - margin; lyh = cy + margin; lzl = cz - margin; lzh = cz + margin;
         }
         if (!wact) { lxl = lyl = lzl = 0x7fffffff; lxh = lyh = lzh = -0x7fffffff; }
-        int Nxl = max(nw_wave_min_i(lxl), 0), Nxh = min(nw_wave_max_i(lxh), g.gx - 1);
-        int Nyl = max(nw_wave_min_i(lyl), 0), Nyh = min(nw_wave_max_i(lyh), g.gy - 1);
-        int Nzl = max(nw_wave_min_i(lzl), 0), Nzh = min(nw_wave_max_i(lzh), g.gz - 1);
+        int Nxl = nw_clampi(nw_wave_min_i(lxl), 0, g.gx - 1), Nxh = nw_clampi(nw_wave_max_i(lxh), 0, g.gx - 1);
+        int Nyl = nw_clampi(nw_wave_min_i(lyl), 0, g.gy - 1), Nyh = nw_clampi(nw_wave_max_i(lyh), 0, g.gy - 1);
+        int Nzl = nw_clampi(nw_wave_min_i(lzl), 0, g.gz - 1), Nzh = nw_clampi(nw_wave_max_i(lzh), 0, g.gz - 1);
         const bool Eok = Exh >= Exl;
         if (Eok) {
             Nxl = min(Nxl, Exl); Nxh = max(Nxh, Exh); Nyl = min(Nyl, Eyl); Nyh = max(Nyh, Eyh); Nzl = min(Nzl, Ezl); Nzh = max(Nzh, Ezh);

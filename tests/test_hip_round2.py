@@ -259,6 +259,45 @@ def test_query_is_exact_in_later_iterations_of_a_block(name, scale, n_before, ba
     assert np.allclose(cg.d[:, 0], d_all, rtol=1e-6)
 
 
+def test_far_away_localizations_do_not_decide_the_grid():
+    """A few localizations far outside the structure (a fiducial, hot pixels: here 20 of them 50-200 um away from a 2 um scene).
+    The cell grid is laid over the mesh and the localizations near it, so such points lie outside the grid: the query must stay exact
+    for them and for everything else, and must not get more expensive for the regular localizations (a grid stretched over the
+    whole extent would put every centroid into a handful of cells -- each wave would then stream the entire mesh)."""
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    from oracle import nanowrap_oracle as O
+    c = synth.make_config('c3', scale=0.2, seed=17)
+    s = 1.0 / c['sigma'].ravel()
+    cand = {}
+    for far in (False, True):
+        pts = c['points'].copy()
+        if far:
+            rng = np.random.default_rng(5)
+            idx = rng.choice(pts.shape[0], 20, replace=False)
+            u = rng.normal(size=(20, 3))
+            u /= np.linalg.norm(u, axis=1)[:, None]
+            pts[idx] = (pts.mean(0) + u * rng.uniform(5e4, 2e5, size=(20, 1))).astype('f4')
+        mesh_a = TriMesh(c['vertices'].copy(), c['faces'])
+        p_n = CG(mesh_a, pts).search(pts, lams=c['lams'], num_iters=2, sigma_inv=s).copy()
+        mesh_b = TriMesh(c['vertices'].copy(), c['faces'])
+        cg = CG(mesh_b, pts)
+        cg.nn_stats()
+        cg.search(pts, lams=c['lams'], num_iters=3, sigma_inv=s)
+        cand[far] = cg.nn_stats()['candidates'] / (3.0 * pts.shape[0])
+        assert np.isfinite(cg.mesh.vertices).all()
+        cent = O.face_centroids(p_n, mesh_b.faces)
+        d_all, f_all = O.nearest_faces(cent, pts)
+        got = cg.nearest_face
+        diff = np.nonzero(got != f_all)[0]
+        if diff.size:
+            dd = np.linalg.norm(pts[diff].astype('f8') - cent[got[diff]].astype('f8'), axis=1)
+            assert np.allclose(dd, d_all[diff], rtol=1e-15, atol=0), 'nearest face differs from cKDTree at %d points' % diff.size
+        assert np.allclose(cg.d[:, 0], d_all, rtol=1e-6)
+    print('candidates per query: %.0f without, %.0f with 20 far localizations' % (cand[False], cand[True]))
+    assert cand[True] < 1.5 * cand[False] + 50
+
+
 def test_search_with_data_other_than_the_localizations():
     """search(data, ...) where `data` is not the array the optimiser was built with (mesh_conj_grad.py:150): the weight matrix comes
     from the localizations, the residual targets `data` (nw_set_data).  Against the reference's own run of that call; a later
