@@ -298,6 +298,53 @@ def test_far_away_localizations_do_not_decide_the_grid():
     assert cand[True] < 1.5 * cand[False] + 50
 
 
+def test_mesh_leaving_the_grid_keeps_the_query_exact_and_triggers_a_new_grid(monkeypatch, capfd):
+    """The cell grid is kept from block to block.  A mesh that leaves its box (here: stretched 2.5x along x by a host edit between
+    two blocks, far more than the grid's margin) has centroids filed in the outermost cells although they lie beyond them: the
+    query of that block must still be exact (projected culling, nw_nn.h), and the block must report it so that the next one gets
+    a new grid."""
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    from oracle import nanowrap_oracle as O
+    c = synth.make_config('c3', scale=0.2, seed=17)
+    pts, s = c['points'].copy(), 1.0 / c['sigma'].ravel()
+    # 40 localizations beyond both ends of the structure along x: outside the grid, and -- once the mesh is stretched -- next to
+    # centroids that are outside it too (the case the projected culling exists for)
+    rng = np.random.default_rng(3)
+    idx = rng.choice(pts.shape[0], 40, replace=False)
+    half = 0.5 * (c['vertices'][:, 0].max() - c['vertices'][:, 0].min())
+    pts[idx, 0] = (pts[:, 0].mean() + rng.choice([-1.0, 1.0], 40) * rng.uniform(1.5, 2.4, 40) * half).astype('f4')
+    mesh = TriMesh(c['vertices'].copy(), c['faces'])
+    monkeypatch.setenv('NW_VERBOSE', '1')
+    monkeypatch.setenv('NW_CELL_SIZE', '18.0')           # pinned cell: no re-grid because the wanted cell size drifted
+    cg = CG(mesh, pts)
+    cg.search(pts, lams=c['lams'], num_iters=2, sigma_inv=s)
+
+    def one_more_block():
+        start = mesh.vertices.copy()
+        cg2 = CG(mesh, pts, native=cg._native)
+        capfd.readouterr()
+        cg2.search(pts, lams=c['lams'], num_iters=1, sigma_inv=s)
+        err = capfd.readouterr().err
+        cent = O.face_centroids(start, mesh.faces)
+        d_all, f_all = O.nearest_faces(cent, pts)
+        got = cg2.nearest_face
+        diff = np.nonzero(got != f_all)[0]
+        if diff.size:
+            dd = np.linalg.norm(pts[diff].astype('f8') - cent[got[diff]].astype('f8'), axis=1)
+            assert np.allclose(dd, d_all[diff], rtol=1e-15, atol=0), 'nearest face differs from cKDTree at %d points' % diff.size
+        assert np.allclose(cg2.d[:, 0], d_all, rtol=1e-6)
+        return '[nanowrap] grid ' in err
+
+    cg.optimize_layout()                                 # the one-off set-up after the first block (second sort: lays a grid of its own)
+    one_more_block()
+    assert not one_more_block()                          # steady state: the grid is kept from block to block
+    centre = pts.mean(0)
+    mesh.vertices[:] = (centre + (mesh.vertices - centre) * np.array([2.5, 1.0, 1.0])).astype('f4')
+    assert not one_more_block()                          # (grid kept:) most centroids now lie outside the grid laid for the un-stretched mesh
+    assert one_more_block(), 'the block after the one whose mesh left the grid did not lay a new grid'
+
+
 def test_search_with_data_other_than_the_localizations():
     """search(data, ...) where `data` is not the array the optimiser was built with (mesh_conj_grad.py:150): the weight matrix comes
     from the localizations, the residual targets `data` (nw_set_data).  Against the reference's own run of that call; a later
