@@ -215,6 +215,7 @@ struct nw_ctx {
     float lam0 = 0.0f;
     bool in_search = false;
     bool begin_ops_pending = false;
+    bool last_direct_out = false;     // the previous block's direct_out (nw_optimize_layout pre-records the next block with it)
     bool searched = false;
 
     void *wb_rows = nullptr;          // strided write-back target registered with nw_set_write_back
@@ -933,7 +934,7 @@ static int resort_by_projection(nw_ctx *ctx)
 
 enum { QP_GRID = 1, QP_NN = 2, QP_FIXUP = 4, QP_ATTRACT = 8, QP_ALL = 15 };     // parts of the first half of an iteration
 static int launch_query(nw_ctx *ctx, int it, int parts = QP_GRID | QP_NN | QP_FIXUP);
-static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters);
+static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool tail = false);
 // Cell-size tuner, once per localization cloud.  The query is exact for every cell size, and its cost depends on more than the rule
 // (desired_cell) can see -- a 200k-localization tube leaves half of the GPU's wave slots empty and prefers smaller cells (fewer
 // candidates per wave) than the 1M-localization vesicle, for which the cost is flat between 9 and 13 nm -- so the query is simply
@@ -1071,7 +1072,14 @@ NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
     if (ctx->searched && ctx->search_iters > 0 && ctx->face_warm) {
         const float lam = ctx->lam0;
         NW_TRY(nw_search_begin(ctx, &lam, 1, ctx->search_iters, ctx->search_flags));
-        (void)block_graph(ctx, ctx->search_iters);
+        ctx->direct_out = ctx->last_direct_out;             // (part of what the graph bakes in: where the last update writes the result)
+        if (ctx->profiling == 4) {                          // the graph of everything after the block's first iteration
+            ctx->search_done = 1;
+            ctx->begin_ops_pending = false;                 // (they belong to the first iteration, which is not part of this graph)
+            (void)block_graph(ctx, ctx->search_iters, true);
+            ctx->search_done = 0;
+        } else (void)block_graph(ctx, ctx->search_iters);
+        ctx->direct_out = false;
         ctx->in_search = false;
         ctx->begin_ops_pending = false;
     }
@@ -1339,7 +1347,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     uint32_t lb; memcpy(&lb, &ctx->lam0, 4); mix(lb);
     uint64_t qb; memcpy(&qb, &ctx->acc_quantum, 8); mix(qb);
     uint32_t sb; memcpy(&sb, &ctx->sinv_scalar, 4); mix(sb); memcpy(&sb, &ctx->w_scalar, 4); mix(sb);
-    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 3 ? 32 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0));
+    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 3 ? 32 : 0) | (ctx->profiling == 4 ? 256 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0));
     mixp(ctx->direct_out ? ctx->pin : nullptr);
     mixp(ctx->have_data ? ctx->dat.p : nullptr);
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
@@ -1354,23 +1362,28 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
 // (the launches are recorded, not run).  nullptr: not eligible, or the capture failed -> the caller launches directly.
 // Profiling level 3 ("sampled") keeps the graphs: the block is captured in two halves around the query kernel of its first
 // iteration, which is launched directly between two events -- one live sample of the dominant kernel per block.
-static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters)
+// Profiling level 4 runs a block's first iteration directly (its query kernel between two events) and replays the REST of the block
+// from a graph (`tail`: called after that first iteration, search_done == 1).
+static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool tail)
 {
     static const bool graphs_on = !(getenv("NW_GRAPH") && atoi(getenv("NW_GRAPH")) == 0);
-    if (!(graphs_on && ctx->own_stream && (ctx->profiling == 0 || ctx->profiling == 3) && num_iters > 0)) return nullptr;
+    if (!(graphs_on && ctx->own_stream && (ctx->profiling == 0 || ctx->profiling == 3 || (tail && ctx->profiling == 4)) && num_iters > (tail ? 1 : 0))) return nullptr;
+    if (tail != (ctx->search_done == 1)) return nullptr;
     const bool split = ctx->profiling == 3;
     const uint64_t key = block_graph_key(ctx);
     for (auto &gph : ctx->graphs) if (gph.exec && gph.key == key) return &gph;
-    if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] capturing a block of %d (%s, key %016llx, warm %d, grid generation %llu)\n", num_iters, split ? "two halves" : "one graph",
+    if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] capturing a block of %d (%s, key %016llx, warm %d, grid generation %llu)\n", num_iters,
+                                      tail ? "all but its first iteration" : split ? "two halves" : "one graph",
                                       (unsigned long long)key, ctx->face_warm ? 1 : 0, (unsigned long long)ctx->grid_generation);
     const bool warm0 = ctx->face_warm;
+    const int done0 = ctx->search_done;
     auto capture = [&](int half) -> hipGraphExec_t {
         if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         ctx->capturing = true;
         int r = NW_OK;
-        if (half != 2) r = enqueue_begin_ops(ctx);
+        if (half != 2 && !tail) r = enqueue_begin_ops(ctx);
         if (half == 1 && r == NW_OK) r = iter_attract_parts(ctx, QP_GRID);
-        for (int i = 0; i < num_iters && r == NW_OK && half != 1; ++i) {
+        for (int i = done0; i < num_iters && r == NW_OK && half != 1; ++i) {
             r = (half == 2 && i == 0) ? iter_attract_parts(ctx, QP_FIXUP | QP_ATTRACT) : iter_attract_parts(ctx, QP_ALL);
             if (r == NW_OK) r = nw_iter_directions(ctx);
             if (r == NW_OK) r = nw_iter_update(ctx);
@@ -1391,8 +1404,8 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters)
         if (!eb) { (void)hipGraphExecDestroy(ea); ea = nullptr; }
     }
     // rewind the host-side bookkeeping the recorded calls advanced
-    ctx->global_iter -= ctx->search_done; ctx->search_done = 0; ctx->face_warm = warm0;
-    ctx->begin_ops_pending = true;          // recorded, not run
+    ctx->global_iter -= ctx->search_done - done0; ctx->search_done = done0; ctx->face_warm = warm0;
+    ctx->begin_ops_pending = !tail;         // recorded, not run
     if (!ea) return nullptr;
     nw_ctx::BlockGraph &dst = ctx->graphs[ctx->graph_next];
     ctx->graph_next = (ctx->graph_next + 1) % 4;
@@ -1422,6 +1435,7 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         // (above ~4 MB the sliced copy, which overlaps the transfer with the host-side copy-out, is the faster one: measured at 810k vertices)
         if (!on_device && 3 * ctx->M * sizeof(float) <= (4u << 20)) { NW_TRY(ensure_staging(ctx)); ctx->direct_out = true; }
     }
+    ctx->last_direct_out = ctx->direct_out;
     bool replayed = false;
     static const bool trace_blocks = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 3;
     static hipEvent_t tb0 = nullptr, tb1 = nullptr;
@@ -1444,6 +1458,14 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         if (r == NW_OK) r = nw_iter_directions(ctx);
         if (r == NW_OK) r = nw_iter_update(ctx);
         if (r != NW_OK) { ctx->in_search = false; return r; }
+        if (i == 0 && ctx->profiling == 4) {
+            // level 4: the first iteration ran directly (its query kernel between two events); the rest of the block from a graph
+            nw_ctx::BlockGraph *tl = block_graph(ctx, num_iters, true);
+            if (tl && hipGraphLaunch(tl->exec, ctx->stream) == hipSuccess) {
+                ctx->global_iter += num_iters - 1; ctx->search_done = num_iters;
+                replayed = true;
+            } else (void)hipGetLastError();
+        }
     }
     const auto t2 = std::chrono::steady_clock::now();
     if (trace_blocks) (void)hipEventRecord(tb1, ctx->stream);

@@ -217,8 +217,9 @@ int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, co
  * the block as a hipGraph (levels 1 and 2 launch every kernel from the host: events inside graph nodes read 0 on ROCm 7.2) and brackets
  * only the NN query of the block's FIRST iteration, launched directly between the two halves of the graph.  (Measured caveat: in a
  * process that has also loaded PyTorch, about one block in twenty at level 3 waits 5-6 ms between its last kernel and the copies that
- * follow; the other levels do not show it.)  4 = like 1, but only the NN query of each block's first iteration is bracketed: every kernel is
- * launched from the host, and the event pairs -- each costs the stream a few microseconds -- come once per block (what bench.py times at). */
+ * follow; the other levels do not show it.)  4 = like 1, but only the NN query of each block's first iteration is bracketed: that
+ * iteration is launched from the host, the rest of the block is one replayed hipGraph, and the event pairs -- each costs the stream a few
+ * microseconds -- come once per block (what bench.py times at). */
 int nw_set_profiling(nw_ctx *ctx, int enable);
 int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
 
