@@ -197,7 +197,8 @@ def test_profiling_levels_do_not_change_the_result_and_sampled_keeps_the_graph()
     """Four identical fits (6 blocks of 5) with profiling off (blocks replayed as hipGraphs), with every query launch
     bracketed (every kernel launched from the host), with every stage bracketed, and 'sampled' (level 3: two half-block graphs around
     one directly launched, event-bracketed query per block; the next block pre-recorded by optimize_layout): bit-identical positions;
-    levels 3 and 4 (4: direct launches, one bracketed query per block -- what bench.py times at) yield one sample per block, level 1
+    levels 3 and 4 (4: the block's first iteration launched directly with its query bracketed, the rest of the block one graph -- what
+    bench.py times at) yield one sample per block, level 1
     one per iteration."""
     TriMesh, CG = _imports()
     from ch_shrinkwrap_amd import synth
