@@ -13,8 +13,12 @@ pts, s = c['points'], 1.0 / c['sigma'].ravel()
 cg = ShrinkwrapMeshConjGrad(TriMesh(c['vertices'], c['faces']), pts)
 t0 = time.time()
 nblocks = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # profiling level of the long run (4 = what bench.py times at)
+cg.set_profiling(level)
 for b in range(nblocks):
     out = cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+    if b == 1:
+        cg.optimize_layout()
     if b % 100 == 0 or b == nblocks - 1:
         r = np.linalg.norm(out - out.mean(0), axis=1)
         print('block %4d  iterations %5d  ress %.6e  mean_dist %.4f  finite %s  extent %.2f' % (b, len(cg.tests), float(cg.ress[-1]), cg.mean_dist, bool(np.isfinite(out).all()), r.max()), flush=True)
