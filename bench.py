@@ -77,6 +77,7 @@ WORKLOADS = {
     'c2': 'BASELINE configs[1]: capped tube r=50 nm, L=1000 nm',
     'c3': 'BASELINE configs[2]: two-lobe vesicle (smooth union of two R=300 nm spheres)',
     'c4': 'BASELINE configs[3]: ERSim2 tube/sheet network with a fenestration (genus 2), twice life size',
+    'c5': 'BASELINE configs[4] as ONE scene on one GPU: 8 two-lobe vesicles on a 2x2x2 lattice (what `--gpus 8` shares out, one vesicle per rank)',
 }
 
 
@@ -137,7 +138,7 @@ def main():
     cfg = synth.make_config(args.config, scale=args.scale, seed=rank)
     if world > 1:
         # tile the vesicles on a 2x2x2 lattice (BASELINE.json configs[4]); ranks never share vertices
-        off = np.array([(rank & 1), (rank >> 1) & 1, (rank >> 2) & 1], 'f4') * np.array([1400.0, 900.0, 900.0], 'f4')
+        off = np.array([(rank & 1), (rank >> 1) & 1, (rank >> 2) & 1], 'f4') * synth.C5_LATTICE
         cfg['points'] = (cfg['points'] + off[None, :]).astype('f4')
         cfg['vertices'] = (cfg['vertices'] + off[None, :]).astype('f4')
     pts, sigma = cfg['points'], cfg['sigma']

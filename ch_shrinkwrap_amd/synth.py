@@ -405,6 +405,9 @@ def _c4_start_mesh(sdf, cell):
     raise RuntimeError('synth c4: no sane start mesh in three attempts (%s)' % last)
 
 
+C5_LATTICE = np.array([1400.0, 900.0, 900.0], 'f4')     # pitch of the 2x2x2 lattice of vesicles in BASELINE configs[4] (nm)
+
+
 def make_config(name, scale=1.0, seed=0):
     """BASELINE.json configs -> dict(points, sigma, mesh vertices, faces, lams, block, iters).
     `scale` < 1 shrinks N and the mesh resolution together (parity-test sizes)."""
@@ -436,4 +439,13 @@ def make_config(name, scale=1.0, seed=0):
         v = project_to_level(sdf, v, 20.0, iters=2).astype('f4')
         pts = sample_surface(sdf, v, f, n, 10.0, seed, iters=6)
         return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5)
+    if name == 'c5':      # BASELINE configs[4] as ONE scene: 8 two-lobe vesicles on a 2x2x2 lattice (the scene 8 ranks share out, tile = vesicle)
+        parts = [make_config('c3', scale=scale, seed=seed + k) for k in range(8)]
+        nv = parts[0]['vertices'].shape[0]
+        off = [np.array([(k & 1), (k >> 1) & 1, (k >> 2) & 1], 'f4') * C5_LATTICE for k in range(8)]
+        return dict(points=np.concatenate([p['points'] + o[None, :] for p, o in zip(parts, off)]).astype('f4'),
+                    sigma=np.concatenate([p['sigma'] for p in parts]),
+                    vertices=np.concatenate([p['vertices'] + o[None, :] for p, o in zip(parts, off)]).astype('f4'),
+                    faces=np.concatenate([p['faces'] + k * nv for k, p in enumerate(parts)]).astype(parts[0]['faces'].dtype),
+                    lams=[10.0], iters=5, block=5)
     raise ValueError(name)

@@ -195,10 +195,11 @@ def test_against_oracle_fresh_inputs(name, scale):
     _close(np.array(cg.ress), np.array(ref.ress), rtol=1e-4, what='ress')
 
 
-@pytest.mark.parametrize('name,n_brute', [('c3', 3000), ('c4', 600)])
+@pytest.mark.parametrize('name,n_brute', [('c3', 3000), ('c4', 600), ('c5', 400)])
 def test_full_size_properties(name, n_brute):
-    """BASELINE.json configs[2] (1M localizations, 198 812 vertices) and configs[3] (5M localizations, ≈810 000 vertices,
-    genus-2 tube/sheet network) at full size: size-independent properties."""
+    """BASELINE.json configs[2] (1M localizations, 198 812 vertices), configs[3] (5M localizations, ≈810 000 vertices,
+    genus-2 tube/sheet network) and the whole scene of configs[4] (8 vesicles, 8M localizations, 1.6M vertices -- on ONE GPU here;
+    `bench.py --gpus 8` gives each rank one vesicle) at full size: size-independent properties."""
     TriMesh, CG = _imports()
     from ch_shrinkwrap_amd import synth
     from oracle import nanowrap_oracle as O
