@@ -1681,7 +1681,17 @@ NW_EXPORT int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, f
         if (f0 && hipMemcpyAsync(df.p, f0, 3 * M * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
         // outputs accumulate into the caller's array, as in the reference (kind 4 overwrites the rows it visits)
         if (hipMemcpyAsync(dout.p, out, 3 * M * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
-        if (kind == 1) hipLaunchKernelGGL(k_lfunc_lh_serial, dim3(1), dim3(64), 0, ctx->stream, (int)M, ctx->NB, ctx->nbr.p, dx.p, dout.p);
+        if (kind == 1) {
+            // gather form (one thread per vertex) when the neighbour table is symmetric -- checked by the kernel itself -- else the serial walk
+            if (ctx->aux_i.ensure(1) != hipSuccess) { rc = NW_ERR_NOMEM; break; }
+            if (hipMemsetAsync(ctx->aux_i.p, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+            hipLaunchKernelGGL(k_lfunc_lh_gather, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, (int)M, ctx->NB, ctx->nbr.p, dx.p, dout.p, df.p, ctx->aux_i.p);
+            int asym = 1;
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&asym, ctx->aux_i.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+            if (asym || getenv("NW_LH_SERIAL")) hipLaunchKernelGGL(k_lfunc_lh_serial, dim3(1), dim3(64), 0, ctx->stream, (int)M, ctx->NB, ctx->nbr.p, dx.p, dout.p);
+            else if (hipMemcpyAsync(dout.p, df.p, 3 * M * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        }
         else if (kind == 3) hipLaunchKernelGGL(k_lfunc_lhw, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, (int)M, ctx->NB, ctx->nbr.p, dx.p, df.p, dout.p);
         else hipLaunchKernelGGL(k_lfunc_gather, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, kind, (int)M, ctx->NB, ctx->nbr.p, dx.p, df.p, dout.p);
         if (hipGetLastError() != hipSuccess) { rc = NW_ERR_HIP; break; }

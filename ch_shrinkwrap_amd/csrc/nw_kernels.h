@@ -1108,6 +1108,42 @@ __global__ void k_lfunc_lhw(int M, int NB, const int *__restrict__ nbr, const fl
     }
 }
 
+// The same operator, one thread per TARGET vertex.  In the serial loop below a vertex n is only ever written while one of the vertices
+// i that list it is visited -- out[n] = (out[n] + x[i] - x[n]) / deg(i) -- and those visits come in increasing i: the value of n is a
+// fold over the vertices listing it, in index order, independent of every other vertex.  With a symmetric neighbour table (a manifold
+// mesh whose rings fit the table) "the vertices listing n" is n's own row: every vertex folds for itself, same operations, same order,
+// bit-identical to the serial walk.  A row that is not mirrored (or lists a vertex twice) raises *asym: the host falls back to the
+// serial kernel.
+__global__ __launch_bounds__(NW_BLOCK) void k_lfunc_lh_gather(int M, int NB, const int *__restrict__ nbr, const float *__restrict__ x, const float *__restrict__ out_in,
+                                                             float *__restrict__ out, int *__restrict__ asym)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= M) return;
+    float v[3] = {out_in[3 * n], out_in[3 * n + 1], out_in[3 * n + 2]};
+    const int *row = nbr + (int64_t)n * NB;
+    int ids[64], cnt = 0;
+    for (int k = 0; k < NB && k < 64; ++k) { const int i = row[k]; if (i == -1) break; ids[cnt++] = i; }
+    if (NB > 64) *asym = 1;
+    for (int a = 1; a < cnt; ++a) {                       // ascending visiting order
+        const int key = ids[a];
+        int b = a - 1;
+        while (b >= 0 && ids[b] > key) { ids[b + 1] = ids[b]; --b; }
+        ids[b + 1] = key;
+    }
+    const float xn[3] = {x[3 * n], x[3 * n + 1], x[3 * n + 2]};
+    for (int a = 0; a < cnt; ++a) {
+        const int i = ids[a];
+        if ((unsigned)i >= (unsigned)M || i == n || (a > 0 && ids[a - 1] == i)) { *asym = 1; continue; }
+        const int *ri = nbr + (int64_t)i * NB;
+        int deg = 0, hits = 0;
+        for (int k = 0; k < NB; ++k) { const int m = ri[k]; if (m == -1) break; ++deg; hits += (m == n); }
+        if (hits != 1) { *asym = 1; continue; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { v[j] += (x[3 * i + j] - xn[j]); v[j] /= deg; }
+    }
+    out[3 * n] = v[0]; out[3 * n + 1] = v[1]; out[3 * n + 2] = v[2];
+}
+
 __global__ void k_lfunc_lh_serial(int M, int NB, const int *__restrict__ nbr, const float *__restrict__ x, float *__restrict__ out)
 {
     // conj_grad_utils.c:344-364: the per-vertex in-place "/= N" on the neighbours makes the result depend on the

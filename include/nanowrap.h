@@ -188,7 +188,8 @@ int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes);
 
 /* alternate regularisers (default off in the reference; selectable through Lfuncs, mesh_conj_grad.py:36-39):
  * kind 0: c_shrinkwrap_l_func   conj_grad_utils.c:249-306      d = L x        (umbrella / N)
- *      1: c_shrinkwrap_lh_func  :308-368                        d = L^H x      (order-dependent in-place /N)
+ *      1: c_shrinkwrap_lh_func  :308-368                        d = L^H x      (order-dependent in-place /N: evaluated per target vertex in the
+ *                                                                            reference's visiting order; serial walk if the table is not symmetric)
  *      2: c_shrinkwrap_lw_func  :370-497                        area-normalised, metric from f0
  *      3: c_shrinkwrap_lhw_func :585-710                        transpose of 2
  *      4: vertex_area_weights   :551-582                        1/sqrt(sum|e|^2+1) replicated x3 (x = positions)

@@ -172,6 +172,48 @@ def test_alternate_regularisers_against_reference_c():
     assert np.array_equal(cg._lfunc(4, f0), g['out_vaw'])
 
 
+def test_lh_operator_one_thread_per_vertex_equals_the_serial_walk(monkeypatch):
+    """`lh` (conj_grad_utils.c:308-368) divides the accumulated neighbours by the visiting vertex's degree after every vertex, so its
+    result depends on the visiting order.  nw_lfunc evaluates it with one thread per target vertex (each vertex folds the vertices that
+    list it in index order) when the neighbour table is symmetric, and with a serial walk in the reference's order otherwise: both
+    must give the same bits on a mesh of 40 000 vertices, and a table that is not symmetric must take the serial walk (checked
+    against the oracle's C restatement of the reference loop)."""
+    import time
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    from oracle import nanowrap_oracle as O
+    c = synth.make_config('c3', scale=0.2, seed=2)
+    mesh = TriMesh(c['vertices'], c['faces'])
+    cg = CG(mesh, c['points'][:1000])
+    x = np.random.default_rng(1).normal(size=3 * cg.M).astype('f4')
+    t0 = time.perf_counter(); a = cg._lfunc(1, x); t1 = time.perf_counter()
+    monkeypatch.setenv('NW_LH_SERIAL', '1')
+    b = cg._lfunc(1, x); t2 = time.perf_counter()
+    monkeypatch.delenv('NW_LH_SERIAL')
+    print('lh on %d vertices: %.1f ms (one thread per vertex), %.1f ms (serial walk)' % (cg.M, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
+    assert np.array_equal(a, b)
+
+    def oracle_lh(nbr):
+        import ctypes
+        nbr = np.ascontiguousarray(nbr, np.int32)
+        d = np.zeros_like(x)
+        P = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+        O.lib().nwo_lhfunc(P(x), P(nbr), nbr.shape[0], nbr.shape[1], P(d))
+        return d
+
+    assert np.array_equal(a, oracle_lh(mesh.neighbor_vertex_table()))
+    # a neighbour table with one-sided entries (vertex 5 lists vertex 900, which does not list it back)
+    v, f = c['vertices'], c['faces']
+    mesh2 = TriMesh(v, f)
+    cg2 = CG(mesh2, c['points'][:1000])
+    nbr = mesh2.neighbor_vertex_table().copy()
+    k = int((nbr[5] >= 0).sum())
+    nbr[5, k] = 900
+    cg2.vertex_neighbors = nbr
+    cg2._upload_mesh()
+    assert np.array_equal(cg2._lfunc(1, x), oracle_lh(nbr))
+
+
 @pytest.mark.parametrize('name,scale', [('c2', 0.1), ('c3', 0.05), ('c4', 0.04)])
 def test_against_oracle_fresh_inputs(name, scale):
     """Seeded capsule / two-lobe / ER-network clouds (BASELINE.json configs[1..3] shapes at reduced size)."""
