@@ -409,13 +409,14 @@ class ShrinkwrapMeshConjGrad(object):
         level = 2 if level is True else int(level)
         self._native.check(self._L.nw_set_profiling(self._h, level))
         self._profiling = level > 0
+        self._profiled_stages = ('nn',) if level in (1, 3, 4) else None          # (levels 1, 3, 4 time nothing else: one query per block, not eight)
         self.stage_ms_total = {k: (0.0, 0) for k in ('total', 'grid', 'nn', 'attract', 'prior', 'as', 'update', 'fixup')}
 
     def _accumulate_stage_ms(self):
         # HIP-event timings of the last search() (per stage: summed ms, number of timed spans), accumulated over calls
         if not getattr(self, '_profiling', False):
             return
-        for k, (ms, n) in self.stage_ms().items():
+        for k, (ms, n) in self.stage_ms(getattr(self, '_profiled_stages', None)).items():
             a, b = self.stage_ms_total[k]
             self.stage_ms_total[k] = (a + ms, b + n)
 
@@ -430,10 +431,12 @@ class ShrinkwrapMeshConjGrad(object):
         names = ['candidates', 'rows_nonempty', 'rows_visited', 'cells_tested', 'cells_visited', 'box_rows', 'rounds', 'max_wave_cycles_16', 'stream_cycles_16', 'wave_cycles_16', 'items']
         return dict(zip(names, [int(v) for v in out]))
 
-    def stage_ms(self):
+    def stage_ms(self, only=None):
         names = ['total', 'grid', 'nn', 'attract', 'prior', 'as', 'update', 'fixup']
         out = {}
         for i, nme in enumerate(names):
+            if only is not None and nme not in only:
+                continue
             ms, n = ctypes.c_double(0), ctypes.c_int64(0)
             self._native.check(self._L.nw_stage_ms(self._h, i, ctypes.byref(ms), ctypes.byref(n)))
             out[nme] = (ms.value, n.value)
