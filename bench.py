@@ -8,13 +8,15 @@ Contract (see the task statement):  python bench.py --gpus N --steps K --warmup 
               grid build + exact nearest-face query, weights, A f, residual, A^T scatter, curvature prior, search
               directions, A.S_k + normal equations, <=3x3 solve, position update.  Iterations are issued in blocks of
               `remesh_frequency` = 5 per nw_search call, as the reference's outer loop does (_membrane_mesh.pyx:1515-1517);
-              topology is held fixed between blocks (no remesher in this round -- stated in DESIGN.md).
+              topology is held fixed between blocks (the remesher is a block-boundary step outside the metric).
   workload  = BASELINE.json configs[2] (the config the metric is quoted on): two-lobe vesicle, 1 000 000 localizations,
               sigma = 10 nm, 198 812-vertex / 397 620-face start mesh offset +20 nm.  Synthetic, seeded, resident in HBM
               before the timed region (upload and optimiser construction are outside it).
   N > 1     = BASELINE.json configs[4]: N such vesicles, one per rank (spatial tiles with an empty boundary set); the scene
               keeps the reference's single global subspace solve, so every iteration all-reduces the 24 normal-equation
               scalars over RCCL (ch_shrinkwrap_amd/parallel.py).  Weak scaling: per-GPU work is fixed.
+              (`--config c5 --gpus 1` runs that whole 8-vesicle scene as one mesh on ONE GPU: the single-process result the ranks
+              must reproduce, and what one MI355X does with it.)
   value     = (valid vertices of all ranks) * K / (max over ranks of the wall time of the K timed steps).
 """
 import argparse
