@@ -2,22 +2,31 @@
 """
 bench.py -- vertex-updates/s of the NanoWrap inner loop (force evaluation + subspace "CG" step) on MI355X.
 
-Contract (see the task statement):  python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on rank 0.
+Contract (see the task statement):  python bench.py --gpus N --steps K --warmup W  prints ONE JSON line.
+  N > 1 started with plain `python`: this process parses the arguments and -- before torch is imported or the GPU touched -- starts N
+  child processes of itself (one rank per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their
+  environment), relays rank 0's JSON line and exits non-zero if any rank failed.  Started under `python -m torch.distributed.run` (the
+  ranks already exist: WORLD_SIZE == N in the environment) it is one of the ranks.
 
   step      = ONE iteration of ShrinkwrapMeshConjGrad.search (/root/reference/ch_shrinkwrap/mesh_conj_grad.py:218-290):
               grid build + exact nearest-face query, weights, A f, residual, A^T scatter, curvature prior, search
               directions, A.S_k + normal equations, <=3x3 solve, position update.  Iterations are issued in blocks of
-              `remesh_frequency` = 5 per nw_search call, as the reference's outer loop does (_membrane_mesh.pyx:1515-1517);
+              `remesh_frequency` = 5 per search call, as the reference's outer loop does (_membrane_mesh.pyx:1515-1517);
               topology is held fixed between blocks (the remesher is a block-boundary step outside the metric).
   workload  = BASELINE.json configs[2] (the config the metric is quoted on): two-lobe vesicle, 1 000 000 localizations,
               sigma = 10 nm, 198 812-vertex / 397 620-face start mesh offset +20 nm.  Synthetic, seeded, resident in HBM
               before the timed region (upload and optimiser construction are outside it).
-  N > 1     = BASELINE.json configs[4]: N such vesicles, one per rank (spatial tiles with an empty boundary set); the scene
-              keeps the reference's single global subspace solve, so every iteration all-reduces the 24 normal-equation
-              scalars over RCCL (ch_shrinkwrap_amd/parallel.py).  Weak scaling: per-GPU work is fixed.
+  N > 1, --mode tiles (default) = BASELINE.json configs[4]: N such vesicles, one per rank (spatial tiles with an empty boundary set);
+              the scene keeps the reference's single global subspace solve, so every iteration all-reduces the 27 normal-equation
+              sums over RCCL (ch_shrinkwrap_amd/parallel.py).  WEAK scaling: per-GPU work is fixed.
               (`--config c5 --gpus 1` runs that whole 8-vesicle scene as one mesh on ONE GPU: the single-process result the ranks
               must reproduce, and what one MI355X does with it.)
-  value     = (valid vertices of all ranks) * K / (max over ranks of the wall time of the K timed steps).
+  N > 1, --mode halo = ONE mesh (the --config workload, c3 by default) sharded over the N ranks by spatial tiles of the cloud
+              (BASELINE.json north_star): every rank holds its tile's localizations and the part of the mesh
+              within one halo radius of it; per iteration the boundary rows of the accumulator, the normal-equation sums and the
+              owners' new boundary positions are all-reduced.  STRONG scaling: the total work is fixed.  (--mode halo --gpus 1 is the
+              plain single-GPU run of that mesh, the N = 1 point of the curve.)
+  value     = (valid vertices of the whole scene) * K / (max over ranks of the wall time of the K timed steps).
 """
 import argparse
 import json
@@ -33,6 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 BLOCK = 5               # remesh_frequency of the headline config
+PMC_FILE = 'r03_pmc_traffic.json'     # PMC passes of the headline workload (tools/profile_round.sh), committed under profiles/
 
 
 def algorithmic_bytes(N, M, F):
@@ -98,24 +108,92 @@ def measured_copy_ceiling(torch, nbytes=1 << 30, reps=10):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='c3')
+    ap.add_argument('--mode', default='tiles', choices=('tiles', 'halo'),
+                    help='N > 1: tiles = one vesicle per rank (BASELINE configs[4], weak scaling); halo = ONE mesh sharded over the ranks (strong scaling)')
+    ap.add_argument('--halo', type=float, default=100.0, help='halo radius of --mode halo in nm (start offset 20 + 5 sigma + a quarter for the drift between re-partitions)')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the workload (debug only; the reported config says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph-pass', action='store_true', help='skip the extra un-instrumented (graph-replay) pass (profiling runs)')
     ap.add_argument('--cpu-iters', type=int, default=0, help='oracle iterations for cpu_baseline (0 = about 10-20 s of CPU work: 10 up to 2M localizations, else 3)')
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args):
+    """Parent of an N-rank run started with plain `python`: N fresh children of this script, one per rank.  Nothing here imports torch or
+    touches the GPU (a process that has initialised HIP must not be replaced or forked into ranks).  Rank 0's standard output is relayed
+    (its JSON line); every rank's standard error is inherited.  First failure ends the others; the exit code is that failure's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   NW_BENCH_CHILD='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, universal_newlines=True))
+    out0 = []
+    rc = 0
+    try:
+        import threading
+        reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+        reader.start()
+        pending = set(range(args.gpus))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        sys.stderr.write('bench.py: rank %d exited with code %d; stopping the other ranks\n' % (r, code))
+            if rc != 0:
+                break
+            time.sleep(0.05)
+        reader.join(timeout=10)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                      # (exactly the children started above, by handle)
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+    for line in out0:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    if rc == 0 and not any(l.startswith('{') for l in out0):
+        sys.stderr.write('bench.py: rank 0 printed no JSON line\n')
+        rc = 1
+    return rc
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and ('RANK' not in os.environ or world == 1):
+        raise SystemExit(spawn_ranks(args))
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
+    run_rank(args)
+
+
+def run_rank(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -125,6 +203,9 @@ def main():
     backend = os.environ.get('NW_BENCH_BACKEND', 'nccl')
     if backend != 'nccl':
         local_rank = min(local_rank, torch.cuda.device_count() - 1)
+    elif world > 1 and torch.cuda.device_count() < world and 'NW_BENCH_CHILD' in os.environ:
+        raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible (RCCL needs one device per rank; NW_BENCH_BACKEND=gloo rehearses on one)'
+                         % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == 'nccl':
@@ -137,8 +218,10 @@ def main():
     from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
     from ch_shrinkwrap_amd import parallel
 
-    cfg = synth.make_config(args.config, scale=args.scale, seed=rank)
-    if world > 1:
+    halo = world > 1 and args.mode == 'halo'
+    # 'halo': every rank generates the SAME scene (seed 0) and takes its share; 'tiles': every rank its own vesicle (seed = rank)
+    cfg = synth.make_config(args.config, scale=args.scale, seed=0 if halo else rank)
+    if world > 1 and not halo:
         # tile the vesicles on a 2x2x2 lattice (BASELINE.json configs[4]); ranks never share vertices
         off = np.array([(rank & 1), (rank >> 1) & 1, (rank >> 2) & 1], 'f4') * synth.C5_LATTICE
         cfg['points'] = (cfg['points'] + off[None, :]).astype('f4')
@@ -150,8 +233,14 @@ def main():
 
     # N > 1: kernels and RCCL collectives share one dedicated (non-default) torch stream
     tstream = torch.cuda.Stream() if world > 1 else None
-    cg = ShrinkwrapMeshConjGrad(mesh, pts, device=local_rank, stream=tstream.cuda_stream if tstream is not None else None)
-    runner = parallel.TiledScene(cg, dist if world > 1 else None, torch_stream=tstream)
+    if halo:
+        scene = parallel.HaloScene(mesh, pts, dist, halo=args.halo, torch_stream=tstream)
+        scene.set_profiling(0)
+        cg_of = lambda: scene.ex.cg                     # (a re-partition builds a new optimiser over the new share)
+    else:
+        cg = ShrinkwrapMeshConjGrad(mesh, pts, device=local_rank, stream=tstream.cuda_stream if tstream is not None else None)
+        runner = parallel.TiledScene(cg, dist if world > 1 else None, torch_stream=tstream)
+        cg_of = lambda: cg
 
     executed = [0]
 
@@ -159,9 +248,18 @@ def main():
         done = 0
         while done < k:
             n = min(BLOCK, k - done)
-            runner.search(pts, cfg['lams'], n, s_inv)
-            executed[0] += cg.loopcount          # iterations that really ran (the device-side stop condition can end a block early)
+            if halo:
+                scene.search(cfg['lams'], n, s_inv)
+            else:
+                runner.search(pts, cfg['lams'], n, s_inv)
+            executed[0] += cg_of().loopcount         # iterations that really ran (the device-side stop condition can end a block early)
             done += n
+
+    def set_profiling(level):
+        if halo:
+            scene.set_profiling(level)
+        else:
+            cg.set_profiling(level)
 
     def fence():
         torch.cuda.synchronize()
@@ -178,15 +276,17 @@ def main():
     # the rate being measured.  That first iteration is launched from the host (events recorded inside hipGraph nodes read 0 on
     # ROCm 7.2); the other four iterations of the block are one replayed hipGraph.
     # The full per-stage breakdown is taken in a short extra pass AFTER the timed region.
-    cg.set_profiling(4)
+    set_profiling(4)
     if args.warmup > 0:
-        cg.optimize_layout()
+        cg_of().optimize_layout()
         # ... and one more untimed block after it: the set-up leaves the GPU idle for tens of milliseconds of host work (clocks drop)
         # and re-sorts the localizations (the first block afterwards runs ~25 % slower than the following ones)
         run_steps(min(args.warmup, BLOCK))
-        cg.set_profiling(4)                    # (drops that block's sample of the query kernel: only the timed region's are reported)
+        set_profiling(4)                    # (drops that block's sample of the query kernel: only the timed region's are reported)
     fence()
+    warmup_executed = executed[0]
     executed[0] = 0
+    reparts0 = scene.repartitions if halo else 0
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
@@ -194,7 +294,9 @@ def main():
     steps_done = executed[0]
     if steps_done != args.steps:
         raise SystemExit('bench: only %d of %d timed iterations executed (stop condition fired): the throughput would be overstated' % (steps_done, args.steps))
-    nn_ms, nn_launches = cg.stage_ms_total['nn']
+    nn_ms, nn_launches = cg_of().stage_ms_total['nn']
+    reparts = (scene.repartitions - reparts0) if halo else 0
+    host_ms = dict(scene.host_ms) if halo else {}
     # the same K steps once more WITHOUT events: every block is then one replayed hipGraph (what a caller who does not profile gets).
     # Reported beside the official number, never instead of it.
     dt_graph = None
@@ -206,45 +308,71 @@ def main():
         run_steps(args.steps)
         fence()
         dt_graph = time.perf_counter() - tg
-    cg.set_profiling(2)
+    set_profiling(2)
     ctimer = None
     if world > 1:
-        ctimer = parallel.CollectiveTimer()          # device time inside the RCCL collectives of the extra iterations
-        runner.ex.collective_timer = ctimer
+        ctimer = parallel.CollectiveTimer()          # device time inside the collectives of the extra iterations
+        (scene.ex if halo else runner.ex).collective_timer = ctimer
     run_steps(2 * BLOCK)
     fence()
     comm_ms, comm_n = ctimer.total_ms() if ctimer is not None else (0.0, 0)
-    stage = dict(cg.stage_ms_total)
+    stage = dict(cg_of().stage_ms_total)
     n_extra = max(stage['update'][1], 1)
+    rccl = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        mt = torch.tensor([float(M)], dtype=torch.float64, device='cuda')
-        dist.all_reduce(mt, op=dist.ReduceOp.SUM)
-        M_total = float(mt.item())
+        if halo:
+            M_total = float(M)                       # one mesh: every rank holds the whole of it on its host
+        else:
+            mt = torch.tensor([float(M)], dtype=torch.float64, device='cuda')
+            dist.all_reduce(mt, op=dist.ReduceOp.SUM)
+            M_total = float(mt.item())
+        devs = [None] * world
+        p = torch.cuda.get_device_properties(torch.cuda.current_device())
+        dist.all_gather_object(devs, dict(rank=rank, device=torch.cuda.current_device(), name=p.name, pci_bus_id=getattr(p, 'pci_bus_id', None)))
+        rccl = dict(backend=dist.get_backend(), world_size_seen=dist.get_world_size(), devices=devs)
     else:
         M_total = float(M)
 
     if rank == 0:
-        per_kernel, per_iter = algorithmic_bytes(N, M, F)
+        # sizes of what THIS rank's kernels work on (a sharded mesh: its share)
+        if halo:
+            d = scene.last_partition.ranks[rank] if scene.last_partition is not None else None
+            Nl = scene._local_points.shape[0]
+            Ml = int(scene.ex.cg.M)
+            Fl = int(np.asarray(scene.ex.cg.faces).shape[0])
+        else:
+            Nl, Ml, Fl = N, M, F
+        per_kernel, per_iter = algorithmic_bytes(Nl, Ml, Fl)
         # dominant kernel by device time, from HIP events recorded around each launch on the library's stream
         kern = {'nn': 'k_nn_wave', 'attract': 'k_attract', 'as': 'k_subspace_point_sums', 'prior': 'k_prior_directions',
                 'update': 'k_solve_update'}          # single-kernel stages (grid build and the NN fix-up are reported in stage_ms_per_iter)
         dom = max((k for k in kern), key=lambda k: stage[k][0] / max(stage[k][1], 1))
-        if dom == 'nn':
+        if dom == 'nn' and nn_launches > 0:
             ms_tot, launches = nn_ms, nn_launches            # measured live over the timed region
         else:
             ms_tot, launches = stage[dom]                    # (extra pass: the NN query is no longer the dominant kernel)
         avg_ms = ms_tot / max(launches, 1)
         achieved = per_kernel[kern[dom]] / (avg_ms * 1e-3) / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')     # PMC passes of the headline workload (tools/profile_round.sh), NOT measured by this run
-        if os.path.exists(tfile) and args.config == 'c3' and args.scale == 1.0:
+        tfile = os.path.join(ROOT, 'profiles', PMC_FILE)     # NOT measured by this run
+        if os.path.exists(tfile) and args.config == 'c3' and args.scale == 1.0 and world == 1:
             try:
                 traffic = json.load(open(tfile)).get(kern[dom])
             except Exception:
                 traffic = None
+        if world == 1:
+            par = 'single GPU'
+        elif halo:
+            par = ('halo%d: ONE mesh sharded by spatial tiles of the cloud (halo radius %.0f nm); per iteration RCCL all-reduces of the boundary rows of the '
+                   'fixed-point accumulator (%d rows x 32 B), of the 27 normal-equation sums x 32 ordered parts and of the owners\' new boundary positions '
+                   '(%d rows x 12 B); per block one all-reduce of the owners\' rows of the whole mesh (%d x 12 B)'
+                   % (world, args.halo, scene.ex.n_boundary, scene.ex.n_boundary, M))
+        else:
+            par = ('tiles%d (one vesicle per GPU; the scene keeps ONE global subspace solve: one RCCL all-reduce of the 27 normal-equation '
+                   'sums x 32 ordered parts = 6.9 KB per iteration, no vertex data)' % world)
         out = {
             'metric': 'vertex-updates/s (force+CG step) + achieved HBM GB/s, 1M pts/200k verts' if args.config == 'c3' else
                       'vertex-updates/s (force+CG step) + achieved HBM GB/s, %s' % args.config,
@@ -253,36 +381,43 @@ def main():
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
+            'warmup_executed': warmup_executed,
             'ms_per_step': dt / args.steps * 1e3,
             'ms_per_step_graph_replay': (dt_graph / args.steps * 1e3) if dt_graph is not None else None,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if halo else 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': '%s, %d localizations sigma=10 nm, %d vertices / %d faces, lams=[10], blocks of %d iterations, fixed topology%s'
                                    % (WORKLOADS[args.config], N, M, F, BLOCK, '' if args.scale == 1.0 else ' [SCALED x%.3g: debug run]' % args.scale),
-                       'localizations_per_gpu': N, 'vertices_per_gpu': M, 'faces_per_gpu': F, 'block': BLOCK,
-                       'one_off_setup': 'nw_optimize_layout after the warm-up, before the timed region: projection re-sort of the localizations, cell-size tuner (a few timed probe queries), heavy-first order of the query work list (one timed query); then one more untimed block of min(warmup, %d) iterations' % BLOCK,
-                       'parallelism': ('tiles%d (one vesicle per GPU; the scene keeps ONE global subspace solve: one RCCL all-reduce of the 27 normal-equation '
-                                       'sums x 32 ordered parts = 6.9 KB per iteration, no vertex data)' % world) if world > 1 else 'single GPU'},
+                       'localizations_per_gpu': Nl, 'vertices_per_gpu': Ml, 'faces_per_gpu': Fl, 'block': BLOCK,
+                       'one_off_setup': 'nw_optimize_layout after the warm-up, before the timed region: projection re-sort of the localizations, cell-size tuner (a few timed probe queries), heavy-first order of the query work list (one timed query); then one more untimed block of min(warmup, %d) iterations: %d iterations ran before the timed region' % (BLOCK, warmup_executed),
+                       'mode': args.mode if world > 1 else 'single',
+                       'parallelism': par},
             'roofline': {'bound': 'hbm', 'kernel': kern[dom], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_source': ('profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this workload, committed; not re-measured by this run)' if traffic is not None else None),
+                         'traffic_source': ('profiles/%s (rocprofv3 --pmc passes of this workload, committed; not re-measured by this run)' % PMC_FILE if traffic is not None else None),
                          'algorithmic_bytes_per_launch': per_kernel[kern[dom]], 'avg_launch_ms': avg_ms, 'launches': launches,
                          'launches_note': 'HIP events on the library stream around the k_nn_wave launch of the first iteration of every block of %d of the timed region (that iteration is launched from the host, the other iterations of the block are a replayed hipGraph)' % BLOCK,
                          'measured_copy_peak': measured_copy_ceiling(torch)},
             'roofline_iteration': {'algorithmic_bytes': per_iter, 'device_ms': stage['total'][0] / n_extra,
                                    'achieved': per_iter / (stage['total'][0] / n_extra * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                                   'unit': 'GB/s', 'note': 'sum of per-stage HIP-event spans of %d extra iterations run after the timed region' % n_extra},
+                                   'unit': 'GB/s', 'note': 'sum of per-stage HIP-event spans of %d extra iterations run after the timed region%s' % (n_extra, ' (rank 0, its share)' if world > 1 else '')},
             'stage_ms_per_iter': {k: stage[k][0] / n_extra for k in stage},
-            'nn_max_ring': cg.nn_max_ring, 'mean_dist_nm': cg.mean_dist,
+            'nn_max_ring': cg_of().nn_max_ring, 'mean_dist_nm': cg_of().mean_dist,
         }
         out['roofline_iteration']['frac'] = out['roofline_iteration']['achieved'] / HBM_PEAK_GBS
         if world > 1:
+            out['rccl'] = rccl
             out['collectives'] = {'ms_per_iter': comm_ms / n_extra, 'per_iter': comm_n / n_extra,
                                   'share_of_device_time': (comm_ms / n_extra) / max(stage['total'][0] / n_extra + comm_ms / n_extra, 1e-12),
                                   'note': 'rank 0, event-bracketed all-reduces of %d extra iterations after the timed region' % n_extra}
+            if halo:
+                out['halo'] = {'radius_nm': args.halo, 'boundary_vertices': scene.ex.n_boundary, 'repartitions_in_timed_region': reparts,
+                               'max_nn_distance_nm': scene.max_dist, 'drift_since_partition_nm': scene.drift,
+                               'host_ms_per_block': host_ms,
+                               'vertices_held_over_owned': float(Ml) * world / max(M, 1)}
         # BASELINE.json north_star: ">= 40 % of the HBM-bandwidth roofline on the curvature+attraction kernel" (SURVEY 8d:
         # <= 0.17 ms/iter for them at C3): the attraction/scatter, curvature-prior, A.S and update kernels together, their
         # SURVEY-8d algorithmic bytes over their HIP-event spans
@@ -304,10 +439,10 @@ def main():
                 vi = None
             if vi:
                 peak = 256 * 4 * 2.4e9 * 0.5
-                out['roofline']['valu_issue'] = {'wave_instructions_per_launch': vi, 'source': 'profiles/r02_pmc_traffic.json (not re-measured by this run)',
+                out['roofline']['valu_issue'] = {'wave_instructions_per_launch': vi, 'source': 'profiles/%s (not re-measured by this run)' % PMC_FILE,
                                                  'achieved': vi / (avg_ms * 1e-3), 'peak': peak, 'unit': 'wave-instructions/s',
                                                  'frac': vi / (avg_ms * 1e-3) / peak, 'frac_of_measured_issue_rate': vi / (avg_ms * 1e-3) / (256 * 4 * 2.4e9 / 4.1)}
-        # a shared box is occasionally throttled (every kernel 5-50x slower for a whole call, seen twice this round): flag it
+        # a shared box is occasionally throttled (every kernel 5-50x slower for a whole call, seen twice in round 2): flag it
         cp = out['roofline'].get('measured_copy_peak', 0.0)
         out['device_health'] = 'ok' if cp >= 3000.0 else 'degraded: device-to-device copy ran at %.0f GB/s (normally ~5100)' % cp
         if not args.no_cpu_baseline and world == 1:
@@ -315,6 +450,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(synth.make_config(args.config, scale=args.scale, seed=rank), cpu_iters)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

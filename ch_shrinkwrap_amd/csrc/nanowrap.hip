@@ -125,7 +125,7 @@ struct nw_ctx {
     int64_t N = 0, M = 0, F = 0;
     int NB = 0;
     // captured search() blocks (hipGraph): replayed while nothing they bake in has changed
-    struct BlockGraph { hipGraphExec_t exec = nullptr, exec_b = nullptr; uint64_t key = 0; };      // exec_b: second half of a block split for sampled profiling
+    struct BlockGraph { hipGraphExec_t exec = nullptr; uint64_t key = 0; };
     bool capturing = false;
     bool direct_out = false;         // nw_search: the last update of the block writes its result into the pinned staging buffer itself
     BlockGraph graphs[4];
@@ -160,6 +160,8 @@ struct nw_ctx {
     double scene_ext = 1.0;           // extent of localizations + mesh at the last grid build
     double quantum_override = 0.0;    // > 0: nw_accumulator_quantum fixed it (multi-GPU: every rank must use the same)
     double acc_quantum = 1.0;         // fixed-point quantum of the LDS scatter accumulators (k_attract): 2^-36 of the cloud extent
+    double extent_hint = 0.0;         // > 0: extent of the WHOLE mesh (a rank of a sharded mesh; nw_set_extent_hint)
+    double local_quantum = 1.0;       // what this ctx would choose for its own localizations and weights (nw_search_begin computes it every block)
     double cell_tune = 1.0;           // multiplier on the cell-size rule (tune_grid)
     bool tuned = false;
     int blocks_done = 0;              // completed search() calls since the localizations were set
@@ -189,6 +191,14 @@ struct nw_ctx {
     DevBuf<int> nbr, nbr_t, faces;
     DevBuf<unsigned char> valid, owned;
     bool have_valid = false, have_owned = false;
+    // sharded mesh ('halo' mode): the boundary vertices this rank holds, the dense exchange buffers over the global boundary list
+    DevBuf<int> hb_local, hb_slot, hb_slot2local, hb_gv;
+    DevBuf<long long> halo_acc;       // (n_boundary, 4) accumulator rows
+    DevBuf<float> halo_rows;          // (n_boundary, 3) position / normal rows (owner-only non-zero)
+    DevBuf<float> halo_full;          // (M_global, 3) owners' rows of the whole mesh (one all-reduce per block)
+    int64_t hb_n = 0, hb_nslot = 0, M_global = 0;
+    bool have_boundary = false;
+    bool pos_unpack_pending = false;  // the owners' new boundary positions are in halo_rows (all-reduced by the caller), not yet taken
     int maxdeg = 0;
     DevBuf<int> d_small;              // small int scratch (maxdeg, flags)
 
@@ -482,7 +492,7 @@ struct StageScope {
     nw_ctx *c; int stage; hipEvent_t a;
     bool on;
     StageScope(nw_ctx *ctx, int s, bool first_of_block = true) : c(ctx), stage(s), a(nullptr),
-        on(!ctx->capturing && (ctx->profiling == 2 || ((ctx->profiling == 1 || ctx->profiling == 3 || (ctx->profiling == 4 && first_of_block)) && s == ST_NN))) { if (on) a = next_event(c); }
+        on(!ctx->capturing && (ctx->profiling == 2 || ((ctx->profiling == 1 || (ctx->profiling == 4 && first_of_block)) && s == ST_NN))) { if (on) a = next_event(c); }
     ~StageScope() { if (on) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
 };
 
@@ -554,10 +564,11 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->owned.release(); ctx->d_small.release();
+    ctx->hb_local.release(); ctx->hb_slot.release(); ctx->hb_slot2local.release(); ctx->hb_gv.release(); ctx->halo_acc.release(); ctx->halo_rows.release(); ctx->halo_full.release();
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->wv.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
-    for (auto &gph : ctx->graphs) { if (gph.exec) (void)hipGraphExecDestroy(gph.exec); if (gph.exec_b) (void)hipGraphExecDestroy(gph.exec_b); }
+    for (auto &gph : ctx->graphs) { if (gph.exec) (void)hipGraphExecDestroy(gph.exec); }
     if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->pin_log) (void)hipHostFree(ctx->pin_log);
@@ -823,6 +834,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     if (topo_change) { ctx->grid_valid = false; }
     ctx->face_warm = false;                               // face ids of another topology are no starting guess
     ctx->have_owned = false;
+    ctx->have_boundary = false; ctx->pos_unpack_pending = false;      // (a sharding belongs to the mesh it was made for)
     // a new mesh object = a new optimiser in the reference (_membrane_mesh.pyx:1510): history restarts
     NwDevState st{};
     st.stop_at = 0x7fffffff;
@@ -845,6 +857,117 @@ NW_EXPORT int nw_set_owned(nw_ctx *ctx, const uint8_t *owned)
     return NW_OK;
 }
 
+// Sharded mesh ('halo' mode): the boundary vertices this rank holds (b_local[k] = local vertex, b_slot[k] = its row in the global
+// boundary list of n_slots rows), ownership flags, and the global id of every local vertex (gv, M_global) for the per-block gather.
+// From then on the split-phase iteration packs / unpacks the exchange buffers itself:
+//   nw_iter_attract    ... -> NW_ARR_HALO_ACC  = this rank's partial accumulator rows      (caller: all-reduce SUM, int64)
+//   nw_iter_directions takes the reduced rows first
+//   nw_iter_update     ... -> NW_ARR_HALO_ROWS = the new positions of the boundary vertices this rank OWNS, zero elsewhere (all-reduce SUM)
+//   the next nw_iter_attract / nw_search_end takes the owners' rows (positions and mesh positions) first.
+// n_local == 0 with n_slots == 0 is a valid sharding (no shared vertex); b_local == NULL with n_slots < 0 clears it.
+NW_EXPORT int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t *b_slot, int64_t n_local, int64_t n_slots, const uint8_t *owned,
+                              const int32_t *gv, int64_t n_global)
+{
+    if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: mesh not set");
+    if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary inside a search");
+    NW_HIP(hipSetDevice(ctx->device));
+    if (n_slots < 0) { ctx->have_boundary = false; ctx->pos_unpack_pending = false; return nw_set_owned(ctx, nullptr); }
+    if (n_local < 0 || n_local > ctx->M || n_local > n_slots || (n_local > 0 && (!b_local || !b_slot)) || !owned || !gv || n_global <= 0 || n_global > 0x7fffffff / 4)
+        return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: bad array/size");
+    // validate on the host (a bad index would fault a kernel): local ids inside the mesh, slots inside the list, each slot at most once
+    {
+        std::vector<int32_t> hl, hs, hg;
+        auto fetch = [&](const int32_t *p, int64_t n, std::vector<int32_t> &dst) -> bool {
+            dst.resize((size_t)n);
+            return n == 0 || hipMemcpy(dst.data(), p, (size_t)n * sizeof(int32_t), hipMemcpyDefault) == hipSuccess;
+        };
+        if (!fetch(b_local, n_local, hl) || !fetch(b_slot, n_local, hs) || !fetch(gv, ctx->M, hg)) return fail(ctx, NW_ERR_HIP, "nw_set_boundary: cannot read the index arrays");
+        std::vector<unsigned char> seen((size_t)n_slots, 0);
+        for (int64_t k = 0; k < n_local; ++k) {
+            if (hl[k] < 0 || hl[k] >= ctx->M || hs[k] < 0 || hs[k] >= n_slots || seen[hs[k]]) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: index out of range or slot listed twice");
+            seen[hs[k]] = 1;
+        }
+        for (int64_t v = 0; v < ctx->M; ++v)
+            if (hg[v] < 0 || hg[v] >= n_global) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: global vertex id out of range");
+        std::vector<int32_t> s2l((size_t)std::max<int64_t>(n_slots, 1), -1);
+        for (int64_t k = 0; k < n_local; ++k) s2l[hs[k]] = hl[k];
+        NW_HIP(ctx->hb_local.ensure((size_t)std::max<int64_t>(n_local, 1)));
+        NW_HIP(ctx->hb_slot.ensure((size_t)std::max<int64_t>(n_local, 1)));
+        NW_HIP(ctx->hb_slot2local.ensure((size_t)std::max<int64_t>(n_slots, 1)));
+        NW_HIP(ctx->hb_gv.ensure((size_t)ctx->M));
+        if (n_local > 0) {
+            NW_HIP(hipMemcpyAsync(ctx->hb_local.p, hl.data(), (size_t)n_local * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            NW_HIP(hipMemcpyAsync(ctx->hb_slot.p, hs.data(), (size_t)n_local * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        }
+        NW_HIP(hipMemcpyAsync(ctx->hb_slot2local.p, s2l.data(), s2l.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        NW_HIP(hipMemcpyAsync(ctx->hb_gv.p, hg.data(), (size_t)ctx->M * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        NW_HIP(hipStreamSynchronize(ctx->stream));          // the staging vectors die with this scope
+    }
+    NW_HIP(ctx->halo_acc.ensure((size_t)4 * std::max<int64_t>(n_slots, 1)));
+    NW_HIP(ctx->halo_rows.ensure((size_t)3 * std::max<int64_t>(n_slots, 1)));
+    NW_HIP(ctx->halo_full.ensure((size_t)3 * n_global));
+    NW_HIP(hipMemsetAsync(ctx->halo_acc.p, 0, (size_t)4 * std::max<int64_t>(n_slots, 1) * sizeof(long long), ctx->stream));
+    NW_HIP(hipMemsetAsync(ctx->halo_rows.p, 0, (size_t)3 * std::max<int64_t>(n_slots, 1) * sizeof(float), ctx->stream));
+    ctx->hb_n = n_local; ctx->hb_nslot = n_slots; ctx->M_global = n_global;
+    NW_TRY(nw_set_owned(ctx, owned));
+    ctx->have_boundary = true;
+    ctx->pos_unpack_pending = false;
+    return NW_OK;
+}
+
+// the exchange buffers by hand (the iteration phases call these themselves; a caller needs them for the vertex normals after
+// nw_refresh_normals): what = NW_ARR_VACC -> NW_ARR_HALO_ACC; NW_ARR_POS / NW_ARR_NRM -> NW_ARR_HALO_ROWS (owner-only rows)
+static int halo_pack(nw_ctx *ctx, int what)
+{
+    const int ns = (int)ctx->hb_nslot;
+    if (ns <= 0) return NW_OK;
+    if (what == NW_ARR_VACC) hipLaunchKernelGGL(k_halo_pack_acc, dim3(nblk(ns)), dim3(NW_BLOCK), 0, ctx->stream, ns, ctx->hb_slot2local.p, ctx->vacc.p, ctx->halo_acc.p);
+    else hipLaunchKernelGGL(k_halo_pack_rows, dim3(nblk(ns)), dim3(NW_BLOCK), 0, ctx->stream, ns, ctx->hb_slot2local.p, ctx->owned.p, what == NW_ARR_NRM ? ctx->nrm.p : ctx->pos.p, ctx->halo_rows.p);
+    NW_HIP(hipGetLastError());
+    return NW_OK;
+}
+
+static int halo_unpack(nw_ctx *ctx, int what)
+{
+    const int n = (int)ctx->hb_n;
+    if (n <= 0) return NW_OK;
+    if (what == NW_ARR_VACC) hipLaunchKernelGGL(k_halo_unpack_acc, dim3(nblk(n)), dim3(NW_BLOCK), 0, ctx->stream, n, ctx->hb_local.p, ctx->hb_slot.p, ctx->halo_acc.p, ctx->vacc.p);
+    else if (what == NW_ARR_NRM) hipLaunchKernelGGL(k_halo_unpack_rows, dim3(nblk(n)), dim3(NW_BLOCK), 0, ctx->stream, n, ctx->hb_local.p, ctx->hb_slot.p, ctx->halo_rows.p, ctx->nrm.p, (float *)nullptr);
+    else hipLaunchKernelGGL(k_halo_unpack_rows, dim3(nblk(n)), dim3(NW_BLOCK), 0, ctx->stream, n, ctx->hb_local.p, ctx->hb_slot.p, ctx->halo_rows.p, ctx->pos.p, ctx->meshpos.p);
+    NW_HIP(hipGetLastError());
+    return NW_OK;
+}
+
+NW_EXPORT int nw_halo_pack(nw_ctx *ctx, int what)
+{
+    if (!ctx || !ctx->have_boundary) return fail(ctx, NW_ERR_BADARG, "nw_halo_pack: no boundary set (nw_set_boundary)");
+    if (what != NW_ARR_VACC && what != NW_ARR_POS && what != NW_ARR_NRM) return fail(ctx, NW_ERR_BADARG, "nw_halo_pack: accumulator, positions or normals");
+    if (what == NW_ARR_VACC && !ctx->vacc.p) return fail(ctx, NW_ERR_BADARG, "nw_halo_pack: no accumulator yet");
+    return halo_pack(ctx, what);
+}
+
+NW_EXPORT int nw_halo_unpack(nw_ctx *ctx, int what)
+{
+    if (!ctx || !ctx->have_boundary) return fail(ctx, NW_ERR_BADARG, "nw_halo_unpack: no boundary set (nw_set_boundary)");
+    if (what != NW_ARR_VACC && what != NW_ARR_POS && what != NW_ARR_NRM) return fail(ctx, NW_ERR_BADARG, "nw_halo_unpack: accumulator, positions or normals");
+    if (what == NW_ARR_VACC && !ctx->vacc.p) return fail(ctx, NW_ERR_BADARG, "nw_halo_unpack: no accumulator yet");
+    if (what == NW_ARR_POS) ctx->pos_unpack_pending = false;
+    return halo_unpack(ctx, what);
+}
+
+// NW_ARR_HALO_FULL <- the rows of NW_ARR_POS / NW_ARR_NRM of the vertices this rank owns at their global ids, zero elsewhere: one
+// all-reduce(sum) over the ranks then holds the whole mesh on every rank (once per block)
+NW_EXPORT int nw_halo_gather_owned(nw_ctx *ctx, int what)
+{
+    if (!ctx || !ctx->have_boundary) return fail(ctx, NW_ERR_BADARG, "nw_halo_gather_owned: no boundary set (nw_set_boundary)");
+    if (what != NW_ARR_POS && what != NW_ARR_NRM) return fail(ctx, NW_ERR_BADARG, "nw_halo_gather_owned: positions or normals");
+    if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_halo_gather_owned inside a search");
+    NW_HIP(hipMemsetAsync(ctx->halo_full.p, 0, (size_t)3 * ctx->M_global * sizeof(float), ctx->stream));
+    hipLaunchKernelGGL(k_halo_gather_owned, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->hb_gv.p, ctx->owned.p, what == NW_ARR_NRM ? ctx->nrm.p : ctx->pos.p, ctx->halo_full.p);
+    NW_HIP(hipGetLastError());
+    return NW_OK;
+}
+
 NW_EXPORT int nw_set_normals(nw_ctx *ctx, const float *nrm)
 {
     if (!ctx || !nrm || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_normals: mesh not set");
@@ -861,18 +984,31 @@ NW_EXPORT int nw_refresh_normals(nw_ctx *ctx, float *nrm_out)
     // the scatter accumulator of the iteration doubles as the normals' accumulator (every block zeroes it before it starts)
     NW_HIP(ctx->vacc.ensure(4 * ctx->M));
     NW_HIP(hipMemsetAsync(ctx->vacc.p, 0, 3 * ctx->M * sizeof(long long), ctx->stream));
-    float mlo[3], mhi[3];
-    bool bad = false;
-    NW_TRY(minmax3(ctx, ctx->meshpos.p, ctx->M, mlo, mhi, &bad));
-    if (bad) return fail(ctx, NW_ERR_NONFINITE, "non-finite vertex coordinate");
     double ext = 1e-30;
-    for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)mhi[k] - (double)mlo[k]);
+    if (ctx->extent_hint > 0) ext = ctx->extent_hint;          // a sharded mesh: the WHOLE mesh's extent, so that every rank uses the same quantum
+    else {
+        float mlo[3], mhi[3];
+        bool bad = false;
+        NW_TRY(minmax3(ctx, ctx->meshpos.p, ctx->M, mlo, mhi, &bad));
+        if (bad) return fail(ctx, NW_ERR_NONFINITE, "non-finite vertex coordinate");
+        for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)mhi[k] - (double)mlo[k]);
+    }
     const double q = std::ldexp(1.0, (int)std::ceil(std::log2(ext * ext)) - 44);      // |cross product| <= extent^2; <= 2^5 terms per vertex
     hipLaunchKernelGGL(k_normals_scatter, dim3(nblk(ctx->F)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->F, ctx->faces.p, ctx->meshpos.p, ctx->vacc.p, 1.0 / q);
     hipLaunchKernelGGL(k_normals_finish, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->vacc.p, ctx->nrm.p);
     NW_HIP(hipGetLastError());
     if (nrm_out) NW_HIP(hipMemcpyAsync(nrm_out, ctx->nrm.p, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
     NW_HIP(hipStreamSynchronize(ctx->stream));
+    return NW_OK;
+}
+
+// Extent of the whole mesh for a rank that holds a share of it: nw_refresh_normals derives the quantum of its fixed-point normal sums
+// from the mesh's bounding box, and ranks whose shares have different boxes would round the same vertex's sum differently.  ext <= 0:
+// back to the local box.
+NW_EXPORT int nw_set_extent_hint(nw_ctx *ctx, double ext)
+{
+    if (!ctx) return NW_ERR_BADARG;
+    ctx->extent_hint = (ext > 0 && std::isfinite(ext)) ? ext : 0.0;
     return NW_OK;
 }
 
@@ -1100,8 +1236,8 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     if (ctx->blocks_done >= 2 && num_iters > 0) NW_TRY(tune_grid(ctx));      // (nw_optimize_layout does it earlier if the caller asks)
     if (ctx->blocks_done >= 3 && num_iters > 0) NW_TRY(order_items_by_cost(ctx));
     // fixed-point quanta of the scatter (k_attract): 2^-36 of a bound on |w res| <= largest weight x scene extent; 2^-40 for sum w
-    ctx->acc_quantum = ctx->quantum_override > 0 ? ctx->quantum_override
-                                                 : std::ldexp(1.0, (int)std::ceil(std::log2(std::max(ctx->scene_ext * ctx->w_bound, 1e-300))) - 36);
+    ctx->local_quantum = std::ldexp(1.0, (int)std::ceil(std::log2(std::max(ctx->scene_ext * ctx->w_bound, 1e-300))) - 36);
+    ctx->acc_quantum = ctx->quantum_override > 0 ? ctx->quantum_override : ctx->local_quantum;
     ctx->w_quantum = std::ldexp(1.0, -40);
     ctx->lam0 = lams[0];
     ctx->search_flags = flags;
@@ -1196,12 +1332,16 @@ static int iter_attract_parts(nw_ctx *ctx, int parts)
 NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_attract outside a search");
-    return iter_attract_parts(ctx, QP_ALL);
+    if (ctx->have_boundary && ctx->pos_unpack_pending) { ctx->pos_unpack_pending = false; NW_TRY(halo_unpack(ctx, NW_ARR_POS)); }      // the owners' rows of the previous update
+    NW_TRY(iter_attract_parts(ctx, QP_ALL));
+    if (ctx->have_boundary) NW_TRY(halo_pack(ctx, NW_ARR_VACC));
+    return NW_OK;
 }
 
 NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_directions outside a search");
+    if (ctx->have_boundary && !ctx->capturing) NW_TRY(halo_unpack(ctx, NW_ARR_VACC));      // the boundary rows summed over the ranks
     const int it = ctx->search_done;
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
     {
@@ -1238,6 +1378,7 @@ NW_EXPORT int nw_iter_update(nw_ctx *ctx)
                            ctx->logs.p + ctx->search_done, it, (ctx->direct_out && it == ctx->search_iters - 1) ? (float *)ctx->pin : nullptr);
     }
     NW_HIP(hipGetLastError());
+    if (ctx->have_boundary && !ctx->capturing) { NW_TRY(halo_pack(ctx, NW_ARR_POS)); ctx->pos_unpack_pending = true; }
     ctx->global_iter += 1;
     ctx->search_done += 1;
     return NW_OK;
@@ -1251,6 +1392,7 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_search_end outside a search");
     if (ctx->begin_ops_pending) NW_TRY(enqueue_begin_ops(ctx));
+    if (ctx->have_boundary && ctx->pos_unpack_pending) { ctx->pos_unpack_pending = false; NW_TRY(halo_unpack(ctx, NW_ARR_POS)); }
     ctx->in_search = false;
     // logs + device state land in PINNED memory: a device-to-host copy into pageable memory blocks the host until everything queued
     // before it has run, which would serialise "wait for the kernels", the two small copies and the position slices below
@@ -1347,7 +1489,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     uint32_t lb; memcpy(&lb, &ctx->lam0, 4); mix(lb);
     uint64_t qb; memcpy(&qb, &ctx->acc_quantum, 8); mix(qb);
     uint32_t sb; memcpy(&sb, &ctx->sinv_scalar, 4); mix(sb); memcpy(&sb, &ctx->w_scalar, 4); mix(sb);
-    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 3 ? 32 : 0) | (ctx->profiling == 4 ? 256 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0));
+    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 4 ? 256 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0) | (ctx->have_boundary ? 512 : 0));
     mixp(ctx->direct_out ? ctx->pin : nullptr);
     mixp(ctx->have_data ? ctx->dat.p : nullptr);
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
@@ -1360,49 +1502,37 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
 
 // The captured form of the block the ctx is about to run (nw_search_begin done): found among the cached ones or captured now
 // (the launches are recorded, not run).  nullptr: not eligible, or the capture failed -> the caller launches directly.
-// Profiling level 3 ("sampled") keeps the graphs: the block is captured in two halves around the query kernel of its first
-// iteration, which is launched directly between two events -- one live sample of the dominant kernel per block.
 // Profiling level 4 runs a block's first iteration directly (its query kernel between two events) and replays the REST of the block
 // from a graph (`tail`: called after that first iteration, search_done == 1).
 static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool tail)
 {
     static const bool graphs_on = !(getenv("NW_GRAPH") && atoi(getenv("NW_GRAPH")) == 0);
-    if (!(graphs_on && ctx->own_stream && (ctx->profiling == 0 || ctx->profiling == 3 || (tail && ctx->profiling == 4)) && num_iters > (tail ? 1 : 0))) return nullptr;
+    if (!(graphs_on && ctx->own_stream && (ctx->profiling == 0 || (tail && ctx->profiling == 4)) && num_iters > (tail ? 1 : 0))) return nullptr;
     if (tail != (ctx->search_done == 1)) return nullptr;
-    const bool split = ctx->profiling == 3;
     const uint64_t key = block_graph_key(ctx);
     for (auto &gph : ctx->graphs) if (gph.exec && gph.key == key) return &gph;
     if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] capturing a block of %d (%s, key %016llx, warm %d, grid generation %llu)\n", num_iters,
-                                      tail ? "all but its first iteration" : split ? "two halves" : "one graph",
+                                      tail ? "all but its first iteration" : "one graph",
                                       (unsigned long long)key, ctx->face_warm ? 1 : 0, (unsigned long long)ctx->grid_generation);
     const bool warm0 = ctx->face_warm;
     const int done0 = ctx->search_done;
-    auto capture = [&](int half) -> hipGraphExec_t {
-        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    hipGraphExec_t ea = nullptr;
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
         ctx->capturing = true;
         int r = NW_OK;
-        if (half != 2 && !tail) r = enqueue_begin_ops(ctx);
-        if (half == 1 && r == NW_OK) r = iter_attract_parts(ctx, QP_GRID);
-        for (int i = done0; i < num_iters && r == NW_OK && half != 1; ++i) {
-            r = (half == 2 && i == 0) ? iter_attract_parts(ctx, QP_FIXUP | QP_ATTRACT) : iter_attract_parts(ctx, QP_ALL);
+        if (!tail) r = enqueue_begin_ops(ctx);
+        for (int i = done0; i < num_iters && r == NW_OK; ++i) {
+            r = iter_attract_parts(ctx, QP_ALL);
             if (r == NW_OK) r = nw_iter_directions(ctx);
             if (r == NW_OK) r = nw_iter_update(ctx);
         }
         ctx->capturing = false;
         hipGraph_t graph = nullptr;
         const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
-        hipGraphExec_t exec = nullptr;
-        if (r == NW_OK && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+        if (r == NW_OK && ce == hipSuccess && graph && hipGraphInstantiate(&ea, graph, nullptr, nullptr, 0) != hipSuccess) ea = nullptr;
         if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        return exec;
-    };
-    hipGraphExec_t ea = capture(split ? 1 : 0), eb = nullptr;
-    if (ea && split) {
-        ctx->begin_ops_pending = false; ctx->face_warm = true;      // the state the second half is recorded in
-        eb = capture(2);
-        if (!eb) { (void)hipGraphExecDestroy(ea); ea = nullptr; }
     }
+    (void)hipGetLastError();
     // rewind the host-side bookkeeping the recorded calls advanced
     ctx->global_iter -= ctx->search_done - done0; ctx->search_done = done0; ctx->face_warm = warm0;
     ctx->begin_ops_pending = !tail;         // recorded, not run
@@ -1410,8 +1540,7 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool tail)
     nw_ctx::BlockGraph &dst = ctx->graphs[ctx->graph_next];
     ctx->graph_next = (ctx->graph_next + 1) % 4;
     if (dst.exec) (void)hipGraphExecDestroy(dst.exec);
-    if (dst.exec_b) (void)hipGraphExecDestroy(dst.exec_b);
-    dst.exec = ea; dst.exec_b = eb; dst.key = key;
+    dst.exec = ea; dst.key = key;
     return &dst;
 }
 
@@ -1419,6 +1548,8 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
 {
     const bool verbose = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 2;
     const auto t0 = std::chrono::steady_clock::now();
+    if (ctx && ctx->have_boundary && ctx->hb_nslot > 0)
+        return fail(ctx, NW_ERR_BADARG, "nw_search on a sharded mesh: the boundary rows must be all-reduced between the phases (nw_search_begin / nw_iter_* / nw_search_end)");
     NW_TRY(nw_search_begin(ctx, lams, n_lams, num_iters, flags));
     const auto t1 = std::chrono::steady_clock::now();
     // A block is a fixed launch sequence (begin ops + num_iters x 11 launches) with block-relative arguments: captured once as a
@@ -1444,11 +1575,6 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     if (slot) {
         if (hipGraphLaunch(slot->exec, ctx->stream) == hipSuccess) {
             ctx->begin_ops_pending = false;
-            if (slot->exec_b) {
-                int r = iter_attract_parts(ctx, QP_NN);                      // the sampled launch, between two events
-                if (r == NW_OK && hipGraphLaunch(slot->exec_b, ctx->stream) != hipSuccess) r = NW_ERR_HIP;
-                if (r != NW_OK) { ctx->in_search = false; return fail(ctx, r, "replay of a captured block failed half-way"); }
-            }
             ctx->global_iter += num_iters; ctx->search_done = num_iters; ctx->face_warm = true;
             replayed = true;
         } else (void)hipGetLastError();
@@ -1525,6 +1651,9 @@ NW_EXPORT int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes)
     case NW_ARR_NRM: p = ctx->nrm.p; nb = 3 * ctx->M * 4; break;
     case NW_ARR_VALID: p = ctx->have_valid ? ctx->valid.p : nullptr; nb = ctx->M; break;
     case NW_ARR_SCALARS: p = ctx->scalars.p; nb = (int64_t)NW_N_SCALARS * NW_SPARTS * 8; break;
+    case NW_ARR_HALO_ACC: p = ctx->have_boundary ? ctx->halo_acc.p : nullptr; nb = 4 * ctx->hb_nslot * 8; break;
+    case NW_ARR_HALO_ROWS: p = ctx->have_boundary ? ctx->halo_rows.p : nullptr; nb = 3 * ctx->hb_nslot * 4; break;
+    case NW_ARR_HALO_FULL: p = ctx->have_boundary ? ctx->halo_full.p : nullptr; nb = 3 * ctx->M_global * 4; break;
     default: return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array is not device-addressable in caller order");
     }
     if (!p) return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array not allocated yet");
@@ -1786,25 +1915,33 @@ NW_EXPORT int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out)
 }
 
 // Quantum of the fixed-point A^T accumulator (NW_ARR_VACC = int64 counts of this quantum).  *q > 0 on entry fixes it for all later
-// searches (ranks that all-reduce NW_ARR_VACC must agree on it: take the MAX of their own values); on return *q = the quantum the
-// CURRENT / next search uses.  May be called between nw_search_begin and the first nw_iter_attract (then it applies at once).
+// searches (ranks that all-reduce NW_ARR_VACC must agree on it: take the MAX of their LOCAL values); *q < 0 drops such an override;
+// *q == 0 only asks.  On return *q = the quantum this ctx chooses by itself for its current localizations, weights and scene extent
+// (computed by every nw_search_begin -- NOT the override: ranks all-reduce this value again for every block, so a scene that grows is
+// followed); the quantum in use is the override if there is one, else that local value.
+// May be called between nw_search_begin and the first nw_iter_attract (then it applies at once).
 NW_EXPORT int nw_accumulator_quantum(nw_ctx *ctx, double *q)
 {
     if (!ctx || !q) return NW_ERR_BADARG;
+    if (*q != 0 && ctx->in_search && ctx->search_done > 0) return fail(ctx, NW_ERR_BADARG, "nw_accumulator_quantum: cannot change the quantum between the iterations of a search");
     if (*q > 0 && std::isfinite(*q)) {
         int e = 0;
         const double m = std::frexp(*q, &e);
         ctx->quantum_override = std::ldexp(1.0, m == 0.5 ? e - 1 : e);          // a power of two (scaling must be exact)
-        if (ctx->in_search && ctx->search_done > 0) return fail(ctx, NW_ERR_BADARG, "nw_accumulator_quantum: cannot change the quantum between the iterations of a search");
         if (ctx->in_search) ctx->acc_quantum = ctx->quantum_override;           // between nw_search_begin and the first iteration: applies at once
+    } else if (*q < 0) {
+        ctx->quantum_override = 0.0;
+        if (ctx->in_search) ctx->acc_quantum = ctx->local_quantum;
     }
-    *q = ctx->quantum_override > 0 ? ctx->quantum_override : ctx->acc_quantum;
+    *q = ctx->local_quantum;
     return NW_OK;
 }
 
 NW_EXPORT int nw_set_profiling(nw_ctx *ctx, int enable)
 {
     if (!ctx) return NW_ERR_BADARG;
+    // (level 3, a block replayed as two half graphs around a directly launched query, was removed in ABI 3: see include/nanowrap.h)
+    if (enable == 3) return fail(ctx, NW_ERR_BADARG, "nw_set_profiling: level 3 (sampled, two half-block graphs) was removed; use 4");
     ctx->profiling = enable < 0 ? 0 : (enable > 4 ? 4 : enable);
     return NW_OK;
 }

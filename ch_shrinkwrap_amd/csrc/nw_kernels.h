@@ -850,8 +850,11 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
     if (threadIdx.x == 0) { if (n_search > 2) nw_solve_small<3>(sc, lam, s_sol); else nw_solve_small<2>(sc, lam, s_sol); }
     __syncthreads();
     const NwSolve sol = s_sol;
+    // a status raised earlier in this iteration (NaN in the weight matrix / A f / A^T r: the reference asserts BEFORE `self.f[:] = fnew`,
+    // mesh_conj_grad.py:514,548,580 vs :288) leaves the estimate, the mesh positions and the staged result at the last good iterate
+    const bool failed = st->status != 0;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < M; v += gridDim.x * blockDim.x) {
-      if (!sol.singular) {
+      if (!sol.singular && !failed) {
         const bool ok = valid ? valid[v] != 0 : true;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
         L.nn_max_ring = st->nn_max_ring;
         if (sol.singular) atomicCAS(&st->status, 0, -4 /* NW_ERR_SINGULAR */);
         L.status = st->status;
-        L.executed = 1;
+        L.executed = (failed || sol.singular) ? 0 : 1;       // (the reference raised inside this iteration: it does not count, and the result is copied out the ordinary way)
         *logrec = L;
         // history + stop condition for the NEXT iteration (mesh_conj_grad.py:1009-1016)
         float a = st->tests[1], b = st->tests[2];
@@ -1008,6 +1011,70 @@ __global__ void k_unpermute(int N, int width, const int *__restrict__ perm, cons
     if (t >= (int64_t)N * width) return;
     const int i = (int)(t / width), k = (int)(t % width);
     out[(int64_t)perm[i] * width + k] = in[t];
+}
+
+// ---- sharded mesh ('halo' mode): boundary rows <-> one dense buffer over the GLOBAL boundary list --------
+// A boundary vertex (held by more than one rank) has one row in the dense buffer every rank all-reduces.  slot2local[s] = this rank's
+// local vertex for global boundary slot s, or -1; b_local[k] / b_slot[k] = local vertex / slot of the k-th boundary vertex held here.
+// pack: one thread per slot (rows this rank does not hold are zero); unpack: one thread per held boundary vertex.
+__global__ __launch_bounds__(NW_BLOCK) void k_halo_pack_acc(int nslot, const int *__restrict__ slot2local, const long long *__restrict__ vacc, long long *__restrict__ buf)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslot) return;
+    const int l = slot2local[s];
+    longlong2 a = make_longlong2(0, 0), b = make_longlong2(0, 0);
+    if (l >= 0) { a = *reinterpret_cast<const longlong2 *>(vacc + 4 * (int64_t)l); b = *reinterpret_cast<const longlong2 *>(vacc + 4 * (int64_t)l + 2); }
+    *reinterpret_cast<longlong2 *>(buf + 4 * (int64_t)s) = a;
+    *reinterpret_cast<longlong2 *>(buf + 4 * (int64_t)s + 2) = b;
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_halo_unpack_acc(int n, const int *__restrict__ b_local, const int *__restrict__ b_slot, const long long *__restrict__ buf,
+                                                             long long *__restrict__ vacc)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int l = b_local[k], s = b_slot[k];
+    *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)l) = *reinterpret_cast<const longlong2 *>(buf + 4 * (int64_t)s);
+    *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)l + 2) = *reinterpret_cast<const longlong2 *>(buf + 4 * (int64_t)s + 2);
+}
+
+// rows of a (M,3) float array (positions, normals): only the OWNER's value goes into the buffer, so that the sum over ranks is the
+// owner's row and every holder takes it -- ghosts get their update, computed copies cannot drift
+__global__ __launch_bounds__(NW_BLOCK) void k_halo_pack_rows(int nslot, const int *__restrict__ slot2local, const unsigned char *__restrict__ owned,
+                                                            const float *__restrict__ rows, float *__restrict__ buf)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslot) return;
+    const int l = slot2local[s];
+    const bool mine = l >= 0 && owned[l];
+    buf[3 * (int64_t)s] = mine ? rows[3 * (int64_t)l] : 0.0f;
+    buf[3 * (int64_t)s + 1] = mine ? rows[3 * (int64_t)l + 1] : 0.0f;
+    buf[3 * (int64_t)s + 2] = mine ? rows[3 * (int64_t)l + 2] : 0.0f;
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_halo_unpack_rows(int n, const int *__restrict__ b_local, const int *__restrict__ b_slot, const float *__restrict__ buf,
+                                                              float *__restrict__ dst, float *__restrict__ dst2 /* second copy (mesh positions) or NULL */)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int l = b_local[k], s = b_slot[k];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = buf[3 * (int64_t)s + c];
+        dst[3 * (int64_t)l + c] = v;
+        if (dst2) dst2[3 * (int64_t)l + c] = v;
+    }
+}
+
+// the owners' rows of a (M_local,3) array into the (M_global,3) array that one all-reduce per block turns into the whole mesh
+// (`full` zeroed beforehand; gv = global id of every local vertex)
+__global__ __launch_bounds__(NW_BLOCK) void k_halo_gather_owned(int M, const int *__restrict__ gv, const unsigned char *__restrict__ owned, const float *__restrict__ rows,
+                                                               float *__restrict__ full)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M || !owned[v]) return;
+    const int64_t g = gv[v];
+    full[3 * g] = rows[3 * (int64_t)v]; full[3 * g + 1] = rows[3 * (int64_t)v + 1]; full[3 * g + 2] = rows[3 * (int64_t)v + 2];
 }
 
 // ---- block-boundary geometry refresh (the reference's `self.face_normals; self.vertex_neighbors` after a block,

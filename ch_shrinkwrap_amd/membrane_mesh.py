@@ -108,8 +108,7 @@ class MembraneMesh(TriMesh):
         if len(verts) > 0 and self.neck_remover is not None:
             self.neck_remover(self, verts)
             self.cg = None
-            if self._native is not None:
-                self._native.mesh_key = None
+            self._host_mesh_changed()
         return verts
 
     # -- curvature (block-boundary kernel) --------------------------------------------------------------------
@@ -239,6 +238,9 @@ class MembraneMesh(TriMesh):
         edited or smoothed positions since the last one) and after every surgery hook."""
         if self._native is not None:
             self._native.mesh_key = None
+        # the cached 1-ring vertex table (TriMesh.neighbor_vertex_table) is derived from the half-edge / vertex records a hook may have
+        # edited in place: the next optimiser rebuilds it from the records as they are now
+        self._ring_vertex_table = None
 
     def _block_boundary(self, points, done, plan):
         # :1524-1527 -- geometry refreshed from the new positions: vertex normals on the device (they feed the next block's

@@ -402,14 +402,13 @@ class ShrinkwrapMeshConjGrad(object):
     # -- timing hooks for bench.py ------------------------------------------------------------------
     def set_profiling(self, level=2):
         """0/False off; 1 = HIP events around every NN query launch; 2/True = around every stage (each event pair serialises the
-        stream for a few microseconds; 1 and 2 launch every kernel from the host); 3 = sampled: blocks stay captured hipGraphs and
-        only the NN query of each block's first iteration is bracketed; 4 = the first iteration of each block is launched
+        stream for a few microseconds; 1 and 2 launch every kernel from the host); 4 = the first iteration of each block is launched
         from the host with its NN query bracketed, the rest of the block is a replayed hipGraph (what bench.py keeps on in its timed
-        region: one event pair per block instead of one per iteration)."""
+        region: one event pair per block instead of one per iteration).  (3, the two-half-graphs form of ABI 2, was removed.)"""
         level = 2 if level is True else int(level)
         self._native.check(self._L.nw_set_profiling(self._h, level))
         self._profiling = level > 0
-        self._profiled_stages = ('nn',) if level in (1, 3, 4) else None          # (levels 1, 3, 4 time nothing else: one query per block, not eight)
+        self._profiled_stages = ('nn',) if level in (1, 4) else None          # (levels 1 and 4 time nothing else)
         self.stage_ms_total = {k: (0.0, 0) for k in ('total', 'grid', 'nn', 'attract', 'prior', 'as', 'update', 'fixup')}
 
     def _accumulate_stage_ms(self):

@@ -48,7 +48,9 @@ class _DevArray(object):
 
 
 class HipExecutor(object):
-    """Phases of one iteration on this rank's nw_ctx + torch views of the buffers that get all-reduced."""
+    """Phases of one iteration on this rank's nw_ctx + torch views of the buffers that get all-reduced.  Nothing here allocates device
+    memory or launches a torch kernel per iteration: the boundary rows of a sharded mesh are packed / taken by the library itself
+    (nw_set_boundary), the views of its exchange buffers are made once."""
 
     def __init__(self, cg):
         self.cg = cg
@@ -57,6 +59,8 @@ class HipExecutor(object):
         self.n_point_scalars = self.L.nw_n_point_scalars() * stride
         self.n_scalars = self.L.nw_n_scalars() * stride
         self._views = {}
+        self.write_back = True                      # end(): copy the rank's (M,3) result to the host mesh (a sharded mesh gathers the whole mesh instead)
+        self.max_dist = 0.0
 
     def new_tensor(self, values):
         import torch
@@ -97,53 +101,53 @@ class HipExecutor(object):
         # (M, 4) int64 fixed-point sums {A^T res, sum w}: integer all-reduce = exact, order independent
         return self._view(nw.NW_ARR_VACC, 4 * self.cg.M, '<i8')
 
-    # -- 'halo' mode: boundary rows <-> one dense buffer over the global boundary list ----------------------------------
-    def set_boundary(self, b_local, b_slot, n_boundary, owned_local):
+    # -- 'halo' mode: boundary rows <-> one dense buffer over the global boundary list (packed / taken inside the phases) ------------
+    def set_boundary(self, b_local, b_slot, n_boundary, owned_local, gv, n_global):
         """b_local: local ids of this rank's vertices that are boundary vertices; b_slot: their rows in the global boundary
-        list (length n_boundary); owned_local: uint8 (M_local) ownership flags."""
-        import torch
-        dev = torch.device('cuda', torch.cuda.current_device())
-        self.b_local = torch.as_tensor(np.ascontiguousarray(b_local, dtype=np.int64), device=dev)
-        self.b_slot = torch.as_tensor(np.ascontiguousarray(b_slot, dtype=np.int64), device=dev)
-        own_b = np.asarray(owned_local, bool)[np.asarray(b_local, np.int64)]
-        self.b_owned = torch.as_tensor(np.ascontiguousarray(own_b), device=dev)
-        self.n_boundary = int(n_boundary)
-        self.native.check(self.L.nw_set_owned(self.h, nw.ptr(np.ascontiguousarray(owned_local, dtype=np.uint8))))
+        list (length n_boundary); owned_local: uint8 (M_local) ownership flags; gv: global id of every local vertex."""
+        bl = np.ascontiguousarray(b_local, dtype=np.int32)
+        bs = np.ascontiguousarray(b_slot, dtype=np.int32)
+        ow = np.ascontiguousarray(owned_local, dtype=np.uint8)
+        g = np.ascontiguousarray(gv, dtype=np.int32)
+        self.native.check(self.L.nw_set_boundary(self.h, nw.ptr(bl), nw.ptr(bs), bl.size, int(n_boundary), nw.ptr(ow), nw.ptr(g), int(n_global)))
+        self.n_boundary, self.n_global = int(n_boundary), int(n_global)
+        self._views = {}
 
-    def pack_boundary_accumulator(self):
-        import torch
-        acc = self.vertex_accumulator().view(-1, 4)
-        buf = torch.zeros((self.n_boundary, 4), dtype=acc.dtype, device=acc.device)
-        buf[self.b_slot] = acc[self.b_local]
-        return buf
+    def boundary_accumulator(self):
+        """(n_boundary, 4) int64: this rank's partial sums of the boundary vertices it holds (filled by attract())"""
+        return self._view(nw.NW_ARR_HALO_ACC, 4 * max(self.n_boundary, 1), '<i8')[:4 * self.n_boundary]
 
-    def unpack_boundary_accumulator(self, buf):
-        self.vertex_accumulator().view(-1, 4)[self.b_local] = buf[self.b_slot]
+    def boundary_rows(self):
+        """(n_boundary, 3) float32: rows of the boundary vertices this rank OWNS, zero elsewhere (filled by update(): the new positions)"""
+        return self._view(nw.NW_ARR_HALO_ROWS, 3 * max(self.n_boundary, 1), '<f4')[:3 * self.n_boundary]
 
-    def _positions(self):
-        M = self.cg.M
-        return self._view(nw.NW_ARR_POS, 3 * M, '<f4').view(-1, 3), self._view(nw.NW_ARR_MESHPOS, 3 * M, '<f4').view(-1, 3)
+    def gather_owned(self, what='pos'):
+        """(n_global * 3) float32: the owners' rows of the whole mesh, zero elsewhere -> one all-reduce per block"""
+        self.native.check(self.L.nw_halo_gather_owned(self.h, nw.NW_ARR_POS if what == 'pos' else nw.NW_ARR_NRM))
+        return self._view(nw.NW_ARR_HALO_FULL, 3 * self.n_global, '<f4')
 
-    def pack_owned_boundary_positions(self):
-        import torch
-        pos, _ = self._positions()
-        buf = torch.zeros((self.n_boundary, 3), dtype=pos.dtype, device=pos.device)
-        rows = pos[self.b_local]
-        buf[self.b_slot] = torch.where(self.b_owned[:, None], rows, torch.zeros_like(rows))
-        return buf
+    def refresh_normals_local(self, extent):
+        """block-boundary refresh (_membrane_mesh.pyx:1524-1527) of this rank's share on the device; the owners' normals of the boundary
+        vertices are left in boundary_rows() for the all-reduce, take_normals() then gives every holder the owner's"""
+        self.native.check(self.L.nw_set_extent_hint(self.h, float(extent)))
+        self.native.check(self.L.nw_refresh_normals(self.h, None))
+        self.native.check(self.L.nw_halo_pack(self.h, nw.NW_ARR_NRM))
 
-    def unpack_boundary_positions(self, buf):
-        # every holder takes the owner's value: ghosts get their update, shared computed copies cannot drift
-        pos, meshpos = self._positions()
-        rows = buf[self.b_slot]
-        pos[self.b_local] = rows
-        meshpos[self.b_local] = rows
+    def take_normals(self):
+        self.native.check(self.L.nw_halo_unpack(self.h, nw.NW_ARR_NRM))
+        self.native.check(self.L.nw_reset_history(self.h))          # a new optimiser per block (_membrane_mesh.pyx:1510)
+        self.cg.tests, self.cg.ress, self.cg.prefs = [], [], []
 
-    def quantum(self, value=0.0):
-        """quantum of the fixed-point accumulator; value > 0 fixes it (ranks that all-reduce the accumulator must agree)"""
-        q = ctypes.c_double(float(value))
+    def local_quantum(self):
+        """the quantum this rank would choose for its own localizations (valid after begin())"""
+        q = ctypes.c_double(0.0)
         self.native.check(self.L.nw_accumulator_quantum(self.h, ctypes.byref(q)))
         return q.value
+
+    def set_quantum(self, value):
+        """fix the quantum of the fixed-point accumulator (ranks that add their accumulators must agree)"""
+        q = ctypes.c_double(float(value))
+        self.native.check(self.L.nw_accumulator_quantum(self.h, ctypes.byref(q)))
 
     def end(self):
         cg = self.cg
@@ -154,14 +158,18 @@ class HipExecutor(object):
         cg.max_dist = 0.0
         cg._consume_logs(logs, lc.value)
         cg._accumulate_stage_ms()
-        cg._finish()
         self.max_dist = cg.max_dist
+        if not self.write_back:
+            return None
+        cg._finish()
         return cg.fs
 
 
-def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
+def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True, quantum=None):
     """One search() call of `num_iters` iterations over all ranks of `dist` (a torch.distributed-like module with an
-    initialised default group).  Every rank calls this collectively with its own executor."""
+    initialised default group).  Every rank calls this collectively with its own executor.
+    quantum: the accumulator quantum all ranks agreed on earlier (a scene object carries it from block to block, piggy-backed on a
+    collective it needs anyway); None = agree now (one blocking all-reduce MAX of the ranks' own values)."""
     if mode not in ('tiles', 'replicated', 'halo'):
         raise ValueError(mode)
     # weights = weights / weights.mean() (mesh_conj_grad.py:160-162): the mean runs over the WHOLE scene, i.e. all ranks
@@ -180,11 +188,13 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
             prenorm = (w_arr / np.float32(float(t[0]) / float(t[1]))).astype(np.float32)
             ex._prenorm_cache = (w_eff, prenorm)
     ex.begin(data, lams, num_iters, sigma_inv, weights, prenorm, pos, last_step)
-    if mode != 'tiles' and hasattr(ex, 'quantum'):
-        # the ranks add their integer accumulators: one common quantum (the coarsest any rank chose for its own localizations)
-        t = ex.new_tensor([ex.quantum()])
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ex.quantum(float(t[0]))
+    if mode != 'tiles' and hasattr(ex, 'set_quantum'):
+        # the ranks add their integer accumulators: one common quantum (the coarsest any rank chooses for its own localizations)
+        if quantum is None:
+            t = ex.new_tensor([ex.local_quantum()])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            quantum = float(t[0])
+        ex.set_quantum(quantum)
     n_red = ex.n_point_scalars if mode == 'replicated' else ex.n_scalars
     timer = getattr(ex, 'collective_timer', None)        # optional (bench.py): device time spent inside the collectives
 
@@ -196,21 +206,17 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
                 dist.all_reduce(t)
 
     for _ in range(int(num_iters)):
-        ex.attract()
+        ex.attract()                                         # 'halo': leaves this rank's partial sums of the boundary vertices packed
         if mode == 'replicated':
             all_reduce(ex.vertex_accumulator())
-        elif mode == 'halo':
-            buf = ex.pack_boundary_accumulator()             # (|B|, 4): this rank's partial sums of the boundary vertices it holds
-            all_reduce(buf)
-            ex.unpack_boundary_accumulator(buf)
-        ex.directions()
+        elif mode == 'halo' and ex.n_boundary > 0:
+            all_reduce(ex.boundary_accumulator())            # (|B|, 4) int64
+        ex.directions()                                      # 'halo': takes the summed boundary rows first
         all_reduce(ex.scalars(n_red))
-        ex.update()
-        if mode == 'halo':
-            buf = ex.pack_owned_boundary_positions()         # (|B|, 3): rows of the boundary vertices this rank OWNS, zero elsewhere
-            all_reduce(buf)
-            ex.unpack_boundary_positions(buf)
-    return ex.end()
+        ex.update()                                          # 'halo': leaves the new positions of the boundary vertices it OWNS packed
+        if mode == 'halo' and ex.n_boundary > 0:
+            all_reduce(ex.boundary_rows())                   # (|B|, 3): owner-only non-zero rows -> every holder takes the owner's value
+    return ex.end()                                          # (the last update's rows are taken here)
 
 
 class CollectiveTimer(object):
@@ -338,13 +344,14 @@ class HaloPartition(object):
     iteration; W_r = further 1-ring neighbours of V_r, ghosts that only carry positions / normals for the curvature prior.
     A vertex is owned by the tile that contains it.  Boundary vertices = present (in V or W) on more than one rank."""
 
-    def __init__(self, pos, nrm, nbr, faces, points, n_ranks, halo):
+    def __init__(self, pos, nrm, nbr, faces, points, n_ranks, halo, tiles=None):
         pos = np.asarray(pos, np.float32)
         faces = np.asarray(faces, np.int32)
         nbr = np.asarray(nbr, np.int32)
         M = pos.shape[0]
         self.M, self.n_ranks, self.halo = M, int(n_ranks), float(halo)
-        self.parts, classify = bisect_tiles(points, n_ranks)
+        # `tiles` = bisect_tiles(points, n_ranks) computed earlier: the tiles of a cloud do not depend on the mesh
+        self.parts, classify = tiles if tiles is not None else bisect_tiles(points, n_ranks)
         self.owner = classify(pos)
         cent = ((pos[faces[:, 0]] + pos[faces[:, 1]]) + pos[faces[:, 2]]) / np.float32(3.0)
         count = np.zeros(M, np.int32)
@@ -418,12 +425,23 @@ class ArrayMesh(object):
 
 
 class HaloScene(object):
-    """Front end of the 'halo' mode: every rank holds the whole mesh on the HOST (it is small: 24 bytes per vertex) and its own
-    share of everything on the DEVICE.  search() = one block: partition for the current mesh, one optimiser over the rank's
-    sub-mesh, run_search(..., 'halo'), then one all-reduce of owner-only rows returns the new positions to every rank's host mesh.
+    """Front end of the 'halo' mode: every rank holds the whole mesh on the HOST (it is small: 24 bytes per vertex) and its own share of
+    everything on the DEVICE, and keeps it there:
+
+      * the tiles of the cloud are cut once (they do not depend on the mesh), a rank's localizations are uploaded once;
+      * the partition of the mesh (HaloPartition: shares, owners, boundary list), the rank's sub-mesh on the device and the optimiser
+        over it are built once per topology -- and again when the mesh has moved by more than a quarter of the halo radius since, or
+        after mesh_changed() (a remesh);
+      * search() = one block on the resident state: run_search(..., 'halo') and then ONE all-reduce of the owners' rows, float32 on the
+        device, that gives every rank the whole new mesh (copied to the host mesh like search() does, mesh_conj_grad.py:288-289);
+      * refresh_normals() = the block-boundary refresh (_membrane_mesh.pyx:1524-1527) for an unchanged topology on the device: every rank
+        refreshes its share, the owners' normals of the boundary vertices go round, the optimiser history restarts.
+
+    The sharded nearest-face query is exact as long as max nearest distance + displacement since the partition <= halo; checked after
+    every block, the run raises otherwise.
 
     make_executor(local_mesh, local_points) -> executor (HipExecutor over a ShrinkwrapMeshConjGrad in production; the CPU tests pass
-    an oracle-backed one).  `halo` = search radius in length units; the run raises if a nearest-face distance exceeds it."""
+    an oracle-backed one)."""
 
     def __init__(self, mesh, points, dist, halo, make_executor=None, native=None, torch_stream=None):
         self.mesh, self.points, self.dist, self.halo = mesh, np.ascontiguousarray(points, np.float32), dist, float(halo)
@@ -432,6 +450,20 @@ class HaloScene(object):
         self.native = native
         self.torch_stream = torch_stream
         self.last_partition = None
+        self.ex = None
+        self._tiles = None
+        self._local_points = None
+        self._local_arrays = {}          # id(global per-localization array) -> (the array, this rank's rows): the same object every block
+        self._quantum = None
+        self._host_full = None
+        self._pos0_t = None
+        self.host_ms = {}                # wall time of the host-side steps of the last block / set-up
+        self.repartitions = 0
+
+    # -- set-up (once per topology) ---------------------------------------------------------------------------------------------
+    def mesh_changed(self):
+        """the host mesh was edited (remesh, surgery, positions set by hand): partition and upload again before the next block"""
+        self.last_partition = None
 
     def _hip_executor(self, local_mesh, local_points):
         from .mesh_conj_grad import ShrinkwrapMeshConjGrad, NativeContext
@@ -439,50 +471,153 @@ class HaloScene(object):
             import torch
             self.native = NativeContext(torch.cuda.current_device(), self.torch_stream.cuda_stream if self.torch_stream is not None else None)
         self.native.mesh_key = None
-        cg = ShrinkwrapMeshConjGrad(local_mesh, local_points, native=self.native)
-        return HipExecutor(cg)
+        cg = ShrinkwrapMeshConjGrad(local_mesh, local_points, native=self.native)       # (the localizations stay resident: same array object)
+        prof = getattr(self, '_profiling', None)
+        if prof is not None:
+            cg.set_profiling(prof)
+        ex = HipExecutor(cg)
+        ex.write_back = False
+        return ex
 
-    def search(self, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
+    def _stream(self):
         import contextlib
+        if self.torch_stream is None:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.torch_stream)
+
+    def _setup(self):
+        import time
+        t0 = time.perf_counter()
         mesh = self.mesh
-        nbr = mesh._halfedges['vertex'][mesh._vertices['neighbors']]
-        nbr[mesh._vertices['neighbors'] == -1] = -1
-        part = HaloPartition(mesh._vertices['position'], mesh.vertex_normals, nbr, mesh.faces, self.points, self.world, self.halo)
+        if self._tiles is None:
+            self._tiles = bisect_tiles(self.points, self.world)
+            self._local_points = np.ascontiguousarray(self.points[self._tiles[0][self.rank]])
+        if hasattr(mesh, 'neighbor_vertex_table'):
+            nbr = mesh.neighbor_vertex_table()
+        else:
+            nbr = mesh._halfedges['vertex'][mesh._vertices['neighbors']]
+            nbr[mesh._vertices['neighbors'] == -1] = -1
+        pos = np.ascontiguousarray(mesh._vertices['position'], np.float32)
+        nrm = np.ascontiguousarray(mesh.vertex_normals, np.float32)
+        part = HaloPartition(pos, nrm, nbr, mesh.faces, self.points, self.world, self.halo, tiles=self._tiles)
         self.last_partition = part
         d = part.ranks[self.rank]
         gv = d['gv']
-        local = ArrayMesh(mesh._vertices['position'][gv], np.asarray(mesh.vertex_normals)[gv], d['nbr'], d['faces'], d['valid'])
-        pidx = d['pidx']
-        lp = np.ascontiguousarray(self.points[pidx])
+        self._gv = gv
+        self._local_mesh = ArrayMesh(pos[gv], nrm[gv], d['nbr'], d['faces'], d['valid'])
+        old = self.ex
+        keep = {k: getattr(old, k) for k in ('collective_timer', '_prenorm_cache') if old is not None and hasattr(old, k)}
+        self.ex = (self.make_executor or self._hip_executor)(self._local_mesh, self._local_points)
+        for k, v in keep.items():
+            setattr(self.ex, k, v)
+        if old is not None and hasattr(old, 'cg') and hasattr(self.ex, 'cg') and hasattr(old.cg, 'stage_ms_total') and getattr(self, '_profiling', None):
+            self.ex.cg.stage_ms_total = old.cg.stage_ms_total          # HIP-event totals run on across a re-partition (bench.py reads them at the end)
+        self.ex.set_boundary(d['b_local'], d['b_slot'], part.boundary.size, d['owned'], gv, part.M)
+        self._pos0 = pos.copy()                       # where the mesh was when the shares were cut (drift budget of the halo)
+        self._pos0_t = None
+        self._valid = mesh._vertices['halfedge'] != -1
+        self._all_valid = bool(self._valid.all())
+        self.repartitions += 1
+        self.host_ms['setup'] = (time.perf_counter() - t0) * 1e3
 
-        def take3(a):
-            if a is None or np.isscalar(a):
-                return a
-            return np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1, 3)[pidx].ravel())
-        ex = (self.make_executor or self._hip_executor)(local, lp)
-        ex.set_boundary(d['b_local'], d['b_slot'], part.boundary.size, d['owned'])
+    def _local(self, a):
+        """this rank's rows of a per-localization (3N,) array -- the SAME object for the same input, so that the residency keys of the
+        optimiser (and the weight normalisation cache of run_search) hold from block to block"""
+        if a is None or np.isscalar(a):
+            return a
+        hit = self._local_arrays.get(id(a))
+        if hit is None or hit[0] is not a:
+            pidx = self._tiles[0][self.rank]
+            hit = (a, np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1, 3)[pidx].ravel()))
+            if len(self._local_arrays) >= 4:
+                self._local_arrays.clear()
+            self._local_arrays[id(a)] = hit
+        return hit[1]
+
+    def _to_host(self, t):
+        """(3M,) float32 tensor -> (M,3) array on the host; a device tensor goes through one pinned buffer, the copy is only ENQUEUED
+        (the caller synchronises once for everything it reads back)"""
+        if getattr(t, 'is_cuda', False):
+            import torch
+            if self._host_full is None or self._host_full.numel() != t.numel():
+                self._host_full = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+            self._host_full.copy_(t, non_blocking=True)
+            return self._host_full.numpy().reshape(-1, 3)
+        return t.numpy().reshape(-1, 3)
+
+    # -- one block ----------------------------------------------------------------------------------------------------------------
+    def search(self, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
+        import time
+        import torch
+        if self.last_partition is None:
+            self._setup()
+        ex, mesh = self.ex, self.mesh
         if type(lams) is float or np.isscalar(lams):
             lams = [float(lams)]
-        ctx = contextlib.nullcontext()
-        if self.torch_stream is not None:
-            import torch
-            ctx = torch.cuda.stream(self.torch_stream)
-        with ctx:
-            out = run_search(ex, self.dist, 'halo', lp, lams, num_iters, take3(sigma_inv), take3(weights), pos, last_step)
-            # exactness of the sharded nearest-face query: no localization further than the halo from its nearest centroid
-            worst = ex.new_tensor([float(getattr(ex, 'max_dist', 0.0))])
-            self.dist.all_reduce(worst, op=self.dist.ReduceOp.MAX)
-            if float(worst[0]) > self.halo:
-                raise RuntimeError("halo mode: a localization is %.3g from its nearest face centroid, beyond the halo radius %.3g: "
-                                   "the sharded query is not guaranteed exact (increase `halo`)" % (float(worst[0]), self.halo))
-            # owners return their rows; one all-reduce per BLOCK gives every rank the whole new mesh
-            full = np.zeros((part.M, 3), np.float64)
-            own = d['owned'].astype(bool)
-            full[gv[own]] = np.asarray(out, np.float64)[own]
-            t = ex.new_tensor(full.ravel())
-            self.dist.all_reduce(t)
-        newpos = np.asarray(t.cpu()).reshape(-1, 3).astype(np.float32)
-        valid = mesh._vertices['halfedge'] != -1
-        mesh._vertices['position'][valid] = newpos[valid]
-        self.ex = ex
-        return mesh._vertices['position'].copy()
+        with self._stream():
+            run_search(ex, self.dist, 'halo', self._local_points, lams, num_iters, self._local(sigma_inv), self._local(weights), pos, last_step,
+                       quantum=self._quantum)
+            t0 = time.perf_counter()
+            # ONE all-reduce of the owners' rows (float32, on the device) gives every rank the whole new mesh
+            full = ex.gather_owned('pos')
+            self.dist.all_reduce(full)
+            if self._pos0_t is None or self._pos0_t.device != full.device:
+                self._pos0_t = torch.from_numpy(self._pos0.ravel()).to(full.device)
+            drift2 = (full - self._pos0_t).view(-1, 3).pow(2).sum(1).max()
+            # exactness of the sharded query, and the common quantum of the NEXT block: one small MAX all-reduce per block carries both
+            stats = ex.new_tensor([float(ex.max_dist), ex.local_quantum() if hasattr(ex, 'local_quantum') else 0.0, 0.0])
+            stats[2] = drift2
+            self.dist.all_reduce(stats, op=self.dist.ReduceOp.MAX)
+            newpos = self._to_host(full)
+            worst, q, d2 = stats.tolist()                 # (the one synchronisation of the block's tail: the whole mesh has landed too)
+        t1 = time.perf_counter()
+        self._quantum = q if q > 0 else None
+        drift = float(np.sqrt(max(d2, 0.0)))
+        if worst + drift > self.halo:
+            raise RuntimeError("halo mode: a localization is %.3g from its nearest face centroid and the mesh has moved %.3g since the shares were cut, "
+                               "beyond the halo radius %.3g: the sharded query is not guaranteed exact (increase `halo`)" % (worst, drift, self.halo))
+        if self._all_valid:
+            mesh._vertices['position'][:] = newpos
+        else:
+            mesh._vertices['position'][self._valid] = newpos[self._valid]
+        self.max_dist, self.drift = worst, drift
+        if drift > 0.25 * self.halo:
+            self.last_partition = None                # cut new shares around the moved mesh before the next block
+        out = np.array(newpos)
+        t2 = time.perf_counter()
+        self.host_ms['block_tail_collectives_and_copy'] = (t1 - t0) * 1e3
+        self.host_ms['block_tail_host_mesh'] = (t2 - t1) * 1e3
+        return out
+
+    def refresh_normals(self, to_host=True):
+        """vertex normals of the next block from the current positions, topology unchanged; restarts the optimiser's history (the
+        reference builds a new optimiser per block)"""
+        if self.last_partition is None:               # the shares are about to be cut again from the host mesh: refresh it there
+            self.mesh.update_geometry()
+            return
+        ex = self.ex
+        with self._stream():
+            if hasattr(ex, 'refresh_normals_local'):
+                p = self.mesh._vertices['position']
+                ext = float((p.max(0).astype(np.float64) - p.min(0).astype(np.float64)).max())
+                ex.refresh_normals_local(ext)
+                if ex.n_boundary > 0:
+                    self.dist.all_reduce(ex.boundary_rows())
+                ex.take_normals()
+                if to_host:
+                    t = ex.gather_owned('nrm')
+                    self.dist.all_reduce(t)
+                    nrm = self._to_host(t)
+                    if getattr(t, 'is_cuda', False):
+                        import torch
+                        torch.cuda.current_stream().synchronize()
+                    self.mesh._vertices['normal'][:] = nrm
+            else:                                     # executor without a device refresh (the CPU tests'): host substrate's definition
+                self.mesh.update_geometry()
+                ex.set_normals(np.ascontiguousarray(np.asarray(self.mesh.vertex_normals, np.float32)[self._gv]))
+
+    def set_profiling(self, level):
+        self._profiling = level
+        if self.ex is not None and hasattr(self.ex, 'cg'):
+            self.ex.cg.set_profiling(level)

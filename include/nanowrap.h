@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NW_ABI_VERSION 2
+#define NW_ABI_VERSION 3
 
 typedef struct nw_ctx nw_ctx;
 
@@ -91,7 +91,13 @@ typedef enum nw_array {
     NW_ARR_SCALARS = 11,    /* f64 device-only: normal-equation partial sums of the current iteration (multi-GPU all-reduce), see nw_scalar_stride */
     NW_ARR_NBR = 12,        /* (M, NB) i32  1-ring vertex ids, -1 padded (as given to, or built by, nw_set_mesh)          */
     NW_ARR_NRM = 13,        /* (M, 3)  f32  vertex normals in use (nw_set_mesh / nw_set_normals / nw_refresh_normals)     */
-    NW_ARR_VALID = 14       /* (M,)    u8   valid flags (only when given to, or built by, nw_set_mesh)                   */
+    NW_ARR_VALID = 14,      /* (M,)    u8   valid flags (only when given to, or built by, nw_set_mesh)                   */
+    NW_ARR_HALO_ACC = 15,   /* (n_slots, 4) i64  device-only, sharded mesh: this rank's accumulator rows of the boundary vertices, one row per
+                               entry of the GLOBAL boundary list (zero where the rank does not hold the vertex): all-reduce(sum) between
+                               nw_iter_attract and nw_iter_directions (nw_set_boundary) */
+    NW_ARR_HALO_ROWS = 16,  /* (n_slots, 3) f32  device-only: rows of the boundary vertices this rank OWNS (new positions after nw_iter_update;
+                               normals after nw_halo_pack(NW_ARR_NRM)), zero elsewhere: all-reduce(sum) = the owner's row on every rank */
+    NW_ARR_HALO_FULL = 17   /* (M_global, 3) f32 device-only: nw_halo_gather_owned -- the owners' rows of the whole mesh */
 } nw_array;
 
 #define NW_N_SCALARS 32
@@ -179,6 +185,28 @@ int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride
  * another rank.  The vertex-side normal-equation sums (S^T S, S.prefs, |prefs|^2) then run over the owned vertices only, so that the
  * all-reduce over ranks counts every vertex once.  NULL = every vertex is owned (default).  Reset by nw_set_mesh. */
 int nw_set_owned(nw_ctx *ctx, const uint8_t *owned);
+/* Sharded mesh, complete form (SURVEY.md section 8e "all-reduce on the boundary-vertex rows only"; no reference counterpart -- the reference is
+ * one process, conj_grad.py:202-219 solves ONE system for the whole mesh, which the all-reduced sums reproduce).  b_local[n_local] = local ids
+ * of the vertices this rank holds that are held by another rank as well; b_slot[n_local] = their rows in the global boundary list of n_slots
+ * entries (the same list on every rank); owned[M] as nw_set_owned; gv[M] = global id of every local vertex, n_global = vertices of the whole
+ * mesh.  After this call the split-phase iteration fills / takes the exchange buffers itself and the caller only all-reduces them:
+ *   nw_iter_attract -> all-reduce NW_ARR_HALO_ACC (int64 sum) -> nw_iter_directions -> all-reduce NW_ARR_SCALARS -> nw_iter_update ->
+ *   all-reduce NW_ARR_HALO_ROWS (f32 sum of owner-only rows); the next nw_iter_attract / nw_search_end takes the owners' positions.
+ * nw_search refuses a mesh with shared vertices.  n_slots < 0 clears the sharding; nw_set_mesh clears it too. */
+int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t *b_slot, int64_t n_local, int64_t n_slots, const uint8_t *owned,
+                    const int32_t *gv, int64_t n_global);
+/* the exchange buffers by hand: what = NW_ARR_VACC (-> / <- NW_ARR_HALO_ACC), NW_ARR_POS or NW_ARR_NRM (owner-only rows -> / <- NW_ARR_HALO_ROWS;
+ * positions are taken into NW_ARR_POS and NW_ARR_MESHPOS).  Needed by a caller only for the vertex normals after nw_refresh_normals (a rank
+ * does not hold every face of the vertices at the rim of its share: the owner's normal is the mesh's, _membrane_mesh.pyx:1524-1527). */
+int nw_halo_pack(nw_ctx *ctx, int what);
+int nw_halo_unpack(nw_ctx *ctx, int what);
+/* NW_ARR_HALO_FULL <- the rows (what = NW_ARR_POS or NW_ARR_NRM) of the vertices this rank owns at their global ids, zero elsewhere: one
+ * all-reduce(sum) per BLOCK gives every rank the whole mesh (the positions search() returns, mesh_conj_grad.py:288-292) */
+int nw_halo_gather_owned(nw_ctx *ctx, int what);
+/* extent (largest bounding-box edge) of the WHOLE mesh, for a rank that holds a share of it: nw_refresh_normals takes the quantum of its
+ * fixed-point normal sums from it instead of from the share's own box, so every holder of a vertex rounds its sum the same way and the
+ * normals are bit-identical to a single-process run.  ext <= 0: back to the local box. */
+int nw_set_extent_hint(nw_ctx *ctx, double ext);
 
 /* registers the strided vertex records (mesh._vertices['position'] rows, `row_stride_bytes` apart) that nw_search / nw_search_end
  * fill together with `pos_out` at the end of every search (valid vertices only, mesh_conj_grad.py:288-289); NULL switches it off */
@@ -213,14 +241,14 @@ int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, co
 
 /* device timing of the last nw_search (ms), split by stage; for bench.py's roofline object.
  * stage: 0 total, 1 grid build, 2 NN query, 3 attraction (weights/residual/scatter), 4 prior+directions,
- * 5 A.S + dots, 6 solve+update, 7 float64 NN fix-up.  nw_set_profiling level: 0 off; 1 = HIP events around the NN query only (the dominant kernel;
- * each event pair costs a few microseconds of stream serialisation); 2 = around every stage; 3 = sampled: nw_search keeps replaying
- * the block as a hipGraph (levels 1 and 2 launch every kernel from the host: events inside graph nodes read 0 on ROCm 7.2) and brackets
- * only the NN query of the block's FIRST iteration, launched directly between the two halves of the graph.  (Measured caveat: in a
- * process that has also loaded PyTorch, about one block in twenty at level 3 waits 5-6 ms between its last kernel and the copies that
- * follow; the other levels do not show it.)  4 = like 1, but only the NN query of each block's first iteration is bracketed: that
- * iteration is launched from the host, the rest of the block is one replayed hipGraph, and the event pairs -- each costs the stream a few
- * microseconds -- come once per block (what bench.py times at). */
+ * 5 A.S + dots, 6 solve+update, 7 float64 NN fix-up (separate launch only with NW_FUSE_FIXUP=0).  nw_set_profiling level: 0 off (nw_search replays
+ * each block as a hipGraph); 1 = HIP events around every NN query launch (the dominant kernel; each event pair costs a few microseconds of
+ * stream serialisation); 2 = around every stage -- levels 1 and 2 launch every kernel from the host, because events inside graph nodes read
+ * 0 on ROCm 7.2; 4 = only the NN query of each block's FIRST iteration is bracketed: that iteration is launched from the host, the rest
+ * of the block is one replayed hipGraph, and the event pairs come once per block (what bench.py times at).
+ * Level 3 (ABI 2: the block as two half graphs around a directly launched query) is gone and returns NW_ERR_BADARG: in a process that
+ * also runs PyTorch's HIP runtime threads about one block in twenty waited 5-6 ms between its last kernel and the copies queued behind
+ * the second graph; level 4 gives the same one-sample-per-block without a second graph launch in the block. */
 int nw_set_profiling(nw_ctx *ctx, int enable);
 int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
 
@@ -230,7 +258,9 @@ int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
 int nw_optimize_layout(nw_ctx *ctx);
 
 /* quantum of NW_ARR_VACC's xyz columns (a power of two).  *q > 0 on entry fixes it for all later searches -- ranks that all-reduce
- * NW_ARR_VACC must agree on it (all-reduce MAX of their own values); on return *q is the quantum the next nw_search_begin uses. */
+ * NW_ARR_VACC must agree on it (all-reduce MAX of their own LOCAL values); *q < 0 drops the override, *q == 0 only asks.  On return *q is
+ * the quantum this ctx would choose by itself (recomputed by every nw_search_begin from its localizations, weights and scene extent), NOT
+ * the override: ranks all-reduce it again for every block. */
 int nw_accumulator_quantum(nw_ctx *ctx, double *q);
 
 /* developer aid, no reference counterpart: counters of the exact nearest-face query accumulated since the previous call (the first

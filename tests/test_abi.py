@@ -23,7 +23,7 @@ def test_library_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), 'libnanowrap_hip.so does not export %s' % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.load().nw_abi_version() == 2
+    assert _lib.load().nw_abi_version() == 3
     assert _lib.load().nw_n_point_scalars() == 13
 
 

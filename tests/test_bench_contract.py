@@ -9,8 +9,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, timeout=600):
+def _run(args, timeout=600, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):           # the parent of an N-rank run is started plainly
+        env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=timeout, universal_newlines=True)
     return p
@@ -23,6 +26,44 @@ def test_help_parses_without_a_gpu():
         assert flag in p.stdout
 
 
+def test_plain_python_with_gpus_2_starts_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus N` as the driver invokes it (no torchrun): the parent starts N ranks of itself.  Without a GPU every rank
+    refuses loudly (there is no CPU fallback) -- the parent must come back promptly with that failure, not hang and not pretend."""
+    p = _run(['--gpus', '2', '--steps', '5', '--warmup', '5', '--scale', '0.05'], timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: the ranks would run (covered by the gpu tests)')
+    assert p.returncode != 0
+    assert 'needs an MI355X' in p.stderr and 'rank' in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith('{')]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('mode', ['tiles', 'halo'])
+def test_two_ranks_started_by_plain_python_print_one_json_line(mode):
+    """The N > 1 entry point on hardware, as the driver runs it: `python3 bench.py --gpus 2 ...` starts its two ranks itself; on this
+    one-GPU box they share cuda:0 and gloo carries the collectives (NW_BENCH_BACKEND=gloo; RCCL refuses duplicate devices).  Both
+    decompositions: 'tiles' (one vesicle per rank, weak scaling) and 'halo' (ONE mesh sharded over the ranks, strong scaling)."""
+    p = _run(['--gpus', '2', '--steps', '10', '--warmup', '5', '--scale', '0.05', '--mode', mode], timeout=800, extra_env={'NW_BENCH_BACKEND': 'gloo'})
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 10 and j['warmup'] == 5 and j['warmup_executed'] == 10
+    assert j['scaling'] == ('strong' if mode == 'halo' else 'weak') and j['config']['mode'] == mode
+    assert j['rccl']['backend'] == 'gloo' and j['rccl']['world_size_seen'] == 2 and len(j['rccl']['devices']) == 2
+    c = j['collectives']
+    assert c['per_iter'] == (3 if mode == 'halo' else 1) and 0 < c['share_of_device_time'] < 1
+    assert j['value'] > 0 and j['roofline']['launches'] == 2
+    if mode == 'halo':
+        h = j['halo']
+        assert h['boundary_vertices'] > 0 and h['max_nn_distance_nm'] + h['drift_since_partition_nm'] <= h['radius_nm']
+        assert j['config']['vertices_per_gpu'] < j['config']['localizations_per_gpu']       # a share, not the whole mesh
+        # one mesh: value counts its vertices once
+        assert abs(j['value'] - float(j['config']['workload'].split(' vertices')[0].split(', ')[-1]) * 1e3 / j['ms_per_step']) <= 1e-6 * j['value']
+
+
 @pytest.mark.gpu
 def test_one_json_line_with_roofline_and_cpu_baseline():
     p = _run(['--gpus', '1', '--steps', '10', '--warmup', '5', '--scale', '0.05', '--cpu-iters', '2'])
@@ -30,7 +71,7 @@ def test_one_json_line_with_roofline_and_cpu_baseline():
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j['n_gpus'] == 1 and j['steps'] == 10 and j['warmup'] == 5
+    assert j['n_gpus'] == 1 and j['steps'] == 10 and j['warmup'] == 5 and j['warmup_executed'] == 10
     assert j['unit'] == 'vertex-updates/s' and j['higher_is_better'] is True and j['scaling'] == 'weak'
     assert j['data'] == 'synthetic' and j['dtype'] == 'f32' and j['vs_baseline'] is None
     assert 'SCALED' in j['config']['workload']                      # a debug-sized run says so

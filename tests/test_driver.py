@@ -311,3 +311,31 @@ def test_recipe_module_end_to_end_on_the_network():
     assert (cn == 2).all() and mesh.vertices.shape[0] - ue.shape[0] + f.shape[0] == -2
     assert [b['iteration'] for b in mesh.block_log] == list(range(5, 40, 5)) and [b['iteration'] for b in mesh.neck_log] == list(range(10, 40, 5))
     assert mesh.block_log[-1]['mean_length'] < mesh.block_log[0]['mean_length']
+
+
+def test_hook_that_edits_the_records_in_place_reaches_the_next_optimiser(recorder):
+    """A surgery hook (hole puncher, edge cleaner, neck remover, a callable remesher driving PYME) may edit the half-edge / vertex
+    records in place.  The 1-ring vertex table the optimiser uploads (mesh_conj_grad.py:50-54) is cached per topology: every hook must
+    drop it, or the next block's curvature prior works on a stale ring."""
+    tables = []
+
+    class Rec(recorder):
+        def __init__(self, mesh, points, **kw):
+            recorder.__init__(self, mesh, points, **kw)
+            tables.append(mesh.neighbor_vertex_table().copy())
+
+    mm.ShrinkwrapMeshConjGrad = Rec            # (the fixture's monkeypatch restores the module attribute afterwards)
+    m = _mesh(kc=1.0, step_size=20.0, max_iter=10, remesh_frequency=5, delaunay_remesh_frequency=0, remesher=None)
+    victim = 17
+    deg = int((m._vertices['neighbors'][victim] != -1).sum())
+
+    def cleaner(mesh):
+        mesh._vertices['neighbors'][victim, deg - 1] = -1          # in place: the last ring entry of one vertex goes
+
+    m.edge_cleaner = cleaner
+    m.remesh = lambda *a, **k: False                                # topology held otherwise
+    pts = np.zeros((7, 3), 'f4')
+    m.shrink_wrap(pts, np.full((7, 3), 10.0, 'f4'), method='conjugate_gradient', minimum_edge_length=5.0)
+    assert len(tables) == 2
+    assert tables[0][victim, deg - 1] >= 0 and tables[1][victim, deg - 1] == -1
+    assert np.array_equal(np.delete(tables[0], victim, 0), np.delete(tables[1], victim, 0))

@@ -127,6 +127,31 @@ def test_zero_iterations_and_argument_errors():
         cg2.search(bad, lams=[5.0], num_iters=1, sigma_inv=0.1)
 
 
+def test_nan_inside_an_iteration_raises_and_leaves_the_mesh_at_the_last_good_iterate():
+    """A NaN that only shows up inside the iteration (a non-finite sigma_inv entry: the localizations themselves are fine, so the upload
+    passes): the reference asserts at mesh_conj_grad.py:548 BEFORE `self.f[:] = fnew` (:288) -- AssertionError, and the mesh keeps the
+    positions it had.  The device-side status is raised by the attraction kernel; the update of that iteration must not run and the
+    caller's mesh must not receive a NaN-tainted step."""
+    from ch_shrinkwrap_amd.trimesh import TriMesh, icosphere
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    from ch_shrinkwrap_amd.synth import sphere_cloud
+    v, f = icosphere(3, 60.0)
+    pts = sphere_cloud(4000, 50.0, 5.0, seed=5)
+    mesh = TriMesh(v, f)
+    cg = ShrinkwrapMeshConjGrad(mesh, pts)
+    good = 1.0 / np.full(pts.size, 5.0, 'f4')
+    out = cg.search(pts, lams=[7.0], num_iters=2, sigma_inv=good).copy()
+    bad = good.copy()
+    bad[3 * 1234 + 1] = np.nan
+    with pytest.raises(AssertionError):
+        cg.search(pts, lams=[7.0], num_iters=3, sigma_inv=bad)
+    assert np.isfinite(mesh._vertices['position']).all()
+    assert np.array_equal(mesh._vertices['position'], out)          # the last good iterate: nothing of the failed block was written
+    # the ctx stays usable
+    out2 = cg.search(pts, lams=[7.0], num_iters=1, sigma_inv=good)
+    assert np.isfinite(out2).all() and not np.array_equal(out2, out)
+
+
 def test_singular_subspace_raises_linalgerror():
     """All residual weights are zero -> A-side matrices vanish; with lambda = 0 the 2x2 system is exactly singular and
     numpy.linalg.solve raises LinAlgError in the reference (conj_grad.py:219)."""

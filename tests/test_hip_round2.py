@@ -193,21 +193,23 @@ def test_host_edit_between_two_fits_reaches_the_device():
     assert rel_rms(b, m1.vertices) <= 1e-6
 
 
-def test_profiling_levels_do_not_change_the_result_and_sampled_keeps_the_graph():
-    """Four identical fits (6 blocks of 5) with profiling off (blocks replayed as hipGraphs), with every query launch
-    bracketed (every kernel launched from the host), with every stage bracketed, and 'sampled' (level 3: two half-block graphs around
-    one directly launched, event-bracketed query per block; the next block pre-recorded by optimize_layout): bit-identical positions;
-    levels 3 and 4 (4: the block's first iteration launched directly with its query bracketed, the rest of the block one graph -- what
-    bench.py times at) yield one sample per block, level 1
-    one per iteration."""
+def test_profiling_levels_do_not_change_the_result():
+    """Identical fits (6 blocks of 5) with profiling off (blocks replayed as hipGraphs), with every query launch bracketed (every
+    kernel launched from the host), with every stage bracketed, and at level 4 (the block's first iteration launched directly with its
+    query bracketed, the rest of the block one replayed graph, the next block pre-recorded by optimize_layout -- what bench.py times
+    at): bit-identical positions; level 4 yields one sample per block, level 1 one per iteration.  Level 3 of ABI 2 (two half-block
+    graphs around a directly launched query) is gone: it is refused."""
     TriMesh, CG = _imports()
     from ch_shrinkwrap_amd import synth
     c = synth.make_config('c3', scale=0.05, seed=9)
     pts, s = c['points'], 1.0 / c['sigma'].ravel()
     results = {}
-    for level in (0, 1, 2, 3, 4):
+    for level in (0, 1, 2, 4):
         mesh = TriMesh(c['vertices'].copy(), c['faces'])
         cg = CG(mesh, pts)
+        if level == 0:
+            with pytest.raises(ValueError):
+                cg.set_profiling(3)
         cg.set_profiling(level)
         samples = 0
         for block in range(6):
@@ -218,9 +220,9 @@ def test_profiling_levels_do_not_change_the_result_and_sampled_keeps_the_graph()
         if level:
             ms, samples = cg.stage_ms_total['nn']
             assert ms > 0
-            assert samples == (4 if level in (3, 4) else 20), (level, samples)      # blocks 2..5 since the last set_profiling
+            assert samples == (4 if level == 4 else 20), (level, samples)      # blocks 2..5 since the last set_profiling
         results[level] = out.copy()
-    for level in (1, 2, 3, 4):
+    for level in (1, 2, 4):
         assert np.array_equal(results[0], results[level]), 'profiling level %d changed the result' % level
 
 

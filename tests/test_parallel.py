@@ -38,37 +38,59 @@ class OracleExecutor(object):
         self.own3 = np.ones(3 * self.M, bool)
         self.max_dist = 0.0
 
-    # -- 'halo' mode hooks (same contract as parallel.HipExecutor) ----------------------------------------------------
-    def set_boundary(self, b_local, b_slot, n_boundary, owned_local):
+    # -- 'halo' mode hooks (same contract as parallel.HipExecutor: the phases pack / take the boundary rows themselves) ---------------
+    n_boundary = 0
+
+    def set_boundary(self, b_local, b_slot, n_boundary, owned_local, gv, n_global):
         self.b_local, self.b_slot, self.n_boundary = np.asarray(b_local), torch.from_numpy(np.asarray(b_slot)), int(n_boundary)
         self.own3 = np.repeat(np.asarray(owned_local, bool), 3)
-        self.b_owned = np.asarray(owned_local, bool)[self.b_local]
+        self.owned = np.asarray(owned_local, bool)
+        self.b_owned = self.owned[self.b_local]
+        self.gv, self.n_global = np.asarray(gv), int(n_global)
+        self.halo = True
 
-    def pack_boundary_accumulator(self):
-        buf = torch.zeros((self.n_boundary, 4), dtype=torch.float32)
-        buf[self.b_slot] = self.vacc.view(-1, 4)[self.b_local]
-        return buf
+    def boundary_accumulator(self):
+        return self.buf_acc
 
-    def unpack_boundary_accumulator(self, buf):
-        self.vacc.view(-1, 4)[self.b_local] = buf[self.b_slot]
+    def boundary_rows(self):
+        return self.buf_rows
 
-    def pack_owned_boundary_positions(self):
-        buf = torch.zeros((self.n_boundary, 3), dtype=torch.float32)
+    def _pack_acc(self):
+        self.buf_acc = torch.zeros((self.n_boundary, 4), dtype=torch.float32)
+        self.buf_acc[self.b_slot] = self.vacc.view(-1, 4)[self.b_local]
+
+    def _take_acc(self):
+        self.vacc.view(-1, 4)[self.b_local] = self.buf_acc[self.b_slot]
+
+    def _pack_rows(self):
+        self.buf_rows = torch.zeros((self.n_boundary, 3), dtype=torch.float32)
         rows = self.f.reshape(-1, 3)[self.b_local] * self.b_owned[:, None]
-        buf[self.b_slot] = torch.from_numpy(rows.astype('f4'))
-        return buf
+        self.buf_rows[self.b_slot] = torch.from_numpy(rows.astype('f4'))
+        self.rows_pending = True
 
-    def unpack_boundary_positions(self, buf):
-        f = self.f.reshape(-1, 3)
-        f[self.b_local] = buf[self.b_slot].numpy()
-        self.f = f.ravel()
-        self.cur = self.f.reshape(-1, 3).copy()
+    def _take_rows(self):
+        if getattr(self, 'rows_pending', False):
+            f = self.f.reshape(-1, 3)
+            f[self.b_local] = self.buf_rows[self.b_slot].numpy()
+            self.f = f.ravel()
+            self.rows_pending = False
+
+    def gather_owned(self, what='pos'):
+        assert what == 'pos'
+        full = torch.zeros((self.n_global, 3), dtype=torch.float32)
+        full[torch.from_numpy(self.gv[self.owned])] = torch.from_numpy(self.f.reshape(-1, 3)[self.owned].astype('f4'))
+        return full.view(-1)
+
+    def set_normals(self, nrm):
+        self.nrm = nrm
+        self.pos0 = self.f.reshape(-1, 3).copy()             # a new optimiser starts from the mesh's positions
 
     def new_tensor(self, values):
         return torch.tensor(values, dtype=torch.float64)
 
     def begin(self, data, lams, num_iters, sigma_inv, weights, prenormalized, pos, last_step):
         self.lam = float(lams[0])
+        self.max_dist = 0.0                                  # per block, like the device-side maximum of the logs
         self.f = self.pos0.copy().ravel()
         self.S = np.zeros((3 * self.M, 3), 'f4')
         self.it = 0
@@ -80,10 +102,14 @@ class OracleExecutor(object):
     def attract(self):
         from oracle import nanowrap_oracle as O
         p = self.points
+        if getattr(self, 'halo', False):
+            self._take_rows()
         self.sc.zero_()
         self.vacc.zero_()
         if p.shape[0] == 0:
             self.wm = None
+            if getattr(self, 'halo', False):
+                self._pack_acc()
             return
         v_idx, w, dmean, _ = O.weight_matrix(self.f.reshape(-1, 3), self.faces, p)
         Af = O.apply_A(self.f, v_idx, w, p)
@@ -98,12 +124,16 @@ class OracleExecutor(object):
         self.vacc += torch.from_numpy(va.ravel())
         r2 = float((res.astype('f8') ** 2).sum())
         self.sc[0], self.sc[1], self.sc[2], self.sc[3] = r2, r2, float(dmean.sum()), float(p.shape[0])
+        if getattr(self, 'halo', False):
+            self._pack_acc()
 
     def vertex_accumulator(self):
         return self.vacc
 
     def directions(self):
         from oracle import nanowrap_oracle as O
+        if getattr(self, 'halo', False):
+            self._take_acc()
         va = self.vacc.numpy().reshape(self.M, 4)
         sw = va[:, 3]
         pi = np.sqrt((sw * sw + sw * sw) + sw * sw)
@@ -152,8 +182,13 @@ class OracleExecutor(object):
         self.S[:, 2] = fnew - self.f
         self.f = fnew
         self.it += 1
+        if getattr(self, 'halo', False):
+            self._pack_rows()
 
     def end(self):
+        if getattr(self, 'halo', False):
+            self._take_rows()
+        self.pos0 = self.f.reshape(-1, 3).copy()             # the mesh's positions: where the next search() starts (mesh_conj_grad.py:170)
         return self.f.reshape(-1, 3).copy()
 
 
@@ -200,8 +235,12 @@ def _worker(rank, world, port, mode, q):
                 nb = lm._halfedges['vertex'][lm._vertices['neighbors']]
                 nb[lm._vertices['neighbors'] == -1] = -1
                 return OracleExecutor(lm.vertices.copy(), lm.vertex_normals.copy(), np.ascontiguousarray(nb, np.int32), lm.faces, local_points)
-            scene = parallel.HaloScene(mesh, pts, dist, halo=35.0, make_executor=make)
-            out = scene.search([7.0], 4, 1.0 / sigma.ravel())
+            scene = parallel.HaloScene(mesh, pts, dist, halo=40.0, make_executor=make)
+            s_inv = 1.0 / sigma.ravel()
+            scene.search([7.0], 4, s_inv)
+            scene.refresh_normals()                           # second block on the RESIDENT shares: new normals, same partition
+            out = scene.search([7.0], 3, s_inv)
+            assert scene.repartitions == 1
             part = scene.last_partition
             q.put((rank, (out, part.boundary.size, [int(d['nV']) for d in part.ranks], [int(d['owned'].sum()) for d in part.ranks])))
             return
@@ -267,6 +306,9 @@ def test_halo_sharded_mesh_gloo():
     (v, f, pts, sigma), = _scene(False)
     mesh = TriMesh(v, f)
     ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, [7.0], 4, 1.0 / sigma.ravel())
+    mesh._vertices['position'][:] = ref.positions.astype('f4')
+    mesh.update_geometry()
+    ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, [7.0], 3, 1.0 / sigma.ravel())
     (out0, nb, nV, nown), (out1, _, _, _) = res[0], res[1]
     assert np.array_equal(out0, out1)                             # every rank ends with the same whole mesh
     assert rel_rms(out0, ref.positions) <= 1e-5
@@ -375,10 +417,13 @@ def _gpu_worker(rank, world, port, mode, q):
         else:
             (v, f, pts, sigma), = _scene(False)
             mesh = TriMesh(v, f)
-            scene = parallel.HaloScene(mesh, pts, dist, halo=35.0, torch_stream=ts)
-            out = scene.search([7.0], 4, 1.0 / sigma.ravel())
-            mesh.update_geometry()
-            out = scene.search([7.0], 3, 1.0 / sigma.ravel())
+            scene = parallel.HaloScene(mesh, pts, dist, halo=40.0, torch_stream=ts)
+            s_inv = 1.0 / sigma.ravel()
+            out = scene.search([7.0], 4, s_inv)
+            scene.refresh_normals()                           # on the device: shares stay resident, owners' normals go round
+            out = scene.search([7.0], 3, s_inv)
+            assert scene.repartitions == 1
+            assert np.array_equal(out, mesh._vertices['position'])
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -416,8 +461,8 @@ def test_hip_executor_two_ranks_share_one_gpu(mode):
     cg = ShrinkwrapMeshConjGrad(mesh, P)
     cg.search(P, lams=[7.0], num_iters=4, sigma_inv=1.0 / S.ravel())
     if mode == 'halo':
-        mesh.update_geometry()
-        cg = ShrinkwrapMeshConjGrad(mesh, P)             # a new optimiser per block, as the sharded run builds one
+        cg.refresh_normals()                             # the single-process form of the same block boundary, on the device
+        cg = ShrinkwrapMeshConjGrad(mesh, P, native=cg._native, reuse_device_mesh=True)      # a new optimiser per block
     ref = cg.search(P, lams=[7.0], num_iters=3, sigma_inv=1.0 / S.ravel())
     rms = rel_rms(got, ref)
     print('HIP executor, 2 ranks on one GPU, mode %s: vertex RMS vs single-process nw_search %.3e' % (mode, rms))
