@@ -1469,6 +1469,7 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
         // clear the sticky device status so the ctx stays usable; report it once
         const int code = st.status;
         NwDevState st2 = st; st2.status = 0;
+        st2.stop_at = 0x7fffffff;                           // (the failure cancelled the rest of its block, not the searches that follow)
         (void)hipMemcpy(ctx->state.p, &st2, sizeof(st2), hipMemcpyHostToDevice);
         if (code == NW_ERR_NAN) return fail(ctx, NW_ERR_NAN, "NaN detected in weight matrix / A f / A^T r (reference asserts at mesh_conj_grad.py:514,548,580)");
         if (code == NW_ERR_SINGULAR) return fail(ctx, NW_ERR_SINGULAR, "singular subspace normal equations (numpy.linalg.solve would raise LinAlgError)");

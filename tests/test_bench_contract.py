@@ -55,7 +55,7 @@ def test_two_ranks_started_by_plain_python_print_one_json_line(mode):
     assert j['rccl']['backend'] == 'gloo' and j['rccl']['world_size_seen'] == 2 and len(j['rccl']['devices']) == 2
     c = j['collectives']
     assert c['per_iter'] == (3 if mode == 'halo' else 1) and 0 < c['share_of_device_time'] < 1
-    assert j['value'] > 0 and j['roofline']['launches'] == 2
+    assert j['value'] > 0 and j['roofline']['launches'] >= 2
     if mode == 'halo':
         h = j['halo']
         assert h['boundary_vertices'] > 0 and h['max_nn_distance_nm'] + h['drift_since_partition_nm'] <= h['radius_nm']
