@@ -23,7 +23,7 @@ SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set
            'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_refresh_normals', 'nw_reset_history', 'nw_search', 'nw_search_begin',
            'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
            'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_debug_items', 'nw_set_data', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned',
-           'nw_set_boundary', 'nw_halo_pack', 'nw_halo_unpack', 'nw_halo_gather_owned', 'nw_set_extent_hint']
+           'nw_set_boundary', 'nw_halo_pack', 'nw_halo_unpack', 'nw_halo_gather_owned', 'nw_set_extent_hint', 'nw_host_copy_rows']
 
 
 class IterLog(ctypes.Structure):
@@ -80,6 +80,7 @@ def load():
     L.nw_halo_unpack.argtypes = [vp, i32]
     L.nw_halo_gather_owned.argtypes = [vp, i32]
     L.nw_set_extent_hint.argtypes = [vp, ctypes.c_double]
+    L.nw_host_copy_rows.argtypes = [vp, vp, i64, vp, vp, i64, vp]
     L.nw_set_data.argtypes = [vp, vp]
     L.nw_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     L.nw_lfunc.argtypes = [vp, i32, vp, vp, vp]

@@ -175,6 +175,8 @@ struct nw_ctx {
     bool item_cost_valid = false;     // a warm query has filled item_cost for the current list
     int nitems = 0;
     int item_level = -1;              // Morton level (block edge = morton_unit * 2^level) the items were cut at
+    // the walk's result kept from one query to the next (k_nn_wave): per item the runs of cells within its lanes' recorded radii
+    DevBuf<unsigned> nn_rows;         // [nitems][NW_ROW_WORDS]: runs recorded (0: no list), the lanes' recorded radii, the runs (nw_nn.h)
     // scratch of the block-boundary / diagnostic entry points (nw_curvature, nw_lfunc): kept, so that a call per block does not
     // allocate and free tens of megabytes
     DevBuf<int> aux_i;
@@ -335,6 +337,16 @@ double desired_cell(const nw_ctx *ctx, double mean_dist, double spacing)
     return std::max(h, 0.5 * mean_dist) * ctx->cell_tune;      // far starts: cells of at least half the mean distance; then the tuner's factor
 }
 
+// the recorded walks (nn_list) name cells of the CURRENT lattice and belong to the CURRENT work list: a new grid, a new list or a new
+// order of the localizations drops them (the next warm query walks and records again)
+int reset_nn_lists(nw_ctx *ctx)
+{
+    if (ctx->nitems <= 0) return NW_OK;
+    NW_HIP(ctx->nn_rows.ensure((size_t)ctx->nitems * NW_ROW_WORDS));
+    NW_HIP(hipMemsetAsync(ctx->nn_rows.p, 0, (size_t)ctx->nitems * NW_ROW_WORDS * sizeof(unsigned), ctx->stream));
+    return NW_OK;
+}
+
 // ---- work list of the NN query ---------------------------------------------------------------------------
 // Items = runs of <= 64 consecutive localizations of the Morton-sorted list that stay inside one aligned Morton block of edge
 // morton_unit * 2^level (about four cells): a dense block is cut into equal runs, a sparse one is a single under-filled wave.
@@ -452,6 +464,7 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     int level = (int)std::lround(std::log2(std::max(block_cells * h / (double)ctx->morton_unit, 1.0)));
     level = std::min(std::max(level, 0), 10);
     NW_TRY(build_items(ctx, level));
+    NW_TRY(reset_nn_lists(ctx));
     ctx->grid_valid = true;
     if (getenv("NW_VERBOSE"))
         fprintf(stderr, "[nanowrap] grid %dx%dx%d h=%.3f (mean_dist %.3f, spacing %.3f) items=%d\n", g.gx, g.gy, g.gz, g.h, mean_dist, spacing, ctx->nitems);
@@ -561,7 +574,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pts_in.release(); ctx->sinv_in.release(); ctx->w_in.release(); ctx->wsum.release();
     ctx->pts.release(); ctx->perm.release(); ctx->mkey.release(); ctx->proj_key.release(); ctx->proj_idx.release(); ctx->sinv.release(); ctx->wnorm.release(); ctx->mask.release();
-    ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
+    ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_rows.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->owned.release(); ctx->d_small.release();
     ctx->hb_local.release(); ctx->hb_slot.release(); ctx->hb_slot2local.release(); ctx->hb_gv.release(); ctx->halo_acc.release(); ctx->halo_rows.release(); ctx->halo_full.release();
@@ -1175,6 +1188,7 @@ static int order_items_by_cost(nw_ctx *ctx)
     NW_HIP(hipStreamSynchronize(ctx->stream));
     ctx->nitems = m;
     ctx->items_by_cost = true;
+    NW_TRY(reset_nn_lists(ctx));
     if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] work list: heavy items first%s: %d -> %d items\n", split ? ", heavy items cut" : "", n, m);
     return NW_OK;
 }
@@ -1197,7 +1211,8 @@ NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
             hipLaunchKernelGGL(k_set_iter_base, dim3(1), dim3(1), 0, ctx->stream, ctx->state.p, ctx->global_iter);
             const int prof = ctx->profiling;
             ctx->profiling = 0;
-            const int rq = launch_query(ctx, 0);
+            int rq = launch_query(ctx, 0);                  // (walks and records its cell lists ...
+            if (rq == NW_OK) rq = launch_query(ctx, 0);     //  ... and this one, the steady state, is what the items are timed in)
             ctx->profiling = prof;
             if (rq != NW_OK) return rq;
         }
@@ -1287,17 +1302,21 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
         StageScope s(ctx, ST_NN, it == 0);
         static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;   // 0 slabs, 1 round-robin, 2 interleaved runs (default)
         static const bool no_outliers = getenv("NW_NO_OUTLIERS") != nullptr;      // developer knob
+        // the walk's result is kept between queries (NW_NN_CACHE=0: walk every time); NW_NN_MARGIN = the slack of a recorded radius in cells
+        static const bool nn_cache = !(getenv("NW_NN_CACHE") && atoi(getenv("NW_NN_CACHE")) == 0);
+        static const float nn_margin = getenv("NW_NN_MARGIN") ? (float)atof(getenv("NW_NN_MARGIN")) : 0.12f;
+        static const float nn_shrink = getenv("NW_NN_SHRINK") ? (float)atof(getenv("NW_NN_SHRINK")) : 0.8f;      // a list is made anew once most balls are below this share of their recorded size
         static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
         const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;   // one wave = one work item
         const int nbp = nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
 if (ctx->nn_stats.p) {
-            hipLaunchKernelGGL(k_nn_wave<true>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, ctx->items_by_cost ? nullptr : ctx->item_cost.p);
+            hipLaunchKernelGGL(k_nn_wave<true>, dim3(nbp), dim3(tb), wpb * sizeof(NwWaveLds), ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (nn_cache ? 32 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
+                           ctx->state.p, it, ctx->nn_stats.p, ctx->items_by_cost ? nullptr : ctx->item_cost.p, ctx->nn_rows.p, nn_margin, nn_shrink);
         } else {
-            hipLaunchKernelGGL(k_nn_wave<false>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, ctx->items_by_cost ? nullptr : ctx->item_cost.p);
+            hipLaunchKernelGGL(k_nn_wave<false>, dim3(nbp), dim3(tb), wpb * sizeof(NwWaveLds), ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (nn_cache ? 32 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
+                           ctx->state.p, it, ctx->nn_stats.p, ctx->items_by_cost ? nullptr : ctx->item_cost.p, ctx->nn_rows.p, nn_margin, nn_shrink);
         }
         if (ctx->face_warm && !ctx->items_by_cost) ctx->item_cost_valid = true;      // (a cold query's costs say little about the warm ones)
         ctx->face_warm = true;
@@ -1496,7 +1515,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
-                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p};
+                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p, ctx->nn_rows.p};
     for (const void *p : ptrs) mixp(p);
     return h;
 }
@@ -1785,6 +1804,39 @@ NW_EXPORT int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t 
     return write_back_impl(ctx, contiguous, rows, row_stride_bytes);
 }
 
+// The host half of that write-back on its own, with the library's copy threads: `src` (n_rows x 3 float32 on the HOST, e.g. the pinned
+// buffer a sharded run's whole-mesh all-reduce landed in) -> `contiguous` (may be NULL) and / or the strided vertex records `rows`
+// (only where valid[v] != 0 if `valid` is given).  No device work.
+NW_EXPORT int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *contiguous, void *rows, int64_t row_stride_bytes, const uint8_t *valid)
+{
+    if (!ctx || !src || n_rows < 0) return NW_ERR_BADARG;
+    if (rows && row_stride_bytes < 12) return fail(ctx, NW_ERR_BADARG, "nw_host_copy_rows: bad stride");
+    if (!ctx->pool) {
+        int T = 8;
+        if (const char *e = getenv("NW_HOST_THREADS")) T = atoi(e);
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && T > hw) T = hw;
+        ctx->pool = new NwHostPool();
+        ctx->pool->start(T, ctx->device);
+        ctx->wb_events.resize(ctx->pool->n);
+        for (auto &e : ctx->wb_events) NW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, n_rows / 25000));
+    auto work = [&](int t) {
+        if (t >= T) return;
+        const int64_t v0 = n_rows * t / T, v1 = n_rows * (t + 1) / T;
+        if (contiguous) memcpy(contiguous + 3 * v0, src + 3 * v0, (size_t)(v1 - v0) * 12);
+        if (rows) {
+            char *dst = (char *)rows;
+            for (int64_t v = v0; v < v1; ++v)
+                if (!valid || valid[v]) memcpy(dst + v * row_stride_bytes, src + 3 * v, 12);
+        }
+    };
+    if (T == 1) work(0);
+    else ctx->pool->run(work);
+    return NW_OK;
+}
+
 // Strided target that nw_search / nw_search_end fill together with `pos_out` (mesh._vertices['position'] rows of the caller's
 // vertex records, valid vertices only: mesh_conj_grad.py:288-289).  rows = NULL switches it off.  The pointer must stay valid
 // until it is replaced.
@@ -1901,16 +1953,20 @@ NW_EXPORT int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out)
 {
     if (!ctx || !out) return NW_ERR_BADARG;
     if (!ctx->nn_stats.p) {
-        NW_HIP(ctx->nn_stats.ensure(NWS_COUNT));
-        NW_HIP(hipMemset(ctx->nn_stats.p, 0, NWS_COUNT * sizeof(unsigned long long)));
+        NW_HIP(ctx->nn_stats.ensure((size_t)NWS_COUNT * NWS_COPIES));
+        NW_HIP(hipMemset(ctx->nn_stats.p, 0, (size_t)NWS_COUNT * NWS_COPIES * sizeof(unsigned long long)));
         for (int k = 0; k <= NWS_COUNT; ++k) out[k] = 0;
         return NW_OK;
     }
-    unsigned long long h[NWS_COUNT];
+    std::vector<unsigned long long> h((size_t)NWS_COUNT * NWS_COPIES);
     NW_HIP(hipStreamSynchronize(ctx->stream));
-    NW_HIP(hipMemcpy(h, ctx->nn_stats.p, sizeof(h), hipMemcpyDeviceToHost));
-    NW_HIP(hipMemset(ctx->nn_stats.p, 0, sizeof(h)));
-    for (int k = 0; k < NWS_COUNT; ++k) out[k] = (int64_t)h[k];
+    NW_HIP(hipMemcpy(h.data(), ctx->nn_stats.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    NW_HIP(hipMemset(ctx->nn_stats.p, 0, h.size() * sizeof(unsigned long long)));
+    for (int k = 0; k < NWS_COUNT; ++k) {
+        unsigned long long v = 0;
+        for (int c = 0; c < NWS_COPIES; ++c) v = (k == NWS_T_WAVE_MAX) ? std::max(v, h[(size_t)c * NWS_COUNT + k]) : v + h[(size_t)c * NWS_COUNT + k];
+        out[k] = (int64_t)v;
+    }
     out[NWS_COUNT] = ctx->nitems;
     return NW_OK;
 }

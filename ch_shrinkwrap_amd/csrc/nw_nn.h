@@ -225,7 +225,8 @@ __device__ __forceinline__ int nw_wave_max_i(int v)
 }
 
 // developer counters of one launch (nw_debug_nn_stats): candidates evaluated, rows listed / visited, cells tested / visited, ...
-enum { NWS_CAND = 0, NWS_ROWS_NONEMPTY, NWS_ROWS_PASS, NWS_CELLS_TESTED, NWS_CELLS_PASS, NWS_BOX_ROWS, NWS_ROUNDS, NWS_T_WAVE_MAX, NWS_T_STREAM, NWS_T_WAVE, NWS_COUNT };   // T_*: s_memtime ticks / 16
+enum { NWS_CAND = 0, NWS_ROWS_NONEMPTY, NWS_ROWS_PASS, NWS_CELLS_TESTED, NWS_CELLS_PASS, NWS_BOX_ROWS, NWS_ROUNDS, NWS_T_WAVE_MAX, NWS_T_STREAM, NWS_T_WAVE, NWS_CACHED, NWS_FAIL_WAVES, NWS_FAIL_LANES, NWS_FAIL_SMALL, NWS_SHRUNK, NWS_T_PRO, NWS_T_REC, NWS_T_TAIL, NWS_RUNS, NWS_COUNT };   // T_*: s_memtime ticks / 16; CACHED: waves that took their kept list
+#define NWS_COPIES 1024
 struct NwStats { int v[NWS_COUNT]; bool timed; };
 
 // Best / runner-up are kept as integer KEYS: the float32 bits of d^2 (non-negative, so they order like unsigned integers)
@@ -289,11 +290,18 @@ __device__ __forceinline__ float nw_slab_d(float a, float b, float kf)
 // ---- wave-private LDS: the list of candidate ranges collected by the walk, and one batch of 64 staged candidates ---------
 #define NW_XCD_RUN 16         // consecutive workgroups of the work list per XCD turn (interleaved-runs mapping)
 #define NW_SEG 8             // cells per row segment (one lane fetches the 9 cell starts of a segment)
-#define NW_RNG_MAX 48        // ranges collected before they are streamed
+#define NW_RNG_MAX 64        // ranges collected before they are streamed (= one page of a kept list: one lane per range)
+#define NW_LIST_CAP 256      // cell runs a wave may keep from one query to the next = rows of cells its box may have (a longer list is not kept)
+// one row of the kept walks per work item (unsigned words): [0] runs recorded (0: no list, ~0: too long to keep), [1] margin level,
+// [4 .. 68) the squared culling radius (cell units, float bits) each lane's share of the list is good for,
+// [68 .. 68 + NW_LIST_CAP) the runs {first cell | (cells - 1) << 25}: one run of consecutive cells per (y,z) row of the lattice
+#define NW_ROW_RAD 4
+#define NW_ROW_RUNS 68
+#define NW_ROW_WORDS (NW_ROW_RUNS + NW_LIST_CAP)
 struct NwWaveLds {
     float4 cand[64];                 // one batch of candidates: lane i stages candidate i, every lane then reads them all (broadcast)
-    int rs[NW_RNG_MAX];              // first slot of range r
-    int pre[NW_RNG_MAX + 1];         // candidates before range r (pre[nr] = total)
+    int rs[NW_LIST_CAP];             // first slot of range r (the walk flushes at NW_RNG_MAX ranges; a kept list brings up to NW_LIST_CAP)
+    int pre[NW_LIST_CAP + 1];        // candidates before range r (pre[nr] = total)
 };
 
 // LDS traffic inside ONE wave is in program order; this only stops the compiler from moving accesses across the point
@@ -304,12 +312,13 @@ __device__ __forceinline__ void nw_wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// lane -> slot of the g-th candidate of the collected list (binary search in the prefix counts; nr <= 48 < 64: six steps)
+// lane -> slot of the g-th candidate of the collected list (binary search in the prefix counts; STEPS = 6 for nr <= 64, 8 for nr <= 256)
+template <int STEPS>
 __device__ __forceinline__ int nw_list_slot(const NwWaveLds *W, int nr, int g)
 {
     int lo = 0, hi = nr;                      // invariant: pre[lo] <= g < pre[hi]
 #pragma unroll
-    for (int step = 0; step < 6; ++step) {
+    for (int step = 0; step < STEPS; ++step) {
         const int mid = (lo + hi) >> 1;
         const bool right = W->pre[mid] <= g;
         lo = right ? mid : lo;
@@ -320,7 +329,7 @@ __device__ __forceinline__ int nw_list_slot(const NwWaveLds *W, int nr, int g)
 
 // Stream the collected ranges: 64 candidates per batch are fetched by the 64 lanes (one coalesced-ish global load each), staged in
 // LDS and evaluated by every lane against its localization; the fetch of batch b+1 is in flight while batch b is evaluated.
-template <bool STATS>
+template <bool STATS, int STEPS = 6>
 __device__ __forceinline__ void nw_stream(NwLane &L, NwWaveLds *W, const float4 *__restrict__ cent, int nr, int total, int lane, NwStats &S,
                                           float Ox, float Oy, float Oz, float K)
 {
@@ -331,14 +340,14 @@ __device__ __forceinline__ void nw_stream(NwLane &L, NwWaveLds *W, const float4 
     nw_wave_lds_sync();
     // lanes past the end of the list stage a far-away dummy (the last group of four of a batch is evaluated whole)
     const float4 far = make_float4(0.0f, 0.0f, 0.0f, 1e30f);
-    float4 C = nw_expand(cent[nw_list_slot(W, nr, min(lane, total - 1))], Ox, Oy, Oz, K);
+    float4 C = nw_expand(cent[nw_list_slot<STEPS>(W, nr, min(lane, total - 1))], Ox, Oy, Oz, K);
     if (lane >= total) C = far;
     for (int g0 = 0; g0 < total; g0 += 64) {
         W->cand[lane] = C;
         nw_wave_lds_sync();
         const int gn = g0 + 64 + lane;
         if (g0 + 64 < total) {                                                            // next batch: in flight during the evaluation
-            C = nw_expand(cent[nw_list_slot(W, nr, min(gn, total - 1))], Ox, Oy, Oz, K);
+            C = nw_expand(cent[nw_list_slot<STEPS>(W, nr, min(gn, total - 1))], Ox, Oy, Oz, K);
             if (gn >= total) C = far;
         }
         const int cnt = min(64, total - g0);
@@ -354,7 +363,7 @@ __device__ __forceinline__ void nw_stream(NwLane &L, NwWaveLds *W, const float4 
         nw_wave_lds_sync();                   // all reads of this batch precede the next staging write
     }
     // lanes whose best changed: position in the list -> slot in the centroid array (the list is about to be reused)
-    if (L.bgi >= 0) L.bslot = nw_list_slot(W, nr, L.bgi + (int)(L.b1 & 15u));
+    if (L.bgi >= 0) L.bslot = nw_list_slot<STEPS>(W, nr, L.bgi + (int)(L.b1 & 15u));
     L.bgi = -1;
     nw_wave_lds_sync();
     if (STATS) S.v[NWS_T_STREAM] += (int)((__builtin_amdgcn_s_memtime() - t_in) >> 4);
@@ -451,10 +460,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                  const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,
                                                  int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
                                                  NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats,
-                                                 unsigned *__restrict__ item_cost)
+                                                 unsigned *__restrict__ item_cost, unsigned *__restrict__ nn_rows, float margin_u, float shrink)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
-    __shared__ NwWaveLds s_wave[4];
+    extern __shared__ float4 s_dyn[];                    // one NwWaveLds per wave of the workgroup (sized by the launch)
     NwStats S;
 #pragma unroll
     for (int k = 0; k < NWS_COUNT; ++k) S.v[k] = 0;
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     else wb = nw_xcd_remap(blockIdx.x, nwb);
     const int wi = __builtin_amdgcn_readfirstlane(wb * wpb + (int)(threadIdx.x >> 6));
     if (wi < 0 || wi >= nitems) return;
-    NwWaveLds *W = &s_wave[threadIdx.x >> 6];
+    NwWaveLds *W = reinterpret_cast<NwWaveLds *>(s_dyn) + (threadIdx.x >> 6);
     const NwItem item = items[wi];
     const bool active = lane < item.n;
     const int gi = item.p0 + (active ? lane : 0);                        // idle lanes shadow lane 0 (they never write)
@@ -555,7 +564,126 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const int cx = nw_clampi((int)floorf(L.ux), 0, g.gx - 1), cy = nw_clampi((int)floorf(L.uy), 0, g.gy - 1), cz = nw_clampi((int)floorf(L.uz), 0, g.gz - 1);
     int Exl = 0, Exh = -1, Eyl = 0, Eyh = -1, Ezl = 0, Ezh = -1;         // visited box (cells), empty
     int margin = 1, rounds = 0;
-    for (;;) {
+    // ---- the walk's result kept from one query to the next (warm & 32) ---------------------------------------------------------------
+    // Which cells a wave has to look at is geometry: the lattice is fixed in space (the centroids are re-filed in it every iteration)
+    // and the localizations never move, so "every cell within R_i of localization i" is the same set tomorrow.  The item's row of
+    // nn_rows holds such a set: runs of cells {first cell, count} around radii R_i = (today's warm radius + a margin), recorded by a
+    // purely geometric walk (every cell of the box is tested, occupied or not: an empty cell may hold a centroid tomorrow; no cell table,
+    // no candidates).  A warm query whose lanes' radii all lie within their recorded ones takes the list as it is -- two cell-table reads
+    // per run -- and streams today's centroids of those cells: a superset of what its own walk would collect, so the result is the same
+    // exact argmin.  One lane beyond its recorded radius (or not in the walk when the list was made) and the wave records a new list
+    // first -- with twice the margin (up to 8 x margin_u: a wave over a part of the surface that is still moving learns to leave room;
+    // the level falls again when a list is re-made because the balls have SHRUNK, below).  A list longer than NW_LIST_CAP runs is not
+    // kept (marker in the row): that wave walks the ordinary way, like every wave of a cold query.
+    if (STATS) S.v[NWS_T_PRO] += (int)((__builtin_amdgcn_s_memtime() - t_wave) >> 4);
+    int nlist = 0;                                                                   // > 0: runs of this wave's list, staged in W->runs
+    if ((warm & 33) == 33 && !__any(wact && !(L.b1 < NW_KEY_INF))) {
+        unsigned *__restrict__ row = nn_rows + (size_t)wi * NW_ROW_WORDS;
+        const unsigned hdr = row[0];
+        int level = (int)row[1];
+        const float rnow = wact ? sqrtf(nw_best_d2(L) * cullk) : -1.0f;              // today's culling radius, cell units (idle and outlier lanes reach nothing)
+        bool valid = false, grew = false;
+        if (hdr > 0u && hdr <= (unsigned)NW_LIST_CAP) {
+            const float r2now = fmaf(rnow, rnow, epsu), Rc2 = __uint_as_float(row[NW_ROW_RAD + lane]);
+            const unsigned long long fails = __ballot(wact && !(r2now <= Rc2));
+            valid = fails == 0ull;
+            grew = !valid;
+            if (STATS && !valid) { const int nf = __popcll(fails); S.v[NWS_FAIL_WAVES] += 1; S.v[NWS_FAIL_LANES] += nf; S.v[NWS_FAIL_SMALL] += nf <= 3 ? 1 : 0; }
+            // a list made for much larger balls (the fit has moved the surface towards the localizations since) still holds every cell it
+            // must, and many it need not: once most lanes' balls -- with the margin a new list would get -- are below `shrink` of their
+            // recorded size, a new list pays for itself
+            if (valid) {
+                const float rm = rnow + margin_u * (float)(1 << max(level - 1, 0));
+                if (2 * __popcll(__ballot(wact && fmaf(rm, rm, epsu) < shrink * Rc2)) > __popcll(__ballot(wact))) { valid = false; if (STATS) S.v[NWS_SHRUNK] += 1; }
+            }
+        }
+        if (valid) {
+            if (STATS) S.v[NWS_CACHED] += 1;
+            nlist = (int)hdr;
+#pragma unroll
+            for (int k = 0; k < NW_LIST_CAP; k += 64) if (k + lane < nlist) W->rs[k + lane] = (int)row[NW_ROW_RUNS + k + lane];
+            nw_wave_lds_sync();
+        } else if (hdr != 0xffffffffu) {
+            // Geometric walk, lane = one (y,z) ROW of the box of the lanes' balls of radius rnow + margin: the lane goes through the wave's
+            // localizations (staged in LDS: broadcast reads) and takes, for every ball that reaches its row's (y,z) square, the cells of
+            // the row inside the ball's chord -- exactly the cells the ordinary walk's box-distance test passes for that ball; the hull
+            // of the chords is the row's run.  Nothing here depends on the cell table or on where the centroids are today.
+            const unsigned long long t_rec = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+            level = grew ? min(level + 1, 3) : max(level - 1, 0);
+            const float rr = wact ? rnow + margin_u * (float)(1 << level) : -1.0f;
+            const float r2u = wact ? fmaf(rr, rr, epsu) : -1.0f;
+            const float ru = fminf(rr + 2.0f * epsu + 1e-3f, 4096.0f);
+            const int Nxl = nw_clampi(nw_wave_min_i(wact ? (int)floorf(L.ux - ru) : 0x7fffffff), 0, g.gx - 1), Nxh = nw_clampi(nw_wave_max_i(wact ? (int)floorf(L.ux + ru) : -0x7fffffff), 0, g.gx - 1);
+            const int Nyl = nw_clampi(nw_wave_min_i(wact ? (int)floorf(L.uy - ru) : 0x7fffffff), 0, g.gy - 1), Nyh = nw_clampi(nw_wave_max_i(wact ? (int)floorf(L.uy + ru) : -0x7fffffff), 0, g.gy - 1);
+            const int Nzl = nw_clampi(nw_wave_min_i(wact ? (int)floorf(L.uz - ru) : 0x7fffffff), 0, g.gz - 1), Nzh = nw_clampi(nw_wave_max_i(wact ? (int)floorf(L.uz + ru) : -0x7fffffff), 0, g.gz - 1);
+            const int ny = Nyh - Nyl + 1, nrows = ny * (Nzh - Nzl + 1);
+            if (STATS) { S.v[NWS_BOX_ROWS] += nrows; S.v[NWS_ROUNDS] += 1; }
+            int nrec = 0;
+            const bool fits = nrows <= NW_LIST_CAP && Nxh - Nxl < 128;
+            if (fits) {
+                W->cand[lane] = make_float4(L.ux, L.uy, L.uz, r2u);                  // (r2u < 0: the lane reaches nothing)
+                nw_wave_lds_sync();
+                const float inv_ny = 1.0f / (float)ny;
+                for (int rb = 0; rb < nrows; rb += 64) {
+                    const int r = rb + lane;
+                    const int rz = (int)(((float)r + 0.5f) * inv_ny);                // exact r / ny for the small ints involved
+                    const float yf = (float)(Nyl + (r - rz * ny)), zf = (float)(Nzl + rz);
+                    float xlo = 1e9f, xhi = -1e9f;
+#pragma unroll 4
+                    for (int j = 0; j < 64; ++j) {
+                        const float4 q = W->cand[j];
+                        const float dy = fmaxf(fmaxf(yf - (q.y + epsu), (q.y - 1.0f - epsu) - yf), 0.0f);
+                        const float dz = fmaxf(fmaxf(zf - (q.z + epsu), (q.z - 1.0f - epsu) - zf), 0.0f);
+                        const float rem = q.w - fmaf(dz, dz, dy * dy);                // >= 0: the ball reaches the row; a cell x passes iff max(x - a, b - x, 0)^2 <= rem
+                        const float sx = sqrtf(fmaxf(rem, 0.0f)) * (1.0f + 1e-6f) + 1e-4f;
+                        const bool hit = rem >= 0.0f && q.w >= 0.0f;
+                        xlo = hit ? fminf(xlo, q.x - 1.0f - epsu - sx) : xlo;           // x >= b - s
+                        xhi = hit ? fmaxf(xhi, q.x + epsu + sx) : xhi;                  // x <= a + s
+                    }
+                    const int x0 = max((int)ceilf(xlo), Nxl), x1 = min((int)floorf(xhi), Nxh);
+                    const bool have = r < nrows && xhi >= xlo && x1 >= x0;
+                    const unsigned long long m = __ballot(have);
+                    if (have) {
+                        const int e = nrec + __popcll(m & ((1ull << lane) - 1ull));
+                        const unsigned pk = (unsigned)(x0 + g.gx * ((int)yf + g.gy * (int)zf)) | ((unsigned)(x1 - x0) << 25);
+                        W->rs[e] = (int)pk;
+                        row[NW_ROW_RUNS + e] = pk;
+                    }
+                    nrec += __popcll(m);
+                    if (STATS) { S.v[NWS_ROWS_PASS] += __popcll(m); }
+                }
+            }
+            nlist = fits ? nrec : 0;
+            if (lane == 0) { row[0] = fits ? (unsigned)nrec : 0xffffffffu; row[1] = (unsigned)level; }
+            row[NW_ROW_RAD + lane] = __float_as_uint(r2u);                           // (-1: the lane is not in the walk)
+            nw_wave_lds_sync();
+            if (STATS) S.v[NWS_T_REC] += (int)((__builtin_amdgcn_s_memtime() - t_rec) >> 4);
+        }
+    }
+    if (STATS) S.v[NWS_RUNS] += nlist;
+    if (nlist > 0) {
+        // ---- stream the centroids filed in the list's cells today: the runs' slot ranges from the cell table (two reads per run), their
+        // prefix counts, and ONE pass of the candidate stream over all of them
+        int pk[NW_LIST_CAP / 64], len[NW_LIST_CAP / 64];
+#pragma unroll
+        for (int k = 0; k < NW_LIST_CAP / 64; ++k) pk[k] = (64 * k + lane < nlist) ? W->rs[64 * k + lane] : 0;
+        nw_wave_lds_sync();                                                          // (every lane has its runs before the slots overwrite them)
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < NW_LIST_CAP / 64; ++k) {
+            if (64 * k < nlist) {
+                const bool have = 64 * k + lane < nlist;
+                const int cell0 = pk[k] & 0x1ffffff, nc = (int)((unsigned)pk[k] >> 25) + 1;
+                const int c0 = have ? cstart[cell0] : 0, c1 = have ? cstart[cell0 + nc] : 0;
+                len[k] = c1 - c0;
+                const int inc = nw_wave_incl_scan(len[k], lane);
+                W->rs[64 * k + lane] = c0;
+                W->pre[64 * k + lane] = base + inc - len[k];
+                base += __builtin_amdgcn_readlane(inc, 63);
+            }
+        }
+        nw_stream<STATS, 8>(L, W, cent, nlist, base, lane, S, Ox, Oy, Oz, Kb);
+    } else for (;;) {
         // ---- the box this round must cover: the lanes' balls (finite b1) or their own cell +- margin (nothing seen yet)
         const bool seen = L.b1 < NW_KEY_INF;
         const bool any_unseen = __any(wact && !seen);
@@ -655,6 +783,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         Exl = Nxl; Exh = Nxh; Eyl = Nyl; Eyh = Nyh; Ezl = Nzl; Ezh = Nzh;
         if (!any_unseen) break;          // the box was built from every lane's ball and b1 only shrinks: all lanes are final
     }
+    const unsigned long long t_tail = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     {
         // (the item, the lane's localization index and its previous face are re-derived here rather than kept alive across the walk:
         // with them in registers the kernel does not fit the 80 VGPRs of six waves per SIMD and spills 20 bytes per lane)
@@ -691,14 +820,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             if (amb) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
         }
     }
+    if (STATS) S.v[NWS_T_TAIL] += (int)((__builtin_amdgcn_s_memtime() - t_tail) >> 4);
     if (lane == 0 && rounds > 1) atomicMax(&st->nn_max_ring, rounds);
     // how long this item took: the work list is ordered by it once (longest first), so that the launch does not end on its heaviest waves
     if (item_cost && lane == 0) item_cost[wi] = (unsigned)min((unsigned long long)0xffffffffu, (__builtin_amdgcn_s_memtime() - t_wave) >> 4);
     if (STATS && stats && lane == 0) {
         S.v[NWS_ROUNDS] = rounds;
         S.v[NWS_T_WAVE] = (int)((__builtin_amdgcn_s_memtime() - t_wave) >> 4);
+        unsigned long long *mine = stats + (size_t)(wi & (NWS_COPIES - 1)) * NWS_COUNT;      // (one of NWS_COPIES sets: same-address atomics of 17 000 waves took 3 ms)
 #pragma unroll
-        for (int k = 0; k < NWS_COUNT; ++k) atomicAdd(stats + k, (unsigned long long)S.v[k]);
-        atomicMax(stats + NWS_T_WAVE_MAX, (unsigned long long)S.v[NWS_T_WAVE]);
+        for (int k = 0; k < NWS_COUNT; ++k) atomicAdd(mine + k, (unsigned long long)S.v[k]);
+        atomicMax(mine + NWS_T_WAVE_MAX, (unsigned long long)S.v[NWS_T_WAVE]);
     }
 }

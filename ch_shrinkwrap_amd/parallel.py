@@ -138,6 +138,11 @@ class HipExecutor(object):
         self.native.check(self.L.nw_reset_history(self.h))          # a new optimiser per block (_membrane_mesh.pyx:1510)
         self.cg.tests, self.cg.ress, self.cg.prefs = [], [], []
 
+    def host_copy_rows(self, src, contiguous, rows, valid_u8):
+        """(M,3) float32 host array -> a contiguous copy and the strided vertex records, by the library's copy threads"""
+        self.native.check(self.L.nw_host_copy_rows(self.h, nw.ptr(src), src.shape[0], nw.ptr(contiguous), ctypes.c_void_p(rows.ctypes.data), rows.strides[0],
+                                                   nw.ptr(valid_u8)))
+
     def local_quantum(self):
         """the quantum this rank would choose for its own localizations (valid after begin())"""
         q = ctypes.c_double(0.0)
@@ -518,6 +523,7 @@ class HaloScene(object):
         self._pos0_t = None
         self._valid = mesh._vertices['halfedge'] != -1
         self._all_valid = bool(self._valid.all())
+        self._valid_u8 = np.ascontiguousarray(self._valid, np.uint8)
         self.repartitions += 1
         self.host_ms['setup'] = (time.perf_counter() - t0) * 1e3
 
@@ -577,14 +583,19 @@ class HaloScene(object):
         if worst + drift > self.halo:
             raise RuntimeError("halo mode: a localization is %.3g from its nearest face centroid and the mesh has moved %.3g since the shares were cut, "
                                "beyond the halo radius %.3g: the sharded query is not guaranteed exact (increase `halo`)" % (worst, drift, self.halo))
-        if self._all_valid:
-            mesh._vertices['position'][:] = newpos
+        posv = mesh._vertices['position']
+        out = np.empty((newpos.shape[0], 3), np.float32)
+        if hasattr(ex, 'host_copy_rows') and posv.dtype == np.float32 and posv.strides[1] == 4 and posv.strides[0] >= 12:
+            ex.host_copy_rows(newpos, out, posv, None if self._all_valid else self._valid_u8)      # the library's copy threads
         else:
-            mesh._vertices['position'][self._valid] = newpos[self._valid]
+            out[:] = newpos
+            if self._all_valid:
+                posv[:] = newpos
+            else:
+                posv[self._valid] = newpos[self._valid]
         self.max_dist, self.drift = worst, drift
         if drift > 0.25 * self.halo:
             self.last_partition = None                # cut new shares around the moved mesh before the next block
-        out = np.array(newpos)
         t2 = time.perf_counter()
         self.host_ms['block_tail_collectives_and_copy'] = (t1 - t0) * 1e3
         self.host_ms['block_tail_host_mesh'] = (t2 - t1) * 1e3

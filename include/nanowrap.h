@@ -181,6 +181,10 @@ int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes);
  * NULL) and/or into a strided host array of vertex records -- `rows` points at the first record's position field, consecutive
  * records are `row_stride_bytes` apart (120 for PYME's vertex_t) -- touching only the valid vertices (halfedge != -1). */
 int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes);
+/* the host half of that write-back alone (mesh_conj_grad.py:288-289 for a result that is already in host memory -- a sharded run's
+ * whole-mesh all-reduce lands in a pinned buffer): src (n_rows,3) float32 HOST -> `contiguous` and / or the strided records `rows`
+ * (only where valid[v] != 0 if `valid` is given), copied by the library's host threads.  No device work. */
+int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *contiguous, void *rows, int64_t row_stride_bytes, const uint8_t *valid);
 /* Sharded mesh ('halo' mode): owned[M] = 1 for the vertices this rank owns, 0 for the copies of vertices owned by
  * another rank.  The vertex-side normal-equation sums (S^T S, S.prefs, |prefs|^2) then run over the owned vertices only, so that the
  * all-reduce over ranks counts every vertex once.  NULL = every vertex is owned (default).  Reset by nw_set_mesh. */

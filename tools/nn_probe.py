@@ -1,0 +1,44 @@
+"""Developer probe of the nearest-face query on the headline workload: per-iteration query time (HIP events, profiling level 1) and the
+walk / list counters of nw_debug_nn_stats, for a few values of NW_NN_MARGIN / NW_NN_CACHE given in the environment.
+usage: python tools/nn_probe.py [config] [scale] [blocks]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ch_shrinkwrap_amd import synth
+from ch_shrinkwrap_amd.trimesh import TriMesh
+from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'c3'
+scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+c = synth.make_config(name, scale=scale, seed=0)
+pts, s = c['points'], 1.0 / c['sigma'].ravel()
+mesh = TriMesh(c['vertices'].copy(), c['faces'])
+cg = ShrinkwrapMeshConjGrad(mesh, pts)
+cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+cg.optimize_layout()
+cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+cg.set_profiling(1)
+for b in range(blocks):
+    cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+    ms, n = cg.stage_ms_total['nn']
+    cg.set_profiling(1)
+    print('block %d: nn %.1f us/query (production kernel)' % (b, ms / max(n, 1) * 1e3), flush=True)
+cg.nn_stats()
+cg.set_profiling(1)
+for b in range(min(blocks, 3)):
+    cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+    st = cg.nn_stats()
+    ms, n = cg.stage_ms_total['nn']
+    cg.set_profiling(1)
+    items = max(st['items'], 1)
+    print('block %d: nn %.1f us/query | per wave: candidates %.0f, from list %.2f, rows tested %.1f, cells tested %.1f, stream share %.2f' % (
+        b, ms / max(n, 1) * 1e3, st['candidates'] / (5.0 * items), st['waves_from_list'] / (5.0 * items), st['rows_visited'] / (5.0 * items),
+        st['cells_tested'] / (5.0 * items), st['stream_cycles_16'] / max(st['wave_cycles_16'], 1)), flush=True)
+    print('         list dropped: radius grew %.3f of the waves (%.1f lanes each, %.2f of them with <= 3 lanes), balls shrunk %.3f' % (
+        st['fail_waves'] / (5.0 * items), st['fail_lanes'] / max(st['fail_waves'], 1), st['fail_small'] / max(st['fail_waves'], 1), st['shrunk_waves'] / (5.0 * items)), flush=True)
+    wc = max(st['wave_cycles_16'], 1)
+    print('         wave time %.0f ticks16: prologue %.2f, record %.2f, stream %.2f, tail %.2f, rest %.2f; runs per wave %.0f; slowest wave %.0f' % (
+        wc / (5.0 * items), st['prologue_cycles_16'] / wc, st['record_cycles_16'] / wc, st['stream_cycles_16'] / wc, st['tail_cycles_16'] / wc,
+        1.0 - (st['prologue_cycles_16'] + st['record_cycles_16'] + st['stream_cycles_16'] + st['tail_cycles_16']) / wc, st['list_runs'] / (5.0 * items), st['max_wave_cycles_16']), flush=True)
