@@ -175,8 +175,6 @@ struct nw_ctx {
     bool item_cost_valid = false;     // a warm query has filled item_cost for the current list
     int nitems = 0;
     int item_level = -1;              // Morton level (block edge = morton_unit * 2^level) the items were cut at
-    // the walk's result kept from one query to the next (k_nn_wave): per item the runs of cells within its lanes' recorded radii
-    DevBuf<unsigned> nn_rows;         // [nitems][NW_ROW_WORDS]: runs recorded (0: no list), the lanes' recorded radii, the runs (nw_nn.h)
     // scratch of the block-boundary / diagnostic entry points (nw_curvature, nw_lfunc): kept, so that a call per block does not
     // allocate and free tens of megabytes
     DevBuf<int> aux_i;
@@ -337,16 +335,6 @@ double desired_cell(const nw_ctx *ctx, double mean_dist, double spacing)
     return std::max(h, 0.5 * mean_dist) * ctx->cell_tune;      // far starts: cells of at least half the mean distance; then the tuner's factor
 }
 
-// the recorded walks (nn_list) name cells of the CURRENT lattice and belong to the CURRENT work list: a new grid, a new list or a new
-// order of the localizations drops them (the next warm query walks and records again)
-int reset_nn_lists(nw_ctx *ctx)
-{
-    if (ctx->nitems <= 0) return NW_OK;
-    NW_HIP(ctx->nn_rows.ensure((size_t)ctx->nitems * NW_ROW_WORDS));
-    NW_HIP(hipMemsetAsync(ctx->nn_rows.p, 0, (size_t)ctx->nitems * NW_ROW_WORDS * sizeof(unsigned), ctx->stream));
-    return NW_OK;
-}
-
 // ---- work list of the NN query ---------------------------------------------------------------------------
 // Items = runs of <= 64 consecutive localizations of the Morton-sorted list that stay inside one aligned Morton block of edge
 // morton_unit * 2^level (about four cells): a dense block is cut into equal runs, a sparse one is a single under-filled wave.
@@ -379,8 +367,8 @@ int build_items(nw_ctx *ctx, int level)
     NW_HIP(hipStreamSynchronize(ctx->stream));          // the temporaries die with this scope
     ctx->nitems = nitems;
     ctx->item_level = level;
-    NW_HIP(ctx->item_cost.ensure((size_t)nitems));
-    NW_HIP(hipMemsetAsync(ctx->item_cost.p, 0, (size_t)nitems * sizeof(unsigned), ctx->stream));
+    NW_HIP(ctx->item_cost.ensure((size_t)2 * nitems));        // (second half: start times, developer aid NW_ITEM_TIMES)
+    NW_HIP(hipMemsetAsync(ctx->item_cost.p, 0, (size_t)2 * nitems * sizeof(unsigned), ctx->stream));
     ctx->items_by_cost = false; ctx->item_cost_valid = false;
     if (getenv("NW_VERBOSE"))
         fprintf(stderr, "[nanowrap] work list: Morton level %d (block %.2f), %d blocks, %d items (%.1f localizations per wave)\n", level,
@@ -464,7 +452,6 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     int level = (int)std::lround(std::log2(std::max(block_cells * h / (double)ctx->morton_unit, 1.0)));
     level = std::min(std::max(level, 0), 10);
     NW_TRY(build_items(ctx, level));
-    NW_TRY(reset_nn_lists(ctx));
     ctx->grid_valid = true;
     if (getenv("NW_VERBOSE"))
         fprintf(stderr, "[nanowrap] grid %dx%dx%d h=%.3f (mean_dist %.3f, spacing %.3f) items=%d\n", g.gx, g.gy, g.gz, g.h, mean_dist, spacing, ctx->nitems);
@@ -574,7 +561,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pts_in.release(); ctx->sinv_in.release(); ctx->w_in.release(); ctx->wsum.release();
     ctx->pts.release(); ctx->perm.release(); ctx->mkey.release(); ctx->proj_key.release(); ctx->proj_idx.release(); ctx->sinv.release(); ctx->wnorm.release(); ctx->mask.release();
-    ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_rows.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
+    ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->owned.release(); ctx->d_small.release();
     ctx->hb_local.release(); ctx->hb_slot.release(); ctx->hb_slot2local.release(); ctx->hb_gv.release(); ctx->halo_acc.release(); ctx->halo_rows.release(); ctx->halo_full.release();
@@ -1178,17 +1165,29 @@ static int order_items_by_cost(nw_ctx *ctx)
     }
     // heavy pieces first -- but in two classes only, each in the list's own (spatial) order: neighbours in the list share centroid
     // cells, and the XCD mapping of the launch keeps them on one L2 (fully sorted by cost the query fetched 148 MB instead of 64)
-    std::stable_partition(out.begin(), out.end(), [&](const Piece &a) { return a.est > 1.5 * median; });
+    auto mid = std::stable_partition(out.begin(), out.end(), [&](const Piece &a) { return a.est > 1.5 * median; });
+    // ... and the LIGHT ones last: a launch is a few rounds of waves, each wave lives for a quarter of it, and the launch ends one wave's
+    // duration after its last wave started -- measured: every wave has started after two thirds of the launch, the rest is waves running
+    // out on a GPU that is emptying.  With the lightest third of the list at its end that last stretch is a light wave's, not an
+    // average one's.  (Same rule: a class keeps its spatial order.)
+    static const double light_share = getenv("NW_ITEM_LIGHT") ? atof(getenv("NW_ITEM_LIGHT")) : 0.35;
+    if (light_share > 0 && out.end() - mid > 8) {
+        std::vector<double> est;
+        for (auto it = mid; it != out.end(); ++it) est.push_back(it->est);
+        const size_t kth = (size_t)std::min<double>((double)est.size() - 1, light_share * (double)out.size());
+        std::nth_element(est.begin(), est.begin() + kth, est.end());
+        const double cut = est[kth];
+        std::stable_partition(mid, out.end(), [&](const Piece &a) { return a.est >= cut; });
+    }
     const int m = (int)out.size();
     std::vector<NwItem> flat(m);
     for (int i = 0; i < m; ++i) flat[i] = out[i].it;
     NW_HIP(ctx->items.ensure((size_t)m));
     NW_HIP(hipMemcpyAsync(ctx->items.p, flat.data(), (size_t)m * sizeof(NwItem), hipMemcpyHostToDevice, ctx->stream));
-    NW_HIP(ctx->item_cost.ensure((size_t)m));
+    NW_HIP(ctx->item_cost.ensure((size_t)2 * m));
     NW_HIP(hipStreamSynchronize(ctx->stream));
     ctx->nitems = m;
     ctx->items_by_cost = true;
-    NW_TRY(reset_nn_lists(ctx));
     if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] work list: heavy items first%s: %d -> %d items\n", split ? ", heavy items cut" : "", n, m);
     return NW_OK;
 }
@@ -1211,8 +1210,7 @@ NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
             hipLaunchKernelGGL(k_set_iter_base, dim3(1), dim3(1), 0, ctx->stream, ctx->state.p, ctx->global_iter);
             const int prof = ctx->profiling;
             ctx->profiling = 0;
-            int rq = launch_query(ctx, 0);                  // (walks and records its cell lists ...
-            if (rq == NW_OK) rq = launch_query(ctx, 0);     //  ... and this one, the steady state, is what the items are timed in)
+            const int rq = launch_query(ctx, 0);
             ctx->profiling = prof;
             if (rq != NW_OK) return rq;
         }
@@ -1302,21 +1300,18 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
         StageScope s(ctx, ST_NN, it == 0);
         static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;   // 0 slabs, 1 round-robin, 2 interleaved runs (default)
         static const bool no_outliers = getenv("NW_NO_OUTLIERS") != nullptr;      // developer knob
-        // the walk's result is kept between queries (NW_NN_CACHE=0: walk every time); NW_NN_MARGIN = the slack of a recorded radius in cells
-        static const bool nn_cache = !(getenv("NW_NN_CACHE") && atoi(getenv("NW_NN_CACHE")) == 0);
-        static const float nn_margin = getenv("NW_NN_MARGIN") ? (float)atof(getenv("NW_NN_MARGIN")) : 0.12f;
-        static const float nn_shrink = getenv("NW_NN_SHRINK") ? (float)atof(getenv("NW_NN_SHRINK")) : 0.8f;      // a list is made anew once most balls are below this share of their recorded size
+        static const bool item_times = getenv("NW_ITEM_TIMES") != nullptr;        // developer aid: nw_debug_items also returns when every item started
         static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
         const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;   // one wave = one work item
         const int nbp = nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
 if (ctx->nn_stats.p) {
-            hipLaunchKernelGGL(k_nn_wave<true>, dim3(nbp), dim3(tb), wpb * sizeof(NwWaveLds), ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (nn_cache ? 32 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, ctx->items_by_cost ? nullptr : ctx->item_cost.p, ctx->nn_rows.p, nn_margin, nn_shrink);
+            hipLaunchKernelGGL(k_nn_wave<true>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (item_times ? 64 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
+                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p);
         } else {
-            hipLaunchKernelGGL(k_nn_wave<false>, dim3(nbp), dim3(tb), wpb * sizeof(NwWaveLds), ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
-                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (nn_cache ? 32 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, ctx->items_by_cost ? nullptr : ctx->item_cost.p, ctx->nn_rows.p, nn_margin, nn_shrink);
+            hipLaunchKernelGGL(k_nn_wave<false>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+                           ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (item_times ? 64 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
+                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p);
         }
         if (ctx->face_warm && !ctx->items_by_cost) ctx->item_cost_valid = true;      // (a cold query's costs say little about the warm ones)
         ctx->face_warm = true;
@@ -1515,7 +1510,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
-                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p, ctx->nn_rows.p};
+                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p};
     for (const void *p : ptrs) mixp(p);
     return h;
 }
@@ -1943,6 +1938,8 @@ NW_EXPORT int nw_debug_items(nw_ctx *ctx, int32_t *out_items, uint32_t *out_cost
     NW_HIP(hipStreamSynchronize(ctx->stream));
     if (out_items && m > 0) NW_HIP(hipMemcpy(out_items, ctx->items.p, (size_t)m * sizeof(NwItem), hipMemcpyDeviceToHost));
     if (out_cost && m > 0) NW_HIP(hipMemcpy(out_cost, ctx->item_cost.p, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToHost));
+    // with NW_ITEM_TIMES set, out_cost must hold 2 * cap entries: the second `cap` receive the items' start times (s_memtime >> 4)
+    if (out_cost && m > 0 && getenv("NW_ITEM_TIMES")) NW_HIP(hipMemcpy(out_cost + cap, ctx->item_cost.p + ctx->nitems, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToHost));
     return NW_OK;
 }
 

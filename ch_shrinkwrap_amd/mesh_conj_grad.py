@@ -425,11 +425,10 @@ class ShrinkwrapMeshConjGrad(object):
 
     def nn_stats(self):
         """developer counters of the nearest-face query since the previous call (first call: switches them on)"""
-        out = (ctypes.c_int64 * 20)()
+        out = (ctypes.c_int64 * 13)()
         self._native.check(self._L.nw_debug_nn_stats(self._h, out))
         names = ['candidates', 'rows_nonempty', 'rows_visited', 'cells_tested', 'cells_visited', 'box_rows', 'rounds', 'max_wave_cycles_16', 'stream_cycles_16', 'wave_cycles_16',
-                 'waves_from_list', 'fail_waves', 'fail_lanes', 'fail_small', 'shrunk_waves',
-                 'prologue_cycles_16', 'record_cycles_16', 'tail_cycles_16', 'list_runs', 'items']
+                 'prologue_cycles_16', 'tail_cycles_16', 'items']
         return dict(zip(names, [int(v) for v in out]))
 
     def stage_ms(self, only=None):

@@ -268,11 +268,14 @@ int nw_optimize_layout(nw_ctx *ctx);
 int nw_accumulator_quantum(nw_ctx *ctx, double *q);
 
 /* developer aid, no reference counterpart: counters of the exact nearest-face query accumulated since the previous call (the first
- * call switches the counting on).  out[9]: candidate evaluations per wave summed, non-empty rows listed, rows visited, cells
- * tested, cells visited, rows of the boxes, rounds, small runs, work items. */
+ * call switches the counting on; the counting variant of the kernel is a few per cent slower).  out[13]: candidate evaluations per wave
+ * summed, non-empty rows listed, rows visited, cells tested, cells visited, rows of the boxes, rounds, slowest wave, and the waves' time
+ * (s_memtime ticks / 16) in the candidate stream / in all / before the walk / after it; out[12] = work items. */
 int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out);
 /* developer aid: work list of the NN query ({first localization in sorted order, count} per item) and the duration (s_memtime ticks / 16)
- * the last query measured for each item; zeros once the list has been ordered longest-first. */
+ * the last query measured for each item; zeros once the list has been ordered (heavy first, light last).  With NW_ITEM_TIMES set in the
+ * environment the timing stays on, durations are in 10 ns ticks of the clock all XCDs share, and out_cost must hold 2 * cap entries: the
+ * second `cap` receive when each item started -- the launch's time line (tools/nn_costs.py). */
 int nw_debug_items(nw_ctx *ctx, int32_t *out_items, uint32_t *out_cost, int cap, int *n);
 
 #ifdef __cplusplus

@@ -1,5 +1,5 @@
 """Developer probe of the nearest-face query on the headline workload: per-iteration query time (HIP events, profiling level 1) and the
-walk / list counters of nw_debug_nn_stats, for a few values of NW_NN_MARGIN / NW_NN_CACHE given in the environment.
+walk counters and phase shares of nw_debug_nn_stats.
 usage: python tools/nn_probe.py [config] [scale] [blocks]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,12 +33,8 @@ for b in range(min(blocks, 3)):
     ms, n = cg.stage_ms_total['nn']
     cg.set_profiling(1)
     items = max(st['items'], 1)
-    print('block %d: nn %.1f us/query | per wave: candidates %.0f, from list %.2f, rows tested %.1f, cells tested %.1f, stream share %.2f' % (
-        b, ms / max(n, 1) * 1e3, st['candidates'] / (5.0 * items), st['waves_from_list'] / (5.0 * items), st['rows_visited'] / (5.0 * items),
-        st['cells_tested'] / (5.0 * items), st['stream_cycles_16'] / max(st['wave_cycles_16'], 1)), flush=True)
-    print('         list dropped: radius grew %.3f of the waves (%.1f lanes each, %.2f of them with <= 3 lanes), balls shrunk %.3f' % (
-        st['fail_waves'] / (5.0 * items), st['fail_lanes'] / max(st['fail_waves'], 1), st['fail_small'] / max(st['fail_waves'], 1), st['shrunk_waves'] / (5.0 * items)), flush=True)
     wc = max(st['wave_cycles_16'], 1)
-    print('         wave time %.0f ticks16: prologue %.2f, record %.2f, stream %.2f, tail %.2f, rest %.2f; runs per wave %.0f; slowest wave %.0f' % (
-        wc / (5.0 * items), st['prologue_cycles_16'] / wc, st['record_cycles_16'] / wc, st['stream_cycles_16'] / wc, st['tail_cycles_16'] / wc,
-        1.0 - (st['prologue_cycles_16'] + st['record_cycles_16'] + st['stream_cycles_16'] + st['tail_cycles_16']) / wc, st['list_runs'] / (5.0 * items), st['max_wave_cycles_16']), flush=True)
+    print('block %d: nn %.1f us/query (counting kernel) | per wave: candidates %.0f, rows visited %.1f, cells tested %.1f; wave time %.0f ticks16: prologue %.2f, stream %.2f, tail %.2f, walk and the rest %.2f; slowest wave %.0f' % (
+        b, ms / max(n, 1) * 1e3, st['candidates'] / (5.0 * items), st['rows_visited'] / (5.0 * items), st['cells_tested'] / (5.0 * items), wc / (5.0 * items),
+        st['prologue_cycles_16'] / wc, st['stream_cycles_16'] / wc, st['tail_cycles_16'] / wc,
+        1.0 - (st['prologue_cycles_16'] + st['stream_cycles_16'] + st['tail_cycles_16']) / wc, st['max_wave_cycles_16']), flush=True)
