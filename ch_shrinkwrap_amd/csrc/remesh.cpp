@@ -573,9 +573,20 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
         if (!(L > 0)) L = L_in;
         const double high = 4.0 / 3.0 * L, low = 4.0 / 5.0 * L;
         m.all_dirty = n_relax > 0;
-        // splitting towards L multiplies the face count by about (typical edge / L)^2: four times that many splits and something feeds on itself
-        const double growth = std::max(1.0, (L_med / L) * (L_med / L));
-        m.split_cap = (int64_t)(4.0 * growth * (double)n_faces) + 100000;
+        // How many splits the target length can explain: a face with longest edges l1 >= l2 ends up as about (l1 / high + 1)(l2 / high + 1)
+        // pieces -- quadratic for a large isotropic face, linear in its length for a sliver (a star-projected tube has 39 x 1 nm faces and
+        // needs half a million splits at L = 3 nm, which a bound from the MEDIAN edge took for a runaway).  Four times the sum over the
+        // faces per iteration and something feeds on itself; more than 2^26 in all (a vertex flung far away: edges of 10^5 targets)
+        // and the input is refused before any work is done.
+        double pieces = 0.0;
+        for (size_t h = 0; h + 2 < m.vert.size(); h += 3) {
+            double e[3] = {std::sqrt(m.len2((int)h)), std::sqrt(m.len2((int)h + 1)), std::sqrt(m.len2((int)h + 2))};
+            std::sort(e, e + 3);
+            pieces += (e[2] / high + 1.0) * (e[1] / high + 1.0);
+        }
+        if (!(pieces < 67108864.0)) return NWR_ERR_RUNAWAY;
+        m.split_cap = (int64_t)(4.0 * pieces * std::max(n_iterations, 1)) + 100000;
+        (void)L_med;
         for (int it = 0; it < n_iterations; ++it) {
             m.cur_it = it + 1;
             const int64_t ops_before = m.n_split + m.n_collapse + m.n_flip;

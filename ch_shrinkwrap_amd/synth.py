@@ -98,9 +98,15 @@ def sdf_sheet(p, halfwidth, r):
 
 def rotate_z_inverse(p, rz):
     """coordinates of p in the frame of a shape rotated by rz about z (RotationShape with rx = ry = 0, shape.py:446-480)"""
-    c, s = np.cos(rz), np.sin(rz)
-    rinv = np.linalg.inv(np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]]))
-    return p @ rinv.T
+    # p @ inv(R).T = p @ R, written out element by element: a matrix product goes through BLAS, whose threaded kernels round the last
+    # bits differently from host to host (and from run to run on a many-core one) -- the generator has to give the same mesh everywhere
+    c, s = float(np.cos(rz)), float(np.sin(rz))
+    p = np.asarray(p, 'f8')
+    out = np.empty_like(p)
+    out[:, 0] = p[:, 0] * c + p[:, 1] * s
+    out[:, 1] = p[:, 1] * c - p[:, 0] * s
+    out[:, 2] = p[:, 2]
+    return out
 
 
 def sdf_three_way_junction(p, h, r, k=0.0, centroid=(0.0, 0.0, 0.0)):
@@ -299,8 +305,8 @@ def isosurface_mesh(sdf, lo, hi, cell, level=0.0, block=32, lipschitz=1.5, slack
     if project:
         pos0 = pos
         pos = project_to_level(sdf, pos, level, iters=project)
-        # a vertex already sits inside a crossed cell: a projection that carries it further than two cells (or to a non-finite place --
-        # seen once in a few dozen runs on a 256-thread host, where the last bits of the BLAS products vary from run to run) is undone
+        # a vertex already sits inside a crossed cell: a projection that carries it further than two cells (or to a non-finite place:
+        # a Newton step across a crease of the distance field) is undone
         off = np.abs(pos - pos0).max(1)
         bad = ~(off < 2.0 * cell)
         if bad.any():
@@ -385,24 +391,16 @@ def sample_surface(sdf, verts, faces, n, sigma, seed, dtype='f4', iters=4):
 def _c4_start_mesh(sdf, cell):
     """Start mesh of config C4: sparse surface nets at +20 nm, then three passes of the isotropic remesher at the mesh's own mean
     edge length (surface nets leave slivers where neighbouring cell vertices project to almost the same point; the real pipeline
-    remeshes its isosurface as well).  The result is checked -- a remesh at the mean edge length changes the face count by ~20 % --
-    and the construction repeated if it is not sane: on a many-core host the last bits of the threaded BLAS products differ from
-    run to run, and one run in a few dozen came back with a mesh several times too dense."""
+    remeshes its isosurface as well).  Every step is fixed-order arithmetic (no BLAS: rotate_z_inverse), so the mesh is the same
+    on every host; the result is still checked -- a remesh at the mean edge length changes the face count by ~20 %."""
     from . import remesh as _remesh
-    last = None
-    for attempt in range(3):
-        v, f = isosurface_mesh(sdf, (-1500, -1500, -420), (1400, 900, 420), cell, level=20.0, slack=60.0)
-        e = np.concatenate([v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 1]], v[f[:, 0]] - v[f[:, 2]]]).astype('f8')
-        target = float(np.sqrt((e * e).sum(1)).mean())
-        try:
-            v2, f2 = _remesh.remesh(v, f, 3, target, 0.5, 0)
-        except RuntimeError as err:
-            last = str(err)
-            continue
-        if 0.5 * f.shape[0] < f2.shape[0] < 2 * f.shape[0]:
-            return v2, f2
-        last = 'remeshing at the mean edge length %.3f turned %d faces into %d' % (target, f.shape[0], f2.shape[0])
-    raise RuntimeError('synth c4: no sane start mesh in three attempts (%s)' % last)
+    v, f = isosurface_mesh(sdf, (-1500, -1500, -420), (1400, 900, 420), cell, level=20.0, slack=60.0)
+    e = np.concatenate([v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 1]], v[f[:, 0]] - v[f[:, 2]]]).astype('f8')
+    target = float(np.sqrt((e * e).sum(1)).mean())
+    v2, f2 = _remesh.remesh(v, f, 3, target, 0.5, 0)
+    if not 0.5 * f.shape[0] < f2.shape[0] < 2 * f.shape[0]:
+        raise RuntimeError('synth c4: remeshing the start surface at its mean edge length %.3f turned %d faces into %d' % (target, f.shape[0], f2.shape[0]))
+    return v2, f2
 
 
 C5_LATTICE = np.array([1400.0, 900.0, 900.0], 'f4')     # pitch of the 2x2x2 lattice of vesicles in BASELINE configs[4] (nm)
@@ -414,7 +412,8 @@ def make_config(name, scale=1.0, seed=0):
     if name == 'c1':      # sphere R=100, 10k localizations, icosphere nsub=4 at 1.2 R, 20 iterations
         v, f = icosphere(4, 120.0)
         pts = sphere_cloud(10000, 100.0, 10.0, seed)
-        return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=20, block=20)
+        return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=20, block=20,
+                    sdf=lambda p: sdf_sphere(p, 100.0), surface=(icosphere(4, 100.0)[0], f))
     if name == 'c2':      # capped tube r=50, L=1000 along y: 200k localizations, 39 692 vertices, 50 iterations in blocks of 5
         sdf = lambda p: sdf_capsule(p, (0, -500, 0), (0, 500, 0), 50.0)
         freq = max(4, int(round(63 * np.sqrt(scale))))
@@ -422,7 +421,7 @@ def make_config(name, scale=1.0, seed=0):
         v0, f = star_mesh(sdf, freq, level=0.0)
         pts = sample_surface(sdf, v0, f, n, 10.0, seed)
         v, _ = star_mesh(sdf, freq, level=20.0)
-        return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=50, block=5)
+        return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=50, block=5, sdf=sdf, surface=(v0, f))
     if name == 'c3':      # two-lobe vesicle (headline): 1M localizations, 198 812 vertices, remesh_frequency=5 -> blocks of 5
         sdf = sdf_two_lobe
         freq = max(4, int(round(141 * np.sqrt(scale))))
@@ -430,15 +429,15 @@ def make_config(name, scale=1.0, seed=0):
         v0, f = star_mesh(sdf, freq, level=0.0, relax=4)
         pts = sample_surface(sdf, v0, f, n, 10.0, seed)
         v, _ = star_mesh(sdf, freq, level=20.0, relax=4)
-        return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5)
+        return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5, sdf=sdf, surface=(v0, f))
     if name == 'c4':      # ER-like tube/sheet network with a fenestration (ERSim2, twice life size): 5M localizations, ~800k vertices
         sdf = lambda p: 2.0 * sdf_er_sim2(np.asarray(p, 'f8') * 0.5)
         n = int(5000000 * scale)
         cell = 2.96 / np.sqrt(scale)
-        v, f = _c4_start_mesh(sdf, cell)
-        v = project_to_level(sdf, v, 20.0, iters=2).astype('f4')
+        v0, f = _c4_start_mesh(sdf, cell)
+        v = project_to_level(sdf, v0, 20.0, iters=2).astype('f4')
         pts = sample_surface(sdf, v, f, n, 10.0, seed, iters=6)
-        return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5)
+        return dict(points=pts, sigma=np.full(pts.shape, 10.0, 'f4'), vertices=v, faces=f, lams=[10.0], iters=5, block=5, sdf=sdf, surface=(v0, f))
     if name == 'c5':      # BASELINE configs[4] as ONE scene: 8 two-lobe vesicles on a 2x2x2 lattice (the scene 8 ranks share out, tile = vesicle)
         parts = [make_config('c3', scale=scale, seed=seed + k) for k in range(8)]
         nv = parts[0]['vertices'].shape[0]
@@ -449,3 +448,15 @@ def make_config(name, scale=1.0, seed=0):
                     faces=np.concatenate([p['faces'] + k * nv for k, p in enumerate(parts)]).astype(parts[0]['faces'].dtype),
                     lams=[10.0], iters=5, block=5)
     raise ValueError(name)
+
+
+def truth_cloud(cfg, density=0.04, seed=12345):
+    """Points ON the true surface of a configuration (no localization error), `density` per nm^2: what the reference's evaluation recipe
+    compares a fitted mesh with (`PointcloudFromShape(no_jitter=True, p=1.0)`, test_evaluation_recipe.yaml; the sampler itself is PYME's,
+    this is the generator's own: area-weighted samples of the zero-level mesh projected onto the level set)."""
+    v0, f = cfg['surface']
+    v = np.asarray(v0, 'f8')
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    area = float((0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)).sum())
+    n = max(1000, int(area * density))
+    return sample_surface(cfg['sdf'], v0, f, n, 0.0, seed, iters=6)

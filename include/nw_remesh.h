@@ -29,7 +29,7 @@ extern "C" {
 #define NWR_ERR_BADARG (-1)      /* bad sizes / indices, or a non-finite vertex coordinate */
 #define NWR_ERR_NONMANIFOLD (-2) /* an edge is used by more than two faces, or twice in the same direction */
 #define NWR_ERR_NOMEM (-3)
-#define NWR_ERR_RUNAWAY (-4)     /* far more splits than the target length can explain (> 4 (median edge / L)^2 per input face): degenerate input */
+#define NWR_ERR_RUNAWAY (-4)     /* far more splits than the target length can explain (> 4 x the pieces the faces' own edge lengths call for, or > 2^26 of those: a vertex flung far away): degenerate input */
 
 typedef struct nwr_stats {
     int64_t n_split, n_collapse, n_flip; /* operations performed over all iterations */

@@ -91,6 +91,23 @@ def load_shapes():
     return mod
 
 
+def load_evaluation_utils():
+    """The reference's `ch_shrinkwrap.evaluation_utils` (points_from_mesh :35-150, average_squared_distance :153-180).  Its module-level
+    imports pull in the reference's own Cython mesh class (`_membrane_mesh`, not buildable here: it cimports PYME) and `shape`; neither is
+    touched by the two functions the fixtures need, so `_membrane_mesh` gets an empty placeholder like the PYME modules."""
+    load_shapes()
+    import importlib.util
+    if 'ch_shrinkwrap._membrane_mesh' not in sys.modules:
+        sys.modules['ch_shrinkwrap._membrane_mesh'] = types.ModuleType('ch_shrinkwrap._membrane_mesh')
+        import ch_shrinkwrap
+        ch_shrinkwrap._membrane_mesh = sys.modules['ch_shrinkwrap._membrane_mesh']
+    spec = importlib.util.spec_from_file_location('ch_shrinkwrap.evaluation_utils', os.path.join(REF_ROOT, 'evaluation_utils.py'))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules['ch_shrinkwrap.evaluation_utils'] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def new_reference_optimiser(mesh, points, **kw):
     """Construct the reference ShrinkwrapMeshConjGrad against a duck-typed mesh (ch_shrinkwrap_amd.trimesh.TriMesh)
     exactly as `_membrane_mesh.pyx:1510-1512` does, and register it as `mesh.cg` (the mesh's `point_influence`

@@ -324,9 +324,36 @@ def golden_sdf_shapes():
     save('sdf_shapes', **out)
 
 
+def golden_fit_quality():
+    """The reference's fit-quality metric (evaluation_utils.points_from_mesh :35-150 with the recipe's defaults dx_min = 5, p = 1;
+    average_squared_distance :153-180 -> mse01, mse10, mse_rms as recipe_modules/surface_feature_extraction.py:133-138 forms them) on a
+    stretched, shifted icosphere against seeded points near it, and on a coarser grid.  Pins ch_shrinkwrap_amd/evaluation.py."""
+    ev = ref_harness.load_evaluation_utils()
+    v, f = icosphere(2, 1.0)
+    v = (v * np.array([60.0, 45.0, 80.0], 'f4') + np.array([300.0, -120.0, 40.0], 'f4')).astype('f4')
+    mesh = TriMesh(v, f)
+    rng = np.random.default_rng(77)
+    d = rng.normal(size=(4000, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    truth = (d * np.array([58.0, 47.0, 77.0]) + np.array([300.0, -120.0, 40.0]) + rng.normal(scale=0.5, size=d.shape)).astype('f4')
+    out = dict(vertices=v, faces=f, truth=truth)
+    for tag, dx in (('dx5', 5.0), ('dx11', 11.0)):
+        np.random.seed(5)                                             # (p = 1: the reference's subsample is a permutation of all points)
+        pts = np.asarray(ev.points_from_mesh(mesh, dx_min=dx, p=1.0))
+        pts = pts[np.lexsort((pts[:, 2], pts[:, 1], pts[:, 0]))]
+        m0, m1 = ev.average_squared_distance(pts, truth)
+        out['points_' + tag] = pts
+        out['mse_' + tag] = np.array([m0, m1, np.sqrt((m0 + m1) / 2)])
+    save('fit_quality', **out)
+
+
 if __name__ == '__main__':
     if not ref_harness.available():
         raise SystemExit('reference not available here')
+    if len(sys.argv) > 1:                                             # python make_golden.py fit_quality ... : only the named fixtures
+        for name in sys.argv[1:]:
+            globals()['golden_' + name]()
+        raise SystemExit(0)
     golden_stages()
     golden_c1()
     golden_variants()
@@ -335,3 +362,4 @@ if __name__ == '__main__':
     golden_lfuncs()
     golden_curvature()
     golden_sdf_shapes()
+    golden_fit_quality()
