@@ -58,25 +58,40 @@ def test_c2_full_size_50_iterations_in_blocks_against_oracle():
     assert worst <= 1e-4
 
 
-def test_c3_full_size_block_against_oracle():
-    """configs[2] (headline): 1 000 000 localizations / 198 812 vertices, one 5-iteration block against the oracle."""
+def test_c3_full_size_three_blocks_against_oracle():
+    """configs[2] (headline): 1 000 000 localizations / 198 812 vertices, three blocks of 5 iterations with the block-boundary refresh
+    of the vertex normals between them (_membrane_mesh.pyx:1515-1527; device: nw_refresh_normals on the resident mesh, a new optimiser
+    per block; oracle: the host substrate's definition) -- two fully independent trajectories of 15 iterations.  Vertex RMS <= 1e-4 of
+    the bounding-box diagonal (north_star) after EVERY block; the nearest faces of the last iteration of every block compared too."""
     TriMesh, CG = _imports()
     from ch_shrinkwrap_amd import synth
+    from ch_shrinkwrap_amd.mesh_conj_grad import NativeContext
     from oracle import nanowrap_oracle as O
     c = synth.make_config('c3', scale=1.0, seed=0)
     pts, s = c['points'], 1.0 / c['sigma'].ravel()
-    mesh = TriMesh(c['vertices'], c['faces'])
-    trace = []
-    r = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, c['lams'], 5, s, trace=trace)
-    cg = CG(mesh, pts)
-    out = cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
-    rms = rel_rms(out, r.positions)
-    mism = int((cg.nearest_face != trace[-1]['face']).sum())
-    print('C3 full size, one block: vertex RMS vs oracle %.3e, %d of %d nearest faces differ in the last iteration' % (rms, mism, pts.shape[0]))
-    assert rms <= 1e-5
-    assert mism <= 200                       # near-ties flipped by 1e-7-level position drift
-    assert np.allclose(np.array(cg.tests, 'f8'), np.array(r.tests, 'f8'), rtol=1e-3, atol=1e-6)
-    assert np.allclose(np.array(cg.ress, 'f8'), np.array(r.ress, 'f8'), rtol=1e-4)
+    assert pts.shape[0] == 1000000
+    mesh, ref = TriMesh(c['vertices'], c['faces']), TriMesh(c['vertices'], c['faces'])
+    nat = NativeContext(0)
+    worst = 0.0
+    for blk in range(3):
+        cg = CG(mesh, pts, native=nat, reuse_device_mesh=True)
+        out = cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+        faces_dev = cg.nearest_face.copy()
+        cg.refresh_normals()
+        trace = []
+        r = O.search(ref.vertices.copy(), ref.vertex_normals.copy(), ref.neighbor_vertex_table(), ref.faces, pts, c['lams'], 5, s, trace=trace)
+        ref._vertices['position'][:] = r.positions
+        ref.update_geometry()
+        rms = rel_rms(out, r.positions)
+        mism = int((faces_dev != trace[-1]['face']).sum())
+        worst = max(worst, rms)
+        print('C3 full size, block %d: vertex RMS vs oracle %.3e, %d of %d nearest faces differ in its last iteration' % (blk, rms, mism, pts.shape[0]))
+        assert cg.loopcount == 5 and r.loopcount == 5
+        assert rms <= 1e-4, 'block %d' % blk
+        assert mism <= 2000, 'block %d' % blk                  # near-ties flipped by 1e-7-level position drift (47 after the first block)
+        assert np.allclose(np.array(cg.tests, 'f8'), np.array(r.tests, 'f8'), rtol=1e-3, atol=1e-6), 'block %d' % blk
+        assert np.allclose(np.array(cg.ress, 'f8'), np.array(r.ress, 'f8'), rtol=2e-4), 'block %d' % blk
+    print('C3 full size, 15 iterations in 3 blocks: worst vertex RMS vs oracle %.3e of the bbox diagonal' % worst)
 
 
 def test_stop_condition_fires_on_the_device():
