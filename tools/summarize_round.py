@@ -3,9 +3,12 @@
   <tag>_bench.json                       the bench line of the same round (no profiler attached)
   <tag>_pmc_and_trace_summary.json       per-kernel HBM traffic from the FETCH_SIZE / WRITE_SIZE passes + average durations
   <tag>_sq_counters.json                 per-kernel SQ counters (mean per dispatch)
-  r02_pmc_traffic.json                   what bench.py reports as roofline.traffic (tagged there as file-sourced)
-HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB and gfx950's FETCH_SIZE counts half of
-the wide coalesced reads (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).
+  r03_pmc_traffic.json                   what bench.py reports as roofline.traffic (tagged there as file-sourced)
+HBM bytes per launch: both counters are in KiB; gfx950's FETCH_SIZE counts exactly half of a WIDE coalesced read (16 B per lane) and other
+access widths are uncalibrated (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).  So the doubling is applied only to
+the kernel whose loads are 16 B per lane -- k_nn_wave: float4 localizations, float4 centroids -- and every kernel gets both bounds:
+lower = (FETCH_SIZE + WRITE_SIZE) * 1024, upper = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The gather kernels (dword and 12-byte
+accesses: k_attract, k_subspace_point_sums, k_prior_directions, k_solve_update, the grid build) report the LOWER bound as their value.
 usage: python tools/summarize_round.py <tag>"""
 import csv, glob, json, os, shutil, sys, collections
 
@@ -58,6 +61,7 @@ for k, v in per.items():
 bench = json.loads(open(os.path.join(src, 'bench.log')).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
 
+WIDE_LOADS = ('k_nn_wave', 'k_nn_fixup')                # kernels whose global loads are 16 B per lane (float4 localizations / centroids)
 fetch, write = counters('fetch'), counters('write')
 iters = 10                                             # bench.py --steps 10 in the PMC passes
 traffic = {}
@@ -66,13 +70,16 @@ for k in sorted(set(fetch) | set(write)):
     w = write.get(k, {}).get('WRITE_SIZE', [0.0])
     per_iter = max(1, round(len(f) / (iters + 10 + 2 * 5)))      # launches per iteration (warm-up 10 + timed 10 + 10 extra)
     fk, wk = mean_tail(f, iters * per_iter), mean_tail(w, iters * per_iter)
-    traffic[k] = dict(FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024, dispatches=len(f),
+    wide = k in WIDE_LOADS
+    traffic[k] = dict(FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk, hbm_bytes_per_launch=((2 if wide else 1) * fk + wk) * 1024,
+                      hbm_bytes_lower=(fk + wk) * 1024, hbm_bytes_upper=(2 * fk + wk) * 1024,
+                      fetch_rule='x2: 16-byte-per-lane loads (guide)' if wide else 'x1: dword / 12-byte gathers, width uncalibrated (upper bound = x2)', dispatches=len(f),
                       avg_us=dur.get(k, {}).get('avg_us'), avg_us_timed_region=dur.get(k, {}).get('avg_us_timed_region'),
                       calls_in_trace=dur.get(k, {}).get('calls'))
 grid = ['k_face_centroids', 'k_scan_tile_sums', 'k_scan_bsums', 'k_scan_final', 'k_centroid_scatter']
 summary = dict(traffic_raw=traffic,
                note='per-kernel means over the last dispatches of `bench.py --steps 10 --warmup 10` under rocprofv3 --pmc (FETCH_SIZE and '
-                    'WRITE_SIZE in separate passes); hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024; avg_us from the '
+                    'WRITE_SIZE in separate passes); hbm_bytes_per_launch = (c*FETCH_SIZE + WRITE_SIZE)*1024 with c = 2 only for the kernels whose loads are 16 B per lane (fetch_rule), both bounds given; avg_us from the '
                     '--kernel-trace --stats pass (' + tag + '_kernel_stats.csv)')
 json.dump(summary, open(os.path.join(dst, tag + '_pmc_and_trace_summary.json'), 'w'), indent=1)
 
@@ -85,11 +92,12 @@ out = {k: traffic[k]['hbm_bytes_per_launch'] for k in ('k_nn_wave', 'k_nn_fixup'
 out['grid_build'] = sum(traffic[k]['hbm_bytes_per_launch'] * (3 if k.startswith('k_scan') and False else 1) for k in grid if k in traffic)
 if 'k_nn_wave' in sq and 'SQ_INSTS_VALU' in sq['k_nn_wave']:
     out['k_nn_wave_valu_wave_instructions'] = mean_tail(sq['k_nn_wave']['SQ_INSTS_VALU'], iters)
-out['_note'] = ('HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts half of '
-                'wide coalesced reads, MI355X_MICROARCH.md section HBM); mean of the timed iterations of bench.py --steps 10 --warmup 10; '
-                'profiles/' + tag + '_*')
+out['_note'] = ('HBM bytes per launch from separate rocprofv3 --pmc passes: (2*FETCH_SIZE + WRITE_SIZE)*1024 for k_nn_wave (16-byte-per-lane loads: gfx950 FETCH_SIZE '
+                'counts half of those, MI355X_MICROARCH.md section HBM), (FETCH_SIZE + WRITE_SIZE)*1024 for the gather kernels (other widths are uncalibrated: their x2 upper '
+                'bound is in _bounds); mean of the timed iterations of bench.py --steps 10 --warmup 10; profiles/' + tag + '_*')
+out['_bounds'] = {k: [traffic[k]['hbm_bytes_lower'], traffic[k]['hbm_bytes_upper']] for k in traffic}
 out['_source_tag'] = tag
-json.dump(out, open(os.path.join(dst, 'r02_pmc_traffic.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(dst, 'r03_pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
 for k in ('k_nn_wave', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_reduce_scalars', 'k_prior_directions', 'k_solve_update', 'k_face_centroids', 'k_scan_tile_sums', 'k_scan_final', 'k_centroid_scatter'):
     if k in dur:
