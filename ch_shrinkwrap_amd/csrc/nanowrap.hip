@@ -210,6 +210,7 @@ struct nw_ctx {
     DevBuf<double> scalars;           // [NW_N_SCALARS][NW_SPARTS] sums of the current iteration, NW_SPARTS ordered parts per slot (k_reduce_scalars)
     DevBuf<float> wv;                 // per-vertex weights of the 'wfunc' regulariser (NW_FLAG_WFUNC)
     DevBuf<double> part_a, part_p, part_s;   // per-workgroup partial sums of k_attract / k_prior_directions / k_subspace_point_sums
+    int attract_rows = 0;             // rows of part_a the last attraction wrote (its workgroups)
     double w_quantum = 1.0;           // fixed-point quantum of the {w} column
     double w_bound = 1.0;             // largest |weight| after normalisation (bounds |res| together with the cloud extent)
     DevBuf<NwDevState> state;
@@ -1070,6 +1071,7 @@ static int resort_by_projection(nw_ctx *ctx)
 
 enum { QP_GRID = 1, QP_NN = 2, QP_FIXUP = 4, QP_ATTRACT = 8, QP_ALL = 15 };     // parts of the first half of an iteration
 static int launch_query(nw_ctx *ctx, int it, int parts = QP_GRID | QP_NN | QP_FIXUP);
+static NwAttractArgs attract_args(const nw_ctx *ctx);
 static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool tail = false);
 // Cell-size tuner, once per localization cloud.  The query is exact for every cell size, and its cost depends on more than the rule
 // (desired_cell) can see -- a 200k-localization tube leaves half of the GPU's wave slots empty and prefers smaller cells (fewer
@@ -1264,6 +1266,19 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     return NW_OK;
 }
 
+// the attraction step's arguments (pointers, weights mode, quanta of this block)
+static NwAttractArgs attract_args(const nw_ctx *ctx)
+{
+    NwAttractArgs a;
+    memset(&a, 0, sizeof(a));
+    a.F = (int)ctx->F; a.sinv_scalar = ctx->sinv_scalar; a.w_scalar = ctx->w_scalar;
+    a.cent_by_face = ctx->cent_tmp.p; a.faces = ctx->faces.p; a.pos = ctx->pos.p;
+    a.sinv = ctx->sinv_array ? ctx->sinv.p : nullptr; a.wnorm = ctx->w_array ? ctx->wnorm.p : nullptr; a.dat = ctx->have_data ? ctx->dat.p : nullptr;
+    a.mask = ctx->mask.p; a.dist = ctx->dist.p; a.wout = ctx->w.p; a.res = ctx->res.p; a.vidx = ctx->vidx.p; a.vacc = ctx->vacc.p; a.part = ctx->part_a.p;
+    a.inv_q = 1.0 / ctx->acc_quantum; a.inv_qw = 1.0 / ctx->w_quantum;
+    return a;
+}
+
 // stream operations at the start of a block (capturable: no host synchronisation)
 static int enqueue_begin_ops(nw_ctx *ctx)
 {
@@ -1330,14 +1345,12 @@ static int iter_attract_parts(nw_ctx *ctx, int parts)
 {
     if (ctx->begin_ops_pending) NW_TRY(enqueue_begin_ops(ctx));
     const int it = ctx->search_done;
-    const int64_t N = ctx->N, F = ctx->F;
+    const int64_t N = ctx->N;
     if (parts & (QP_GRID | QP_NN | QP_FIXUP)) NW_TRY(launch_query(ctx, it, parts & (QP_GRID | QP_NN | QP_FIXUP)));
     if (parts & QP_ATTRACT) {
         StageScope s(ctx, ST_ATTRACT);
-        hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, (int)F, ctx->pts.p, ctx->face.p, ctx->cent_tmp.p, ctx->dist.p, ctx->faces.p, ctx->pos.p,
-                           ctx->sinv_array ? ctx->sinv.p : nullptr, ctx->sinv_scalar, ctx->w_array ? ctx->wnorm.p : nullptr, ctx->w_scalar, ctx->mask.p,
-                           ctx->vidx.p, ctx->w.p, ctx->res.p, ctx->vacc.p, ctx->part_a.p, ctx->state.p, it, 1.0 / ctx->acc_quantum, 1.0 / ctx->w_quantum,
-                           ctx->have_data ? ctx->dat.p : nullptr);
+        hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts.p, ctx->face.p, attract_args(ctx), ctx->state.p, it);
+        ctx->attract_rows = attract_blocks(ctx);
     }
     NW_HIP(hipGetLastError());
     return NW_OK;
@@ -1372,7 +1385,7 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
         hipLaunchKernelGGL(k_subspace_point_sums, dim3(subspace_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
                            ctx->mask.p, ctx->S.p, ctx->part_s.p, ctx->state.p, it, n_search);
         // the 24 sums of this iteration, added in a fixed order (deterministic); multi-GPU runs all-reduce them after this call
-        hipLaunchKernelGGL(k_reduce_scalars, dim3(3 * NW_SPARTS), dim3(NW_BLOCK), 0, ctx->stream, ctx->part_a.p, attract_blocks(ctx), ctx->part_p.p, prior_blocks(ctx),
+        hipLaunchKernelGGL(k_reduce_scalars, dim3(3 * NW_SPARTS), dim3(NW_BLOCK), 0, ctx->stream, ctx->part_a.p, ctx->attract_rows, ctx->part_p.p, prior_blocks(ctx),
                            ctx->part_s.p, subspace_blocks(ctx), ctx->scalars.p, ctx->state.p, it);
     }
     NW_HIP(hipGetLastError());

@@ -362,7 +362,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const floa
     cent[start[fcell[f]] + frank[f]] = cent_tmp[f];
 }
 
-// K4a: the exact nearest-face query (k_nn_wave) and the set-up kernels of its work list
+// K4a: the exact nearest-face query (k_nn_wave) and the set-up kernels of its work list; K4b, the attraction step, in its tail
+#include "nw_attract.h"
 #include "nw_nn.h"
 
 // exact float64 re-resolution of the ambiguous points (runner-up inside the float32 error band of the best) as its own launch: one
@@ -383,44 +384,15 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
     }
 }
 
-// K4b: weight matrix row, A f, weighted + de-weighted residual, and the A^T scatter -- one thread per
-// localization (cell-sorted order, so the three vertices of neighbouring threads sit in the same L2 lines).
-//   v_idx = faces[face]; d_j = |f[v_j] - p| (f32); w_j = 1/max(d_j,1e-6), row-normalised    mesh_conj_grad.py:488-510
-//   Af = sum_j f[v_j] w_j (f32, corner order)                                                :544-545
-//   res = weights*(p - Af); res *= 1/(d*sigma_inv/2 + 1) (float64 factor, float32 store)      :222,231,248
-//   vacc[v_j] += {w_j*res, w_j}  -> S0 = A^T res and A^T 1 in ONE pass                        :253, conj_grad_utils.c:153-162,
-//                                                                                            _membrane_mesh.pyx:1633
-// Scatter: the localizations are brick-sorted, so the 256 points of a workgroup reference only a few hundred distinct
-// vertices.  Contributions are first summed per vertex in an LDS hash table, then flushed with ONE global float atomic
-// per (vertex, component), four adjacent lanes covering the vertex's contiguous float4, i.e. one memory-side atomic
-// request per touched vertex instead of twelve per point (MI355X_MICROARCH.md "Global float atomics": scattered
-// single-dword atomics run ~17x below the contiguous rate).
-// The accumulators are 64-bit FIXED POINT, in LDS (ds_add_u64) and in HBM (`vacc`, global_atomic_add_x2), not float: measured on
-// MI355X, the twelve ds_add_f32 per point cost 67 us per launch at 1M points (LDS float atomics retire ~1 lane every 3 cycles
-// per CU), twelve ds_add_u64 25 us.  The quanta are powers of two (scaling a float32 product by one is exact): for {w res} 2^-36
-// of (cloud extent x largest weight), a bound on |res| -- ~10^-11 relative resolution, far below the float32 rounding of each
-// product, 2^27 such terms of headroom; for {w} 2^-40 (w <= 1).  Integer addition is associative, so the sums are EXACT and
-// independent of the order in which lanes, waves and workgroups arrive: the scatter is bitwise reproducible (the reference's is a
-// serial, deterministic loop, conj_grad_utils.c:153-162); k_prior_directions rounds each sum once to float32.
-// round-to-nearest-even of |x| < 2^51 to a 64-bit integer: adding 1.5 * 2^52 leaves the integer in the low mantissa bits (one f64 add
-// and a 64-bit subtract instead of the dozen instructions of the f64 -> i64 conversion sequence)
-__device__ __forceinline__ long long nw_round_to_i64(double x)
-{
-    return __double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000LL;
-}
-
+// K4b as a launch of its own (the multi-GPU phases and NW_FUSE_ATTRACT=0; the single-GPU iteration runs the step in the tail of the
+// query kernel): one thread per localization, nw_attract_point (nw_attract.h), the workgroup's 256 localizations share one table.
 #define NW_HT 512          // slots of the per-workgroup table: 18 KB of LDS, 8 workgroups per CU (1024 slots: 36 KB, 4 per CU, 10 us slower)
 #define NW_HT_BITS 9
 #define NW_ATTRACT_PPT 1      // (2: 39.7 us against 36.5 -- the two dependent load chains of a thread do not overlap)
 #define NW_HT_PROBES 48    // a contribution that finds no slot within this many probes goes to HBM directly (unsorted input only)
 
-__global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4 *__restrict__ pts, const int *__restrict__ face, const float4 *__restrict__ cent_by_face, float *__restrict__ dist,
-                                                     const int *__restrict__ faces, const float *__restrict__ pos,
-                                                     const float *__restrict__ sinv, float sinv_scalar, const float *__restrict__ wnorm, float w_scalar,
-                                                     const unsigned char *__restrict__ mask,
-                                                     int *__restrict__ vidx, float *__restrict__ wout, float *__restrict__ res, long long *__restrict__ vacc,
-                                                     double *__restrict__ part, NwDevState *__restrict__ st, int it, double inv_q, double inv_qw,
-                                                     const float *__restrict__ dat /* target of the residual if it is not the localizations (nw_set_data), else NULL */)
+__global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__restrict__ pts, const int *__restrict__ face, const NwAttractArgs A,
+                                                     NwDevState *__restrict__ st, int it)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ int s_key[NW_HT];
@@ -430,107 +402,26 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
     __syncthreads();
     // each XCD takes one contiguous range of the brick-sorted localizations: the vertices its workgroups gather and the
     // accumulator lines their atomics touch then live in ONE L2 instead of being spread round-robin over all eight
-    // NW_ATTRACT_PPT localizations per thread (consecutive tiles of 256): the table's set-up and flush and the workgroup reduction
-    // are paid once per 512 localizations
     const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK * NW_ATTRACT_PPT - 1) / (NW_BLOCK * NW_ATTRACT_PPT));
     double red[4] = {0.0, 0.0, 0.0, 0.0};
     float dmax = 0.0f;
 #pragma unroll 1
     for (int pp = 0; pp < NW_ATTRACT_PPT; ++pp) {
-    const int i = blk < 0 ? N : (blk * NW_ATTRACT_PPT + pp) * (int)blockDim.x + (int)threadIdx.x;
-    const int f_raw = i < N ? face[i] : 0;
-    // a face id outside [0, F) can only come from a bug in the NN query: never dereference it (a faulting kernel can
-    // take the whole node down), raise the internal-error status instead
-    if (i < N && (unsigned)f_raw >= (unsigned)F) atomicCAS(&st->status, 0, -7 /* NW_ERR_INTERNAL */);
-    if (i < N && (unsigned)f_raw < (unsigned)F) {
-        const float4 P = pts[i];
-        const int f = f_raw;
-        const float p[3] = {P.x, P.y, P.z};
-        int v[3];
-        float w[3], fv[3][3];
-        float wsum;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            v[j] = faces[3 * f + j];
-            float dd = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                fv[j][k] = pos[3 * v[j] + k];
-                const float d = fv[j][k] - p[k];
-                const float sq = d * d;
-                dd = (k == 0) ? sq : dd + sq;
-            }
-            w[j] = 1.0f / fmaxf(sqrtf(dd), 1e-6f);
+        const int i = blk < 0 ? N : (blk * NW_ATTRACT_PPT + pp) * (int)blockDim.x + (int)threadIdx.x;
+        const int f_raw = i < N ? face[i] : 0;
+        // a face id outside [0, F) can only come from a bug in the NN query: never dereference it (a faulting kernel can
+        // take the whole node down), raise the internal-error status instead
+        if (i < N && (unsigned)f_raw >= (unsigned)A.F) atomicCAS(&st->status, 0, -7 /* NW_ERR_INTERNAL */);
+        if (i < N && (unsigned)f_raw < (unsigned)A.F) {
+            bool bad = false;
+            nw_attract_point<NW_HT, NW_HT_BITS, NW_HT_PROBES>(A, i, pts[i], f_raw, (int)(threadIdx.x % 3u), s_key, s_val, red, dmax, bad);
+            if (bad) atomicCAS(&st->status, 0, -3 /* NW_ERR_NAN */);
         }
-        wsum = (w[0] + w[1]) + w[2];
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { w[j] = w[j] / wsum; bad |= isnan(w[j]); }
-        // dmean: float64 Euclidean distance to the nearest centroid (what cKDTree returns), rounded once to float32
-        float d;
-        {
-            const float4 C = cent_by_face[f];
-            const double ddx = (double)P.x - (double)C.x, ddy = (double)P.y - (double)C.y, ddz = (double)P.z - (double)C.z;
-            d = (float)sqrt(fma(ddz, ddz, fma(ddy, ddy, ddx * ddx)));
-            dist[i] = d;
-        }
-        const unsigned m = mask[i];
-        float r[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float af = 0.0f + fv[0][k] * w[0];
-            af = af + fv[1][k] * w[1];
-            af = af + fv[2][k] * w[2];
-            bad |= isnan(af);
-            const float wt = wnorm ? wnorm[3 * i + k] : w_scalar;
-            const float r0 = wt * ((dat ? dat[3 * i + k] : p[k]) - af);
-            const double si = sinv ? (double)sinv[3 * i + k] : (double)sinv_scalar;
-            const double wd = 1.0 / ((double)d * si / 2.0 + 1.0);
-            r[k] = (float)((double)r0 * wd);
-            const double r2 = (double)r[k] * (double)r[k];
-            red[0] += r2;
-            if (m & (1u << k)) red[1] += r2;
-        }
-        red[2] += (double)d;
-        red[3] += 1.0;
-        dmax = fmaxf(dmax, d);
-        __builtin_memcpy(res + 3 * (int64_t)i, r, 12);           // three 12-byte stores instead of nine dword stores
-        __builtin_memcpy(vidx + 3 * (int64_t)i, v, 12);
-        __builtin_memcpy(wout + 3 * (int64_t)i, w, 12);
-        // Neighbouring lanes mostly share their face (the localizations are sorted by foot point), i.e. all three vertices: corner
-        // (j + lane) % 3 in turn j makes them hit three different accumulators at the same time instead of serialising on one
-        // (integer sums: the order of the additions does not matter)
-        const int rot = (int)(threadIdx.x % 3u);
-#pragma unroll
-        for (int j0 = 0; j0 < 3; ++j0) {
-            const int jr = j0 + rot, j = jr >= 3 ? jr - 3 : jr;
-            const int vj = j == 0 ? v[0] : (j == 1 ? v[1] : v[2]);
-            const float wj = j == 0 ? w[0] : (j == 1 ? w[1] : w[2]);
-            unsigned hsh = ((unsigned)vj * 2654435761u) >> (32 - NW_HT_BITS);
-            bool slot = false;
-            for (int probe = 0; probe < NW_HT_PROBES; ++probe) {
-                const int old = atomicCAS(&s_key[hsh], -1, vj);
-                if (old == -1 || old == vj) { slot = true; break; }
-                hsh = (hsh + 1) & (NW_HT - 1);
-            }
-            unsigned long long *a = s_val + hsh;
-            const float c[4] = {wj * r[0], wj * r[1], wj * r[2], wj};     // float32 products, as the reference forms them
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double x = (double)c[k] * (k < 3 ? inv_q : inv_qw);           // exact scaling (powers of two)
-                bad |= !(fabs(x) < 7.0e13);                                         // far beyond the bound behind the quantum / inf / NaN: raise the NaN status
-                const unsigned long long q = (unsigned long long)nw_round_to_i64(x);
-                if (slot) atomicAdd(a + k * NW_HT, q);
-                else atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + 4 * (int64_t)vj + k, q);      // (integer sums: the path taken does not change the result)
-            }
-        }
-        if (bad) atomicCAS(&st->status, 0, -3 /* NW_ERR_NAN */);
-    }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < NW_HT * 4; t += NW_BLOCK) {
         const int key = s_key[t >> 2];                     // four adjacent lanes flush the four components of one vertex
-        if (key >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + 4 * (int64_t)key + (t & 3), s_val[(t & 3) * NW_HT + (t >> 2)]);
+        if (key >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(A.vacc) + 4 * (int64_t)key + (t & 3), s_val[(t & 3) * NW_HT + (t >> 2)]);
     }
     // per-workgroup partial sums (row of 5: four sums + the largest NN distance of the workgroup, which a sharded run checks against
     // its halo radius; a same-address atomicMax from every wave serialised: 40 us at 1M localizations, 0.7 ms at 5M).  The four sums
@@ -551,9 +442,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, int F, const float4
             for (int k = 0; k < 4; ++k) {
                 const double *c = s_red + k * NW_BLOCK + tid;
                 const double sk = nw_wave_sum((c[0] + c[64]) + (c[128] + c[192]));
-                if (tid == 0) part[(int64_t)blockIdx.x * 5 + k] = sk;
+                if (tid == 0) A.part[(int64_t)blockIdx.x * 5 + k] = sk;
             }
-            if (tid == 0) part[(int64_t)blockIdx.x * 5 + 4] = (double)fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
+            if (tid == 0) A.part[(int64_t)blockIdx.x * 5 + 4] = (double)fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
         }
     }
 }
