@@ -251,8 +251,8 @@ int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, co
  * 0 on ROCm 7.2; 4 = only the NN query of each block's FIRST iteration is bracketed: that iteration is launched from the host, the rest
  * of the block is one replayed hipGraph, and the event pairs come once per block (what bench.py times at).
  * Level 3 (ABI 2: the block as two half graphs around a directly launched query) is gone and returns NW_ERR_BADARG: in a process that
- * also runs PyTorch's HIP runtime threads about one block in twenty waited 5-6 ms between its last kernel and the copies queued behind
- * the second graph; level 4 gives the same one-sample-per-block without a second graph launch in the block. */
+ * had also loaded PyTorch about one block in twenty waited 5-6 ms behind its last kernel, the traces kept from then do not contain such
+ * a block, and level 4 gives the same one sample per block with a single graph launch per block. */
 int nw_set_profiling(nw_ctx *ctx, int enable);
 int nw_stage_ms(nw_ctx *ctx, int stage, double *ms, int64_t *launches);
 
