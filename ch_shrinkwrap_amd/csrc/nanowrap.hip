@@ -210,6 +210,7 @@ struct nw_ctx {
     DevBuf<double> scalars;           // [NW_N_SCALARS][NW_SPARTS] sums of the current iteration, NW_SPARTS ordered parts per slot (k_reduce_scalars)
     DevBuf<float> wv;                 // per-vertex weights of the 'wfunc' regulariser (NW_FLAG_WFUNC)
     DevBuf<double> part_a, part_p, part_s;   // per-workgroup partial sums of k_attract / k_prior_directions / k_subspace_point_sums
+    bool vacc_dirty = true;           // something other than the iteration has written the scatter accumulator since it was last zeroed
     int attract_rows = 0;             // rows of part_a the last attraction wrote (its workgroups)
     double w_quantum = 1.0;           // fixed-point quantum of the {w} column
     double w_bound = 1.0;             // largest |weight| after normalisation (bounds |res| together with the cloud extent)
@@ -515,6 +516,7 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->vidx.ensure(3 * N));
     NW_HIP(ctx->w.ensure(3 * N));
     NW_HIP(ctx->res.ensure(3 * N));
+    if (ctx->vacc.n < (size_t)(4 * M)) ctx->vacc_dirty = true;
     NW_HIP(ctx->vacc.ensure(4 * M));
     NW_HIP(ctx->S.ensure(9 * M));
     NW_HIP(ctx->fdef.ensure(3 * M));
@@ -984,6 +986,7 @@ NW_EXPORT int nw_refresh_normals(nw_ctx *ctx, float *nrm_out)
     if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_refresh_normals inside a search");
     // the scatter accumulator of the iteration doubles as the normals' accumulator (every block zeroes it before it starts)
     NW_HIP(ctx->vacc.ensure(4 * ctx->M));
+    ctx->vacc_dirty = true;                              // (the next block zeroes it again before its first scatter)
     NW_HIP(hipMemsetAsync(ctx->vacc.p, 0, 3 * ctx->M * sizeof(long long), ctx->stream));
     double ext = 1e-30;
     if (ctx->extent_hint > 0) ext = ctx->extent_hint;          // a sharded mesh: the WHOLE mesh's extent, so that every rank uses the same quantum
@@ -1284,12 +1287,15 @@ static int enqueue_begin_ops(nw_ctx *ctx)
 {
     ctx->begin_ops_pending = false;
     const int n = std::max(ctx->search_iters, 1);
-    // start_guess: fs = vertices.copy() -> f restarts from the mesh positions (mesh_conj_grad.py:170, :1002-1007)
-    NW_HIP(hipMemcpyAsync(ctx->pos.p, ctx->meshpos.p, 3 * ctx->M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-    NW_HIP(hipMemsetAsync(ctx->logs.p, 0, (size_t)n * sizeof(NwIterLogDev), ctx->stream));
-    NW_HIP(hipMemsetAsync(ctx->S.p, 0, 9 * ctx->M * sizeof(float), ctx->stream));         // S = zeros (:207)
-    NW_HIP(hipMemsetAsync(ctx->res.p, 0, 3 * ctx->N * sizeof(float), ctx->stream));       // res = 0*data (:181)
-    NW_HIP(hipMemsetAsync(ctx->vacc.p, 0, 4 * ctx->M * sizeof(long long), ctx->stream));
+    // one launch: f restarts from the mesh positions, logs cleared, and the reference's zero-initialised arrays zeroed where the block
+    // would not overwrite them anyway (k_block_begin)
+    const int flag = (ctx->search_iters <= 0 ? 1 : 0) | ((ctx->search_flags & NW_FLAG_NO_LAST_STEP) ? 2 : 0);
+    const int64_t work = std::max<int64_t>(9 * ctx->M, flag & 1 ? 3 * ctx->N : 0);
+    const int blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (work + NW_BLOCK - 1) / NW_BLOCK));
+    hipLaunchKernelGGL(k_block_begin, dim3(blocks), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, (int64_t)(3 * ctx->N), ctx->pos.p, ctx->meshpos.p, ctx->S.p, ctx->res.p,
+                       ctx->vacc.p, (unsigned *)ctx->logs.p, (int)((size_t)n * sizeof(NwIterLogDev) / 4), ctx->state.p, flag, ctx->vacc_dirty ? 1 : 0);
+    NW_HIP(hipGetLastError());
+    if (!ctx->capturing) ctx->vacc_dirty = false;          // (a captured launch bakes the flag in: the graph's key carries it)
     return NW_OK;
 }
 
@@ -1517,7 +1523,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     uint32_t lb; memcpy(&lb, &ctx->lam0, 4); mix(lb);
     uint64_t qb; memcpy(&qb, &ctx->acc_quantum, 8); mix(qb);
     uint32_t sb; memcpy(&sb, &ctx->sinv_scalar, 4); mix(sb); memcpy(&sb, &ctx->w_scalar, 4); mix(sb);
-    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 4 ? 256 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0) | (ctx->have_boundary ? 512 : 0));
+    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 4 ? 256 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0) | (ctx->have_boundary ? 512 : 0) | (ctx->vacc_dirty ? 1024 : 0));
     mixp(ctx->direct_out ? ctx->pin : nullptr);
     mixp(ctx->have_data ? ctx->dat.p : nullptr);
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
@@ -1603,6 +1609,7 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     if (slot) {
         if (hipGraphLaunch(slot->exec, ctx->stream) == hipSuccess) {
             ctx->begin_ops_pending = false;
+            ctx->vacc_dirty = false;                       // (a graph recorded while the accumulator was dirty zeroes it: the key carries the flag)
             ctx->global_iter += num_iters; ctx->search_done = num_iters; ctx->face_warm = true;
             replayed = true;
         } else (void)hipGetLastError();

@@ -647,6 +647,31 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const i
     nw_block_reduce_store_lds<9>(red, part, s_red);
 }
 
+// Start of a block (search() call) in ONE launch: the estimate restarts from the mesh positions (fs = vertices.copy(),
+// mesh_conj_grad.py:170, :1002-1007), the log records are cleared, and the arrays the reference zero-initialises are zeroed WHERE THE
+// BLOCK WILL NOT OVERWRITE THEM BEFORE ANYTHING READS THEM:
+//   res = 0 * data (:181): k_attract writes every entry in the block's first iteration -> zeroed only if that iteration will not run
+//         (the stop condition already holds, or the call asks for no iteration);
+//   S = zeros (:207): columns 0 and 1 are written by k_prior_directions, column 2 by k_solve_update before it is first read (n_search is 2
+//         in a block's first iteration) -> zeroed only if the first iteration will not run or last_step is off (column 2 then stays zero);
+//   the scatter accumulator: every k_solve_update leaves it zeroed for the next scatter -> zeroed here only when the host knows something
+//         else has used it since (nw_refresh_normals borrows it; a fresh allocation).
+// Five memset / copy nodes of 2-12 MB each were ~30 us of launch latency per block.
+__global__ __launch_bounds__(NW_BLOCK) void k_block_begin(int M, int64_t n_res, float *__restrict__ pos, const float *__restrict__ meshpos, float *__restrict__ S,
+                                                         float *__restrict__ res, long long *__restrict__ vacc, unsigned *__restrict__ logs_words, int n_log_words,
+                                                         const NwDevState *__restrict__ st, int no_iteration_or_no_last_step, int zero_vacc)
+{
+    const bool first_runs = st->iter_base < st->stop_at;      // (k_set_iter_base ran before this launch)
+    const bool zero_res = !first_runs || (no_iteration_or_no_last_step & 1);
+    const bool zero_S = !first_runs || no_iteration_or_no_last_step != 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < 3 * (int64_t)M; t += stride) pos[t] = meshpos[t];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_log_words; t += stride) logs_words[t] = 0u;
+    if (zero_S) for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < 9 * (int64_t)M; t += stride) S[t] = 0.0f;
+    if (zero_res) for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_res; t += stride) res[t] = 0.0f;
+    if (zero_vacc) for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < 4 * (int64_t)M; t += stride) vacc[t] = 0ll;
+}
+
 // K7: <=3x3 regularised normal equations (every workgroup solves them redundantly from the reduced sums),
 // f += S c, last step -> S2, write-back, per-iteration log, stop condition.
 //   H = Hc + lam^2 Hw accumulated in place in float32, G likewise (conj_grad.py:208-215); float32 LU with
