@@ -259,3 +259,55 @@ def test_tens_of_thousands_of_exact_ties_take_the_lowest_face_id():
     wrong = np.nonzero(got != want)[0]
     print('%d exact ties among %d localizations, %d resolved differently' % (n_ties, N, wrong.size))
     assert wrong.size == 0, (wrong[:10], got[wrong[:10]], want[wrong[:10]])
+
+
+def test_sharded_mesh_entry_points_check_their_arguments():
+    """nw_set_boundary / nw_halo_* (include/nanowrap.h): indices are validated on the host (a bad one would fault a kernel), the hand-off
+    buffers exist only once a boundary is set, nw_search refuses a mesh with shared vertices (its boundary rows must be all-reduced between
+    the phases), and nw_host_copy_rows fills a contiguous copy and strided records with the valid-vertex mask."""
+    import ctypes
+    from ch_shrinkwrap_amd import _lib as nw
+    from ch_shrinkwrap_amd.trimesh import TriMesh, icosphere
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    from ch_shrinkwrap_amd.synth import sphere_cloud
+    v, f = icosphere(2, 60.0)
+    pts = sphere_cloud(2000, 50.0, 5.0, seed=1)
+    mesh = TriMesh(v, f)
+    cg = ShrinkwrapMeshConjGrad(mesh, pts)
+    L, h = cg._L, cg._h
+    M = v.shape[0]
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    owned = np.ones(M, np.uint8)
+    gv = i32(np.arange(M))
+    with pytest.raises(ValueError):                                   # no boundary yet
+        cg._native.check(L.nw_halo_pack(h, nw.NW_ARR_POS))
+    for bl, bs, ns in ((i32([M]), i32([0]), 4), (i32([3]), i32([4]), 4), (i32([3, 5]), i32([1, 1]), 4)):      # vertex out of range / slot out of range / slot twice
+        with pytest.raises(ValueError):
+            cg._native.check(L.nw_set_boundary(h, nw.ptr(bl), nw.ptr(bs), bl.size, ns, nw.ptr(owned), nw.ptr(gv), M))
+    with pytest.raises(ValueError):                                   # global id out of range
+        cg._native.check(L.nw_set_boundary(h, nw.ptr(i32([3])), nw.ptr(i32([0])), 1, 4, nw.ptr(owned), nw.ptr(i32(np.arange(M) + 1)), M))
+    cg._native.check(L.nw_set_boundary(h, nw.ptr(i32([3, 7])), nw.ptr(i32([2, 0])), 2, 4, nw.ptr(owned), nw.ptr(gv), M))
+    p, nb = ctypes.c_void_p(), ctypes.c_int64()
+    cg._native.check(L.nw_device_ptr(h, nw.NW_ARR_HALO_ACC, ctypes.byref(p), ctypes.byref(nb)))
+    assert p.value and nb.value == 4 * 4 * 8
+    cg._native.check(L.nw_device_ptr(h, nw.NW_ARR_HALO_FULL, ctypes.byref(p), ctypes.byref(nb)))
+    assert nb.value == 3 * M * 4
+    with pytest.raises(ValueError):                                   # shared vertices: the split-phase calls with all-reduces between them
+        cg.search(pts, lams=[5.0], num_iters=1, sigma_inv=0.2)
+    # owners' rows at their global ids: every vertex is owned here, so the gather is the whole mesh
+    cg._native.check(L.nw_halo_gather_owned(h, nw.NW_ARR_POS))
+    full = np.empty((M, 3), np.float32)
+    cg._native.check(L.nw_get(h, nw.NW_ARR_HALO_FULL, nw.ptr(full), full.nbytes))
+    assert np.array_equal(full, v)
+    cg._native.check(L.nw_set_boundary(h, None, None, 0, -1, None, None, 0))         # cleared: nw_search works again
+    out = cg.search(pts, lams=[5.0], num_iters=1, sigma_inv=0.2)
+    assert np.isfinite(out).all()
+    # host half of the write-back
+    src = np.arange(3 * 60000, dtype=np.float32).reshape(-1, 3)
+    rec = np.zeros(60000, dtype=[('position', '3f4'), ('pad', 'f8', 4)])
+    valid = (np.arange(60000) % 7 != 0).astype(np.uint8)
+    dst = np.empty_like(src)
+    posv = rec['position']
+    cg._native.check(L.nw_host_copy_rows(h, nw.ptr(src), src.shape[0], nw.ptr(dst), ctypes.c_void_p(posv.ctypes.data), posv.strides[0], nw.ptr(valid)))
+    assert np.array_equal(dst, src)
+    assert np.array_equal(posv[valid != 0], src[valid != 0]) and (posv[valid == 0] == 0).all()
