@@ -124,16 +124,21 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def spawn_ranks(args):
-    """Parent of an N-rank run started with plain `python`: N fresh children of this script, one per rank.  Nothing here imports torch or
-    touches the GPU (a process that has initialised HIP must not be replaced or forked into ranks).  Rank 0's standard output is relayed
-    (its JSON line); every rank's standard error is inherited.  First failure ends the others; the exit code is that failure's."""
+def free_port():
     import socket
-    import subprocess
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """Parent of an N-rank run started with plain `python`: N fresh children of this script, one per rank.  Nothing here imports torch or
+    touches the GPU (a process that has initialised HIP must not be replaced or forked into ranks).  Rank 0's standard output is relayed
+    (its JSON line); every rank's standard error is inherited.  First failure ends the others; the exit code is that failure's."""
+    import subprocess
+    port = free_port()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ)
@@ -207,7 +212,15 @@ def run_rank(args):
         raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible (RCCL needs one device per rank; NW_BENCH_BACKEND=gloo rehearses on one)'
                          % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # developer hook: NW_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, split-phase iteration, collectives, recorded blocks)
+    # with ONE rank -- the only way to run RCCL collectives inside a captured block on a one-GPU box
+    multi = world > 1 or bool(os.environ.get('NW_BENCH_FORCE_DIST'))
+    if multi and world == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if multi:
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
@@ -218,10 +231,10 @@ def run_rank(args):
     from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
     from ch_shrinkwrap_amd import parallel
 
-    halo = world > 1 and args.mode == 'halo'
+    halo = multi and args.mode == 'halo'
     # 'halo': every rank generates the SAME scene (seed 0) and takes its share; 'tiles': every rank its own vesicle (seed = rank)
     cfg = synth.make_config(args.config, scale=args.scale, seed=0 if halo else rank)
-    if world > 1 and not halo:
+    if multi and not halo:
         # tile the vesicles on a 2x2x2 lattice (BASELINE.json configs[4]); ranks never share vertices
         off = np.array([(rank & 1), (rank >> 1) & 1, (rank >> 2) & 1], 'f4') * synth.C5_LATTICE
         cfg['points'] = (cfg['points'] + off[None, :]).astype('f4')
@@ -232,14 +245,14 @@ def run_rank(args):
     N, M, F = pts.shape[0], int((mesh._vertices['halfedge'] != -1).sum()), mesh.faces.shape[0]
 
     # N > 1: kernels and RCCL collectives share one dedicated (non-default) torch stream
-    tstream = torch.cuda.Stream() if world > 1 else None
+    tstream = torch.cuda.Stream() if multi else None
     if halo:
         scene = parallel.HaloScene(mesh, pts, dist, halo=args.halo, torch_stream=tstream)
         scene.set_profiling(0)
         cg_of = lambda: scene.ex.cg                     # (a re-partition builds a new optimiser over the new share)
     else:
         cg = ShrinkwrapMeshConjGrad(mesh, pts, device=local_rank, stream=tstream.cuda_stream if tstream is not None else None)
-        runner = parallel.TiledScene(cg, dist if world > 1 else None, torch_stream=tstream)
+        runner = parallel.TiledScene(cg, dist if multi else None, torch_stream=tstream)
         cg_of = lambda: cg
 
     executed = [0]
@@ -263,7 +276,7 @@ def run_rank(args):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -300,7 +313,7 @@ def run_rank(args):
     # the same K steps once more WITHOUT events: every block is then one replayed hipGraph (what a caller who does not profile gets).
     # Reported beside the official number, never instead of it.
     dt_graph = None
-    if world == 1 and not args.no_graph_pass:
+    if not multi and not args.no_graph_pass:
         cg.set_profiling(0)
         run_steps(BLOCK)                       # captures (first un-instrumented block)
         fence()
@@ -309,8 +322,10 @@ def run_rank(args):
         fence()
         dt_graph = time.perf_counter() - tg
     set_profiling(2)
+    ex_of = (lambda: scene.ex) if halo else (lambda: runner.ex)
+    replayed_blocks = ex_of().blocks_replayed if multi else 0
     ctimer = None
-    if world > 1:
+    if multi:
         ctimer = parallel.CollectiveTimer()          # device time inside the collectives of the extra iterations
         (scene.ex if halo else runner.ex).collective_timer = ctimer
     run_steps(2 * BLOCK)
@@ -319,7 +334,7 @@ def run_rank(args):
     stage = dict(cg_of().stage_ms_total)
     n_extra = max(stage['update'][1], 1)
     rccl = None
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -363,7 +378,7 @@ def run_rank(args):
                 traffic = json.load(open(tfile)).get(kern[dom])
             except Exception:
                 traffic = None
-        if world == 1:
+        if not multi:
             par = 'single GPU'
         elif halo:
             par = ('halo%d: ONE mesh sharded by spatial tiles of the cloud (halo radius %.0f nm); per iteration RCCL all-reduces of the boundary rows of the '
@@ -393,7 +408,7 @@ def run_rank(args):
                                    % (WORKLOADS[args.config], N, M, F, BLOCK, '' if args.scale == 1.0 else ' [SCALED x%.3g: debug run]' % args.scale),
                        'localizations_per_gpu': Nl, 'vertices_per_gpu': Ml, 'faces_per_gpu': Fl, 'block': BLOCK,
                        'one_off_setup': 'nw_optimize_layout after the warm-up, before the timed region: projection re-sort of the localizations, cell-size tuner (a few timed probe queries), heavy-first order of the query work list (one timed query); then one more untimed block of min(warmup, %d) iterations: %d iterations ran before the timed region' % (BLOCK, warmup_executed),
-                       'mode': args.mode if world > 1 else 'single',
+                       'mode': args.mode if multi else 'single',
                        'parallelism': par},
             'roofline': {'bound': 'hbm', 'kernel': kern[dom], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
@@ -408,11 +423,13 @@ def run_rank(args):
             'nn_max_ring': cg_of().nn_max_ring, 'mean_dist_nm': cg_of().mean_dist,
         }
         out['roofline_iteration']['frac'] = out['roofline_iteration']['achieved'] / HBM_PEAK_GBS
-        if world > 1:
+        if multi:
             out['rccl'] = rccl
             out['collectives'] = {'ms_per_iter': comm_ms / n_extra, 'per_iter': comm_n / n_extra,
                                   'share_of_device_time': (comm_ms / n_extra) / max(stage['total'][0] / n_extra + comm_ms / n_extra, 1e-12),
-                                  'note': 'rank 0, event-bracketed all-reduces of %d extra iterations after the timed region' % n_extra}
+                                  'note': 'rank 0, event-bracketed all-reduces of %d extra iterations after the timed region' % n_extra,
+                                  'blocks_replayed_with_their_collectives': replayed_blocks,
+                                  'blocks_note': 'blocks of the warm-up and the timed region whose iterations 2..%d -- launches AND collectives -- were one replayed recording (hipGraph capture of the shared stream; RCCL only); the first iteration of a block stays live for the event pair around its query' % BLOCK}
             if halo:
                 out['halo'] = {'radius_nm': args.halo, 'boundary_vertices': scene.ex.n_boundary, 'repartitions_in_timed_region': reparts,
                                'max_nn_distance_nm': scene.max_dist, 'drift_since_partition_nm': scene.drift,
@@ -451,7 +468,7 @@ def run_rank(args):
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, 'libnanowrap_hip.so')
 NW_OK = 0
 NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM = -1, -2, -3, -4, -5, -6
 NW_WEIGHTS_FROM_SIGMA_INV, NW_WEIGHTS_SCALAR, NW_WEIGHTS_ARRAY, NW_WEIGHTS_PRENORMALIZED = 0, 1, 2, 3
-NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP, NW_FLAG_WFUNC = 1, 2, 4
+NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP, NW_FLAG_WFUNC, NW_FLAG_RESULT_TO_HOST = 1, 2, 4, 8
 (NW_ARR_S, NW_ARR_RES, NW_ARR_VIDX, NW_ARR_W, NW_ARR_DIST, NW_ARR_FACE, NW_ARR_POS, NW_ARR_FDEF, NW_ARR_PI,
  NW_ARR_MESHPOS, NW_ARR_VACC, NW_ARR_SCALARS, NW_ARR_NBR, NW_ARR_NRM, NW_ARR_VALID, NW_ARR_HALO_ACC, NW_ARR_HALO_ROWS,
  NW_ARR_HALO_FULL) = range(18)
@@ -23,7 +23,8 @@ SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set
            'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_refresh_normals', 'nw_reset_history', 'nw_search', 'nw_search_begin',
            'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
            'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_debug_items', 'nw_set_data', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned',
-           'nw_set_boundary', 'nw_halo_pack', 'nw_halo_unpack', 'nw_halo_gather_owned', 'nw_set_extent_hint', 'nw_host_copy_rows']
+           'nw_set_boundary', 'nw_halo_pack', 'nw_halo_unpack', 'nw_halo_gather_owned', 'nw_set_extent_hint', 'nw_host_copy_rows',
+           'nw_capture_begin', 'nw_capture_end', 'nw_block_key', 'nw_block_replayed']
 
 
 class IterLog(ctypes.Structure):
@@ -81,6 +82,10 @@ def load():
     L.nw_halo_gather_owned.argtypes = [vp, i32]
     L.nw_set_extent_hint.argtypes = [vp, ctypes.c_double]
     L.nw_host_copy_rows.argtypes = [vp, vp, i64, vp, vp, i64, vp]
+    L.nw_capture_begin.argtypes = [vp]
+    L.nw_capture_end.argtypes = [vp, vp]
+    L.nw_block_key.argtypes = [vp, vp]
+    L.nw_block_replayed.argtypes = [vp, ctypes.c_int]
     L.nw_set_data.argtypes = [vp, vp]
     L.nw_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     L.nw_lfunc.argtypes = [vp, i32, vp, vp, vp]

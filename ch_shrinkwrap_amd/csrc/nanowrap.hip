@@ -127,6 +127,8 @@ struct nw_ctx {
     // captured search() blocks (hipGraph): replayed while nothing they bake in has changed
     struct BlockGraph { hipGraphExec_t exec = nullptr; uint64_t key = 0; };
     bool capturing = false;
+    bool ext_capture = false;              // the CALLER is capturing the stream (nw_capture_begin): phases record, collectives of the caller between them
+    int cap_done0 = 0; int64_t cap_iter0 = 0; bool cap_warm0 = false, cap_pending0 = false, cap_begin0 = false, cap_dirty0 = false;
     bool direct_out = false;         // nw_search: the last update of the block writes its result into the pinned staging buffer itself
     BlockGraph graphs[4];
     int graph_next = 0;
@@ -1241,6 +1243,7 @@ NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
 }
 
 // ---- the iteration -------------------------------------------------------------------------------------------
+static int ensure_staging(nw_ctx *ctx);
 NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags)
 {
     if (!ctx) return NW_ERR_BADARG;
@@ -1258,7 +1261,12 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     ctx->acc_quantum = ctx->quantum_override > 0 ? ctx->quantum_override : ctx->local_quantum;
     ctx->w_quantum = std::ldexp(1.0, -40);
     ctx->lam0 = lams[0];
-    ctx->search_flags = flags;
+    ctx->search_flags = flags & ~NW_FLAG_RESULT_TO_HOST;
+    ctx->direct_out = false;
+    if ((flags & NW_FLAG_RESULT_TO_HOST) && num_iters > 0 && 3 * ctx->M * sizeof(float) <= (4u << 20) && !(getenv("NW_DIRECT_OUT") && atoi(getenv("NW_DIRECT_OUT")) == 0)) {
+        NW_TRY(ensure_staging(ctx));                // (larger results: the sliced copy of nw_search_end is the faster one)
+        ctx->direct_out = true;
+    }
     ctx->search_iters = num_iters;
     ctx->search_done = 0;
     NW_HIP(ctx->logs.ensure((size_t)std::max(num_iters, 1)));
@@ -1374,7 +1382,7 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
 NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_directions outside a search");
-    if (ctx->have_boundary && !ctx->capturing) NW_TRY(halo_unpack(ctx, NW_ARR_VACC));      // the boundary rows summed over the ranks
+    if (ctx->have_boundary && (!ctx->capturing || ctx->ext_capture)) NW_TRY(halo_unpack(ctx, NW_ARR_VACC));      // the boundary rows summed over the ranks
     const int it = ctx->search_done;
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
     {
@@ -1411,7 +1419,7 @@ NW_EXPORT int nw_iter_update(nw_ctx *ctx)
                            ctx->logs.p + ctx->search_done, it, (ctx->direct_out && it == ctx->search_iters - 1) ? (float *)ctx->pin : nullptr);
     }
     NW_HIP(hipGetLastError());
-    if (ctx->have_boundary && !ctx->capturing) { NW_TRY(halo_pack(ctx, NW_ARR_POS)); ctx->pos_unpack_pending = true; }
+    if (ctx->have_boundary && (!ctx->capturing || ctx->ext_capture)) { NW_TRY(halo_pack(ctx, NW_ARR_POS)); ctx->pos_unpack_pending = true; }
     ctx->global_iter += 1;
     ctx->search_done += 1;
     return NW_OK;
@@ -1529,7 +1537,9 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
-                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p};
+                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p,
+                          ctx->hb_local.p, ctx->hb_slot.p, ctx->hb_slot2local.p, ctx->halo_acc.p, ctx->halo_rows.p};
+    mix((uint64_t)ctx->hb_n); mix((uint64_t)ctx->hb_nslot); mix((uint64_t)(uintptr_t)ctx->stream);
     for (const void *p : ptrs) mixp(p);
     return h;
 }
@@ -1576,6 +1586,56 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool tail)
     if (dst.exec) (void)hipGraphExecDestroy(dst.exec);
     dst.exec = ea; dst.key = key;
     return &dst;
+}
+
+// ---- a block's phases recorded by the CALLER (multi-GPU: the collectives between the phases belong to the caller) ------------------
+// The caller puts the ctx's stream (nw_set_stream: its own) into capture, calls nw_capture_begin, then the phases of the block's remaining
+// iterations with its collectives between them exactly as it would run them, nw_capture_end, and ends its capture.  Nothing has run:
+// the bookkeeping the recorded calls advanced is rewound.  It then replays the recording for this and every later block whose
+// nw_block_key (asked after nw_search_begin) equals the one nw_capture_end returned, and tells the ctx with nw_block_replayed.
+NW_EXPORT int nw_capture_begin(nw_ctx *ctx)
+{
+    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_capture_begin outside a search (nw_search_begin first)");
+    if (ctx->capturing) return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: already recording");
+    if (ctx->own_stream) return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: the caller records its own stream (nw_set_stream)");
+    if (!(ctx->profiling == 0 || (ctx->profiling == 4 && ctx->search_done >= 1)))
+        return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: per-launch profiling needs live events (levels 1, 2; level 4: the block's first iteration)");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusActive) {
+        (void)hipGetLastError();
+        return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: the stream is not being captured");
+    }
+    ctx->cap_done0 = ctx->search_done; ctx->cap_iter0 = ctx->global_iter; ctx->cap_warm0 = ctx->face_warm;
+    ctx->cap_pending0 = ctx->pos_unpack_pending; ctx->cap_begin0 = ctx->begin_ops_pending; ctx->cap_dirty0 = ctx->vacc_dirty;
+    ctx->capturing = true; ctx->ext_capture = true;
+    return NW_OK;
+}
+
+NW_EXPORT int nw_capture_end(nw_ctx *ctx, uint64_t *key)
+{
+    if (!ctx || !ctx->ext_capture) return fail(ctx, NW_ERR_BADARG, "nw_capture_end without nw_capture_begin");
+    ctx->capturing = false; ctx->ext_capture = false;
+    ctx->search_done = ctx->cap_done0; ctx->global_iter = ctx->cap_iter0; ctx->face_warm = ctx->cap_warm0;
+    ctx->pos_unpack_pending = ctx->cap_pending0; ctx->begin_ops_pending = ctx->cap_begin0; ctx->vacc_dirty = ctx->cap_dirty0;
+    if (key) *key = block_graph_key(ctx) ^ (0x9e3779b97f4a7c15ull * (uint64_t)(ctx->search_done + 1));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_block_key(nw_ctx *ctx, uint64_t *key)
+{
+    if (!ctx || !key || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_block_key outside a search");
+    *key = block_graph_key(ctx) ^ (0x9e3779b97f4a7c15ull * (uint64_t)(ctx->search_done + 1));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_block_replayed(nw_ctx *ctx, int iters)
+{
+    if (!ctx || !ctx->in_search || ctx->capturing) return fail(ctx, NW_ERR_BADARG, "nw_block_replayed outside a search");
+    if (iters < 1 || ctx->search_done + iters > ctx->search_iters) return fail(ctx, NW_ERR_BADARG, "nw_block_replayed: more iterations than announced");
+    if (ctx->search_done == 0) { ctx->begin_ops_pending = false; ctx->vacc_dirty = false; }
+    ctx->global_iter += iters; ctx->search_done += iters; ctx->face_warm = true;
+    ctx->pos_unpack_pending = ctx->have_boundary;          // the recording ends with the owners' rows of the last update packed (and the caller's all-reduce)
+    return NW_OK;
 }
 
 NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags, float *pos_out, nw_iter_log *log, int *loopcount)

@@ -408,6 +408,7 @@ class ShrinkwrapMeshConjGrad(object):
         level = 2 if level is True else int(level)
         self._native.check(self._L.nw_set_profiling(self._h, level))
         self._profiling = level > 0
+        self._profiling_level = level
         self._profiled_stages = ('nn',) if level in (1, 4) else None          # (levels 1 and 4 time nothing else)
         self.stage_ms_total = {k: (0.0, 0) for k in ('total', 'grid', 'nn', 'attract', 'prior', 'as', 'update', 'fixup')}
 

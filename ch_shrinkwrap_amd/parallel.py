@@ -61,6 +61,9 @@ class HipExecutor(object):
         self._views = {}
         self.write_back = True                      # end(): copy the rank's (M,3) result to the host mesh (a sharded mesh gathers the whole mesh instead)
         self.max_dist = 0.0
+        self.graphs = {}                            # recorded blocks (phases + the collectives between them), by nw_block_key
+        self.blocks_run = 0
+        self.blocks_replayed = 0
 
     def new_tensor(self, values):
         import torch
@@ -71,6 +74,11 @@ class HipExecutor(object):
         cg._upload_points(sigma_inv, weights, prenormalized)
         lams_a = np.ascontiguousarray(lams, dtype=np.float32)
         flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP) | cg._regulariser_flag()
+        posv = cg.mesh._vertices['position']
+        # the result goes straight from the block's last update kernel to the host (as in cg.search) when end() copies it into the mesh
+        self._direct = bool(self.write_back and posv.dtype == np.float32 and posv.strides[1] == 4 and posv.strides[0] >= 12)
+        if self._direct:
+            flags |= nw.NW_FLAG_RESULT_TO_HOST
         cg._cache = {}
         self.native.check(self.L.nw_search_begin(self.h, nw.ptr(lams_a), lams_a.size, int(num_iters), flags))
         self._num_iters = int(num_iters)
@@ -112,6 +120,7 @@ class HipExecutor(object):
         self.native.check(self.L.nw_set_boundary(self.h, nw.ptr(bl), nw.ptr(bs), bl.size, int(n_boundary), nw.ptr(ow), nw.ptr(g), int(n_global)))
         self.n_boundary, self.n_global = int(n_boundary), int(n_global)
         self._views = {}
+        self.graphs = {}
 
     def boundary_accumulator(self):
         """(n_boundary, 4) int64: this rank's partial sums of the boundary vertices it holds (filled by attract())"""
@@ -143,6 +152,26 @@ class HipExecutor(object):
         self.native.check(self.L.nw_host_copy_rows(self.h, nw.ptr(src), src.shape[0], nw.ptr(contiguous), ctypes.c_void_p(rows.ctypes.data), rows.strides[0],
                                                    nw.ptr(valid_u8)))
 
+    # -- a block recorded with its collectives (nw_capture_begin .. nw_block_replayed, include/nanowrap.h) --------------------------------
+    def profiling_level(self):
+        return int(getattr(self.cg, '_profiling_level', 0))
+
+    def block_key(self):
+        k = ctypes.c_uint64(0)
+        self.native.check(self.L.nw_block_key(self.h, ctypes.byref(k)))
+        return k.value
+
+    def capture_begin(self):
+        self.native.check(self.L.nw_capture_begin(self.h))
+
+    def capture_end(self):
+        k = ctypes.c_uint64(0)
+        self.native.check(self.L.nw_capture_end(self.h, ctypes.byref(k)))
+        return k.value
+
+    def replayed(self, iterations):
+        self.native.check(self.L.nw_block_replayed(self.h, int(iterations)))
+
     def local_quantum(self):
         """the quantum this rank would choose for its own localizations (valid after begin())"""
         q = ctypes.c_double(0.0)
@@ -158,7 +187,14 @@ class HipExecutor(object):
         cg = self.cg
         logs = (nw.IterLog * max(self._num_iters, 1))()
         lc = ctypes.c_int(0)
-        code = self.L.nw_search_end(self.h, None, logs, ctypes.byref(lc))
+        out = None
+        if self._direct:
+            out = cg._result_buffer()
+            posv = cg.mesh._vertices['position']
+            self.native.check(self.L.nw_set_write_back(self.h, ctypes.c_void_p(posv.ctypes.data), posv.strides[0]))
+        code = self.L.nw_search_end(self.h, nw.ptr(out) if out is not None else None, logs, ctypes.byref(lc))
+        if self._direct:
+            self.native.check(self.L.nw_set_write_back(self.h, None, 0))
         self.native.check(code)
         cg.max_dist = 0.0
         cg._consume_logs(logs, lc.value)
@@ -166,7 +202,12 @@ class HipExecutor(object):
         self.max_dist = cg.max_dist
         if not self.write_back:
             return None
-        cg._finish()
+        if out is not None:
+            cg.fs = out
+            cg.f = out.ravel()
+            cg.mesh._initialize_curvature_vectors()
+        else:
+            cg._finish()
         return cg.fs
 
 
@@ -210,7 +251,7 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
             with timer:
                 dist.all_reduce(t)
 
-    for _ in range(int(num_iters)):
+    def iteration():
         ex.attract()                                         # 'halo': leaves this rank's partial sums of the boundary vertices packed
         if mode == 'replicated':
             all_reduce(ex.vertex_accumulator())
@@ -221,7 +262,71 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
         ex.update()                                          # 'halo': leaves the new positions of the boundary vertices it OWNS packed
         if mode == 'halo' and ex.n_boundary > 0:
             all_reduce(ex.boundary_rows())                   # (|B|, 3): owner-only non-zero rows -> every holder takes the owner's value
+
+    n = int(num_iters)
+    done = 0
+    if n > 0 and timer is None and _recordable(ex, dist):
+        # The block as ONE recording -- the phases' launches AND the RCCL collectives between them (hipGraph capture of the shared
+        # stream) -- replayed for every later block that bakes the same things in (nw_block_key): a sharded iteration is ~12 launches
+        # and up to 3 collective calls, which the host otherwise issues one by one.  Profiling level 4 keeps the block's first iteration
+        # live (its query kernel between two events), as nw_search does on one GPU.  Every rank takes the same branch: the conditions
+        # are the same on all of them, and whether a capture worked is agreed with one all-reduce.
+        if ex.profiling_level() == 4:
+            iteration()
+            done = 1
+        if n - done > 0:
+            key = (ex.block_key(), mode, done, n - done, n_red)
+            g = ex.graphs.get(key)
+            if g is None:
+                g = _record_block(ex, dist, iteration, n - done)
+                while len(ex.graphs) >= 4:
+                    ex.graphs.pop(next(iter(ex.graphs)))
+                ex.graphs[key] = g
+            if g is not False:
+                g.replay()
+                ex.replayed(n - done)
+                ex.blocks_replayed += 1
+                done = n
+    for _ in range(done, n):
+        iteration()
+    ex.blocks_run = getattr(ex, 'blocks_run', 0) + 1
     return ex.end()                                          # (the last update's rows are taken here)
+
+
+def _recordable(ex, dist):
+    """Blocks are recorded when the collectives can be (RCCL: backend nccl), from the executor's second block on (the first one runs the
+    collectives once outside a capture, and a cold query has a key of its own anyway).  NW_GRAPH_COLLECTIVES=0 turns it off."""
+    import os
+    if not hasattr(ex, 'capture_begin') or os.environ.get('NW_GRAPH_COLLECTIVES', '1') == '0':
+        return False
+    if getattr(ex, 'blocks_run', 0) < 1 or ex.profiling_level() not in (0, 4):
+        return False
+    try:
+        return dist.get_backend() == 'nccl'
+    except Exception:
+        return False
+
+
+def _record_block(ex, dist, iteration, count):
+    """Capture `count` iterations (phases + collectives) on the current torch stream; False if any rank could not."""
+    import torch
+    ok = 1.0
+    g = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode='thread_local'):
+            ex.capture_begin()
+            try:
+                for _ in range(count):
+                    iteration()
+            finally:
+                ex.capture_end()
+    except Exception as e:                                   # e.g. a collective that cannot be captured on this stack
+        import sys
+        sys.stderr.write('[nanowrap] recording a block with its collectives failed (%s: %s): blocks are issued launch by launch\n' % (type(e).__name__, e))
+        ok = 0.0
+    t = ex.new_tensor([ok])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return g if float(t[0]) > 0.5 else False
 
 
 class CollectiveTimer(object):
@@ -512,7 +617,7 @@ class HaloScene(object):
         self._gv = gv
         self._local_mesh = ArrayMesh(pos[gv], nrm[gv], d['nbr'], d['faces'], d['valid'])
         old = self.ex
-        keep = {k: getattr(old, k) for k in ('collective_timer', '_prenorm_cache') if old is not None and hasattr(old, k)}
+        keep = {k: getattr(old, k) for k in ('collective_timer', '_prenorm_cache', 'blocks_replayed') if old is not None and hasattr(old, k)}
         self.ex = (self.make_executor or self._hip_executor)(self._local_mesh, self._local_points)
         for k, v in keep.items():
             setattr(self.ex, k, v)

@@ -54,6 +54,8 @@ typedef enum nw_weights_mode {
                                         S1 = -w prefs, LS_k = w S_k with w = vertex_area_weights(f) (conj_grad_utils.c:500-548).  The other
                                         names the reference offers (Lfunc, Lfunc2..4) fail upstream in the first iteration: they hand the
                                         float64 `f - _ncc()` to float32 C code (conj_grad_utils.c:286-302 reads it blindly) */
+#define NW_FLAG_RESULT_TO_HOST 8u    /* nw_search_begin only: nw_search_end will be given a HOST pos_out -- the block's last nw_iter_update then writes the
+                                        result into the pinned staging buffer itself, as nw_search arranges on its own (the write-back, mesh_conj_grad.py:288-289) */
 
 /* per-iteration record; the reference keeps these as Python lists / attributes:
  * tests, ress, prefs (mesh_conj_grad.py:269-271), cpred, wpreds (:274, conj_grad.py:223-225) */
@@ -185,6 +187,19 @@ int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride
  * whole-mesh all-reduce lands in a pinned buffer): src (n_rows,3) float32 HOST -> `contiguous` and / or the strided records `rows`
  * (only where valid[v] != 0 if `valid` is given), copied by the library's host threads.  No device work. */
 int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *contiguous, void *rows, int64_t row_stride_bytes, const uint8_t *valid);
+/* A block recorded by the CALLER (no reference counterpart: the reference launches nothing).  In a multi-GPU run the
+ * collectives between the phases belong to the caller, so the library cannot capture such a block itself (nw_search does, for one GPU).
+ * The caller puts the stream it gave to nw_set_stream into capture, then:
+ *   nw_search_begin(...);  [level 4: the block's first iteration, live]  nw_block_key(&k);   -- a recording with this key? replay it; else:
+ *   <begin capture>  nw_capture_begin();  { nw_iter_attract, <all-reduce>, nw_iter_directions, <all-reduce>, nw_iter_update, <all-reduce> } x remaining
+ *   iterations;  nw_capture_end(&k);  <end capture>          -- nothing ran: the ctx's bookkeeping is rewound
+ *   <replay>;  nw_block_replayed(iterations);  nw_search_end(...).
+ * The key covers everything the recorded launches bake in (sizes, buffers, stream, cell grid, work list, flags, lambda, quantum, warm or cold
+ * query, boundary set, where in the block the recording starts).  Levels 1 and 2 of nw_set_profiling need live events and refuse. */
+int nw_capture_begin(nw_ctx *ctx);
+int nw_capture_end(nw_ctx *ctx, uint64_t *key);
+int nw_block_key(nw_ctx *ctx, uint64_t *key);
+int nw_block_replayed(nw_ctx *ctx, int iterations);
 /* Sharded mesh ('halo' mode): owned[M] = 1 for the vertices this rank owns, 0 for the copies of vertices owned by
  * another rank.  The vertex-side normal-equation sums (S^T S, S.prefs, |prefs|^2) then run over the owned vertices only, so that the
  * all-reduce over ranks counts every vertex once.  NULL = every vertex is owned (default).  Reset by nw_set_mesh. */

@@ -388,6 +388,60 @@ def test_split_phase_equals_search_on_one_gpu(mode):
     assert np.array_equal(m2.vertices, c)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,level', [('tiles', 0), ('tiles', 4), ('replicated', 0), ('halo', 0), ('halo', 4)])
+def test_blocks_recorded_with_their_collectives_equal_launch_by_launch(mode, level, monkeypatch):
+    """nw_capture_begin .. nw_block_replayed (include/nanowrap.h): from an executor's second block on, run_search records a block -- the
+    phases' launches AND the RCCL all-reduces between them -- as one hipGraph and replays it.  World size 1 over nccl is what a one-GPU
+    box can run; the collectives are real RCCL calls on the captured stream.  Six blocks of 5 (the cell-size tuner changes the grid at
+    the third: a new key, a new recording), with the normals refreshed between blocks in 'halo' mode: bit-identical to the same blocks
+    issued launch by launch (NW_GRAPH_COLLECTIVES=0); profiling level 4 keeps each block's first iteration live."""
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    v, f = icosphere(4, 120.0)
+    pts = sphere_cloud(20000, 100.0, 10.0, seed=9)
+    s = 1.0 / np.random.default_rng(1).uniform(5.0, 15.0, size=pts.shape).astype('f4').ravel()
+    own = not dist.is_initialized()
+    if own:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(_free_port())
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+
+    def fit(graphs):
+        monkeypatch.setenv('NW_GRAPH_COLLECTIVES', '1' if graphs else '0')
+        mesh = TriMesh(v, f)
+        ts = torch.cuda.Stream()
+        outs = []
+        if mode == 'halo':
+            scene = parallel.HaloScene(mesh, pts, dist, halo=200.0, torch_stream=ts)
+            scene.set_profiling(level)
+            for b in range(6):
+                outs.append(scene.search([10.0], 5, s).copy())
+                scene.refresh_normals()
+            ex = scene.ex
+            assert scene.repartitions == 1
+        else:
+            cg = ShrinkwrapMeshConjGrad(mesh, pts, stream=ts.cuda_stream)
+            cg.set_profiling(level)
+            scene = parallel.TiledScene(cg, dist, mode=mode, torch_stream=ts)
+            for b in range(6):
+                outs.append(scene.search(pts, [10.0], 5, s).copy())
+            ex = scene.ex
+            assert len(cg.tests) == 30
+        return outs, ex.blocks_replayed, len(ex.graphs)
+
+    try:
+        a, replayed, recordings = fit(True)
+        b, none, _ = fit(False)
+    finally:
+        if own:
+            dist.destroy_process_group()
+    assert replayed == 5 and none == 0 and recordings >= 2          # every block but the executor's first; at least the pre- and post-tuner recordings
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(a[-1], a[-2])
+
+
 # ---- the HIP executor at world_size 2 (two fresh processes sharing cuda:0, gloo carrying the device tensors) -------------------
 def _gpu_worker(rank, world, port, mode, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
