@@ -199,6 +199,9 @@ def run_rank(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # blocks are replayed with their RCCL collectives inside (parallel.run_search): torch's event cache must be off for that, see
+    # parallel._recordable -- read when the process group is created
+    os.environ.setdefault('TORCH_NCCL_CUDA_EVENT_CACHE', '0')
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():

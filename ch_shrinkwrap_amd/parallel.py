@@ -295,9 +295,17 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
 
 def _recordable(ex, dist):
     """Blocks are recorded when the collectives can be (RCCL: backend nccl), from the executor's second block on (the first one runs the
-    collectives once outside a capture, and a cold query has a key of its own anyway).  NW_GRAPH_COLLECTIVES=0 turns it off."""
+    collectives once outside a capture, and a cold query has a key of its own anyway).  NW_GRAPH_COLLECTIVES=0 turns it off.
+
+    Only with TORCH_NCCL_CUDA_EVENT_CACHE=0 in the environment BEFORE the process group was created (bench.py sets it): with torch's
+    event cache on, an event a captured collective recorded is handed to a later eager collective; the process group's watchdog thread
+    then polls it while the next capture is active, HIP answers hipErrorCapturedEvent (the event still names the capturing stream),
+    the capture is invalidated and the watchdog takes the process down.  tools/experiments/capture_race.py reproduces it within a few
+    hundred captures on one GPU (torch 2.10 + ROCm 7.0 runtime); 800 captures without the cache show none."""
     import os
     if not hasattr(ex, 'capture_begin') or os.environ.get('NW_GRAPH_COLLECTIVES', '1') == '0':
+        return False
+    if os.environ.get('TORCH_NCCL_CUDA_EVENT_CACHE', '1') != '0':
         return False
     if getattr(ex, 'blocks_run', 0) < 1 or ex.profiling_level() not in (0, 4):
         return False
@@ -442,6 +450,8 @@ def bisect_tiles(points, n_ranks):
             walk(tr, idx[~left])
         walk(tree, np.arange(xyz.shape[0]))
         return out
+    # bounding boxes of the tiles' localizations: like the tiles they depend on the cloud alone (a pass over every localization)
+    classify.boxes = [(points[p].min(0), points[p].max(0)) if p.size else None for p in parts]
     return parts, classify
 
 
@@ -454,7 +464,11 @@ class HaloPartition(object):
     iteration; W_r = further 1-ring neighbours of V_r, ghosts that only carry positions / normals for the curvature prior.
     A vertex is owned by the tile that contains it.  Boundary vertices = present (in V or W) on more than one rank."""
 
-    def __init__(self, pos, nrm, nbr, faces, points, n_ranks, halo, tiles=None):
+    def __init__(self, pos, nrm, nbr, faces, points, n_ranks, halo, tiles=None, detail_ranks=None, membership_ranks=None):
+        """detail_ranks: the ranks whose share is worked out in full (index maps, local faces, local ring table); None = all.
+        membership_ranks: the ranks whose MEMBERSHIP (which vertices they hold) is computed here; None = all.  Who else holds a vertex
+        decides the boundary list, which all ranks must agree on: a process that computes only its own membership leaves `count`
+        partial and must call set_count() with the sum over the ranks (one all-reduce of M int32) before using `boundary`."""
         pos = np.asarray(pos, np.float32)
         faces = np.asarray(faces, np.int32)
         nbr = np.asarray(nbr, np.int32)
@@ -464,26 +478,44 @@ class HaloPartition(object):
         self.parts, classify = tiles if tiles is not None else bisect_tiles(points, n_ranks)
         self.owner = classify(pos)
         cent = ((pos[faces[:, 0]] + pos[faces[:, 1]]) + pos[faces[:, 2]]) / np.float32(3.0)
+        fowner = self.owner[faces]                                  # (F, 3): owners of a face's vertices
         count = np.zeros(M, np.int32)
         self.ranks = []
+        nbr_ok = nbr >= 0
+        nbr_safe = np.where(nbr_ok, nbr, 0)
+        boxes = getattr(classify, 'boxes', None)
         for r in range(self.n_ranks):
-            p = points[self.parts[r]]
-            if p.shape[0]:
-                lo, hi = p.min(0) - self.halo, p.max(0) + self.halo
-                fsel = np.nonzero(((cent >= lo) & (cent <= hi)).all(1))[0]
+            if membership_ranks is not None and r not in membership_ranks:
+                self.ranks.append(dict(pidx=self.parts[r]))
+                continue
+            if boxes is not None:
+                box = boxes[r]
             else:
-                fsel = np.zeros(0, np.int64)
+                p = points[self.parts[r]]
+                box = (p.min(0), p.max(0)) if p.shape[0] else None
+            if box is not None:
+                lo, hi = box[0] - self.halo, box[1] + self.halo
+                fmask = ((cent >= lo) & (cent <= hi)).all(1)
+            else:
+                fmask = np.zeros(faces.shape[0], bool)
             # the faces of every owned vertex belong to the owner as well (its prior and its update must be complete there)
-            own_v = np.nonzero(self.owner == r)[0]
-            if own_v.size:
-                isown = np.zeros(M, bool)
-                isown[own_v] = True
-                fsel = np.union1d(fsel, np.nonzero(isown[faces].any(1))[0])
-            gV = np.unique(faces[fsel].ravel()) if fsel.size else np.zeros(0, np.int64)
-            gV = np.union1d(gV, own_v)
-            ring = nbr[gV]
-            ring = np.unique(ring[ring >= 0]) if gV.size else np.zeros(0, np.int64)
-            gW = np.setdiff1d(ring, gV)
+            fmask |= (fowner == r).any(1)
+            inV = self.owner == r
+            if fmask.any():
+                inV[faces[fmask].ravel()] = True
+            # W = 1-ring of V outside V: ghosts
+            inW = np.zeros(M, bool)
+            rows_ok = nbr_ok[inV]
+            inW[nbr_safe[inV][rows_ok]] = True
+            inW &= ~inV
+            count += inV
+            count += inW
+            if detail_ranks is not None and r not in detail_ranks:
+                self.ranks.append(dict(pidx=self.parts[r]))
+                continue
+            fsel = np.nonzero(fmask)[0]
+            gV = np.nonzero(inV)[0]
+            gW = np.nonzero(inW)[0]
             gv = np.concatenate([gV, gW]).astype(np.int64)
             g2l = -np.ones(M, np.int64)
             g2l[gv] = np.arange(gv.size)
@@ -494,13 +526,22 @@ class HaloPartition(object):
             valid[:gV.size] = 1
             owned = (self.owner[gv] == r).astype(np.uint8)
             owned[gV.size:] = 0
-            count[gv] += 1
             self.ranks.append(dict(pidx=self.parts[r], gv=gv, nV=int(gV.size), faces=g2l[faces[fsel]].astype(np.int32),
                                    nbr=nbr_l, valid=valid, owned=owned))
-        self.boundary = np.nonzero(count > 1)[0]
-        slot = -np.ones(M, np.int64)
+        self.count = count
+        self.boundary = None
+        if membership_ranks is None:
+            self.set_count(count)
+
+    def set_count(self, count):
+        """count[v] = number of ranks holding vertex v (summed over the ranks) -> the boundary list and every detailed rank's rows in it"""
+        self.count = np.asarray(count)
+        self.boundary = np.nonzero(self.count > 1)[0]
+        slot = -np.ones(self.M, np.int64)
         slot[self.boundary] = np.arange(self.boundary.size)
         for d in self.ranks:
+            if 'gv' not in d:
+                continue
             s = slot[d['gv']]
             d['b_local'] = np.nonzero(s >= 0)[0]
             d['b_slot'] = s[s >= 0]
@@ -569,6 +610,8 @@ class HaloScene(object):
         self._pos0_t = None
         self.host_ms = {}                # wall time of the host-side steps of the last block / set-up
         self.repartitions = 0
+        self._last_step = 0.0                         # movement of the mesh over the previous block (nm)
+        self._blocks_since_partition = 0
 
     # -- set-up (once per topology) ---------------------------------------------------------------------------------------------
     def mesh_changed(self):
@@ -610,7 +653,17 @@ class HaloScene(object):
             nbr[mesh._vertices['neighbors'] == -1] = -1
         pos = np.ascontiguousarray(mesh._vertices['position'], np.float32)
         nrm = np.ascontiguousarray(mesh.vertex_normals, np.float32)
-        part = HaloPartition(pos, nrm, nbr, mesh.faces, self.points, self.world, self.halo, tiles=self._tiles)
+        t1 = time.perf_counter()
+        # every rank works out its OWN share only; who else holds a vertex (the boundary list) comes from one all-reduce of the counts
+        part = HaloPartition(pos, nrm, nbr, mesh.faces, self.points, self.world, self.halo, tiles=self._tiles, detail_ranks=(self.rank,),
+                             membership_ranks=(self.rank,))
+        import torch
+        cnt = torch.from_numpy(part.count)
+        if self.make_executor is None:
+            cnt = cnt.cuda()
+        self.dist.all_reduce(cnt)
+        part.set_count(cnt.cpu().numpy())
+        t2 = time.perf_counter()
         self.last_partition = part
         d = part.ranks[self.rank]
         gv = d['gv']
@@ -625,12 +678,15 @@ class HaloScene(object):
             self.ex.cg.stage_ms_total = old.cg.stage_ms_total          # HIP-event totals run on across a re-partition (bench.py reads them at the end)
         self.ex.set_boundary(d['b_local'], d['b_slot'], part.boundary.size, d['owned'], gv, part.M)
         self._pos0 = pos.copy()                       # where the mesh was when the shares were cut (drift budget of the halo)
+        self._blocks_since_partition = 0
         self._pos0_t = None
         self._valid = mesh._vertices['halfedge'] != -1
         self._all_valid = bool(self._valid.all())
         self._valid_u8 = np.ascontiguousarray(self._valid, np.uint8)
         self.repartitions += 1
-        self.host_ms['setup'] = (time.perf_counter() - t0) * 1e3
+        t3 = time.perf_counter()
+        self.host_ms['setup'] = (t3 - t0) * 1e3
+        self.host_ms['setup_parts'] = {'tiles_ring_table_normals': (t1 - t0) * 1e3, 'partition_and_count_all_reduce': (t2 - t1) * 1e3, 'sub_mesh_optimiser_boundary': (t3 - t2) * 1e3}
 
     def _local(self, a):
         """this rank's rows of a per-localization (3N,) array -- the SAME object for the same input, so that the residency keys of the
@@ -698,8 +754,15 @@ class HaloScene(object):
                 posv[:] = newpos
             else:
                 posv[self._valid] = newpos[self._valid]
+        # New shares before the next block?  The query of a block is exact if (largest nearest distance + drift since the shares were
+        # cut) stays within the halo radius THROUGH the block, which is only known afterwards: so cut again as soon as another block
+        # like the faster of the last two (twice its movement, for margin) could exceed it.
+        step = max(drift - (self.drift if self._blocks_since_partition > 0 else 0.0), 0.0)
+        recent = max(step, self._last_step)           # (the last two blocks: a fit slows down as it converges)
+        self._last_step = step
+        self._blocks_since_partition += 1
         self.max_dist, self.drift = worst, drift
-        if drift > 0.25 * self.halo:
+        if worst + drift + 2.0 * recent > self.halo:
             self.last_partition = None                # cut new shares around the moved mesh before the next block
         t2 = time.perf_counter()
         self.host_ms['block_tail_collectives_and_copy'] = (t1 - t0) * 1e3

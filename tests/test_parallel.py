@@ -14,6 +14,7 @@ import os
 import socket
 import numpy as np
 import pytest
+os.environ.setdefault('TORCH_NCCL_CUDA_EVENT_CACHE', '0')       # recorded blocks need torch's NCCL event cache off (parallel._recordable); read at process-group creation
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -226,7 +227,7 @@ def _worker(rank, world, port, mode, q):
             mine = parts[rank]
             ex = OracleExecutor(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts[mine])
             out = parallel.run_search(ex, dist, 'replicated', pts[mine], [7.0], 4, 1.0 / sigma[mine].ravel())
-        elif mode == 'halo':
+        elif mode in ('halo', 'halo_tight'):
             (v, f, pts, sigma), = _scene(False)
             mesh = TriMesh(v, f)
 
@@ -235,14 +236,18 @@ def _worker(rank, world, port, mode, q):
                 nb = lm._halfedges['vertex'][lm._vertices['neighbors']]
                 nb[lm._vertices['neighbors'] == -1] = -1
                 return OracleExecutor(lm.vertices.copy(), lm.vertex_normals.copy(), np.ascontiguousarray(nb, np.int32), lm.faces, local_points)
-            scene = parallel.HaloScene(mesh, pts, dist, halo=40.0, make_executor=make)
+            # 'halo': a radius with room for the fit's movement -> both blocks on the shares cut at the start;
+            # 'halo_tight': largest nearest distance + movement comes close to the radius after the first block -> new shares are cut
+            scene = parallel.HaloScene(mesh, pts, dist, halo=50.0 if mode == 'halo' else 40.0, make_executor=make)
             s_inv = 1.0 / sigma.ravel()
             scene.search([7.0], 4, s_inv)
             scene.refresh_normals()                           # second block on the RESIDENT shares: new normals, same partition
             out = scene.search([7.0], 3, s_inv)
-            assert scene.repartitions == 1
+            assert scene.repartitions == (1 if mode == 'halo' else 2), (scene.repartitions, scene.max_dist, scene.drift)
             part = scene.last_partition
-            q.put((rank, (out, part.boundary.size, [int(d['nV']) for d in part.ranks], [int(d['owned'].sum()) for d in part.ranks])))
+            d = part.ranks[rank]                        # (a rank works out its own share only; the boundary list comes from the all-reduced counts)
+            assert all('gv' not in o for r, o in enumerate(part.ranks) if r != rank)
+            q.put((rank, (out, part.boundary.size, int(d['nV']), int(d['owned'].sum()))))
             return
         else:
             v, f, pts, sigma = _scene(True)[rank]
@@ -300,16 +305,19 @@ def test_tiles_two_vesicles_gloo():
 
 
 @pytest.mark.timeout(300)
-def test_halo_sharded_mesh_gloo():
+@pytest.mark.parametrize('mode', ['halo', 'halo_tight'])
+def test_halo_sharded_mesh_gloo(mode):
     from oracle import nanowrap_oracle as O
-    res = _run('halo')
+    res = _run(mode)
     (v, f, pts, sigma), = _scene(False)
     mesh = TriMesh(v, f)
     ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, [7.0], 4, 1.0 / sigma.ravel())
     mesh._vertices['position'][:] = ref.positions.astype('f4')
     mesh.update_geometry()
     ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, [7.0], 3, 1.0 / sigma.ravel())
-    (out0, nb, nV, nown), (out1, _, _, _) = res[0], res[1]
+    (out0, nb, nV0, nown0), (out1, nb1, nV1, nown1) = res[0], res[1]
+    nV, nown = [nV0, nV1], [nown0, nown1]
+    assert nb == nb1
     assert np.array_equal(out0, out1)                             # every rank ends with the same whole mesh
     assert rel_rms(out0, ref.positions) <= 1e-5
     M = v.shape[0]
@@ -401,6 +409,7 @@ def test_blocks_recorded_with_their_collectives_equal_launch_by_launch(mode, lev
     pts = sphere_cloud(20000, 100.0, 10.0, seed=9)
     s = 1.0 / np.random.default_rng(1).uniform(5.0, 15.0, size=pts.shape).astype('f4').ravel()
     own = not dist.is_initialized()
+    assert os.environ.get('TORCH_NCCL_CUDA_EVENT_CACHE') == '0'
     if own:
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(_free_port())
@@ -471,7 +480,7 @@ def _gpu_worker(rank, world, port, mode, q):
         else:
             (v, f, pts, sigma), = _scene(False)
             mesh = TriMesh(v, f)
-            scene = parallel.HaloScene(mesh, pts, dist, halo=40.0, torch_stream=ts)
+            scene = parallel.HaloScene(mesh, pts, dist, halo=50.0, torch_stream=ts)
             s_inv = 1.0 / sigma.ravel()
             out = scene.search([7.0], 4, s_inv)
             scene.refresh_normals()                           # on the device: shares stay resident, owners' normals go round
