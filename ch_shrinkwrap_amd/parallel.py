@@ -40,6 +40,9 @@ import numpy as np
 from . import _lib as nw
 
 
+RECORD_BELOW_LOCALIZATIONS = 500000      # run_search records blocks with their collectives for ranks holding fewer localizations (NW_GRAPH_COLLECTIVES=1: always)
+
+
 class _DevArray(object):
     """Minimal __cuda_array_interface__ carrier so torch can view library-owned device memory without a copy."""
 
@@ -303,9 +306,14 @@ def _recordable(ex, dist):
     the capture is invalidated and the watchdog takes the process down.  tools/experiments/capture_race.py reproduces it within a few
     hundred captures on one GPU (torch 2.10 + ROCm 7.0 runtime); 800 captures without the cache show none."""
     import os
-    if not hasattr(ex, 'capture_begin') or os.environ.get('NW_GRAPH_COLLECTIVES', '1') == '0':
+    want = os.environ.get('NW_GRAPH_COLLECTIVES', 'auto')
+    if not hasattr(ex, 'capture_begin') or want == '0':
         return False
     if os.environ.get('TORCH_NCCL_CUDA_EVENT_CACHE', '1') != '0':
+        return False
+    # 'auto': where the host is the bound.  Measured on one GPU (tools/graph_rehearsal.sh): a rank with 10^6 localizations is device-bound
+    # either way (0.308 against 0.309 ms per iteration), one with 10^5 gains 5 % ('tiles') to 18 % ('halo': three collectives per iteration)
+    if want != '1' and np.asarray(ex.cg._points_f32).size // 3 > RECORD_BELOW_LOCALIZATIONS:
         return False
     if getattr(ex, 'blocks_run', 0) < 1 or ex.profiling_level() not in (0, 4):
         return False
