@@ -370,7 +370,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const floa
 // wave per point, nw_fixup_point (nw_nn.h).  Only used when the query kernel does not resolve them itself (NW_FUSE_FIXUP=0).
 __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__restrict__ ambig_list, const int *__restrict__ ambig_count, const float4 *__restrict__ pts,
                                                       const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face,
-                                                      int *__restrict__ face_out, const NwDevState *__restrict__ st, int it)
+                                                      int *__restrict__ face_out, const NwDevState *__restrict__ st, int it, const int *__restrict__ face_orig)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     const int na = *ambig_count;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
     for (int a = wave; a < na; a += nwaves) {
         const int gi = ambig_list[a];
         const float4 P = pts[gi];
-        const int bf = nw_fixup_point(g, P.x, P.y, P.z, cent_by_face[face_out[gi]], cstart, cent, lane);
+        const int bf = nw_fixup_point(g, P.x, P.y, P.z, cent_by_face[face_out[gi]], cstart, cent, lane, face_orig);
         if (lane == 0) face_out[gi] = bf;
     }
 }

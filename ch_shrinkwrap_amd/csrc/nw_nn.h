@@ -77,6 +77,54 @@ __global__ void k_morton_keys(const float *__restrict__ xyz, int N, float lox, f
     idx[i] = i;
 }
 
+// Internal order of the faces (nw_set_mesh): key = Morton code of the face centroid, like the localizations'.  The caller's face ids are
+// whatever a mesher or seven remeshing passes left behind; every kernel that walks faces or gathers by face id (centroid binning, the
+// warm start of the query, the attraction step) wants neighbours in space to be neighbours in memory.
+__global__ void k_face_morton_keys(const float *__restrict__ pos, const int *__restrict__ faces, int F, int M, float lox, float loy, float loz, float inv_unit,
+                                   unsigned *__restrict__ key, int *__restrict__ idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    float c[3] = {0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < 3; ++k) {
+        const int v = faces[3 * i + k];
+        if ((unsigned)v < (unsigned)M)
+            for (int a = 0; a < 3; ++a) c[a] += pos[3 * v + a];
+    }
+    const float third = 1.0f / 3.0f;
+    const float fx = (c[0] * third - lox) * inv_unit, fy = (c[1] * third - loy) * inv_unit, fz = (c[2] * third - loz) * inv_unit;
+    // (a non-finite centroid sorts to the front: any order is a valid one)
+    const int qx = fx == fx ? nw_clampi((int)fminf(fmaxf(fx, 0.0f), 1023.0f), 0, 1023) : 0;
+    const int qy = fy == fy ? nw_clampi((int)fminf(fmaxf(fy, 0.0f), 1023.0f), 0, 1023) : 0;
+    const int qz = fz == fz ? nw_clampi((int)fminf(fmaxf(fz, 0.0f), 1023.0f), 0, 1023) : 0;
+    key[i] = nw_spread10((unsigned)qx) | (nw_spread10((unsigned)qy) << 1) | (nw_spread10((unsigned)qz) << 2);
+    idx[i] = i;
+}
+
+__global__ void k_face_regather(int F, const int *__restrict__ order, const int *__restrict__ faces_in, int *__restrict__ faces_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    const int o = order[i];
+    faces_out[3 * i] = faces_in[3 * o]; faces_out[3 * i + 1] = faces_in[3 * o + 1]; faces_out[3 * i + 2] = faces_in[3 * o + 2];
+}
+
+// internal face ids -> the caller's (nw_get(NW_ARR_FACE)); ids outside [0, F) are left alone
+__global__ void k_translate_ids(int n, int *__restrict__ ids, const int *__restrict__ orig, int F)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f = ids[i];
+    if ((unsigned)f < (unsigned)F) ids[i] = orig[f];
+}
+
+// "lower face id" of the tie rule, in the CALLER's numbering (orig = internal -> caller, NULL = the same); the sentinel loses
+__device__ __forceinline__ bool nw_id_less(int a, int b, const int *__restrict__ orig)
+{
+    if (orig && a != 0x7fffffff && b != 0x7fffffff) return orig[a] < orig[b];
+    return a < b;
+}
+
 // gather the localizations into sorted order, baking the residual weighting of search() (mesh_conj_grad.py:156-164):
 // weights = weights / weights.mean(), mask = weights > 0 (array) or isfinite(data) (scalar)
 __global__ void k_point_gather(int N, const float *__restrict__ xyz, const int *__restrict__ order,
@@ -385,7 +433,7 @@ __device__ __forceinline__ float nw_readlane_f(float v, int j) { return __builti
 // (binary search in the scanned offsets through shuffles), evaluated in float64, and reduced (lowest face id on exact ties).
 // Every lane returns the face id.
 __device__ __forceinline__ int nw_fixup_point(const NwGrid &g, float Px, float Py, float Pz, const float4 C0, const int *__restrict__ cstart,
-                                           const float4 *__restrict__ cent, int lane)
+                                           const float4 *__restrict__ cent, int lane, const int *__restrict__ face_orig)
 {
     const float r = sqrtf((Px - C0.x) * (Px - C0.x) + (Py - C0.y) * (Py - C0.y) + (Pz - C0.z) * (Pz - C0.z)) * (1.0f + 1e-4f) + g.eps;
     int lx, ly, lz, hx, hy, hz;
@@ -433,7 +481,7 @@ __device__ __forceinline__ int nw_fixup_point(const NwGrid &g, float Px, float P
                 const double dx = (double)Px - (double)C.x, dy = (double)Py - (double)C.y, dz = (double)Pz - (double)C.z;
                 const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
                 const int fid = __float_as_int(C.w);
-                if (d2 < best || (d2 == best && fid < bf)) { best = d2; bf = fid; }
+                if (d2 < best || (d2 == best && nw_id_less(fid, bf, face_orig))) { best = d2; bf = fid; }
             }
         }
     }
@@ -441,7 +489,7 @@ __device__ __forceinline__ int nw_fixup_point(const NwGrid &g, float Px, float P
     for (int off = 32; off > 0; off >>= 1) {
         const double od = __shfl_xor(best, off, 64);
         const int of = __shfl_xor(bf, off, 64);
-        if (od < best || (od == best && of < bf)) { best = od; bf = of; }
+        if (od < best || (od == best && nw_id_less(of, bf, face_orig))) { best = od; bf = of; }
     }
     return bf;
 }
@@ -452,7 +500,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                  const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,
                                                  int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
                                                  NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats,
-                                                 unsigned *__restrict__ item_cost)
+                                                 unsigned *__restrict__ item_cost, const int *__restrict__ face_orig)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ NwWaveLds s_wave[4];
@@ -686,7 +734,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const float4 C0 = cent_by_face[__builtin_amdgcn_readlane(fid, j)];
-                const int res = nw_fixup_point(g, nw_readlane_f(Pw.x, j), nw_readlane_f(Pw.y, j), nw_readlane_f(Pw.z, j), C0, cstart, cent, lane);
+                const int res = nw_fixup_point(g, nw_readlane_f(Pw.x, j), nw_readlane_f(Pw.y, j), nw_readlane_f(Pw.z, j), C0, cstart, cent, lane, face_orig);
                 if (lane == j) fid = res;
             }
             if (active) face_io[gi] = fid;
