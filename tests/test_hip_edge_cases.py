@@ -311,3 +311,31 @@ def test_sharded_mesh_entry_points_check_their_arguments():
     cg._native.check(L.nw_host_copy_rows(h, nw.ptr(src), src.shape[0], nw.ptr(dst), ctypes.c_void_p(posv.ctypes.data), posv.strides[0], nw.ptr(valid)))
     assert np.array_equal(dst, src)
     assert np.array_equal(posv[valid != 0], src[valid != 0]) and (posv[valid == 0] == 0).all()
+
+
+def test_the_order_of_the_callers_faces_does_not_matter():
+    """The library keeps the faces in an order of its own (Morton order of the centroids, nw_set_mesh): the SAME mesh -- positions,
+    normals and 1-ring table identical -- handed over with its faces array shuffled must give bit-identical positions, and nearest
+    faces that name the same triangle (nw_get(NW_ARR_FACE) answers in the caller's ids)."""
+    from ch_shrinkwrap_amd.trimesh import TriMesh, icosphere
+    from ch_shrinkwrap_amd.parallel import ArrayMesh
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+    from ch_shrinkwrap_amd.synth import sphere_cloud
+    v, f = icosphere(4, 110.0)
+    pts = sphere_cloud(30000, 100.0, 8.0, seed=3)
+    s = 1.0 / np.random.default_rng(5).uniform(4.0, 12.0, size=pts.shape).astype('f4').ravel()
+    order = np.random.default_rng(11).permutation(f.shape[0])
+    base = TriMesh(v.copy(), f)                 # (a host mesh's normals and ring order depend on the order of ITS faces: taken once)
+    nrm, nbr = np.ascontiguousarray(base.vertex_normals, 'f4'), base.neighbor_vertex_table()
+    res = []
+    for faces in (f, np.ascontiguousarray(f[order])):
+        mesh = ArrayMesh(v.copy(), nrm, nbr, faces, np.ones(v.shape[0], np.uint8))
+        cg = ShrinkwrapMeshConjGrad(mesh, pts)
+        outs = [cg.search(pts, lams=[10.0], num_iters=5, sigma_inv=s).copy() for _ in range(2)]
+        res.append((outs, cg.nearest_face.copy(), faces))
+    (oa, fa, _), (ob, fb, fs) = res
+    for a, b in zip(oa, ob):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(fa, fb)                           # different ids ...
+    assert np.array_equal(f[fa], fs[fb])                        # ... of the same triangles, vertex for vertex
+    assert np.array_equal(order[fb], fa)
