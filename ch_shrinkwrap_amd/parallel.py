@@ -340,6 +340,13 @@ def _record_block(ex, dist, iteration, count):
         import sys
         sys.stderr.write('[nanowrap] recording a block with its collectives failed (%s: %s): blocks are issued launch by launch\n' % (type(e).__name__, e))
         ok = 0.0
+        if torch.cuda.is_current_stream_capturing():         # an invalidated capture that torch could not close: nothing can be launched any more
+            try:
+                g.capture_end()
+            except Exception:
+                pass
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('nanowrap: the stream is stuck in a failed capture (%s); NW_GRAPH_COLLECTIVES=0 issues every block launch by launch' % e)
     t = ex.new_tensor([ok])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return g if float(t[0]) > 0.5 else False
