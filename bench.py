@@ -287,9 +287,9 @@ def run_rank(args):
     # one-off set-up of the library that would otherwise fall into the first timed block: after its first completed block the
     # library re-sorts the localizations once by their foot point on the surface (radix sort + regather + new work list, ~2 ms)
     # tunes the cell size of the query (a few probe queries) and puts the heavy items of the query's work list first (one timed query)
-    # timed region: HIP events on the library's stream around the launch of the dominant kernel (the NN query) in the first iteration
+    # timed region: HIP events on the library's stream around the launch of the dominant kernel (the NN query) in the LAST iteration
     # of every block of 5 -- K/5 live samples; an event pair costs the stream a few microseconds, and one per iteration took ~5 % off
-    # the rate being measured.  That first iteration is launched from the host (events recorded inside hipGraph nodes read 0 on
+    # the rate being measured.  That last iteration is launched from the host (events recorded inside hipGraph nodes read 0 on
     # ROCm 7.2); the other four iterations of the block are one replayed hipGraph.
     # The full per-stage breakdown is taken in a short extra pass AFTER the timed region.
     set_profiling(4)
@@ -417,7 +417,7 @@ def run_rank(args):
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': ('profiles/%s (rocprofv3 --pmc passes of this workload, committed; not re-measured by this run)' % PMC_FILE if traffic is not None else None),
                          'algorithmic_bytes_per_launch': per_kernel[kern[dom]], 'avg_launch_ms': avg_ms, 'launches': launches,
-                         'launches_note': 'HIP events on the library stream around the k_nn_wave launch of the first iteration of every block of %d of the timed region (that iteration is launched from the host, the other iterations of the block are a replayed hipGraph)' % BLOCK,
+                         'launches_note': 'HIP events on the library stream around the k_nn_wave launch of the last iteration of every block of %d of the timed region (that iteration is launched from the host while the replayed hipGraph of the block\'s other iterations is still running)' % BLOCK,
                          'measured_copy_peak': measured_copy_ceiling(torch)},
             'roofline_iteration': {'algorithmic_bytes': per_iter, 'device_ms': stage['total'][0] / n_extra,
                                    'achieved': per_iter / (stage['total'][0] / n_extra * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
@@ -432,7 +432,7 @@ def run_rank(args):
                                   'share_of_device_time': (comm_ms / n_extra) / max(stage['total'][0] / n_extra + comm_ms / n_extra, 1e-12),
                                   'note': 'rank 0, event-bracketed all-reduces of %d extra iterations after the timed region' % n_extra,
                                   'blocks_replayed_with_their_collectives': replayed_blocks,
-                                  'blocks_note': 'blocks of the warm-up and the timed region whose iterations 2..%d -- launches AND collectives -- were one replayed recording (hipGraph capture of the shared stream; RCCL only); the first iteration of a block stays live for the event pair around its query' % BLOCK}
+                                  'blocks_note': 'blocks of the warm-up and the timed region whose iterations 1..%d -- launches AND collectives -- were one replayed recording (hipGraph capture of the shared stream; RCCL only); the last iteration of a block stays live for the event pair around its query' % (BLOCK - 1)}
             if halo:
                 out['halo'] = {'radius_nm': args.halo, 'boundary_vertices': scene.ex.n_boundary, 'repartitions_in_timed_region': reparts,
                                'max_nn_distance_nm': scene.max_dist, 'drift_since_partition_nm': scene.drift,

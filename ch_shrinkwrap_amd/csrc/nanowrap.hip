@@ -497,8 +497,8 @@ thread_local StageMarks g_marks;
 struct StageScope {
     nw_ctx *c; int stage; hipEvent_t a;
     bool on;
-    StageScope(nw_ctx *ctx, int s, bool first_of_block = true) : c(ctx), stage(s), a(nullptr),
-        on(!ctx->capturing && (ctx->profiling == 2 || ((ctx->profiling == 1 || (ctx->profiling == 4 && first_of_block)) && s == ST_NN))) { if (on) a = next_event(c); }
+    StageScope(nw_ctx *ctx, int s, bool sampled_iteration = true) : c(ctx), stage(s), a(nullptr),
+        on(!ctx->capturing && (ctx->profiling == 2 || ((ctx->profiling == 1 || (ctx->profiling == 4 && sampled_iteration)) && s == ST_NN))) { if (on) a = next_event(c); }
     ~StageScope() { if (on) { hipEvent_t b = next_event(c); g_marks.spans.push_back({stage, {a, b}}); c->stage_launches[stage] += 1; } }
 };
 
@@ -1114,7 +1114,7 @@ static int resort_by_projection(nw_ctx *ctx)
 enum { QP_GRID = 1, QP_NN = 2, QP_FIXUP = 4, QP_ATTRACT = 8, QP_ALL = 15 };     // parts of the first half of an iteration
 static int launch_query(nw_ctx *ctx, int it, int parts = QP_GRID | QP_NN | QP_FIXUP);
 static NwAttractArgs attract_args(const nw_ctx *ctx);
-static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool tail = false);
+static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head = false);
 // Cell-size tuner, once per localization cloud.  The query is exact for every cell size, and its cost depends on more than the rule
 // (desired_cell) can see -- a 200k-localization tube leaves half of the GPU's wave slots empty and prefers smaller cells (fewer
 // candidates per wave) than the 1M-localization vesicle, for which the cost is flat between 9 and 13 nm -- so the query is simply
@@ -1266,12 +1266,7 @@ NW_EXPORT int nw_optimize_layout(nw_ctx *ctx)
         const float lam = ctx->lam0;
         NW_TRY(nw_search_begin(ctx, &lam, 1, ctx->search_iters, ctx->search_flags));
         ctx->direct_out = ctx->last_direct_out;             // (part of what the graph bakes in: where the last update writes the result)
-        if (ctx->profiling == 4) {                          // the graph of everything after the block's first iteration
-            ctx->search_done = 1;
-            ctx->begin_ops_pending = false;                 // (they belong to the first iteration, which is not part of this graph)
-            (void)block_graph(ctx, ctx->search_iters, true);
-            ctx->search_done = 0;
-        } else (void)block_graph(ctx, ctx->search_iters);
+        (void)block_graph(ctx, ctx->search_iters, ctx->profiling == 4);      // (level 4: everything before the block's last iteration)
         ctx->direct_out = false;
         ctx->in_search = false;
         ctx->begin_ops_pending = false;
@@ -1363,7 +1358,7 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
                            ctx->cent.p, ctx->state.p, it);
     }
     if (parts & QP_NN) {
-        StageScope s(ctx, ST_NN, it == 0);
+        StageScope s(ctx, ST_NN, it == ctx->search_iters - 1);      // level 4 samples the block's LAST iteration (the one launched from the host)
         static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;   // 0 slabs, 1 round-robin, 2 interleaved runs (default)
         static const bool no_outliers = getenv("NW_NO_OUTLIERS") != nullptr;      // developer knob
         static const bool item_times = getenv("NW_ITEM_TIMES") != nullptr;        // developer aid: nw_debug_items also returns when every item started
@@ -1583,26 +1578,26 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
 
 // The captured form of the block the ctx is about to run (nw_search_begin done): found among the cached ones or captured now
 // (the launches are recorded, not run).  nullptr: not eligible, or the capture failed -> the caller launches directly.
-// Profiling level 4 runs a block's first iteration directly (its query kernel between two events) and replays the REST of the block
-// from a graph (`tail`: called after that first iteration, search_done == 1).
-static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool tail)
+// Profiling level 4 replays everything BEFORE the block's last iteration from a graph (`head`) and launches that last iteration from
+// the host, its query kernel between two events: the host enqueues it while the graph is still running, so the GPU never waits for a
+// launch (with the live iteration FIRST, as until round 3, the block started launch-bound: 0.03 ms per step on a box with a slow host).
+static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head)
 {
     static const bool graphs_on = !(getenv("NW_GRAPH") && atoi(getenv("NW_GRAPH")) == 0);
-    if (!(graphs_on && ctx->own_stream && (ctx->profiling == 0 || (tail && ctx->profiling == 4)) && num_iters > (tail ? 1 : 0))) return nullptr;
-    if (tail != (ctx->search_done == 1)) return nullptr;
+    if (!(graphs_on && ctx->own_stream && (ctx->profiling == 0 || (head && ctx->profiling == 4)) && num_iters > (head ? 1 : 0))) return nullptr;
+    if (ctx->search_done != 0) return nullptr;
     const uint64_t key = block_graph_key(ctx);
     for (auto &gph : ctx->graphs) if (gph.exec && gph.key == key) return &gph;
     if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] capturing a block of %d (%s, key %016llx, warm %d, grid generation %llu)\n", num_iters,
-                                      tail ? "all but its first iteration" : "one graph",
+                                      head ? "all but its last iteration" : "one graph",
                                       (unsigned long long)key, ctx->face_warm ? 1 : 0, (unsigned long long)ctx->grid_generation);
     const bool warm0 = ctx->face_warm;
-    const int done0 = ctx->search_done;
+    const int last = head ? num_iters - 1 : num_iters;
     hipGraphExec_t ea = nullptr;
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
         ctx->capturing = true;
-        int r = NW_OK;
-        if (!tail) r = enqueue_begin_ops(ctx);
-        for (int i = done0; i < num_iters && r == NW_OK; ++i) {
+        int r = enqueue_begin_ops(ctx);
+        for (int i = 0; i < last && r == NW_OK; ++i) {
             r = iter_attract_parts(ctx, QP_ALL);
             if (r == NW_OK) r = nw_iter_directions(ctx);
             if (r == NW_OK) r = nw_iter_update(ctx);
@@ -1615,8 +1610,8 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool tail)
     }
     (void)hipGetLastError();
     // rewind the host-side bookkeeping the recorded calls advanced
-    ctx->global_iter -= ctx->search_done - done0; ctx->search_done = done0; ctx->face_warm = warm0;
-    ctx->begin_ops_pending = !tail;         // recorded, not run
+    ctx->global_iter -= ctx->search_done; ctx->search_done = 0; ctx->face_warm = warm0;
+    ctx->begin_ops_pending = true;          // recorded, not run
     if (!ea) return nullptr;
     nw_ctx::BlockGraph &dst = ctx->graphs[ctx->graph_next];
     ctx->graph_next = (ctx->graph_next + 1) % 4;
@@ -1635,8 +1630,8 @@ NW_EXPORT int nw_capture_begin(nw_ctx *ctx)
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_capture_begin outside a search (nw_search_begin first)");
     if (ctx->capturing) return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: already recording");
     if (ctx->own_stream) return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: the caller records its own stream (nw_set_stream)");
-    if (!(ctx->profiling == 0 || (ctx->profiling == 4 && ctx->search_done >= 1)))
-        return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: per-launch profiling needs live events (levels 1, 2; level 4: the block's first iteration)");
+    if (!(ctx->profiling == 0 || ctx->profiling == 4))
+        return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: per-launch profiling needs live events (levels 1, 2; at level 4 leave the block's last iteration out of the recording)");
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusActive) {
         (void)hipGetLastError();
@@ -1702,28 +1697,23 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     static const bool trace_blocks = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 3;
     static hipEvent_t tb0 = nullptr, tb1 = nullptr;
     if (trace_blocks) { if (!tb0) { (void)hipEventCreate(&tb0); (void)hipEventCreate(&tb1); } (void)hipEventRecord(tb0, ctx->stream); }
-    nw_ctx::BlockGraph *slot = block_graph(ctx, num_iters);
+    // level 4: the graph holds everything before the last iteration, which is launched below (its query kernel between two events)
+    const bool head = ctx->profiling == 4 && num_iters > 1;
+    nw_ctx::BlockGraph *slot = block_graph(ctx, num_iters, head);
     if (slot) {
         if (hipGraphLaunch(slot->exec, ctx->stream) == hipSuccess) {
+            const int n_done = head ? num_iters - 1 : num_iters;
             ctx->begin_ops_pending = false;
             ctx->vacc_dirty = false;                       // (a graph recorded while the accumulator was dirty zeroes it: the key carries the flag)
-            ctx->global_iter += num_iters; ctx->search_done = num_iters; ctx->face_warm = true;
+            ctx->global_iter += n_done; ctx->search_done = n_done; ctx->face_warm = true;
             replayed = true;
         } else (void)hipGetLastError();
     }
-    for (int i = 0; !replayed && i < num_iters; ++i) {
+    for (int i = ctx->search_done; i < num_iters; ++i) {
         int r = nw_iter_attract(ctx);
         if (r == NW_OK) r = nw_iter_directions(ctx);
         if (r == NW_OK) r = nw_iter_update(ctx);
         if (r != NW_OK) { ctx->in_search = false; return r; }
-        if (i == 0 && ctx->profiling == 4) {
-            // level 4: the first iteration ran directly (its query kernel between two events); the rest of the block from a graph
-            nw_ctx::BlockGraph *tl = block_graph(ctx, num_iters, true);
-            if (tl && hipGraphLaunch(tl->exec, ctx->stream) == hipSuccess) {
-                ctx->global_iter += num_iters - 1; ctx->search_done = num_iters;
-                replayed = true;
-            } else (void)hipGetLastError();
-        }
     }
     const auto t2 = std::chrono::steady_clock::now();
     if (trace_blocks) (void)hipEventRecord(tb1, ctx->stream);

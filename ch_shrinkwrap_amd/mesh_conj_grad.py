@@ -402,9 +402,9 @@ class ShrinkwrapMeshConjGrad(object):
     # -- timing hooks for bench.py ------------------------------------------------------------------
     def set_profiling(self, level=2):
         """0/False off; 1 = HIP events around every NN query launch; 2/True = around every stage (each event pair serialises the
-        stream for a few microseconds; 1 and 2 launch every kernel from the host); 4 = the first iteration of each block is launched
-        from the host with its NN query bracketed, the rest of the block is a replayed hipGraph (what bench.py keeps on in its timed
-        region: one event pair per block instead of one per iteration).  (3, the two-half-graphs form of ABI 2, was removed.)"""
+        stream for a few microseconds; 1 and 2 launch every kernel from the host); 4 = the LAST iteration of each block is launched
+        from the host with its NN query bracketed (while the replayed hipGraph of everything before it is still running: what bench.py keeps
+        on in its timed region: one event pair per block instead of one per iteration).  (3, the two-half-graphs form of ABI 2, was removed.)"""
         level = 2 if level is True else int(level)
         self._native.check(self._L.nw_set_profiling(self._h, level))
         self._profiling = level > 0

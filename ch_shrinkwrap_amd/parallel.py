@@ -271,25 +271,24 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
     if n > 0 and timer is None and _recordable(ex, dist):
         # The block as ONE recording -- the phases' launches AND the RCCL collectives between them (hipGraph capture of the shared
         # stream) -- replayed for every later block that bakes the same things in (nw_block_key): a sharded iteration is ~12 launches
-        # and up to 3 collective calls, which the host otherwise issues one by one.  Profiling level 4 keeps the block's first iteration
-        # live (its query kernel between two events), as nw_search does on one GPU.  Every rank takes the same branch: the conditions
-        # are the same on all of them, and whether a capture worked is agreed with one all-reduce.
-        if ex.profiling_level() == 4:
-            iteration()
-            done = 1
-        if n - done > 0:
-            key = (ex.block_key(), mode, done, n - done, n_red)
+        # and up to 3 collective calls, which the host otherwise issues one by one.  Profiling level 4 keeps the block's LAST iteration
+        # live (its query kernel between two events; the host issues it while the recording is still running), as nw_search does on
+        # one GPU.  Every rank takes the same branch: the conditions are the same on all of them, and whether a capture worked is
+        # agreed with one all-reduce.
+        count = n - 1 if ex.profiling_level() == 4 else n
+        if count > 0:
+            key = (ex.block_key(), mode, count, n_red)
             g = ex.graphs.get(key)
             if g is None:
-                g = _record_block(ex, dist, iteration, n - done)
+                g = _record_block(ex, dist, iteration, count)
                 while len(ex.graphs) >= 4:
                     ex.graphs.pop(next(iter(ex.graphs)))
                 ex.graphs[key] = g
             if g is not False:
                 g.replay()
-                ex.replayed(n - done)
+                ex.replayed(count)
                 ex.blocks_replayed += 1
-                done = n
+                done = count
     for _ in range(done, n):
         iteration()
     ex.blocks_run = getattr(ex, 'blocks_run', 0) + 1

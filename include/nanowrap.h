@@ -190,10 +190,10 @@ int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *cont
 /* A block recorded by the CALLER (no reference counterpart: the reference launches nothing).  In a multi-GPU run the
  * collectives between the phases belong to the caller, so the library cannot capture such a block itself (nw_search does, for one GPU).
  * The caller puts the stream it gave to nw_set_stream into capture, then:
- *   nw_search_begin(...);  [level 4: the block's first iteration, live]  nw_block_key(&k);   -- a recording with this key? replay it; else:
- *   <begin capture>  nw_capture_begin();  { nw_iter_attract, <all-reduce>, nw_iter_directions, <all-reduce>, nw_iter_update, <all-reduce> } x remaining
- *   iterations;  nw_capture_end(&k);  <end capture>          -- nothing ran: the ctx's bookkeeping is rewound
- *   <replay>;  nw_block_replayed(iterations);  nw_search_end(...).
+ *   nw_search_begin(...);  nw_block_key(&k);   -- a recording with this key? replay it; else:
+ *   <begin capture>  nw_capture_begin();  { nw_iter_attract, <all-reduce>, nw_iter_directions, <all-reduce>, nw_iter_update, <all-reduce> } x the
+ *   iterations to record (level 4: all but the block's LAST, which stays live);  nw_capture_end(&k);  <end capture>   -- nothing ran: the ctx's
+ *   bookkeeping is rewound;  <replay>;  nw_block_replayed(iterations);  [level 4: the last iteration, live]  nw_search_end(...).
  * The key covers everything the recorded launches bake in (sizes, buffers, stream, cell grid, work list, flags, lambda, quantum, warm or cold
  * query, boundary set, where in the block the recording starts).  Levels 1 and 2 of nw_set_profiling need live events and refuse. */
 int nw_capture_begin(nw_ctx *ctx);
@@ -263,8 +263,9 @@ int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, co
  * 5 A.S + dots, 6 solve+update, 7 float64 NN fix-up (separate launch only with NW_FUSE_FIXUP=0).  nw_set_profiling level: 0 off (nw_search replays
  * each block as a hipGraph); 1 = HIP events around every NN query launch (the dominant kernel; each event pair costs a few microseconds of
  * stream serialisation); 2 = around every stage -- levels 1 and 2 launch every kernel from the host, because events inside graph nodes read
- * 0 on ROCm 7.2; 4 = only the NN query of each block's FIRST iteration is bracketed: that iteration is launched from the host, the rest
- * of the block is one replayed hipGraph, and the event pairs come once per block (what bench.py times at).
+ * 0 on ROCm 7.2; 4 = only the NN query of each block's LAST iteration is bracketed: everything before it is one replayed hipGraph, the last
+ * iteration is launched from the host while that graph is still running (the GPU never waits for a launch), and the event pairs come once per
+ * block (what bench.py times at).
  * Level 3 (ABI 2: the block as two half graphs around a directly launched query) is gone and returns NW_ERR_BADARG: in a process that
  * had also loaded PyTorch about one block in twenty waited 5-6 ms behind its last kernel, the traces kept from then do not contain such
  * a block, and level 4 gives the same one sample per block with a single graph launch per block. */

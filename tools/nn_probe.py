@@ -38,3 +38,6 @@ for b in range(min(blocks, 3)):
         b, ms / max(n, 1) * 1e3, st['candidates'] / (5.0 * items), st['rows_visited'] / (5.0 * items), st['cells_tested'] / (5.0 * items), wc / (5.0 * items),
         st['prologue_cycles_16'] / wc, st['stream_cycles_16'] / wc, st['tail_cycles_16'] / wc,
         1.0 - (st['prologue_cycles_16'] + st['stream_cycles_16'] + st['tail_cycles_16']) / wc, st['max_wave_cycles_16']), flush=True)
+    print('         per wave: segments with centroids %.1f, of them a ball reaches %.1f; cells tested %.1f, reached %.1f; box rows %.1f, rounds %.2f' % (
+        st.get('rows_nonempty', 0) / (5.0 * items), st.get('rows_visited', 0) / (5.0 * items), st['cells_tested'] / (5.0 * items), st.get('cells_visited', 0) / (5.0 * items),
+        st.get('box_rows', 0) / (5.0 * items), st.get('rounds', 0) / (5.0 * items)), flush=True)
