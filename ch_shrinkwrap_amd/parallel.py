@@ -770,13 +770,12 @@ class HaloScene(object):
                 posv[self._valid] = newpos[self._valid]
         # New shares before the next block?  The query of a block is exact if (largest nearest distance + drift since the shares were
         # cut) stays within the halo radius THROUGH the block, which is only known afterwards: so cut again as soon as another block
-        # like the faster of the last two (twice its movement, for margin) could exceed it.
+        # like the last one (one and a half times its movement, for margin) could exceed it.
         step = max(drift - (self.drift if self._blocks_since_partition > 0 else 0.0), 0.0)
-        recent = max(step, self._last_step)           # (the last two blocks: a fit slows down as it converges)
         self._last_step = step
         self._blocks_since_partition += 1
         self.max_dist, self.drift = worst, drift
-        if worst + drift + 2.0 * recent > self.halo:
+        if worst + drift + 1.5 * step > self.halo:    # (a fit slows down as it converges: C3 moves 26, 14, 9, 3, 2 ... nm per block of 5)
             self.last_partition = None                # cut new shares around the moved mesh before the next block
         t2 = time.perf_counter()
         self.host_ms['block_tail_collectives_and_copy'] = (t1 - t0) * 1e3

@@ -238,7 +238,7 @@ def _worker(rank, world, port, mode, q):
                 return OracleExecutor(lm.vertices.copy(), lm.vertex_normals.copy(), np.ascontiguousarray(nb, np.int32), lm.faces, local_points)
             # 'halo': a radius with room for the fit's movement -> both blocks on the shares cut at the start;
             # 'halo_tight': largest nearest distance + movement comes close to the radius after the first block -> new shares are cut
-            scene = parallel.HaloScene(mesh, pts, dist, halo=50.0 if mode == 'halo' else 40.0, make_executor=make)
+            scene = parallel.HaloScene(mesh, pts, dist, halo=50.0 if mode == 'halo' else 35.0, make_executor=make)
             s_inv = 1.0 / sigma.ravel()
             scene.search([7.0], 4, s_inv)
             scene.refresh_normals()                           # second block on the RESIDENT shares: new normals, same partition
