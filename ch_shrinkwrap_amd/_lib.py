@@ -15,7 +15,7 @@ NW_WEIGHTS_FROM_SIGMA_INV, NW_WEIGHTS_SCALAR, NW_WEIGHTS_ARRAY, NW_WEIGHTS_PRENO
 NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP, NW_FLAG_WFUNC, NW_FLAG_RESULT_TO_HOST = 1, 2, 4, 8
 (NW_ARR_S, NW_ARR_RES, NW_ARR_VIDX, NW_ARR_W, NW_ARR_DIST, NW_ARR_FACE, NW_ARR_POS, NW_ARR_FDEF, NW_ARR_PI,
  NW_ARR_MESHPOS, NW_ARR_VACC, NW_ARR_SCALARS, NW_ARR_NBR, NW_ARR_NRM, NW_ARR_VALID, NW_ARR_HALO_ACC, NW_ARR_HALO_ROWS,
- NW_ARR_HALO_FULL) = range(18)
+ NW_ARR_HALO_FULL, NW_ARR_HALO_STATS) = range(19)
 NW_N_SCALARS = 32
 
 # every symbol include/nanowrap.h declares (tests/test_abi.py checks the exports against the header)
@@ -24,7 +24,7 @@ SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set
            'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
            'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_debug_items', 'nw_set_data', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned',
            'nw_set_boundary', 'nw_halo_pack', 'nw_halo_unpack', 'nw_halo_gather_owned', 'nw_set_extent_hint', 'nw_host_copy_rows',
-           'nw_capture_begin', 'nw_capture_end', 'nw_block_key', 'nw_block_replayed']
+           'nw_capture_begin', 'nw_capture_end', 'nw_block_key', 'nw_block_replayed', 'nw_halo_set_reference', 'nw_halo_block_stats']
 
 
 class IterLog(ctypes.Structure):
@@ -86,6 +86,8 @@ def load():
     L.nw_capture_end.argtypes = [vp, vp]
     L.nw_block_key.argtypes = [vp, vp]
     L.nw_block_replayed.argtypes = [vp, ctypes.c_int]
+    L.nw_halo_set_reference.argtypes = [vp, vp]
+    L.nw_halo_block_stats.argtypes = [vp, ctypes.c_double]
     L.nw_set_data.argtypes = [vp, vp]
     L.nw_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     L.nw_lfunc.argtypes = [vp, i32, vp, vp, vp]

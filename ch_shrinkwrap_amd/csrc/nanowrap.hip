@@ -200,6 +200,9 @@ struct nw_ctx {
     DevBuf<long long> halo_acc;       // (n_boundary, 4) accumulator rows
     DevBuf<float> halo_rows;          // (n_boundary, 3) position / normal rows (owner-only non-zero)
     DevBuf<float> halo_full;          // (M_global, 3) owners' rows of the whole mesh (one all-reduce per block)
+    DevBuf<float> halo_ref;           // (M_global, 3) the whole mesh when the shares were cut (nw_halo_set_reference)
+    DevBuf<float> halo_stats;         // {largest nearest distance, quantum, max drift^2, 0}: one MAX all-reduce per block
+    bool have_halo_ref = false;
     int64_t hb_n = 0, hb_nslot = 0, M_global = 0;
     bool have_boundary = false;
     bool pos_unpack_pending = false;  // the owners' new boundary positions are in halo_rows (all-reduced by the caller), not yet taken
@@ -571,7 +574,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->owned.release(); ctx->d_small.release();
-    ctx->hb_local.release(); ctx->hb_slot.release(); ctx->hb_slot2local.release(); ctx->hb_gv.release(); ctx->halo_acc.release(); ctx->halo_rows.release(); ctx->halo_full.release();
+    ctx->hb_local.release(); ctx->hb_slot.release(); ctx->hb_slot2local.release(); ctx->hb_gv.release(); ctx->halo_acc.release(); ctx->halo_rows.release(); ctx->halo_full.release(); ctx->halo_ref.release(); ctx->halo_stats.release();
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->wv.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
@@ -948,6 +951,9 @@ NW_EXPORT int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t
     NW_HIP(ctx->halo_acc.ensure((size_t)4 * std::max<int64_t>(n_slots, 1)));
     NW_HIP(ctx->halo_rows.ensure((size_t)3 * std::max<int64_t>(n_slots, 1)));
     NW_HIP(ctx->halo_full.ensure((size_t)3 * n_global));
+    NW_HIP(ctx->halo_ref.ensure((size_t)3 * n_global));
+    NW_HIP(ctx->halo_stats.ensure(4));
+    ctx->have_halo_ref = false;
     NW_HIP(hipMemsetAsync(ctx->halo_acc.p, 0, (size_t)4 * std::max<int64_t>(n_slots, 1) * sizeof(long long), ctx->stream));
     NW_HIP(hipMemsetAsync(ctx->halo_rows.p, 0, (size_t)3 * std::max<int64_t>(n_slots, 1) * sizeof(float), ctx->stream));
     ctx->hb_n = n_local; ctx->hb_nslot = n_slots; ctx->M_global = n_global;
@@ -995,6 +1001,30 @@ NW_EXPORT int nw_halo_unpack(nw_ctx *ctx, int what)
     if (what == NW_ARR_VACC && !ctx->vacc.p) return fail(ctx, NW_ERR_BADARG, "nw_halo_unpack: no accumulator yet");
     if (what == NW_ARR_POS) ctx->pos_unpack_pending = false;
     return halo_unpack(ctx, what);
+}
+
+// where the WHOLE mesh was when the shares were cut ((M_global,3) float32, host or device): the drift budget of the halo is measured from it
+NW_EXPORT int nw_halo_set_reference(nw_ctx *ctx, const float *full)
+{
+    if (!ctx || !ctx->have_boundary || !full) return fail(ctx, NW_ERR_BADARG, "nw_halo_set_reference: no boundary set (nw_set_boundary)");
+    NW_HIP(hipMemcpyAsync(ctx->halo_ref.p, full, (size_t)3 * ctx->M_global * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->have_halo_ref = true;
+    return NW_OK;
+}
+
+// NW_ARR_HALO_STATS <- {max_dist, this rank's accumulator quantum, max |NW_ARR_HALO_FULL - reference|^2, 0} (float32): what the ranks
+// agree on at the end of a block with ONE MAX all-reduce (exactness of the sharded query, drift of the mesh, quantum of the next block)
+NW_EXPORT int nw_halo_block_stats(nw_ctx *ctx, double max_dist)
+{
+    if (!ctx || !ctx->have_boundary || !ctx->have_halo_ref) return fail(ctx, NW_ERR_BADARG, "nw_halo_block_stats: boundary and reference first (nw_set_boundary, nw_halo_set_reference)");
+    if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_halo_block_stats inside a search");
+    NW_HIP(hipMemsetAsync(ctx->halo_stats.p, 0, 4 * sizeof(float), ctx->stream));
+    const int blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (ctx->M_global + NW_BLOCK - 1) / NW_BLOCK));
+    hipLaunchKernelGGL(k_halo_block_stats, dim3(blocks), dim3(NW_BLOCK), 0, ctx->stream, ctx->M_global, ctx->halo_full.p, ctx->halo_ref.p, (float)max_dist,
+                       (float)ctx->local_quantum, ctx->halo_stats.p);
+    NW_HIP(hipGetLastError());
+    return NW_OK;
 }
 
 // NW_ARR_HALO_FULL <- the rows of NW_ARR_POS / NW_ARR_NRM of the vertices this rank owns at their global ids, zero elsewhere: one
@@ -1776,6 +1806,7 @@ NW_EXPORT int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes)
     case NW_ARR_HALO_ACC: p = ctx->have_boundary ? ctx->halo_acc.p : nullptr; nb = 4 * ctx->hb_nslot * 8; break;
     case NW_ARR_HALO_ROWS: p = ctx->have_boundary ? ctx->halo_rows.p : nullptr; nb = 3 * ctx->hb_nslot * 4; break;
     case NW_ARR_HALO_FULL: p = ctx->have_boundary ? ctx->halo_full.p : nullptr; nb = 3 * ctx->M_global * 4; break;
+    case NW_ARR_HALO_STATS: p = ctx->have_boundary ? ctx->halo_stats.p : nullptr; nb = 4 * 4; break;
     default: return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array is not device-addressable in caller order");
     }
     if (!p) return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array not allocated yet");

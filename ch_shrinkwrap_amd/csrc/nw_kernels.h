@@ -993,6 +993,25 @@ __global__ __launch_bounds__(NW_BLOCK) void k_halo_gather_owned(int M, const int
     full[3 * g] = rows[3 * (int64_t)v]; full[3 * g + 1] = rows[3 * (int64_t)v + 1]; full[3 * g + 2] = rows[3 * (int64_t)v + 2];
 }
 
+// End-of-block statistics of a sharded mesh in one launch: stats = {largest nearest distance of the block (from the host's logs), this
+// rank's accumulator quantum, max over the WHOLE mesh of |full - ref|^2} as float32 (a power-of-two quantum is exact in float32), for one
+// MAX all-reduce over the ranks.  `full` = the whole mesh after the all-reduce of the owners' rows, `ref` = where the mesh was when the
+// shares were cut.  stats[2] must be zero before the launch (non-negative floats order like unsigned integers: atomicMax on the bits).
+__global__ __launch_bounds__(NW_BLOCK) void k_halo_block_stats(int64_t n_global, const float *__restrict__ full, const float *__restrict__ ref, float max_dist, float quantum,
+                                                              float *__restrict__ stats)
+{
+    float m = 0.0f;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_global; v += (int64_t)gridDim.x * blockDim.x) {
+        const float dx = full[3 * v] - ref[3 * v], dy = full[3 * v + 1] - ref[3 * v + 1], dz = full[3 * v + 2] - ref[3 * v + 2];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        m = d2 > m ? d2 : m;                               // (a NaN never wins: the block's NaN status is raised elsewhere)
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned *>(stats) + 2, __float_as_uint(m));
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = max_dist; stats[1] = quantum; }
+}
+
 // ---- block-boundary geometry refresh (the reference's `self.face_normals; self.vertex_neighbors` after a block,
 // _membrane_mesh.pyx:1524-1527, for an unchanged topology): area-weighted vertex normals from the CURRENT device positions.
 // Definition (this build's, PYME's is unpinned -- trimesh.py): n_v = normalise( sum over incident faces of

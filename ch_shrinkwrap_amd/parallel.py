@@ -138,6 +138,17 @@ class HipExecutor(object):
         self.native.check(self.L.nw_halo_gather_owned(self.h, nw.NW_ARR_POS if what == 'pos' else nw.NW_ARR_NRM))
         return self._view(nw.NW_ARR_HALO_FULL, 3 * self.n_global, '<f4')
 
+    def set_reference(self, full_positions):
+        """(M_global,3) float32: where the whole mesh was when the shares were cut (the drift of the halo is measured from it)"""
+        a = np.ascontiguousarray(full_positions, np.float32)
+        self.native.check(self.L.nw_halo_set_reference(self.h, nw.ptr(a)))
+
+    def block_stats(self, max_dist):
+        """(4,) float32 on the device: {largest nearest distance, this rank's quantum, max drift^2 of gather_owned()'s (all-reduced)
+        array against the reference, 0} -> one all-reduce(MAX) per block"""
+        self.native.check(self.L.nw_halo_block_stats(self.h, float(max_dist)))
+        return self._view(nw.NW_ARR_HALO_STATS, 4, '<f4')
+
     def refresh_normals_local(self, extent):
         """block-boundary refresh (_membrane_mesh.pyx:1524-1527) of this rank's share on the device; the owners' normals of the boundary
         vertices are left in boundary_rows() for the all-reduce, take_normals() then gives every holder the owner's"""
@@ -692,6 +703,8 @@ class HaloScene(object):
             self.ex.cg.stage_ms_total = old.cg.stage_ms_total          # HIP-event totals run on across a re-partition (bench.py reads them at the end)
         self.ex.set_boundary(d['b_local'], d['b_slot'], part.boundary.size, d['owned'], gv, part.M)
         self._pos0 = pos.copy()                       # where the mesh was when the shares were cut (drift budget of the halo)
+        if hasattr(self.ex, 'set_reference'):
+            self.ex.set_reference(self._pos0)
         self._blocks_since_partition = 0
         self._pos0_t = None
         self._valid = mesh._vertices['halfedge'] != -1
@@ -743,15 +756,18 @@ class HaloScene(object):
             # ONE all-reduce of the owners' rows (float32, on the device) gives every rank the whole new mesh
             full = ex.gather_owned('pos')
             self.dist.all_reduce(full)
-            if self._pos0_t is None or self._pos0_t.device != full.device:
-                self._pos0_t = torch.from_numpy(self._pos0.ravel()).to(full.device)
-            drift2 = (full - self._pos0_t).view(-1, 3).pow(2).sum(1).max()
-            # exactness of the sharded query, and the common quantum of the NEXT block: one small MAX all-reduce per block carries both
-            stats = ex.new_tensor([float(ex.max_dist), ex.local_quantum() if hasattr(ex, 'local_quantum') else 0.0, 0.0])
-            stats[2] = drift2
+            # exactness of the sharded query, drift of the mesh and the common quantum of the NEXT block: one small MAX all-reduce per block
+            if hasattr(ex, 'block_stats'):
+                stats = ex.block_stats(ex.max_dist)           # one launch of the library (no torch arithmetic, no allocation)
+            else:
+                if self._pos0_t is None or self._pos0_t.device != full.device:
+                    self._pos0_t = torch.from_numpy(self._pos0.ravel()).to(full.device)
+                drift2 = (full - self._pos0_t).view(-1, 3).pow(2).sum(1).max()
+                stats = ex.new_tensor([float(ex.max_dist), ex.local_quantum() if hasattr(ex, 'local_quantum') else 0.0, 0.0])
+                stats[2] = drift2
             self.dist.all_reduce(stats, op=self.dist.ReduceOp.MAX)
             newpos = self._to_host(full)
-            worst, q, d2 = stats.tolist()                 # (the one synchronisation of the block's tail: the whole mesh has landed too)
+            worst, q, d2 = stats.tolist()[:3]             # (the one synchronisation of the block's tail: the whole mesh has landed too)
         t1 = time.perf_counter()
         self._quantum = q if q > 0 else None
         drift = float(np.sqrt(max(d2, 0.0)))

@@ -99,7 +99,8 @@ typedef enum nw_array {
                                nw_iter_attract and nw_iter_directions (nw_set_boundary) */
     NW_ARR_HALO_ROWS = 16,  /* (n_slots, 3) f32  device-only: rows of the boundary vertices this rank OWNS (new positions after nw_iter_update;
                                normals after nw_halo_pack(NW_ARR_NRM)), zero elsewhere: all-reduce(sum) = the owner's row on every rank */
-    NW_ARR_HALO_FULL = 17   /* (M_global, 3) f32 device-only: nw_halo_gather_owned -- the owners' rows of the whole mesh */
+    NW_ARR_HALO_FULL = 17,  /* (M_global, 3) f32 device-only: nw_halo_gather_owned -- the owners' rows of the whole mesh */
+    NW_ARR_HALO_STATS = 18  /* (4,) f32 device-only: nw_halo_block_stats -- {largest nearest distance, accumulator quantum, max drift^2, 0}: all-reduce(MAX) */
 } nw_array;
 
 #define NW_N_SCALARS 32
@@ -222,6 +223,13 @@ int nw_halo_unpack(nw_ctx *ctx, int what);
 /* NW_ARR_HALO_FULL <- the rows (what = NW_ARR_POS or NW_ARR_NRM) of the vertices this rank owns at their global ids, zero elsewhere: one
  * all-reduce(sum) per BLOCK gives every rank the whole mesh (the positions search() returns, mesh_conj_grad.py:288-292) */
 int nw_halo_gather_owned(nw_ctx *ctx, int what);
+/* end of a block of a sharded mesh (no reference counterpart): nw_halo_set_reference = where the WHOLE mesh was when the shares were cut
+ * ((M_global,3) float32, host or device); nw_halo_block_stats fills NW_ARR_HALO_STATS from NW_ARR_HALO_FULL (after its all-reduce), that
+ * reference, the block's largest nearest distance (the caller has it from the iteration logs) and this rank's accumulator quantum -- the
+ * three numbers the ranks agree on with ONE all-reduce(MAX) per block: is the sharded query still exact, how far has the mesh drifted,
+ * which quantum do the integer accumulators of the next block share. */
+int nw_halo_set_reference(nw_ctx *ctx, const float *full);
+int nw_halo_block_stats(nw_ctx *ctx, double max_dist);
 /* extent (largest bounding-box edge) of the WHOLE mesh, for a rank that holds a share of it: nw_refresh_normals takes the quantum of its
  * fixed-point normal sums from it instead of from the share's own box, so every holder of a vertex rounds its sum the same way and the
  * normals are bit-identical to a single-process run.  ext <= 0: back to the local box. */
