@@ -299,6 +299,17 @@ def test_sharded_mesh_entry_points_check_their_arguments():
     full = np.empty((M, 3), np.float32)
     cg._native.check(L.nw_get(h, nw.NW_ARR_HALO_FULL, nw.ptr(full), full.nbytes))
     assert np.array_equal(full, v)
+    # end-of-block statistics: largest distance handed in, the rank's quantum, and the drift of the whole mesh against the reference
+    with pytest.raises(ValueError):                                   # no reference yet
+        cg._native.check(L.nw_halo_block_stats(h, 1.0))
+    ref = v.copy()
+    ref[17] += np.array([3.0, -4.0, 12.0], 'f4')                      # one vertex 13 nm away from where it was
+    cg._native.check(L.nw_halo_set_reference(h, nw.ptr(ref)))
+    cg._native.check(L.nw_halo_block_stats(h, 42.5))
+    stats = np.empty(4, np.float32)
+    cg._native.check(L.nw_get(h, nw.NW_ARR_HALO_STATS, nw.ptr(stats), stats.nbytes))
+    d = (v[17].astype('f4') - ref[17]).astype('f4')
+    assert stats[0] == np.float32(42.5) and stats[2] == np.float32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) and abs(float(stats[2]) - 169.0) < 1e-2 and stats[3] == 0
     cg._native.check(L.nw_set_boundary(h, None, None, 0, -1, None, None, 0))         # cleared: nw_search works again
     out = cg.search(pts, lams=[5.0], num_iters=1, sigma_inv=0.2)
     assert np.isfinite(out).all()
