@@ -353,6 +353,28 @@ def test_halo_partition_invariants():
         assert np.array_equal(np.nonzero(held > 1)[0], part.boundary)
 
 
+def test_a_rank_that_works_out_only_its_own_share_agrees_with_the_full_partition():
+    """HaloScene gives every rank its OWN share only (detail_ranks / membership_ranks) and all-reduces the holders' counts: the shares and
+    the boundary list must be those of the partition computed in full on one process."""
+    v, f = icosphere(4, 60.0)
+    mesh = TriMesh(v, f)
+    pts = sphere_cloud(9000, 50.0, 5.0, seed=4)
+    args = (mesh.vertices, mesh.vertex_normals, mesh.neighbor_vertex_table(), mesh.faces, pts)
+    for n in (2, 3, 8):
+        tiles = parallel.bisect_tiles(pts, n)
+        full = parallel.HaloPartition(*args, n, halo=20.0, tiles=tiles)
+        own = [parallel.HaloPartition(*args, n, halo=20.0, tiles=tiles, detail_ranks=(r,), membership_ranks=(r,)) for r in range(n)]
+        count = sum(p.count for p in own)                         # what the all-reduce does
+        assert np.array_equal(count, full.count)
+        for r, p in enumerate(own):
+            assert p.boundary is None
+            p.set_count(count)
+            assert np.array_equal(p.boundary, full.boundary)
+            assert all('gv' not in d for q, d in enumerate(p.ranks) if q != r)
+            for k, a in full.ranks[r].items():
+                assert np.array_equal(p.ranks[r][k], a), (n, r, k)
+
+
 def test_partition_by_tiles_is_a_partition():
     pts = sphere_cloud(5000, 50.0, 5.0, seed=2)
     for n in (1, 2, 3, 4, 8):
