@@ -279,13 +279,18 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
 
     n = int(num_iters)
     done = 0
+    if hasattr(ex, 'capture_begin') and getattr(ex, 'blocks_run', 0) == 0 and not hasattr(ex, 'largest_share'):
+        t = ex.new_tensor([float(np.asarray(ex.cg._points_f32).size // 3)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)             # (the executor's first block: every rank is here)
+        ex.largest_share = int(t[0])
     if n > 0 and timer is None and _recordable(ex, dist):
         # The block as ONE recording -- the phases' launches AND the RCCL collectives between them (hipGraph capture of the shared
         # stream) -- replayed for every later block that bakes the same things in (nw_block_key): a sharded iteration is ~12 launches
         # and up to 3 collective calls, which the host otherwise issues one by one.  Profiling level 4 keeps the block's LAST iteration
         # live (its query kernel between two events; the host issues it while the recording is still running), as nw_search does on
-        # one GPU.  Every rank takes the same branch: the conditions are the same on all of them, and whether a capture worked is
-        # agreed with one all-reduce.
+        # one GPU.  Every rank comes to the same decision (the conditions of _recordable are the same on all of them), but nothing
+        # here depends on it: a rank that replays a recording and a rank that issues the same block launch by launch -- its key changed,
+        # or its capture failed -- run the same collectives in the same order, so no agreement (and no extra collective) is needed.
         count = n - 1 if ex.profiling_level() == 4 else n
         if count > 0:
             key = (ex.block_key(), mode, count, n_red)
@@ -323,7 +328,8 @@ def _recordable(ex, dist):
         return False
     # 'auto': where the host is the bound.  Measured on one GPU (tools/graph_rehearsal.sh): a rank with 10^6 localizations is device-bound
     # either way (0.308 against 0.309 ms per iteration), one with 10^5 gains 5 % ('tiles') to 18 % ('halo': three collectives per iteration)
-    if want != '1' and np.asarray(ex.cg._points_f32).size // 3 > RECORD_BELOW_LOCALIZATIONS:
+    # (the LARGEST share of any rank decides, agreed once per executor in its first block: every rank must come to the same answer)
+    if want != '1' and getattr(ex, 'largest_share', 1 << 62) > RECORD_BELOW_LOCALIZATIONS:
         return False
     if getattr(ex, 'blocks_run', 0) < 1 or ex.profiling_level() not in (0, 4):
         return False
@@ -334,9 +340,10 @@ def _recordable(ex, dist):
 
 
 def _record_block(ex, dist, iteration, count):
-    """Capture `count` iterations (phases + collectives) on the current torch stream; False if any rank could not."""
+    """Capture `count` iterations (phases + collectives) on the current torch stream; False if this rank could not (it then issues its
+    blocks launch by launch: the same collectives in the same order as the ranks that replay)."""
     import torch
-    ok = 1.0
+    ok = True
     g = torch.cuda.CUDAGraph()
     try:
         with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode='thread_local'):
@@ -349,7 +356,7 @@ def _record_block(ex, dist, iteration, count):
     except Exception as e:                                   # e.g. a collective that cannot be captured on this stack
         import sys
         sys.stderr.write('[nanowrap] recording a block with its collectives failed (%s: %s): blocks are issued launch by launch\n' % (type(e).__name__, e))
-        ok = 0.0
+        ok = False
         if torch.cuda.is_current_stream_capturing():         # an invalidated capture that torch could not close: nothing can be launched any more
             try:
                 g.capture_end()
@@ -357,9 +364,7 @@ def _record_block(ex, dist, iteration, count):
                 pass
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError('nanowrap: the stream is stuck in a failed capture (%s); NW_GRAPH_COLLECTIVES=0 issues every block launch by launch' % e)
-    t = ex.new_tensor([ok])
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return g if float(t[0]) > 0.5 else False
+    return g if ok else False
 
 
 class CollectiveTimer(object):
