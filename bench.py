@@ -216,7 +216,8 @@ def run_rank(args):
                          % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     # developer hook: NW_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, split-phase iteration, collectives, recorded blocks)
-    # with ONE rank -- the only way to run RCCL collectives inside a captured block on a one-GPU box
+    # with ONE rank -- the only way to run the NCCL process group inside a captured block on a one-GPU box (with one rank RCCL itself
+    # enqueues no kernel for an in-place all-reduce: this rehearses the host side and the capture, not RCCL)
     multi = world > 1 or bool(os.environ.get('NW_BENCH_FORCE_DIST'))
     if multi and world == 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

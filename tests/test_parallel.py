@@ -423,7 +423,8 @@ def test_split_phase_equals_search_on_one_gpu(mode):
 def test_blocks_recorded_with_their_collectives_equal_launch_by_launch(mode, level, monkeypatch):
     """nw_capture_begin .. nw_block_replayed (include/nanowrap.h): from an executor's second block on, run_search records a block -- the
     phases' launches AND the RCCL all-reduces between them -- as one hipGraph and replays it.  World size 1 over nccl is what a one-GPU
-    box can run; the collectives are real RCCL calls on the captured stream.  Six blocks of 5 (the cell-size tuner changes the grid at
+    box can run (the collectives go through the NCCL process group's stream fork and join inside the capture; with one rank RCCL itself
+    enqueues no kernel for them).  Six blocks of 5 (the cell-size tuner changes the grid at
     the third: a new key, a new recording), with the normals refreshed between blocks in 'halo' mode: bit-identical to the same blocks
     issued launch by launch (NW_GRAPH_COLLECTIVES=0); profiling level 4 keeps each block's first iteration live."""
     from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
