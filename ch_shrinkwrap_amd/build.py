@@ -13,8 +13,9 @@ SRC = os.path.join(HERE, 'csrc', 'nanowrap.hip')
 SRC_SORT = os.path.join(HERE, 'csrc', 'nw_sort.hip')      # set-up radix sort (hipCUB), its own translation unit
 OBJ_SORT = os.path.join(HERE, 'csrc', 'nw_sort.o')
 OBJ_MAIN = os.path.join(HERE, 'csrc', 'nanowrap.o')
-DEPS = [SRC, SRC_SORT, os.path.join(HERE, 'csrc', 'nw_kernels.h'), os.path.join(HERE, 'csrc', 'nw_nn.h'), os.path.join(HERE, 'csrc', 'nw_device.h'),
-        os.path.join(os.path.dirname(HERE), 'include', 'nanowrap.h')]
+import glob
+# every header of csrc/ is included by nanowrap.hip (directly or through nw_kernels.h): editing any of them must rebuild the library
+DEPS = [SRC, SRC_SORT] + sorted(glob.glob(os.path.join(HERE, 'csrc', '*.h'))) + [os.path.join(os.path.dirname(HERE), 'include', 'nanowrap.h')]
 
 # -ffp-contract=off : the parity-critical float32 arithmetic must round products before adding, exactly like
 #                     the NumPy reference (explicit fma() is used where contraction is wanted);
