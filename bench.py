@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 BLOCK = 5               # remesh_frequency of the headline config
-PMC_FILE = 'r03_pmc_traffic.json'     # PMC passes of the headline workload (tools/profile_round.sh), committed under profiles/
+PMC_FILE = 'r04_pmc_traffic.json'     # PMC passes of the headline workload (tools/profile_round.sh), committed under profiles/
 
 
 def algorithmic_bytes(N, M, F):
@@ -120,6 +120,7 @@ def parse_args(argv=None):
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the workload (debug only; the reported config says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph-pass', action='store_true', help='skip the extra un-instrumented (graph-replay) pass (profiling runs)')
+    ap.add_argument('--rank-timeout', type=float, default=600.0, help='--gpus N started with plain python: seconds after which ranks that are still running are ended and the run fails')
     ap.add_argument('--cpu-iters', type=int, default=0, help='oracle iterations for cpu_baseline (0 = about 10-20 s of CPU work: 10 up to 2M localizations, else 3)')
     return ap.parse_args(argv)
 
@@ -155,7 +156,12 @@ def spawn_ranks(args):
         reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
         reader.start()
         pending = set(range(args.gpus))
+        deadline = time.monotonic() + max(args.rank_timeout, 1.0)
         while pending:
+            if time.monotonic() > deadline:
+                rc = 124
+                sys.stderr.write('bench.py: ranks %s still running after %.0f s (--rank-timeout); stopping them\n' % (sorted(pending), args.rank_timeout))
+                break
             for r in sorted(pending):
                 code = procs[r].poll()
                 if code is not None:
@@ -199,9 +205,6 @@ def run_rank(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    # blocks are replayed with their RCCL collectives inside (parallel.run_search): torch's event cache must be off for that, see
-    # parallel._recordable -- read when the process group is created
-    os.environ.setdefault('TORCH_NCCL_CUDA_EVENT_CACHE', '0')
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -215,9 +218,9 @@ def run_rank(args):
         raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible (RCCL needs one device per rank; NW_BENCH_BACKEND=gloo rehearses on one)'
                          % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    # developer hook: NW_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, split-phase iteration, collectives, recorded blocks)
-    # with ONE rank -- the only way to run the NCCL process group inside a captured block on a one-GPU box (with one rank RCCL itself
-    # enqueues no kernel for an in-place all-reduce: this rehearses the host side and the capture, not RCCL)
+    # developer hook: NW_BENCH_FORCE_DIST=1 takes the N > 1 code path (the library's own RCCL communicator, blocks with their collectives
+    # recorded in the library's hipGraph) with ONE rank -- what a one-GPU box can run of it (with one rank RCCL enqueues no kernel for an
+    # in-place all-reduce: this rehearses the host side and the capture, not RCCL's kernels)
     multi = world > 1 or bool(os.environ.get('NW_BENCH_FORCE_DIST'))
     if multi and world == 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -248,15 +251,25 @@ def run_rank(args):
     mesh = TriMesh(cfg['vertices'], cfg['faces'])
     N, M, F = pts.shape[0], int((mesh._vertices['halfedge'] != -1).sum()), mesh.faces.shape[0]
 
-    # N > 1: kernels and RCCL collectives share one dedicated (non-default) torch stream
-    tstream = torch.cuda.Stream() if multi else None
+    # N > 1 over RCCL (the driver's runs): the LIBRARY owns the communicator and issues a block's collectives itself on its own stream
+    # (parallel.NativeComm -> nw_comm_init; torch's process group only carries the communicator's id, the barriers and the timing).
+    # NW_BENCH_BACKEND=gloo (ranks sharing one GPU, which RCCL refuses): the same protocol through the split-phase C-ABI with the process
+    # group's all-reduces between the phases, kernels and collectives on one dedicated torch stream.
+    from ch_shrinkwrap_amd.mesh_conj_grad import NativeContext
+    native_comm = multi and backend == 'nccl'
+    tstream = torch.cuda.Stream() if (multi and not native_comm) else None
+    native = NativeContext(local_rank, None) if native_comm else None
+    comm = parallel.NativeComm(native, dist) if native_comm else None
     if halo:
-        scene = parallel.HaloScene(mesh, pts, dist, halo=args.halo, torch_stream=tstream)
+        scene = parallel.HaloScene(mesh, pts, dist, halo=args.halo, torch_stream=tstream, native=native, comm=comm)
         scene.set_profiling(0)
         cg_of = lambda: scene.ex.cg                     # (a re-partition builds a new optimiser over the new share)
     else:
-        cg = ShrinkwrapMeshConjGrad(mesh, pts, device=local_rank, stream=tstream.cuda_stream if tstream is not None else None)
-        runner = parallel.TiledScene(cg, dist if multi else None, torch_stream=tstream)
+        if native_comm:
+            cg = ShrinkwrapMeshConjGrad(mesh, pts, native=native)
+        else:
+            cg = ShrinkwrapMeshConjGrad(mesh, pts, device=local_rank, stream=tstream.cuda_stream if tstream is not None else None)
+        runner = parallel.TiledScene(cg, dist if multi else None, torch_stream=tstream, comm=comm)
         cg_of = lambda: cg
 
     executed = [0]
@@ -279,7 +292,7 @@ def run_rank(args):
             cg.set_profiling(level)
 
     def fence():
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                 # (device-wide: the library's own stream included)
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
@@ -326,10 +339,8 @@ def run_rank(args):
         fence()
         dt_graph = time.perf_counter() - tg
     set_profiling(2)
-    ex_of = (lambda: scene.ex) if halo else (lambda: runner.ex)
-    replayed_blocks = ex_of().blocks_replayed if multi else 0
     ctimer = None
-    if multi:
+    if multi and not native_comm:
         ctimer = parallel.CollectiveTimer()          # device time inside the collectives of the extra iterations
         (scene.ex if halo else runner.ex).collective_timer = ctimer
     run_steps(2 * BLOCK)
@@ -351,7 +362,9 @@ def run_rank(args):
         devs = [None] * world
         p = torch.cuda.get_device_properties(torch.cuda.current_device())
         dist.all_gather_object(devs, dict(rank=rank, device=torch.cuda.current_device(), name=p.name, pci_bus_id=getattr(p, 'pci_bus_id', None)))
-        rccl = dict(backend=dist.get_backend(), world_size_seen=dist.get_world_size(), devices=devs)
+        rccl = dict(backend=dist.get_backend(), world_size_seen=dist.get_world_size(), devices=devs,
+                    collectives_issued_by=('the library: ncclAllReduce on the nw_ctx stream between the phases, part of the block\'s hipGraph (nw_comm_init, include/nanowrap.h)'
+                                           if native_comm else 'the process group, between the phases of the split-phase C-ABI'))
     else:
         M_total = float(M)
 
@@ -386,12 +399,12 @@ def run_rank(args):
             par = 'single GPU'
         elif halo:
             par = ('halo%d: ONE mesh sharded by spatial tiles of the cloud (halo radius %.0f nm); per iteration RCCL all-reduces of the boundary rows of the '
-                   'fixed-point accumulator (%d rows x 32 B), of the 27 normal-equation sums x 32 ordered parts and of the owners\' new boundary positions '
+                   'fixed-point accumulator (%d rows x 32 B), of the normal-equation sums (nw_n_scalars() slots x 32 ordered parts) and of the owners\' new boundary positions '
                    '(%d rows x 12 B); per block one all-reduce of the owners\' rows of the whole mesh (%d x 12 B)'
                    % (world, args.halo, scene.ex.n_boundary, scene.ex.n_boundary, M))
         else:
-            par = ('tiles%d (one vesicle per GPU; the scene keeps ONE global subspace solve: one RCCL all-reduce of the 27 normal-equation '
-                   'sums x 32 ordered parts = 6.9 KB per iteration, no vertex data)' % world)
+            par = ('tiles%d (one vesicle per GPU; the scene keeps ONE global subspace solve: one RCCL all-reduce of the normal-equation '
+                   'sums (28 slots x 32 ordered parts = 7.2 KB) per iteration, no vertex data)' % world)
         out = {
             'metric': 'vertex-updates/s (force+CG step) + achieved HBM GB/s, 1M pts/200k verts' if args.config == 'c3' else
                       'vertex-updates/s (force+CG step) + achieved HBM GB/s, %s' % args.config,
@@ -429,11 +442,13 @@ def run_rank(args):
         out['roofline_iteration']['frac'] = out['roofline_iteration']['achieved'] / HBM_PEAK_GBS
         if multi:
             out['rccl'] = rccl
-            out['collectives'] = {'ms_per_iter': comm_ms / n_extra, 'per_iter': comm_n / n_extra,
-                                  'share_of_device_time': (comm_ms / n_extra) / max(stage['total'][0] / n_extra + comm_ms / n_extra, 1e-12),
-                                  'note': 'rank 0, event-bracketed all-reduces of %d extra iterations after the timed region' % n_extra,
-                                  'blocks_replayed_with_their_collectives': replayed_blocks,
-                                  'blocks_note': 'blocks of the warm-up and the timed region whose iterations 1..%d -- launches AND collectives -- were one replayed recording (hipGraph capture of the shared stream; RCCL only); the last iteration of a block stays live for the event pair around its query' % (BLOCK - 1)}
+            if native_comm:
+                out['collectives'] = {'per_iter': 3 if halo else 1, 'ms_per_iter': None,
+                                      'note': 'issued inside nw_search (not bracketed by events: they are nodes of the block\'s hipGraph); their cost is the difference between ms_per_step and the device time of the stages'}
+            else:
+                out['collectives'] = {'ms_per_iter': comm_ms / n_extra, 'per_iter': comm_n / n_extra,
+                                      'share_of_device_time': (comm_ms / n_extra) / max(stage['total'][0] / n_extra + comm_ms / n_extra, 1e-12),
+                                      'note': 'rank 0, event-bracketed all-reduces of %d extra iterations after the timed region' % n_extra}
             if halo:
                 out['halo'] = {'radius_nm': args.halo, 'boundary_vertices': scene.ex.n_boundary, 'repartitions_in_timed_region': reparts,
                                'max_nn_distance_nm': scene.max_dist, 'drift_since_partition_nm': scene.drift,
@@ -474,6 +489,8 @@ def run_rank(args):
         sys.stdout.flush()
     if multi:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -10,9 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libnanowrap_hip.so')
 
 NW_OK = 0
-NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM, NW_ERR_INTERNAL, NW_ERR_REMOTE = -1, -2, -3, -4, -5, -6, -7, -8
 NW_WEIGHTS_FROM_SIGMA_INV, NW_WEIGHTS_SCALAR, NW_WEIGHTS_ARRAY, NW_WEIGHTS_PRENORMALIZED = 0, 1, 2, 3
 NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP, NW_FLAG_WFUNC, NW_FLAG_RESULT_TO_HOST = 1, 2, 4, 8
+NW_FLAG_COMM_TILES, NW_FLAG_COMM_REPLICATED, NW_FLAG_COMM_HALO = 16, 32, 64
 (NW_ARR_S, NW_ARR_RES, NW_ARR_VIDX, NW_ARR_W, NW_ARR_DIST, NW_ARR_FACE, NW_ARR_POS, NW_ARR_FDEF, NW_ARR_PI,
  NW_ARR_MESHPOS, NW_ARR_VACC, NW_ARR_SCALARS, NW_ARR_NBR, NW_ARR_NRM, NW_ARR_VALID, NW_ARR_HALO_ACC, NW_ARR_HALO_ROWS,
  NW_ARR_HALO_FULL, NW_ARR_HALO_STATS) = range(19)
@@ -24,7 +25,7 @@ SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set
            'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
            'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_debug_items', 'nw_set_data', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned',
            'nw_set_boundary', 'nw_halo_pack', 'nw_halo_unpack', 'nw_halo_gather_owned', 'nw_set_extent_hint', 'nw_host_copy_rows',
-           'nw_capture_begin', 'nw_capture_end', 'nw_block_key', 'nw_block_replayed', 'nw_halo_set_reference', 'nw_halo_block_stats']
+           'nw_comm_unique_id', 'nw_comm_init', 'nw_comm_all_reduce', 'nw_halo_set_reference', 'nw_halo_block_stats']
 
 
 class IterLog(ctypes.Structure):
@@ -82,10 +83,9 @@ def load():
     L.nw_halo_gather_owned.argtypes = [vp, i32]
     L.nw_set_extent_hint.argtypes = [vp, ctypes.c_double]
     L.nw_host_copy_rows.argtypes = [vp, vp, i64, vp, vp, i64, vp]
-    L.nw_capture_begin.argtypes = [vp]
-    L.nw_capture_end.argtypes = [vp, vp]
-    L.nw_block_key.argtypes = [vp, vp]
-    L.nw_block_replayed.argtypes = [vp, ctypes.c_int]
+    L.nw_comm_unique_id.argtypes = [vp, i64]
+    L.nw_comm_init.argtypes = [vp, vp, i64, i32, i32]
+    L.nw_comm_all_reduce.argtypes = [vp, vp, i64, i32, i32]
     L.nw_halo_set_reference.argtypes = [vp, vp]
     L.nw_halo_block_stats.argtypes = [vp, ctypes.c_double]
     L.nw_set_data.argtypes = [vp, vp]
@@ -101,7 +101,7 @@ def load():
     for s in SYMBOLS:
         if s not in ('nw_destroy', 'nw_last_error'):
             getattr(L, s).restype = i32
-    if L.nw_abi_version() != 3:
+    if L.nw_abi_version() != 4:
         raise RuntimeError('libnanowrap_hip.so ABI version mismatch')
     _lib = L
     return L
@@ -134,4 +134,6 @@ def check(L, ctx, code):
         raise np.linalg.LinAlgError(msg)                # numpy.linalg.solve, conj_grad.py:219
     if code == NW_ERR_BADARG:
         raise ValueError(msg)
+    if code == NW_ERR_REMOTE:
+        msg = msg or 'another rank raised a status in this iteration (its own exception names it); this rank stopped with it'
     raise NanoWrapError(code, msg)

@@ -28,6 +28,35 @@ static_assert(SC_COUNT <= NW_N_SCALARS, "scalar slots");
 
 #define NW_EXPORT extern "C" __attribute__((visibility("default")))
 
+// RCCL is bound at run time (dlopen): a process that never calls nw_comm_init does not need it, and one that has torch loaded shares
+// torch's copy (same soname).  Only the header is needed to build.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+struct NwRccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load()
+    {
+        if (lib) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) { err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return false; }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce) { err = "RCCL: a symbol is missing"; (void)dlclose(lib); lib = nullptr; return false; }
+        return true;
+    }
+};
+static NwRccl g_rccl;
+
 namespace {
 
 template <typename T>
@@ -129,8 +158,12 @@ struct nw_ctx {
     DevBuf<int> face_orig;            // internal face id -> the caller's (faces are kept in Morton order of their centroids, nw_set_mesh)
     bool face_sorted = false;
     bool capturing = false;
-    bool ext_capture = false;              // the CALLER is capturing the stream (nw_capture_begin): phases record, collectives of the caller between them
-    int cap_done0 = 0; int64_t cap_iter0 = 0; bool cap_warm0 = false, cap_pending0 = false, cap_begin0 = false, cap_dirty0 = false;
+    // multi-GPU: this rank's RCCL communicator (nw_comm_init).  A block of nw_search then runs its collectives itself, on the ctx's stream,
+    // between the phases -- recorded into the block's hipGraph like every launch (NW_FLAG_COMM_*: which buffers go round).
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_ranks = 1;
+    uint32_t comm_mode = 0;                // NW_FLAG_COMM_* of the current search
+    DevBuf<unsigned char> comm_scratch;    // staging of host buffers given to nw_comm_all_reduce
     bool direct_out = false;         // nw_search: the last update of the block writes its result into the pinned staging buffer itself
     BlockGraph graphs[4];
     int graph_next = 0;
@@ -566,6 +599,7 @@ NW_EXPORT int nw_create(int device, nw_ctx **out)
 
 NW_EXPORT void nw_destroy(nw_ctx *ctx)
 {
+    if (ctx && ctx->comm) (void)nw_comm_init(ctx, nullptr, 0, 0, 0);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -1323,7 +1357,8 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     ctx->acc_quantum = ctx->quantum_override > 0 ? ctx->quantum_override : ctx->local_quantum;
     ctx->w_quantum = std::ldexp(1.0, -40);
     ctx->lam0 = lams[0];
-    ctx->search_flags = flags & ~NW_FLAG_RESULT_TO_HOST;
+    ctx->comm_mode = flags & (NW_FLAG_COMM_TILES | NW_FLAG_COMM_REPLICATED | NW_FLAG_COMM_HALO);
+    ctx->search_flags = flags & ~(NW_FLAG_RESULT_TO_HOST | NW_FLAG_COMM_TILES | NW_FLAG_COMM_REPLICATED | NW_FLAG_COMM_HALO);
     ctx->direct_out = false;
     if ((flags & NW_FLAG_RESULT_TO_HOST) && num_iters > 0 && 3 * ctx->M * sizeof(float) <= (4u << 20) && !(getenv("NW_DIRECT_OUT") && atoi(getenv("NW_DIRECT_OUT")) == 0)) {
         NW_TRY(ensure_staging(ctx));                // (larger results: the sliced copy of nw_search_end is the faster one)
@@ -1444,7 +1479,7 @@ NW_EXPORT int nw_iter_attract(nw_ctx *ctx)
 NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
 {
     if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_iter_directions outside a search");
-    if (ctx->have_boundary && (!ctx->capturing || ctx->ext_capture)) NW_TRY(halo_unpack(ctx, NW_ARR_VACC));      // the boundary rows summed over the ranks
+    if (ctx->have_boundary) NW_TRY(halo_unpack(ctx, NW_ARR_VACC));      // the boundary rows summed over the ranks
     const int it = ctx->search_done;
     const int n_search = (ctx->search_done == 0 || (ctx->search_flags & NW_FLAG_NO_LAST_STEP)) ? 2 : 3;
     {
@@ -1481,7 +1516,7 @@ NW_EXPORT int nw_iter_update(nw_ctx *ctx)
                            ctx->logs.p + ctx->search_done, it, (ctx->direct_out && it == ctx->search_iters - 1) ? (float *)ctx->pin : nullptr);
     }
     NW_HIP(hipGetLastError());
-    if (ctx->have_boundary && (!ctx->capturing || ctx->ext_capture)) { NW_TRY(halo_pack(ctx, NW_ARR_POS)); ctx->pos_unpack_pending = true; }
+    if (ctx->have_boundary) { NW_TRY(halo_pack(ctx, NW_ARR_POS)); ctx->pos_unpack_pending = true; }
     ctx->global_iter += 1;
     ctx->search_done += 1;
     return NW_OK;
@@ -1602,6 +1637,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
                           ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p,
                           ctx->hb_local.p, ctx->hb_slot.p, ctx->hb_slot2local.p, ctx->halo_acc.p, ctx->halo_rows.p, ctx->face_sorted ? ctx->face_orig.p : nullptr};
     mix((uint64_t)ctx->hb_n); mix((uint64_t)ctx->hb_nslot); mix((uint64_t)(uintptr_t)ctx->stream);
+    mix((uint64_t)(uintptr_t)ctx->comm); mix((uint64_t)ctx->comm_mode);
     for (const void *p : ptrs) mixp(p);
     return h;
 }
@@ -1611,6 +1647,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
 // Profiling level 4 replays everything BEFORE the block's last iteration from a graph (`head`) and launches that last iteration from
 // the host, its query kernel between two events: the host enqueues it while the graph is still running, so the GPU never waits for a
 // launch (with the live iteration FIRST, as until round 3, the block started launch-bound: 0.03 ms per step on a box with a slow host).
+static int run_iteration(nw_ctx *ctx);
 static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head)
 {
     static const bool graphs_on = !(getenv("NW_GRAPH") && atoi(getenv("NW_GRAPH")) == 0);
@@ -1621,17 +1658,13 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head)
     if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] capturing a block of %d (%s, key %016llx, warm %d, grid generation %llu)\n", num_iters,
                                       head ? "all but its last iteration" : "one graph",
                                       (unsigned long long)key, ctx->face_warm ? 1 : 0, (unsigned long long)ctx->grid_generation);
-    const bool warm0 = ctx->face_warm;
+    const bool warm0 = ctx->face_warm, pend0 = ctx->pos_unpack_pending;
     const int last = head ? num_iters - 1 : num_iters;
     hipGraphExec_t ea = nullptr;
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
         ctx->capturing = true;
         int r = enqueue_begin_ops(ctx);
-        for (int i = 0; i < last && r == NW_OK; ++i) {
-            r = iter_attract_parts(ctx, QP_ALL);
-            if (r == NW_OK) r = nw_iter_directions(ctx);
-            if (r == NW_OK) r = nw_iter_update(ctx);
-        }
+        for (int i = 0; i < last && r == NW_OK; ++i) r = run_iteration(ctx);
         ctx->capturing = false;
         hipGraph_t graph = nullptr;
         const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
@@ -1641,6 +1674,7 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head)
     (void)hipGetLastError();
     // rewind the host-side bookkeeping the recorded calls advanced
     ctx->global_iter -= ctx->search_done; ctx->search_done = 0; ctx->face_warm = warm0;
+    ctx->pos_unpack_pending = pend0;
     ctx->begin_ops_pending = true;          // recorded, not run
     if (!ea) return nullptr;
     nw_ctx::BlockGraph &dst = ctx->graphs[ctx->graph_next];
@@ -1650,53 +1684,103 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head)
     return &dst;
 }
 
-// ---- a block's phases recorded by the CALLER (multi-GPU: the collectives between the phases belong to the caller) ------------------
-// The caller puts the ctx's stream (nw_set_stream: its own) into capture, calls nw_capture_begin, then the phases of the block's remaining
-// iterations with its collectives between them exactly as it would run them, nw_capture_end, and ends its capture.  Nothing has run:
-// the bookkeeping the recorded calls advanced is rewound.  It then replays the recording for this and every later block whose
-// nw_block_key (asked after nw_search_begin) equals the one nw_capture_end returned, and tells the ctx with nw_block_replayed.
-NW_EXPORT int nw_capture_begin(nw_ctx *ctx)
+// ---- multi-GPU: the collectives of a block, issued by the library on its own stream -----------------------------------------------
+static int comm_all_reduce_dev(nw_ctx *ctx, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op)
 {
-    if (!ctx || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_capture_begin outside a search (nw_search_begin first)");
-    if (ctx->capturing) return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: already recording");
-    if (ctx->own_stream) return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: the caller records its own stream (nw_set_stream)");
-    if (!(ctx->profiling == 0 || ctx->profiling == 4))
-        return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: per-launch profiling needs live events (levels 1, 2; at level 4 leave the block's last iteration out of the recording)");
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusActive) {
-        (void)hipGetLastError();
-        return fail(ctx, NW_ERR_BADARG, "nw_capture_begin: the stream is not being captured");
+    if (!ctx->comm) return fail(ctx, NW_ERR_BADARG, "no communicator (nw_comm_init)");
+    if (count == 0) return NW_OK;
+    const ncclResult_t r = g_rccl.AllReduce(buf, buf, count, dt, op, ctx->comm, ctx->stream);
+    if (r != ncclSuccess) return fail(ctx, NW_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+    return NW_OK;
+}
+
+// what goes round between the phases of one iteration (ch_shrinkwrap_amd/parallel.py run_search is the same protocol
+// over an external process group):
+//   after the attraction step   'replicated': the whole per-vertex accumulator (M x 4 int64);  'halo': its boundary rows (n_slots x 4 int64)
+//   after the directions        the normal-equation sums ('replicated': the point-side ones only) -- every rank then solves the same system
+//   after the update            'halo': the owners' new positions of the boundary vertices (n_slots x 3 float32, owner-only non-zero rows)
+static int comm_after_attract(nw_ctx *ctx)
+{
+    if (!ctx->comm || !ctx->comm_mode) return NW_OK;
+    if (ctx->comm_mode & NW_FLAG_COMM_REPLICATED) return comm_all_reduce_dev(ctx, ctx->vacc.p, (size_t)4 * ctx->M, ncclInt64, ncclSum);
+    if ((ctx->comm_mode & NW_FLAG_COMM_HALO) && ctx->have_boundary && ctx->hb_nslot > 0) return comm_all_reduce_dev(ctx, ctx->halo_acc.p, (size_t)4 * ctx->hb_nslot, ncclInt64, ncclSum);
+    return NW_OK;
+}
+static int comm_after_directions(nw_ctx *ctx)
+{
+    if (!ctx->comm || !ctx->comm_mode) return NW_OK;
+    const size_t n = (size_t)((ctx->comm_mode & NW_FLAG_COMM_REPLICATED) ? SC_NPOINT : SC_MAXD) * NW_SPARTS;
+    return comm_all_reduce_dev(ctx, ctx->scalars.p, n, ncclDouble, ncclSum);
+}
+static int comm_after_update(nw_ctx *ctx)
+{
+    if (!ctx->comm || !ctx->comm_mode) return NW_OK;
+    if ((ctx->comm_mode & NW_FLAG_COMM_HALO) && ctx->have_boundary && ctx->hb_nslot > 0) return comm_all_reduce_dev(ctx, ctx->halo_rows.p, (size_t)3 * ctx->hb_nslot, ncclFloat, ncclSum);
+    return NW_OK;
+}
+
+// one iteration of a block, with its collectives (none without a communicator)
+static int run_iteration(nw_ctx *ctx)
+{
+    int r = nw_iter_attract(ctx);
+    if (r == NW_OK) r = comm_after_attract(ctx);
+    if (r == NW_OK) r = nw_iter_directions(ctx);
+    if (r == NW_OK) r = comm_after_directions(ctx);
+    if (r == NW_OK) r = nw_iter_update(ctx);
+    if (r == NW_OK) r = comm_after_update(ctx);
+    return r;
+}
+
+NW_EXPORT int nw_comm_unique_id(uint8_t *out, int64_t nbytes)
+{
+    if (!out || nbytes < (int64_t)sizeof(ncclUniqueId)) return NW_ERR_BADARG;
+    if (!g_rccl.load()) return NW_ERR_HIP;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return NW_ERR_HIP;
+    memcpy(out, &id, sizeof(id));
+    return NW_OK;
+}
+
+NW_EXPORT int nw_comm_init(nw_ctx *ctx, const uint8_t *unique_id, int64_t nbytes, int rank, int nranks)
+{
+    if (!ctx) return NW_ERR_BADARG;
+    NW_HIP(hipSetDevice(ctx->device));
+    if (ctx->comm) {                                           // (nranks <= 0: just leave)
+        NW_HIP(hipStreamSynchronize(ctx->stream));
+        for (auto &gph : ctx->graphs) if (gph.exec) { (void)hipGraphExecDestroy(gph.exec); gph.exec = nullptr; }      // recorded blocks hold the communicator's kernels
+        (void)g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_ranks = 1;
     }
-    ctx->cap_done0 = ctx->search_done; ctx->cap_iter0 = ctx->global_iter; ctx->cap_warm0 = ctx->face_warm;
-    ctx->cap_pending0 = ctx->pos_unpack_pending; ctx->cap_begin0 = ctx->begin_ops_pending; ctx->cap_dirty0 = ctx->vacc_dirty;
-    ctx->capturing = true; ctx->ext_capture = true;
+    if (nranks <= 0) return NW_OK;
+    if (!unique_id || nbytes < (int64_t)sizeof(ncclUniqueId) || rank < 0 || rank >= nranks) return fail(ctx, NW_ERR_BADARG, "nw_comm_init: unique id (nw_comm_unique_id of rank 0), 0 <= rank < nranks");
+    if (!g_rccl.load()) return fail(ctx, NW_ERR_HIP, g_rccl.err);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    const ncclResult_t r = g_rccl.CommInitRank(&ctx->comm, nranks, id, rank);
+    if (r != ncclSuccess) { ctx->comm = nullptr; return fail(ctx, NW_ERR_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error")); }
+    ctx->comm_rank = rank; ctx->comm_ranks = nranks;
     return NW_OK;
 }
 
-NW_EXPORT int nw_capture_end(nw_ctx *ctx, uint64_t *key)
+NW_EXPORT int nw_comm_all_reduce(nw_ctx *ctx, void *buf, int64_t count, int dtype, int op)
 {
-    if (!ctx || !ctx->ext_capture) return fail(ctx, NW_ERR_BADARG, "nw_capture_end without nw_capture_begin");
-    ctx->capturing = false; ctx->ext_capture = false;
-    ctx->search_done = ctx->cap_done0; ctx->global_iter = ctx->cap_iter0; ctx->face_warm = ctx->cap_warm0;
-    ctx->pos_unpack_pending = ctx->cap_pending0; ctx->begin_ops_pending = ctx->cap_begin0; ctx->vacc_dirty = ctx->cap_dirty0;
-    if (key) *key = block_graph_key(ctx) ^ (0x9e3779b97f4a7c15ull * (uint64_t)(ctx->search_done + 1));
-    return NW_OK;
-}
-
-NW_EXPORT int nw_block_key(nw_ctx *ctx, uint64_t *key)
-{
-    if (!ctx || !key || !ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_block_key outside a search");
-    *key = block_graph_key(ctx) ^ (0x9e3779b97f4a7c15ull * (uint64_t)(ctx->search_done + 1));
-    return NW_OK;
-}
-
-NW_EXPORT int nw_block_replayed(nw_ctx *ctx, int iters)
-{
-    if (!ctx || !ctx->in_search || ctx->capturing) return fail(ctx, NW_ERR_BADARG, "nw_block_replayed outside a search");
-    if (iters < 1 || ctx->search_done + iters > ctx->search_iters) return fail(ctx, NW_ERR_BADARG, "nw_block_replayed: more iterations than announced");
-    if (ctx->search_done == 0) { ctx->begin_ops_pending = false; ctx->vacc_dirty = false; }
-    ctx->global_iter += iters; ctx->search_done += iters; ctx->face_warm = true;
-    ctx->pos_unpack_pending = ctx->have_boundary;          // the recording ends with the owners' rows of the last update packed (and the caller's all-reduce)
+    if (!ctx || !buf || count < 0 || dtype < 0 || dtype > 3 || op < 0 || op > 1) return fail(ctx, NW_ERR_BADARG, "nw_comm_all_reduce: buffer, count >= 0, dtype 0..3 (f32, f64, i64, i32), op 0 (sum) / 1 (max)");
+    if (!ctx->comm) return fail(ctx, NW_ERR_BADARG, "nw_comm_all_reduce: no communicator (nw_comm_init)");
+    if (ctx->in_search && ctx->capturing) return fail(ctx, NW_ERR_BADARG, "nw_comm_all_reduce while a block is being recorded");
+    NW_HIP(hipSetDevice(ctx->device));
+    static const ncclDataType_t dts[4] = {ncclFloat, ncclDouble, ncclInt64, ncclInt32};
+    static const size_t sz[4] = {4, 8, 8, 4};
+    hipPointerAttribute_t attr;
+    const bool on_device = hipPointerGetAttributes(&attr, buf) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    if (on_device) return comm_all_reduce_dev(ctx, buf, (size_t)count, dts[dtype], op ? ncclMax : ncclSum);
+    // a host buffer (set-up: weight means, quanta, counts): staged through device memory, blocking
+    const size_t bytes = (size_t)count * sz[dtype];
+    NW_HIP(ctx->comm_scratch.ensure(std::max<size_t>(bytes, 256)));
+    NW_HIP(hipMemcpyAsync(ctx->comm_scratch.p, buf, bytes, hipMemcpyHostToDevice, ctx->stream));
+    NW_TRY(comm_all_reduce_dev(ctx, ctx->comm_scratch.p, (size_t)count, dts[dtype], op ? ncclMax : ncclSum));
+    NW_HIP(hipMemcpyAsync(buf, ctx->comm_scratch.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NW_HIP(hipStreamSynchronize(ctx->stream));
     return NW_OK;
 }
 
@@ -1704,8 +1788,10 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
 {
     const bool verbose = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 2;
     const auto t0 = std::chrono::steady_clock::now();
-    if (ctx && ctx->have_boundary && ctx->hb_nslot > 0)
-        return fail(ctx, NW_ERR_BADARG, "nw_search on a sharded mesh: the boundary rows must be all-reduced between the phases (nw_search_begin / nw_iter_* / nw_search_end)");
+    const uint32_t cmode = flags & (NW_FLAG_COMM_TILES | NW_FLAG_COMM_REPLICATED | NW_FLAG_COMM_HALO);
+    if (ctx && cmode && !ctx->comm) return fail(ctx, NW_ERR_BADARG, "nw_search: NW_FLAG_COMM_* without a communicator (nw_comm_init)");
+    if (ctx && ctx->have_boundary && ctx->hb_nslot > 0 && !(cmode & NW_FLAG_COMM_HALO))
+        return fail(ctx, NW_ERR_BADARG, "nw_search on a sharded mesh: the boundary rows must go round between the phases (NW_FLAG_COMM_HALO with a communicator, or nw_search_begin / nw_iter_* / nw_search_end with the caller's collectives)");
     NW_TRY(nw_search_begin(ctx, lams, n_lams, num_iters, flags));
     const auto t1 = std::chrono::steady_clock::now();
     // A block is a fixed launch sequence (begin ops + num_iters x 11 launches) with block-relative arguments: captured once as a
@@ -1736,13 +1822,12 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
             ctx->begin_ops_pending = false;
             ctx->vacc_dirty = false;                       // (a graph recorded while the accumulator was dirty zeroes it: the key carries the flag)
             ctx->global_iter += n_done; ctx->search_done = n_done; ctx->face_warm = true;
+            ctx->pos_unpack_pending = ctx->have_boundary;      // (the recording ends with the owners' rows of its last update packed and all-reduced)
             replayed = true;
         } else (void)hipGetLastError();
     }
     for (int i = ctx->search_done; i < num_iters; ++i) {
-        int r = nw_iter_attract(ctx);
-        if (r == NW_OK) r = nw_iter_directions(ctx);
-        if (r == NW_OK) r = nw_iter_update(ctx);
+        const int r = run_iteration(ctx);
         if (r != NW_OK) { ctx->in_search = false; return r; }
     }
     const auto t2 = std::chrono::steady_clock::now();
@@ -2126,6 +2211,13 @@ NW_EXPORT int nw_accumulator_quantum(nw_ctx *ctx, double *q)
     } else if (*q < 0) {
         ctx->quantum_override = 0.0;
         if (ctx->in_search) ctx->acc_quantum = ctx->local_quantum;
+    }
+    if (!ctx->in_search && ctx->have_points && ctx->have_mesh) {
+        // asked before the block (a rank of a multi-GPU run agrees on the quantum first, then calls nw_search): what nw_search_begin would choose
+        NW_HIP(hipSetDevice(ctx->device));
+        NW_TRY(alloc_work(ctx));
+        NW_TRY(ensure_grid(ctx));
+        ctx->local_quantum = std::ldexp(1.0, (int)std::ceil(std::log2(std::max(ctx->scene_ext * ctx->w_bound, 1e-300))) - 36);
     }
     *q = ctx->local_quantum;
     return NW_OK;

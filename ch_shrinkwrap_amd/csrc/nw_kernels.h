@@ -12,16 +12,17 @@ enum {
     SC_NPTS = 3,     // number of points contributing
     SC_HC = 4,       // 6: AS^T AS (00,01,02,11,12,22)            conj_grad.py:202
     SC_GC = 10,      // 3: AS^T res                               conj_grad.py:203
-    SC_NPOINT = 13,
+    SC_STATUS = 13,  // > 0: a status was raised in this iteration (on this rank, or -- summed over the ranks -- on any): every rank stops with it
+    SC_NPOINT = 14,
     // vertex-side sums (replicated on every rank)
-    SC_SS = 13,      // 6: S^T S = Hw                             conj_grad.py:211
-    SC_SP = 19,      // 3: S_k . prefs64 (Gw = -SP)               conj_grad.py:212
-    SC_PP64 = 22,    // sum prefs64^2 -> wpreds                   conj_grad.py:192
-    SC_PP32 = 23,    // sum prefs32^2 -> prefs log                mesh_conj_grad.py:271
-    SC_T = 24,       // 3: S0.S0, S0.S1, S1.S1 of the RAW directions -> test statistic (mesh_conj_grad.py:262-265); equal to SC_SS
+    SC_SS = 14,      // 6: S^T S = Hw                             conj_grad.py:211
+    SC_SP = 20,      // 3: S_k . prefs64 (Gw = -SP)               conj_grad.py:212
+    SC_PP64 = 23,    // sum prefs64^2 -> wpreds                   conj_grad.py:192
+    SC_PP32 = 24,    // sum prefs32^2 -> prefs log                mesh_conj_grad.py:271
+    SC_T = 25,       // 3: S0.S0, S0.S1, S1.S1 of the RAW directions -> test statistic (mesh_conj_grad.py:262-265); equal to SC_SS
                      //    entries 0, 1, 3 unless a regulariser other than the identity scales the directions (wfunc)
-    SC_MAXD = 27,    // largest NN distance (a MAX, not a sum: k_reduce_scalars / k_solve_update treat this slot accordingly)
-    SC_COUNT = 28
+    SC_MAXD = 28,    // largest NN distance (a MAX, not a sum: k_reduce_scalars / k_solve_update treat this slot accordingly)
+    SC_COUNT = 29
 };
 
 #define NW_SPARTS 32      // ordered partial sums per scalar slot (k_reduce_scalars)
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
     const NwSolve sol = s_sol;
     // a status raised earlier in this iteration (NaN in the weight matrix / A f / A^T r: the reference asserts BEFORE `self.f[:] = fnew`,
     // mesh_conj_grad.py:514,548,580 vs :288) leaves the estimate, the mesh positions and the staged result at the last good iterate
-    const bool failed = st->status != 0;
+    const bool failed = st->status != 0 || sc[SC_STATUS] > 0.0;     // (the second: another rank's, summed in with the normal-equation sums)
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < M; v += gridDim.x * blockDim.x) {
       if (!sol.singular && !failed) {
         const bool ok = valid ? valid[v] != 0 : true;
@@ -824,6 +825,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
         L.n_search = n_search;
         L.nn_max_ring = st->nn_max_ring;
         if (sol.singular) atomicCAS(&st->status, 0, -4 /* NW_ERR_SINGULAR */);
+        if (sc[SC_STATUS] > 0.0) atomicCAS(&st->status, 0, -8 /* NW_ERR_REMOTE */);
         L.status = st->status;
         L.executed = (failed || sol.singular) ? 0 : 1;       // (the reference raised inside this iteration: it does not count, and the result is copied out the ordinary way)
         *logrec = L;
@@ -880,6 +882,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_reduce_scalars(const double *__res
     __shared__ double s_acc[NW_BLOCK];
     // 3 x NW_SPARTS workgroups: the three tables are reduced side by side (one memory round trip instead of three in a row)
     const int table = (int)blockIdx.x / NW_SPARTS, bid = (int)blockIdx.x % NW_SPARTS;
+    if (table == 0 && threadIdx.x == 0) sc[SC_STATUS * NW_SPARTS + bid] = (bid == 0 && st->status != 0) ? 1.0 : 0.0;
     if (table == 0) nw_reduce_columns<5, 255, 4, SC_MAXD>(part_a, nblk_a, s_acc, sc, SC_RES2, bid);   // k_attract: res^2, masked res^2, sum d, count; max d
     else if (table == 1) nw_reduce_columns<9, 252, -1, 0>(part_s, nblk_s, s_acc, sc, SC_HC, bid);     // k_subspace_point_sums: Hc (6), Gc (3)
     else nw_reduce_columns<14, 252, -1, 0>(part_p, nblk_p, s_acc, sc, SC_SS, bid);                    // k_prior_directions: LS^T LS (6), LS.prefs (3), |prefs|^2 (2), raw S.S (3)

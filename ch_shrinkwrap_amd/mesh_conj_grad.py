@@ -195,8 +195,13 @@ class ShrinkwrapMeshConjGrad(object):
         raise NotImplementedError('Lfuncs=%r / Lhfuncs=%r: only ["I"] and ["wfunc"] run in the reference\'s loop' % (L, Lh))
 
     # -- the hot path ---------------------------------------------------------------------------
-    def search(self, data, lams, defaults=None, num_iters=10, weights=None, sigma_inv=1.0, pos=False, last_step=True):
-        """mesh_conj_grad.py:150-292.  Returns the (M,3) float32 vertex estimate."""
+    def search(self, data, lams, defaults=None, num_iters=10, weights=None, sigma_inv=1.0, pos=False, last_step=True,
+               comm_flags=0, prenormalized=None, to_host=True):
+        """mesh_conj_grad.py:150-292.  Returns the (M,3) float32 vertex estimate.
+
+        comm_flags / prenormalized / to_host are this rank's part of a multi-GPU block (parallel.run_search over a NativeComm): one of
+        NW_FLAG_COMM_*, the weights divided by the mean over ALL ranks, and whether this rank's result goes to the host mesh (a sharded
+        mesh gathers the whole mesh afterwards instead)."""
         # `data` is the target of the residual (mesh_conj_grad.py:164, 180-181, 222); the weight matrix always comes from the
         # localizations the optimiser was built with (:222 -> :433).  Upstream passes the same array for both (_membrane_mesh.pyx:1516).
         target = None
@@ -209,16 +214,22 @@ class ShrinkwrapMeshConjGrad(object):
         if type(lams) is float or np.isscalar(lams):
             lams = [float(lams)]
         lams_a = np.ascontiguousarray(lams, dtype=np.float32)
-        self._upload_points(sigma_inv, weights)
+        self._upload_points(sigma_inv, weights, prenormalized)
         dkey = None if target is None else (id(data), self._native.points_key)
         if getattr(self._native, 'data_key', None) != dkey or (target is not None and not getattr(self, '_data_is_static', False)):
             self._native.check(self._L.nw_set_data(self._h, nw.ptr(target)))
             self._native.data_key = dkey
         num_iters = int(num_iters)
-        flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP) | self._regulariser_flag()
+        flags = (nw.NW_FLAG_POSITIVITY if pos else 0) | (0 if last_step else nw.NW_FLAG_NO_LAST_STEP) | self._regulariser_flag() | int(comm_flags)
         logs = (nw.IterLog * max(num_iters, 1))()
         lc = ctypes.c_int(0)
         self._cache = {}
+        if not to_host:
+            code = self._L.nw_search(self._h, nw.ptr(lams_a), lams_a.size, num_iters, flags, None, logs, ctypes.byref(lc))
+            self._native.check(code)
+            self._consume_logs(logs, lc.value)
+            self._accumulate_stage_ms()
+            return None
         # write-back (mesh_conj_grad.py:288-290) inside the call: the library copies the positions out in slices (the (M,3) result and
         # the strided mesh._vertices['position'] rows of the valid vertices) while the rest of the transfer is still in flight
         out = self._result_buffer()

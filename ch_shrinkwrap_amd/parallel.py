@@ -27,12 +27,17 @@ localization cloud, because A is row-separable -- each localization touches the 
                      The nearest-face query stays exact as long as no localization is further than H from its nearest centroid
                      (checked every iteration from the device-side maximum).
 
-Collectives are issued on the stream the kernels run on (the optimiser is constructed with torch's current stream), so
-an iteration is kernels -> all-reduce -> kernels with no host synchronisation.  Messages are KB..MB sized: the per-link
-xGMI bandwidth is irrelevant for the scalar exchange (latency-bound), and the vertex accumulator is one bucket.
+Who issues the collectives.  In production the LIBRARY does: every rank joins an RCCL communicator of its own nw_ctx (NativeComm ->
+nw_comm_init) and a block is ONE nw_search call with an NW_FLAG_COMM_* flag -- phases and ncclAllReduce on the ctx's own stream,
+recorded into the block's hipGraph like every kernel launch (include/nanowrap.h "multi-GPU: RCCL inside the library").  Python keeps
+the partition and the set-up; torch.distributed is only the host channel that carries the communicator's id (and whatever barriers
+the application wants).  Messages are KB..MB sized: the per-link xGMI bandwidth is irrelevant for the scalar exchange
+(latency-bound), and the vertex accumulator is one bucket.
 
-The orchestration below is backend-agnostic: it talks to an "executor" (HipExecutor for the product; tests drive the
-same code over gloo with a CPU executor built from the oracle) so that the N > 1 protocol is covered on CPU.
+The same protocol over an EXTERNAL process group -- the split-phase C-ABI (nw_iter_attract / nw_iter_directions / nw_iter_update)
+with the caller's all-reduces between the phases -- is what run_search does for an executor without a communicator: the CPU tests
+drive it over gloo with an executor built from the oracle, and the GPU tests with two gloo ranks sharing one GPU (RCCL refuses two
+ranks on one device), so the N > 1 protocol is covered where no multi-GPU node is available.
 """
 import ctypes
 import numpy as np
@@ -40,7 +45,41 @@ import numpy as np
 from . import _lib as nw
 
 
-RECORD_BELOW_LOCALIZATIONS = 500000      # run_search records blocks with their collectives for ranks holding fewer localizations (NW_GRAPH_COLLECTIVES=1: always)
+class NativeComm(object):
+    """This rank's RCCL communicator inside the library (nw_comm_init), created over a NativeContext.  `dist`: any initialised
+    torch.distributed-like module -- used ONCE, to hand rank 0's unique id to the others (and for rank / world size)."""
+
+    SUM, MAX = 0, 1
+    _DT = {np.dtype('float32'): 0, np.dtype('float64'): 1, np.dtype('int64'): 2, np.dtype('int32'): 3}
+
+    def __init__(self, native, dist):
+        self.native, self.L, self.h = native, native.L, native.h
+        self.rank, self.world = int(dist.get_rank()), int(dist.get_world_size())
+        ident = np.zeros(128, np.uint8)
+        if self.rank == 0:
+            native.check(self.L.nw_comm_unique_id(nw.ptr(ident), ident.size))
+        box = [ident.tobytes()]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0)
+        ident = np.frombuffer(box[0], np.uint8).copy()
+        native.check(self.L.nw_comm_init(self.h, nw.ptr(ident), ident.size, self.rank, self.world))
+
+    def all_reduce_host(self, a, op=0):
+        """in place over a C-contiguous host array (float32 / float64 / int64 / int32); blocking"""
+        self.native.check(self.L.nw_comm_all_reduce(self.h, nw.ptr(a), a.size, self._DT[a.dtype], int(op)))
+        return a
+
+    def all_reduce_device(self, what, count, dtype, op=0):
+        """in place over a library-owned device array (NW_ARR_*), asynchronous on the ctx's stream"""
+        p, nb = ctypes.c_void_p(), ctypes.c_int64()
+        self.native.check(self.L.nw_device_ptr(self.h, what, ctypes.byref(p), ctypes.byref(nb)))
+        self.native.check(self.L.nw_comm_all_reduce(self.h, p, int(count), self._DT[np.dtype(dtype)], int(op)))
+
+    def close(self):
+        self.native.check(self.L.nw_comm_init(self.h, None, 0, 0, 0))
+
+
+_COMM_FLAG = {'tiles': nw.NW_FLAG_COMM_TILES, 'replicated': nw.NW_FLAG_COMM_REPLICATED, 'halo': nw.NW_FLAG_COMM_HALO}
 
 
 class _DevArray(object):
@@ -64,9 +103,8 @@ class HipExecutor(object):
         self._views = {}
         self.write_back = True                      # end(): copy the rank's (M,3) result to the host mesh (a sharded mesh gathers the whole mesh instead)
         self.max_dist = 0.0
-        self.graphs = {}                            # recorded blocks (phases + the collectives between them), by nw_block_key
+        self.comm = None                            # NativeComm: the library issues the block's collectives itself (run_search)
         self.blocks_run = 0
-        self.blocks_replayed = 0
 
     def new_tensor(self, values):
         import torch
@@ -123,7 +161,6 @@ class HipExecutor(object):
         self.native.check(self.L.nw_set_boundary(self.h, nw.ptr(bl), nw.ptr(bs), bl.size, int(n_boundary), nw.ptr(ow), nw.ptr(g), int(n_global)))
         self.n_boundary, self.n_global = int(n_boundary), int(n_global)
         self._views = {}
-        self.graphs = {}
 
     def boundary_accumulator(self):
         """(n_boundary, 4) int64: this rank's partial sums of the boundary vertices it holds (filled by attract())"""
@@ -166,28 +203,8 @@ class HipExecutor(object):
         self.native.check(self.L.nw_host_copy_rows(self.h, nw.ptr(src), src.shape[0], nw.ptr(contiguous), ctypes.c_void_p(rows.ctypes.data), rows.strides[0],
                                                    nw.ptr(valid_u8)))
 
-    # -- a block recorded with its collectives (nw_capture_begin .. nw_block_replayed, include/nanowrap.h) --------------------------------
-    def profiling_level(self):
-        return int(getattr(self.cg, '_profiling_level', 0))
-
-    def block_key(self):
-        k = ctypes.c_uint64(0)
-        self.native.check(self.L.nw_block_key(self.h, ctypes.byref(k)))
-        return k.value
-
-    def capture_begin(self):
-        self.native.check(self.L.nw_capture_begin(self.h))
-
-    def capture_end(self):
-        k = ctypes.c_uint64(0)
-        self.native.check(self.L.nw_capture_end(self.h, ctypes.byref(k)))
-        return k.value
-
-    def replayed(self, iterations):
-        self.native.check(self.L.nw_block_replayed(self.h, int(iterations)))
-
     def local_quantum(self):
-        """the quantum this rank would choose for its own localizations (valid after begin())"""
+        """the quantum this rank would choose for its own localizations (after begin(), or before a block once points and mesh are set)"""
         q = ctypes.c_double(0.0)
         self.native.check(self.L.nw_accumulator_quantum(self.h, ctypes.byref(q)))
         return q.value
@@ -232,6 +249,8 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
     collective it needs anyway); None = agree now (one blocking all-reduce MAX of the ranks' own values)."""
     if mode not in ('tiles', 'replicated', 'halo'):
         raise ValueError(mode)
+    if getattr(ex, 'comm', None) is not None:
+        return _run_search_native(ex, mode, data, lams, num_iters, sigma_inv, weights, pos, last_step, quantum)
     # weights = weights / weights.mean() (mesh_conj_grad.py:160-162): the mean runs over the WHOLE scene, i.e. all ranks
     w_eff = weights if weights is not None else sigma_inv
     prenorm = None
@@ -277,94 +296,38 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
         if mode == 'halo' and ex.n_boundary > 0:
             all_reduce(ex.boundary_rows())                   # (|B|, 3): owner-only non-zero rows -> every holder takes the owner's value
 
-    n = int(num_iters)
-    done = 0
-    if hasattr(ex, 'capture_begin') and getattr(ex, 'blocks_run', 0) == 0 and not hasattr(ex, 'largest_share'):
-        t = ex.new_tensor([float(np.asarray(ex.cg._points_f32).size // 3)])
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)             # (the executor's first block: every rank is here)
-        ex.largest_share = int(t[0])
-    if n > 0 and timer is None and _recordable(ex, dist):
-        # The block as ONE recording -- the phases' launches AND the RCCL collectives between them (hipGraph capture of the shared
-        # stream) -- replayed for every later block that bakes the same things in (nw_block_key): a sharded iteration is ~12 launches
-        # and up to 3 collective calls, which the host otherwise issues one by one.  Profiling level 4 keeps the block's LAST iteration
-        # live (its query kernel between two events; the host issues it while the recording is still running), as nw_search does on
-        # one GPU.  Every rank comes to the same decision (the conditions of _recordable are the same on all of them), but nothing
-        # here depends on it: a rank that replays a recording and a rank that issues the same block launch by launch -- its key changed,
-        # or its capture failed -- run the same collectives in the same order, so no agreement (and no extra collective) is needed.
-        count = n - 1 if ex.profiling_level() == 4 else n
-        if count > 0:
-            key = (ex.block_key(), mode, count, n_red)
-            g = ex.graphs.get(key)
-            if g is None:
-                g = _record_block(ex, dist, iteration, count)
-                while len(ex.graphs) >= 4:
-                    ex.graphs.pop(next(iter(ex.graphs)))
-                ex.graphs[key] = g
-            if g is not False:
-                g.replay()
-                ex.replayed(count)
-                ex.blocks_replayed += 1
-                done = count
-    for _ in range(done, n):
+    for _ in range(int(num_iters)):
         iteration()
     ex.blocks_run = getattr(ex, 'blocks_run', 0) + 1
     return ex.end()                                          # (the last update's rows are taken here)
 
 
-def _recordable(ex, dist):
-    """Blocks are recorded when the collectives can be (RCCL: backend nccl), from the executor's second block on (the first one runs the
-    collectives once outside a capture, and a cold query has a key of its own anyway).  NW_GRAPH_COLLECTIVES=0 turns it off.
-
-    Only with TORCH_NCCL_CUDA_EVENT_CACHE=0 in the environment BEFORE the process group was created (bench.py sets it): with torch's
-    event cache on, an event a captured collective recorded is handed to a later eager collective; the process group's watchdog thread
-    then polls it while the next capture is active, HIP answers hipErrorCapturedEvent (the event still names the capturing stream),
-    the capture is invalidated and the watchdog takes the process down.  tools/experiments/capture_race.py reproduces it within a few
-    hundred captures on one GPU (torch 2.10 + ROCm 7.0 runtime); 800 captures without the cache show none."""
-    import os
-    want = os.environ.get('NW_GRAPH_COLLECTIVES', 'auto')
-    if not hasattr(ex, 'capture_begin') or want == '0':
-        return False
-    if os.environ.get('TORCH_NCCL_CUDA_EVENT_CACHE', '1') != '0':
-        return False
-    # 'auto': where the host is the bound.  Measured on one GPU (tools/graph_rehearsal.sh): a rank with 10^6 localizations is device-bound
-    # either way (0.308 against 0.309 ms per iteration), one with 10^5 gains 5 % ('tiles') to 18 % ('halo': three collectives per iteration)
-    # (the LARGEST share of any rank decides, agreed once per executor in its first block: every rank must come to the same answer)
-    if want != '1' and getattr(ex, 'largest_share', 1 << 62) > RECORD_BELOW_LOCALIZATIONS:
-        return False
-    if getattr(ex, 'blocks_run', 0) < 1 or ex.profiling_level() not in (0, 4):
-        return False
-    try:
-        return dist.get_backend() == 'nccl'
-    except Exception:
-        return False
-
-
-def _record_block(ex, dist, iteration, count):
-    """Capture `count` iterations (phases + collectives) on the current torch stream; False if this rank could not (it then issues its
-    blocks launch by launch: the same collectives in the same order as the ranks that replay)."""
-    import torch
-    ok = True
-    g = torch.cuda.CUDAGraph()
-    try:
-        with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode='thread_local'):
-            ex.capture_begin()
-            try:
-                for _ in range(count):
-                    iteration()
-            finally:
-                ex.capture_end()
-    except Exception as e:                                   # e.g. a collective that cannot be captured on this stack
-        import sys
-        sys.stderr.write('[nanowrap] recording a block with its collectives failed (%s: %s): blocks are issued launch by launch\n' % (type(e).__name__, e))
-        ok = False
-        if torch.cuda.is_current_stream_capturing():         # an invalidated capture that torch could not close: nothing can be launched any more
-            try:
-                g.capture_end()
-            except Exception:
-                pass
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError('nanowrap: the stream is stuck in a failed capture (%s); NW_GRAPH_COLLECTIVES=0 issues every block launch by launch' % e)
-    return g if ok else False
+def _run_search_native(ex, mode, data, lams, num_iters, sigma_inv, weights, pos, last_step, quantum):
+    """The block of run_search for an executor with a NativeComm: set-up collectives through the communicator, then ONE nw_search call
+    that runs the phases and the collectives between them on the library's own stream (captured as the block's hipGraph)."""
+    comm, cg = ex.comm, ex.cg
+    w_eff = weights if weights is not None else sigma_inv
+    prenorm = None
+    if not np.isscalar(w_eff):
+        cached = getattr(ex, '_prenorm_cache', None)
+        if cached is not None and cached[0] is w_eff:
+            prenorm = cached[1]
+        else:
+            w_arr = np.asarray(w_eff, dtype=np.float32).ravel()
+            t = comm.all_reduce_host(np.array([float(w_arr.astype(np.float64).sum()), float(w_arr.size)], np.float64))
+            prenorm = (w_arr / np.float32(float(t[0]) / float(t[1]))).astype(np.float32)
+            ex._prenorm_cache = (w_eff, prenorm)
+    cg._upload_points(sigma_inv, weights, prenorm)
+    if mode != 'tiles':
+        if quantum is None:
+            quantum = float(comm.all_reduce_host(np.array([ex.local_quantum()], np.float64), NativeComm.MAX)[0])
+        ex.set_quantum(quantum)
+    cg.max_dist = 0.0
+    out = cg.search(data, lams, num_iters=num_iters, weights=weights, sigma_inv=sigma_inv, pos=pos, last_step=last_step,
+                    comm_flags=_COMM_FLAG[mode], prenormalized=prenorm, to_host=ex.write_back)
+    ex.max_dist = cg.max_dist
+    ex.blocks_run = getattr(ex, 'blocks_run', 0) + 1
+    return out
 
 
 class CollectiveTimer(object):
@@ -399,25 +362,31 @@ class CollectiveTimer(object):
 class TiledScene(object):
     """Convenience front end used by bench.py: single-GPU -> plain cg.search; multi-GPU -> run_search.
 
-    Stream discipline for N > 1: kernels and collectives must share ONE stream.  torch's default stream has the handle 0,
-    which the C-ABI reads as "use your own stream", so the optimiser must be constructed on a dedicated `torch.cuda.Stream`
-    (`stream=s.cuda_stream`) and that same torch stream is made current around every collective here."""
+    `comm` (NativeComm over the optimiser's NativeContext): the library runs the collectives on its own stream.  Without it the
+    collectives go through `dist` (an external process group) and kernels and collectives must share ONE stream: torch's default
+    stream has the handle 0, which the C-ABI reads as "use your own stream", so the optimiser must then be constructed on a dedicated
+    `torch.cuda.Stream` (`stream=s.cuda_stream`) and that same torch stream is made current around every collective here."""
 
-    def __init__(self, cg, dist=None, mode='tiles', torch_stream=None):
+    def __init__(self, cg, dist=None, mode='tiles', torch_stream=None, comm=None):
         self.cg = cg
         self.dist = dist
         self.mode = mode
         self.torch_stream = torch_stream
-        if dist is not None and torch_stream is None:
-            raise ValueError('multi-GPU runs need the torch stream the optimiser was constructed on (see class docstring)')
-        self.ex = HipExecutor(cg) if dist is not None else None
+        self.comm = comm                       # NativeComm over cg's NativeContext: the library issues the collectives (production)
+        if dist is not None and comm is None and torch_stream is None:
+            raise ValueError('multi-GPU runs over an external process group need the torch stream the optimiser was constructed on (see class docstring)')
+        self.ex = HipExecutor(cg) if (dist is not None or comm is not None) else None
+        if self.ex is not None:
+            self.ex.comm = comm
 
     def search(self, data, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
-        if self.dist is None:
+        if self.ex is None:
             return self.cg.search(data, lams=lams, num_iters=num_iters, sigma_inv=sigma_inv, weights=weights, pos=pos, last_step=last_step)
-        import torch
         if type(lams) is float or np.isscalar(lams):
             lams = [float(lams)]
+        if self.comm is not None:
+            return run_search(self.ex, None, self.mode, data, lams, num_iters, sigma_inv, weights, pos, last_step)
+        import torch
         with torch.cuda.stream(self.torch_stream):
             return run_search(self.ex, self.dist, self.mode, data, lams, num_iters, sigma_inv, weights, pos, last_step)
 
@@ -624,9 +593,13 @@ class HaloScene(object):
     make_executor(local_mesh, local_points) -> executor (HipExecutor over a ShrinkwrapMeshConjGrad in production; the CPU tests pass
     an oracle-backed one)."""
 
-    def __init__(self, mesh, points, dist, halo, make_executor=None, native=None, torch_stream=None):
+    def __init__(self, mesh, points, dist, halo, make_executor=None, native=None, torch_stream=None, comm=None):
         self.mesh, self.points, self.dist, self.halo = mesh, np.ascontiguousarray(points, np.float32), dist, float(halo)
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.comm = comm                  # NativeComm over `native`: every collective of the run goes through the library's communicator
+        if comm is not None and native is None:
+            raise ValueError('HaloScene(comm=...) needs the NativeContext the communicator was created on (native=...)')
+        self.rank, self.world = (comm.rank, comm.world) if comm is not None else (dist.get_rank(), dist.get_world_size())
+        self.drift, self.max_dist = 0.0, 0.0
         self.make_executor = make_executor
         self.native = native
         self.torch_stream = torch_stream
@@ -660,6 +633,7 @@ class HaloScene(object):
             cg.set_profiling(prof)
         ex = HipExecutor(cg)
         ex.write_back = False
+        ex.comm = self.comm
         return ex
 
     def _stream(self):
@@ -687,12 +661,15 @@ class HaloScene(object):
         # every rank works out its OWN share only; who else holds a vertex (the boundary list) comes from one all-reduce of the counts
         part = HaloPartition(pos, nrm, nbr, mesh.faces, self.points, self.world, self.halo, tiles=self._tiles, detail_ranks=(self.rank,),
                              membership_ranks=(self.rank,))
-        import torch
-        cnt = torch.from_numpy(part.count)
-        if self.make_executor is None:
-            cnt = cnt.cuda()
-        self.dist.all_reduce(cnt)
-        part.set_count(cnt.cpu().numpy())
+        if self.comm is not None:
+            part.set_count(self.comm.all_reduce_host(np.ascontiguousarray(part.count, np.int64)).astype(part.count.dtype))
+        else:
+            import torch
+            cnt = torch.from_numpy(part.count)
+            if self.make_executor is None:
+                cnt = cnt.cuda()
+            self.dist.all_reduce(cnt)
+            part.set_count(cnt.cpu().numpy())
         t2 = time.perf_counter()
         self.last_partition = part
         d = part.ranks[self.rank]
@@ -700,7 +677,7 @@ class HaloScene(object):
         self._gv = gv
         self._local_mesh = ArrayMesh(pos[gv], nrm[gv], d['nbr'], d['faces'], d['valid'])
         old = self.ex
-        keep = {k: getattr(old, k) for k in ('collective_timer', '_prenorm_cache', 'blocks_replayed') if old is not None and hasattr(old, k)}
+        keep = {k: getattr(old, k) for k in ('collective_timer', '_prenorm_cache') if old is not None and hasattr(old, k)}
         self.ex = (self.make_executor or self._hip_executor)(self._local_mesh, self._local_points)
         for k, v in keep.items():
             setattr(self.ex, k, v)
@@ -748,12 +725,30 @@ class HaloScene(object):
     # -- one block ----------------------------------------------------------------------------------------------------------------
     def search(self, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
         import time
-        import torch
         if self.last_partition is None:
             self._setup()
         ex, mesh = self.ex, self.mesh
         if type(lams) is float or np.isscalar(lams):
             lams = [float(lams)]
+        if self.comm is not None:
+            # the library's communicator and stream: the block, then the owners' rows of the whole mesh and the block's statistics go round
+            run_search(ex, None, 'halo', self._local_points, lams, num_iters, self._local(sigma_inv), self._local(weights), pos, last_step,
+                       quantum=self._quantum)
+            t0 = time.perf_counter()
+            L, h, chk = ex.L, ex.h, ex.native.check
+            chk(L.nw_halo_gather_owned(h, nw.NW_ARR_POS))
+            self.comm.all_reduce_device(nw.NW_ARR_HALO_FULL, 3 * ex.n_global, np.float32)
+            chk(L.nw_halo_block_stats(h, float(ex.max_dist)))
+            self.comm.all_reduce_device(nw.NW_ARR_HALO_STATS, 4, np.float32, NativeComm.MAX)
+            if self._host_full is None or self._host_full.shape[0] != ex.n_global:
+                self._host_full = np.empty((ex.n_global, 3), np.float32)
+            newpos = self._host_full
+            chk(L.nw_get(h, nw.NW_ARR_HALO_FULL, nw.ptr(newpos), newpos.nbytes))
+            st4 = np.zeros(4, np.float32)
+            chk(L.nw_get(h, nw.NW_ARR_HALO_STATS, nw.ptr(st4), st4.nbytes))
+            worst, q, d2 = float(st4[0]), float(st4[1]), float(st4[2])
+            return self._finish_block(ex, mesh, newpos, worst, q, d2, t0)
+        import torch
         with self._stream():
             run_search(ex, self.dist, 'halo', self._local_points, lams, num_iters, self._local(sigma_inv), self._local(weights), pos, last_step,
                        quantum=self._quantum)
@@ -773,6 +768,10 @@ class HaloScene(object):
             self.dist.all_reduce(stats, op=self.dist.ReduceOp.MAX)
             newpos = self._to_host(full)
             worst, q, d2 = stats.tolist()[:3]             # (the one synchronisation of the block's tail: the whole mesh has landed too)
+        return self._finish_block(ex, mesh, newpos, worst, q, d2, t0)
+
+    def _finish_block(self, ex, mesh, newpos, worst, q, d2, t0):
+        import time
         t1 = time.perf_counter()
         self._quantum = q if q > 0 else None
         drift = float(np.sqrt(max(d2, 0.0)))
@@ -810,6 +809,19 @@ class HaloScene(object):
             self.mesh.update_geometry()
             return
         ex = self.ex
+        if self.comm is not None:
+            p = self.mesh._vertices['position']
+            ex.refresh_normals_local(float((p.max(0).astype(np.float64) - p.min(0).astype(np.float64)).max()))
+            if ex.n_boundary > 0:
+                self.comm.all_reduce_device(nw.NW_ARR_HALO_ROWS, 3 * ex.n_boundary, np.float32)
+            ex.take_normals()
+            if to_host:
+                ex.native.check(ex.L.nw_halo_gather_owned(ex.h, nw.NW_ARR_NRM))
+                self.comm.all_reduce_device(nw.NW_ARR_HALO_FULL, 3 * ex.n_global, np.float32)
+                nrm = np.empty((ex.n_global, 3), np.float32)
+                ex.native.check(ex.L.nw_get(ex.h, nw.NW_ARR_HALO_FULL, nw.ptr(nrm), nrm.nbytes))
+                self.mesh._vertices['normal'][:] = nrm
+            return
         with self._stream():
             if hasattr(ex, 'refresh_normals_local'):
                 p = self.mesh._vertices['position']

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NW_ABI_VERSION 3
+#define NW_ABI_VERSION 4
 
 typedef struct nw_ctx nw_ctx;
 
@@ -35,7 +35,8 @@ typedef enum nw_status {
     NW_ERR_SINGULAR = -4,    /* subspace normal equations singular: numpy.linalg.solve raises LinAlgError, conj_grad.py:219 */
     NW_ERR_NONFINITE = -5,   /* non-finite localization or vertex coordinate (cKDTree cannot index it) */
     NW_ERR_NOMEM = -6,
-    NW_ERR_INTERNAL = -7     /* invariant violated inside the library (reported instead of risking a GPU fault) */
+    NW_ERR_INTERNAL = -7,    /* invariant violated inside the library (reported instead of risking a GPU fault) */
+    NW_ERR_REMOTE = -8       /* multi-GPU: another rank raised a status in this iteration (its own code is in that rank's log); this rank stopped with it */
 } nw_status;
 
 /* how the residual weights are given -- mirrors `search(..., weights=None, sigma_inv=1.0)`,
@@ -54,6 +55,9 @@ typedef enum nw_weights_mode {
                                         S1 = -w prefs, LS_k = w S_k with w = vertex_area_weights(f) (conj_grad_utils.c:500-548).  The other
                                         names the reference offers (Lfunc, Lfunc2..4) fail upstream in the first iteration: they hand the
                                         float64 `f - _ncc()` to float32 C code (conj_grad_utils.c:286-302 reads it blindly) */
+#define NW_FLAG_COMM_TILES      16u   /* nw_search with a communicator (nw_comm_init): which buffers go round between the phases, see there */
+#define NW_FLAG_COMM_REPLICATED 32u
+#define NW_FLAG_COMM_HALO       64u
 #define NW_FLAG_RESULT_TO_HOST 8u    /* nw_search_begin only: nw_search_end will be given a HOST pos_out -- the block's last nw_iter_update then writes the
                                         result into the pinned staging buffer itself, as nw_search arranges on its own (the write-back, mesh_conj_grad.py:288-289) */
 
@@ -188,19 +192,24 @@ int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride
  * whole-mesh all-reduce lands in a pinned buffer): src (n_rows,3) float32 HOST -> `contiguous` and / or the strided records `rows`
  * (only where valid[v] != 0 if `valid` is given), copied by the library's host threads.  No device work. */
 int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *contiguous, void *rows, int64_t row_stride_bytes, const uint8_t *valid);
-/* A block recorded by the CALLER (no reference counterpart: the reference launches nothing).  In a multi-GPU run the
- * collectives between the phases belong to the caller, so the library cannot capture such a block itself (nw_search does, for one GPU).
- * The caller puts the stream it gave to nw_set_stream into capture, then:
- *   nw_search_begin(...);  nw_block_key(&k);   -- a recording with this key? replay it; else:
- *   <begin capture>  nw_capture_begin();  { nw_iter_attract, <all-reduce>, nw_iter_directions, <all-reduce>, nw_iter_update, <all-reduce> } x the
- *   iterations to record (level 4: all but the block's LAST, which stays live);  nw_capture_end(&k);  <end capture>   -- nothing ran: the ctx's
- *   bookkeeping is rewound;  <replay>;  nw_block_replayed(iterations);  [level 4: the last iteration, live]  nw_search_end(...).
- * The key covers everything the recorded launches bake in (sizes, buffers, stream, cell grid, work list, flags, lambda, quantum, warm or cold
- * query, boundary set, where in the block the recording starts).  Levels 1 and 2 of nw_set_profiling need live events and refuse. */
-int nw_capture_begin(nw_ctx *ctx);
-int nw_capture_end(nw_ctx *ctx, uint64_t *key);
-int nw_block_key(nw_ctx *ctx, uint64_t *key);
-int nw_block_replayed(nw_ctx *ctx, int iterations);
+/* ---- multi-GPU: RCCL inside the library ------------------------------------------------------------------------------------------
+ * (No reference counterpart: the reference is one process; SURVEY.md section 8e designs the exchange.)  One process per GPU, one nw_ctx
+ * per process.  Rank 0 asks for a unique id (128 bytes) and hands it to the other ranks by whatever host channel the application has;
+ * every rank then joins with nw_comm_init(ctx, id, 128, rank, nranks) -- collective, blocking.  nranks <= 0 leaves the communicator
+ * (nw_destroy does too).  From then on nw_search with ONE of the NW_FLAG_COMM_* flags runs a block's collectives itself: ncclAllReduce
+ * on the ctx's own stream between the phases, recorded into the block's hipGraph like every kernel launch --
+ *   NW_FLAG_COMM_TILES       disjoint tiles (every rank owns its localizations AND the mesh components inside its tile): the normal-equation
+ *                            sums only (nw_n_scalars() x nw_scalar_stride() doubles): one global <=3x3 solve, conj_grad.py:202-219;
+ *   NW_FLAG_COMM_REPLICATED  mesh replicated, localizations sharded: the per-vertex accumulator (M x 4 int64) and the point-side sums;
+ *   NW_FLAG_COMM_HALO        one mesh sharded with nw_set_boundary: the accumulator's boundary rows, the sums, the owners' new boundary rows.
+ * Every rank must call nw_search with the same flags, num_iters and lams.  A status raised on one rank (NaN, ...) travels with the sums:
+ * the other ranks stop in the same iteration with NW_ERR_REMOTE.
+ * nw_comm_all_reduce: the set-up and block-boundary collectives of such a run (weight means, quanta, the whole mesh of a sharded run) on the
+ * same communicator and stream.  buf: device pointer (in place, asynchronous on the ctx's stream) or host pointer (staged, blocking);
+ * dtype 0 float32, 1 float64, 2 int64, 3 int32; op 0 sum, 1 max. */
+int nw_comm_unique_id(uint8_t *out, int64_t nbytes);
+int nw_comm_init(nw_ctx *ctx, const uint8_t *unique_id, int64_t nbytes, int rank, int nranks);
+int nw_comm_all_reduce(nw_ctx *ctx, void *buf, int64_t count, int dtype, int op);
 /* Sharded mesh ('halo' mode): owned[M] = 1 for the vertices this rank owns, 0 for the copies of vertices owned by
  * another rank.  The vertex-side normal-equation sums (S^T S, S.prefs, |prefs|^2) then run over the owned vertices only, so that the
  * all-reduce over ranks counts every vertex once.  NULL = every vertex is owned (default).  Reset by nw_set_mesh. */
@@ -212,7 +221,7 @@ int nw_set_owned(nw_ctx *ctx, const uint8_t *owned);
  * mesh.  After this call the split-phase iteration fills / takes the exchange buffers itself and the caller only all-reduces them:
  *   nw_iter_attract -> all-reduce NW_ARR_HALO_ACC (int64 sum) -> nw_iter_directions -> all-reduce NW_ARR_SCALARS -> nw_iter_update ->
  *   all-reduce NW_ARR_HALO_ROWS (f32 sum of owner-only rows); the next nw_iter_attract / nw_search_end takes the owners' positions.
- * nw_search refuses a mesh with shared vertices.  n_slots < 0 clears the sharding; nw_set_mesh clears it too. */
+ * nw_search runs such a mesh only with a communicator and NW_FLAG_COMM_HALO.  n_slots < 0 clears the sharding; nw_set_mesh clears it too. */
 int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t *b_slot, int64_t n_local, int64_t n_slots, const uint8_t *owned,
                     const int32_t *gv, int64_t n_global);
 /* the exchange buffers by hand: what = NW_ARR_VACC (-> / <- NW_ARR_HALO_ACC), NW_ARR_POS or NW_ARR_NRM (owner-only rows -> / <- NW_ARR_HALO_ROWS;

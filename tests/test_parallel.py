@@ -8,13 +8,13 @@ stage functions (test infrastructure), and the sharded result is compared with t
                        on the union scene (ONE global subspace solve, conj_grad.py:202-219).
   * mode 'halo'      : ONE mesh sharded by spatial tiles (owned vertices + halo, ghosts); all-reduce of the boundary rows of the
                        accumulator, of the scalars, and the owners' boundary positions; must equal the single-process run.
-GPU (world_size 1, nccl = RCCL): the split-phase C-ABI path must reproduce nw_search.
+GPU: the library's own RCCL communicator (nw_comm_init) with ONE rank -- all a one-GPU box can run of it -- must reproduce nw_search,
+recorded as a hipGraph or launched one by one; two gloo ranks sharing the GPU drive the split-phase C-ABI (RCCL refuses two ranks on a device).
 """
 import os
 import socket
 import numpy as np
 import pytest
-os.environ.setdefault('TORCH_NCCL_CUDA_EVENT_CACHE', '0')       # recorded blocks need torch's NCCL event cache off (parallel._recordable); read at process-group creation
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -384,11 +384,24 @@ def test_partition_by_tiles_is_a_partition():
         assert max(p.size for p in parts) - min(p.size for p in parts) <= 5000 // n // 2 + 2
 
 
+class _OneRank(object):
+    """the host channel of a one-rank run (NativeComm only asks for rank, world size and a broadcast it does not need)"""
+
+    @staticmethod
+    def get_rank():
+        return 0
+
+    @staticmethod
+    def get_world_size():
+        return 1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('mode', ['tiles', 'replicated'])
-def test_split_phase_equals_search_on_one_gpu(mode):
-    """world_size 1 over nccl (= RCCL): kernels -> all-reduce -> kernels on one stream, torch viewing library memory."""
-    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+def test_library_communicator_equals_search_on_one_gpu(mode):
+    """nw_comm_init with one rank (RCCL itself): nw_search with NW_FLAG_COMM_* runs kernels -> ncclAllReduce -> kernels on the library's own
+    stream; with one rank the sums are this rank's, so the result must be nw_search's, bit for bit."""
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad, NativeContext
     v, f = icosphere(4, 120.0)
     pts = sphere_cloud(20000, 100.0, 10.0, seed=9)
     rng = np.random.default_rng(1)
@@ -396,82 +409,94 @@ def test_split_phase_equals_search_on_one_gpu(mode):
     s = 1.0 / sigma.ravel()
     m1 = TriMesh(v, f)
     a = ShrinkwrapMeshConjGrad(m1, pts).search(pts, lams=[10.0], num_iters=5, sigma_inv=s).copy()
-    own = not dist.is_initialized()
-    if own:
-        os.environ['MASTER_ADDR'] = '127.0.0.1'
-        os.environ['MASTER_PORT'] = str(_free_port())
-        torch.cuda.set_device(0)
-        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    m2 = TriMesh(v, f)
+    native = NativeContext(0)
+    comm = parallel.NativeComm(native, _OneRank)
     try:
-        m2 = TriMesh(v, f)
-        ts = torch.cuda.Stream()
-        assert ts.cuda_stream != 0
-        cg = ShrinkwrapMeshConjGrad(m2, pts, stream=ts.cuda_stream)
-        scene = parallel.TiledScene(cg, dist, mode=mode, torch_stream=ts)
+        cg = ShrinkwrapMeshConjGrad(m2, pts, native=native)
+        scene = parallel.TiledScene(cg, mode=mode, comm=comm)
         b = scene.search(pts, [10.0], 5, s).copy()
         c = scene.search(pts, [10.0], 3, s).copy()          # second call continues from the mesh
+        # the set-up collectives of a run: host and device buffers through the same communicator
+        h = comm.all_reduce_host(np.array([1.5, -2.0], np.float64))
+        assert np.array_equal(h, [1.5, -2.0])
+        assert np.array_equal(comm.all_reduce_host(np.arange(5, dtype=np.int64), parallel.NativeComm.MAX), np.arange(5))
     finally:
-        if own:
-            dist.destroy_process_group()
-    assert rel_rms(b, a) <= 1e-6
+        comm.close()
+    assert np.array_equal(b, a)
     assert cg.loopcount == 3 and len(cg.tests) == 8
     assert np.array_equal(m2.vertices, c)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode,level', [('tiles', 0), ('tiles', 4), ('replicated', 0), ('halo', 0), ('halo', 4)])
-def test_blocks_recorded_with_their_collectives_equal_launch_by_launch(mode, level, monkeypatch):
-    """nw_capture_begin .. nw_block_replayed (include/nanowrap.h): from an executor's second block on, run_search records a block -- the
-    phases' launches AND the RCCL all-reduces between them -- as one hipGraph and replays it.  World size 1 over nccl is what a one-GPU
-    box can run (the collectives go through the NCCL process group's stream fork and join inside the capture; with one rank RCCL itself
-    enqueues no kernel for them).  Six blocks of 5 (the cell-size tuner changes the grid at
-    the third: a new key, a new recording), with the normals refreshed between blocks in 'halo' mode: bit-identical to the same blocks
-    issued launch by launch (NW_GRAPH_COLLECTIVES=0); profiling level 4 keeps each block's first iteration live."""
-    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad
+@pytest.mark.parametrize('mode', ['tiles', 'replicated', 'halo'])
+def test_blocks_recorded_with_their_collectives_equal_launch_by_launch(mode):
+    """A block of nw_search with a communicator is recorded -- the phases' launches AND the ncclAllReduce calls between them -- as one
+    hipGraph of the library's own stream and replayed for later blocks (profiling level 0; level 4 keeps the block's last iteration
+    live); with per-launch profiling (level 2) the same block is issued launch by launch.  Six blocks of 5 (the cell-size tuner changes
+    the grid at the third: a new recording), the normals refreshed between blocks in 'halo' mode: bit-identical in all three forms.
+    One rank: what a one-GPU box can run of it (RCCL enqueues no kernel for a one-rank all-reduce -- this exercises the capture and
+    the host side, not RCCL's kernels as graph nodes)."""
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad, NativeContext
     v, f = icosphere(4, 120.0)
     pts = sphere_cloud(20000, 100.0, 10.0, seed=9)
     s = 1.0 / np.random.default_rng(1).uniform(5.0, 15.0, size=pts.shape).astype('f4').ravel()
-    own = not dist.is_initialized()
-    assert os.environ.get('TORCH_NCCL_CUDA_EVENT_CACHE') == '0'
-    if own:
-        os.environ['MASTER_ADDR'] = '127.0.0.1'
-        os.environ['MASTER_PORT'] = str(_free_port())
-        torch.cuda.set_device(0)
-        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
 
-    def fit(graphs):
-        monkeypatch.setenv('NW_GRAPH_COLLECTIVES', '1' if graphs else '0')
+    def fit(level):
         mesh = TriMesh(v, f)
-        ts = torch.cuda.Stream()
+        native = NativeContext(0)
+        comm = parallel.NativeComm(native, _OneRank)
         outs = []
-        if mode == 'halo':
-            scene = parallel.HaloScene(mesh, pts, dist, halo=200.0, torch_stream=ts)
-            scene.set_profiling(level)
-            for b in range(6):
-                outs.append(scene.search([10.0], 5, s).copy())
-                scene.refresh_normals()
-            ex = scene.ex
-            assert scene.repartitions == 1
-        else:
-            cg = ShrinkwrapMeshConjGrad(mesh, pts, stream=ts.cuda_stream)
-            cg.set_profiling(level)
-            scene = parallel.TiledScene(cg, dist, mode=mode, torch_stream=ts)
-            for b in range(6):
-                outs.append(scene.search(pts, [10.0], 5, s).copy())
-            ex = scene.ex
-            assert len(cg.tests) == 30
-        return outs, ex.blocks_replayed, len(ex.graphs)
+        try:
+            if mode == 'halo':
+                scene = parallel.HaloScene(mesh, pts, None, halo=200.0, native=native, comm=comm)
+                scene.set_profiling(level)
+                for b in range(6):
+                    outs.append(scene.search([10.0], 5, s).copy())
+                    scene.refresh_normals()
+                assert scene.repartitions == 1
+            else:
+                cg = ShrinkwrapMeshConjGrad(mesh, pts, native=native)
+                cg.set_profiling(level)
+                scene = parallel.TiledScene(cg, mode=mode, comm=comm)
+                for b in range(6):
+                    outs.append(scene.search(pts, [10.0], 5, s).copy())
+                assert len(cg.tests) == 30
+        finally:
+            comm.close()
+        return outs
 
-    try:
-        a, replayed, recordings = fit(True)
-        b, none, _ = fit(False)
-    finally:
-        if own:
-            dist.destroy_process_group()
-    assert replayed == 5 and none == 0 and recordings >= 2          # every block but the executor's first; at least the pre- and post-tuner recordings
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    a, b, c = fit(0), fit(2), fit(4)
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
     assert not np.array_equal(a[-1], a[-2])
+
+
+@pytest.mark.gpu
+def test_a_status_raised_on_one_rank_travels_with_the_sums():
+    """A NaN localization raises NW_ERR_NAN inside an iteration; the status slot of the normal-equation sums carries it (summed over the
+    ranks it reaches every one of them: they stop in the same iteration instead of solving with another rank's stale sums).  One rank:
+    the slot is set, the block stops where it would on one GPU, the estimate stays at the last good iterate."""
+    from ch_shrinkwrap_amd.mesh_conj_grad import ShrinkwrapMeshConjGrad, NativeContext
+    v, f = icosphere(3, 120.0)
+    pts = sphere_cloud(5000, 100.0, 10.0, seed=3)
+    mesh = TriMesh(v, f)
+    native = NativeContext(0)
+    comm = parallel.NativeComm(native, _OneRank)
+    try:
+        cg = ShrinkwrapMeshConjGrad(mesh, pts, native=native)
+        scene = parallel.TiledScene(cg, mode='tiles', comm=comm)
+        ok = np.full(pts.size, 0.1, np.float32)
+        good = scene.search(pts, [10.0], 2, ok).copy()
+        bad = ok.copy()
+        bad[3 * 1234 + 1] = np.nan                           # the localizations are fine, so the upload passes: the NaN shows up inside the iteration
+        with pytest.raises(AssertionError):
+            scene.search(pts, [10.0], 3, bad)
+        assert np.array_equal(np.asarray(mesh._vertices['position']), good)
+        again = scene.search(pts, [10.0], 1, ok)             # the context stays usable
+        assert np.isfinite(again).all() and not np.array_equal(again, good)
+    finally:
+        comm.close()
 
 
 # ---- the HIP executor at world_size 2 (two fresh processes sharing cuda:0, gloo carrying the device tensors) -------------------
