@@ -116,7 +116,7 @@ def parse_args(argv=None):
     ap.add_argument('--config', default='c3')
     ap.add_argument('--mode', default='tiles', choices=('tiles', 'halo'),
                     help='N > 1: tiles = one vesicle per rank (BASELINE configs[4], weak scaling); halo = ONE mesh sharded over the ranks (strong scaling)')
-    ap.add_argument('--halo', type=float, default=100.0, help='halo radius of --mode halo in nm (start offset 20 + 5 sigma + a quarter for the drift between re-partitions)')
+    ap.add_argument('--halo', type=float, default=60.0, help='--mode halo: margin (nm) of the first shares -- every rank holds the faces within (nearest distance + margin) of each of its localizations; budget for the growth of a nearest distance + the drift of the mesh until new shares are cut (bench.py cuts them again, with three times the last block\'s movement, after its warm-up)')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the workload (debug only; the reported config says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph-pass', action='store_true', help='skip the extra un-instrumented (graph-replay) pass (profiling runs)')
@@ -308,10 +308,18 @@ def run_rank(args):
     # The full per-stage breakdown is taken in a short extra pass AFTER the timed region.
     set_profiling(4)
     if args.warmup > 0:
-        cg_of().optimize_layout()
+        if halo:
+            scene.optimize_layout()         # (also: new shares with the margin the fit needs from here on, see HaloScene.optimize_layout)
+        else:
+            cg_of().optimize_layout()
         # ... and one more untimed block after it: the set-up leaves the GPU idle for tens of milliseconds of host work (clocks drop)
         # and re-sorts the localizations (the first block afterwards runs ~25 % slower than the following ones)
         run_steps(min(args.warmup, BLOCK))
+        if halo:
+            # new shares mean a new sub-mesh on the device: the block above was its first (a cold query), and the library's own set-up
+            # (cell tuner, work-list order) needs a warm one -- once more, and one more untimed block behind it
+            scene.optimize_layout()
+            run_steps(min(args.warmup, BLOCK))
         set_profiling(4)                    # (drops that block's sample of the query kernel: only the timed region's are reported)
     fence()
     warmup_executed = executed[0]
@@ -450,7 +458,9 @@ def run_rank(args):
                                       'share_of_device_time': (comm_ms / n_extra) / max(stage['total'][0] / n_extra + comm_ms / n_extra, 1e-12),
                                       'note': 'rank 0, event-bracketed all-reduces of %d extra iterations after the timed region' % n_extra}
             if halo:
-                out['halo'] = {'radius_nm': args.halo, 'boundary_vertices': scene.ex.n_boundary, 'repartitions_in_timed_region': reparts,
+                out['halo'] = {'radius_nm': args.halo, 'per_localization_halos': bool(scene.per_point), 'margin_nm': float(getattr(scene, '_cut_margin', args.halo)),
+                               'exchange_bytes_per_iteration': int(scene.ex.n_boundary) * (32 + 12) + 28 * 32 * 8,
+                               'boundary_vertices': scene.ex.n_boundary, 'repartitions_in_timed_region': reparts,
                                'max_nn_distance_nm': scene.max_dist, 'drift_since_partition_nm': scene.drift,
                                'host_ms_per_block': host_ms,
                                'vertices_held_over_owned': float(Ml) * world / max(M, 1)}

@@ -86,7 +86,7 @@ def load():
     L.nw_comm_unique_id.argtypes = [vp, i64]
     L.nw_comm_init.argtypes = [vp, vp, i64, i32, i32]
     L.nw_comm_all_reduce.argtypes = [vp, vp, i64, i32, i32]
-    L.nw_halo_set_reference.argtypes = [vp, vp]
+    L.nw_halo_set_reference.argtypes = [vp, vp, vp, i64]
     L.nw_halo_block_stats.argtypes = [vp, ctypes.c_double]
     L.nw_set_data.argtypes = [vp, vp]
     L.nw_device_ptr.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i64)]

@@ -234,6 +234,9 @@ struct nw_ctx {
     DevBuf<float> halo_rows;          // (n_boundary, 3) position / normal rows (owner-only non-zero)
     DevBuf<float> halo_full;          // (M_global, 3) owners' rows of the whole mesh (one all-reduce per block)
     DevBuf<float> halo_ref;           // (M_global, 3) the whole mesh when the shares were cut (nw_halo_set_reference)
+    DevBuf<float> halo_d0;            // (N,) caller order: this rank's nearest distances when the shares were cut (per-localization halos), or unused
+    bool have_halo_d0 = false;
+    int64_t halo_d0_n = 0;
     DevBuf<float> halo_stats;         // {largest nearest distance, quantum, max drift^2, 0}: one MAX all-reduce per block
     bool have_halo_ref = false;
     int64_t hb_n = 0, hb_nslot = 0, M_global = 0;
@@ -777,6 +780,7 @@ NW_EXPORT int nw_set_points(nw_ctx *ctx, const float *xyz, int64_t n_points, con
     ctx->item_level = -1;
     ctx->nitems = 0;
     ctx->face_warm = false;
+    if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 2) fprintf(stderr, "[nanowrap] warm start dropped (%s)\n", __func__);
     ctx->proj_ready = false; ctx->proj_sorted = false;
     ctx->tuned = false; ctx->cell_tune = 1.0; ctx->blocks_done = 0;
     ctx->last_mean_dist = -1.0;
@@ -912,6 +916,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     else NW_TRY(nw_refresh_normals(ctx, nullptr));         // area-weighted vertex normals from positions + faces on the device
     if (topo_change) { ctx->grid_valid = false; }
     ctx->face_warm = false;                               // face ids of another topology are no starting guess
+    if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 2) fprintf(stderr, "[nanowrap] warm start dropped (%s)\n", __func__);
     ctx->have_owned = false;
     ctx->have_boundary = false; ctx->pos_unpack_pending = false;      // (a sharding belongs to the mesh it was made for)
     // a new mesh object = a new optimiser in the reference (_membrane_mesh.pyx:1510): history restarts
@@ -987,7 +992,7 @@ NW_EXPORT int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t
     NW_HIP(ctx->halo_full.ensure((size_t)3 * n_global));
     NW_HIP(ctx->halo_ref.ensure((size_t)3 * n_global));
     NW_HIP(ctx->halo_stats.ensure(4));
-    ctx->have_halo_ref = false;
+    ctx->have_halo_ref = false; ctx->have_halo_d0 = false;
     NW_HIP(hipMemsetAsync(ctx->halo_acc.p, 0, (size_t)4 * std::max<int64_t>(n_slots, 1) * sizeof(long long), ctx->stream));
     NW_HIP(hipMemsetAsync(ctx->halo_rows.p, 0, (size_t)3 * std::max<int64_t>(n_slots, 1) * sizeof(float), ctx->stream));
     ctx->hb_n = n_local; ctx->hb_nslot = n_slots; ctx->M_global = n_global;
@@ -1038,10 +1043,17 @@ NW_EXPORT int nw_halo_unpack(nw_ctx *ctx, int what)
 }
 
 // where the WHOLE mesh was when the shares were cut ((M_global,3) float32, host or device): the drift budget of the halo is measured from it
-NW_EXPORT int nw_halo_set_reference(nw_ctx *ctx, const float *full)
+NW_EXPORT int nw_halo_set_reference(nw_ctx *ctx, const float *full, const float *d0, int64_t n_d0)
 {
     if (!ctx || !ctx->have_boundary || !full) return fail(ctx, NW_ERR_BADARG, "nw_halo_set_reference: no boundary set (nw_set_boundary)");
     NW_HIP(hipMemcpyAsync(ctx->halo_ref.p, full, (size_t)3 * ctx->M_global * sizeof(float), hipMemcpyDefault, ctx->stream));
+    ctx->have_halo_d0 = false; ctx->halo_d0_n = 0;
+    if (d0) {
+        if (n_d0 < 1) return fail(ctx, NW_ERR_BADARG, "nw_halo_set_reference: d0 needs its length (the rank's localizations)");
+        NW_HIP(ctx->halo_d0.ensure((size_t)n_d0));
+        NW_HIP(hipMemcpyAsync(ctx->halo_d0.p, d0, (size_t)n_d0 * sizeof(float), hipMemcpyDefault, ctx->stream));
+        ctx->have_halo_d0 = true; ctx->halo_d0_n = n_d0;      // (the localizations may be uploaded later: nw_search_begin checks the length)
+    }
     NW_HIP(hipStreamSynchronize(ctx->stream));
     ctx->have_halo_ref = true;
     return NW_OK;
@@ -1347,6 +1359,8 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     if (!lams || n_lams < 1 || num_iters < 0) return fail(ctx, NW_ERR_BADARG, "nw_search: need at least one lambda and num_iters >= 0");
     if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_search_begin: previous search not ended");
     NW_HIP(hipSetDevice(ctx->device));
+    if (ctx->have_boundary && ctx->have_halo_d0 && ctx->halo_d0_n != ctx->N)
+        return fail(ctx, NW_ERR_BADARG, "nw_search: the distances given to nw_halo_set_reference are not this rank's localizations' (length)");
     NW_TRY(alloc_work(ctx));
     if (ctx->proj_ready && !ctx->proj_sorted && num_iters > 0 && !getenv("NW_NO_PROJ_SORT")) NW_TRY(resort_by_projection(ctx));
     NW_TRY(ensure_grid(ctx));
@@ -1384,6 +1398,7 @@ static NwAttractArgs attract_args(const nw_ctx *ctx)
     a.sinv = ctx->sinv_array ? ctx->sinv.p : nullptr; a.wnorm = ctx->w_array ? ctx->wnorm.p : nullptr; a.dat = ctx->have_data ? ctx->dat.p : nullptr;
     a.mask = ctx->mask.p; a.dist = ctx->dist.p; a.wout = ctx->w.p; a.res = ctx->res.p; a.vidx = ctx->vidx.p; a.vacc = ctx->vacc.p; a.part = ctx->part_a.p;
     a.inv_q = 1.0 / ctx->acc_quantum; a.inv_qw = 1.0 / ctx->w_quantum;
+    a.d0 = (ctx->have_boundary && ctx->have_halo_d0) ? ctx->halo_d0.p : nullptr; a.perm = ctx->perm.p;
     return a;
 }
 
@@ -1637,7 +1652,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
                           ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p,
                           ctx->hb_local.p, ctx->hb_slot.p, ctx->hb_slot2local.p, ctx->halo_acc.p, ctx->halo_rows.p, ctx->face_sorted ? ctx->face_orig.p : nullptr};
     mix((uint64_t)ctx->hb_n); mix((uint64_t)ctx->hb_nslot); mix((uint64_t)(uintptr_t)ctx->stream);
-    mix((uint64_t)(uintptr_t)ctx->comm); mix((uint64_t)ctx->comm_mode);
+    mix((uint64_t)(uintptr_t)ctx->comm); mix((uint64_t)ctx->comm_mode); mixp((ctx->have_boundary && ctx->have_halo_d0) ? ctx->halo_d0.p : nullptr);
     for (const void *p : ptrs) mixp(p);
     return h;
 }

@@ -46,6 +46,8 @@ struct NwAttractArgs {
     long long *vacc;
     double *part;                                // rows of 5: sum res^2, masked sum res^2, sum d, count, max d
     double inv_q, inv_qw;
+    const float *d0;                             // sharded mesh with per-localization halos (nw_halo_set_reference): the nearest distances when the shares
+    const int *perm;                             // were cut, caller order (perm: sorted slot -> caller index); the "max d" column then holds max (d - d0)
 };
 
 // One localization i (position P, nearest face f in [0, F)): stores its row of the weight matrix, residual and distance, adds its
@@ -104,7 +106,7 @@ __device__ __forceinline__ void nw_attract_point(const NwAttractArgs &A, int i, 
     }
     red[2] += (double)d;
     red[3] += 1.0;
-    dmax = fmaxf(dmax, d);
+    dmax = fmaxf(dmax, A.d0 ? d - A.d0[A.perm[i]] : d);
     __builtin_memcpy(A.res + 3 * (int64_t)i, r, 12);           // three 12-byte stores instead of nine dword stores
     __builtin_memcpy(A.vidx + 3 * (int64_t)i, v, 12);
     __builtin_memcpy(A.wout + 3 * (int64_t)i, w, 12);

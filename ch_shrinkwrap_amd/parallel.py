@@ -175,10 +175,14 @@ class HipExecutor(object):
         self.native.check(self.L.nw_halo_gather_owned(self.h, nw.NW_ARR_POS if what == 'pos' else nw.NW_ARR_NRM))
         return self._view(nw.NW_ARR_HALO_FULL, 3 * self.n_global, '<f4')
 
-    def set_reference(self, full_positions):
-        """(M_global,3) float32: where the whole mesh was when the shares were cut (the drift of the halo is measured from it)"""
+    supports_reach = True
+
+    def set_reference(self, full_positions, d0=None):
+        """(M_global,3) float32: where the whole mesh was when the shares were cut (the drift of the halo is measured from it); d0 (N,):
+        this rank's nearest distances then (shares cut with per-localization halos: max_dist becomes the largest growth of one)"""
         a = np.ascontiguousarray(full_positions, np.float32)
-        self.native.check(self.L.nw_halo_set_reference(self.h, nw.ptr(a)))
+        d = None if d0 is None else np.ascontiguousarray(d0, np.float32)
+        self.native.check(self.L.nw_halo_set_reference(self.h, nw.ptr(a), nw.ptr(d), 0 if d is None else d.size))
 
     def block_stats(self, max_dist):
         """(4,) float32 on the device: {largest nearest distance, this rank's quantum, max drift^2 of gather_owned()'s (all-reduced)
@@ -454,6 +458,48 @@ def bisect_tiles(points, n_ranks):
     return parts, classify
 
 
+def faces_within_reach(cent, pts, reach, classes=16, voxel=None):
+    """Mask of the centroids `cent` (F,3) that lie within reach_i of at least one point pts[i] -- a superset, never less: the points are
+    put into classes of similar reach (geometric steps) and, per class, into voxels of a quarter of the class's reach; a centroid is taken
+    when it is within (the class's largest reach + half a voxel diagonal) of an occupied voxel's centre.  One k-d tree over the
+    occupied voxels' centres and one bounded nearest-neighbour query of the candidate centroids per class.  `voxel`: upper limit of the
+    voxel edge (the slack it adds -- 0.87 voxel edges -- widens the halo of every localization of the class)."""
+    from scipy.spatial import cKDTree
+    F = cent.shape[0]
+    out = np.zeros(F, bool)
+    if pts.shape[0] == 0 or F == 0:
+        return out
+    reach = np.maximum(np.asarray(reach, np.float64), 1e-30)
+    pts = np.asarray(pts, np.float64)
+    rmax = float(reach.max())
+    lo, hi = pts.min(0) - rmax, pts.max(0) + rmax
+    cand = np.nonzero(((cent >= lo) & (cent <= hi)).all(1))[0]          # nothing outside the tile's box + largest reach can qualify
+    if cand.size == 0:
+        return out
+    c = np.asarray(cent[cand], np.float64)
+    rmin = float(reach.min())
+    edges = rmin * (rmax / rmin) ** (np.arange(1, classes + 1) / float(classes)) if rmax > rmin else np.array([rmax])
+    edges[-1] = rmax
+    cls = np.minimum(np.searchsorted(edges, reach, side='left'), edges.size - 1)
+    todo = np.ones(cand.size, bool)
+    for k in range(edges.size - 1, -1, -1):                              # widest class first: it settles most candidates
+        sel = cls == k
+        if not sel.any() or not todo.any():
+            continue
+        g = max(float(edges[k]) / 4.0, 1e-30)
+        if voxel is not None and voxel > 0:
+            g = min(g, float(voxel))
+        vox = np.unique(np.floor(pts[sel] / g).astype(np.int64), axis=0)
+        centres = (vox + 0.5) * g
+        bound = float(edges[k]) + 0.5 * g * np.sqrt(3.0) * (1.0 + 1e-9) + 1e-9 * (abs(float(edges[k])) + float(np.abs(c).max()))
+        idx = np.nonzero(todo)[0]
+        d, _ = cKDTree(centres).query(c[idx], k=1, distance_upper_bound=bound, workers=-1)
+        hit = np.isfinite(d)
+        todo[idx[hit]] = False
+    out[cand[~todo]] = True
+    return out
+
+
 class HaloPartition(object):
     """Host-side decomposition of ONE mesh for the 'halo' mode, computed identically on every rank (no communication).
 
@@ -463,11 +509,17 @@ class HaloPartition(object):
     iteration; W_r = further 1-ring neighbours of V_r, ghosts that only carry positions / normals for the curvature prior.
     A vertex is owned by the tile that contains it.  Boundary vertices = present (in V or W) on more than one rank."""
 
-    def __init__(self, pos, nrm, nbr, faces, points, n_ranks, halo, tiles=None, detail_ranks=None, membership_ranks=None):
+    def __init__(self, pos, nrm, nbr, faces, points, n_ranks, halo, tiles=None, detail_ranks=None, membership_ranks=None, reach=None, reach_voxel=None):
         """detail_ranks: the ranks whose share is worked out in full (index maps, local faces, local ring table); None = all.
         membership_ranks: the ranks whose MEMBERSHIP (which vertices they hold) is computed here; None = all.  Who else holds a vertex
         decides the boundary list, which all ranks must agree on: a process that computes only its own membership leaves `count`
-        partial and must call set_count() with the sum over the ranks (one all-reduce of M int32) before using `boundary`."""
+        partial and must call set_count() with the sum over the ranks (one all-reduce of M int32) before using `boundary`.
+
+        reach: {rank: (n_r,) array} -- PER-LOCALIZATION radii for the ranks whose membership is computed here (in the order of
+        parts[rank]): the rank then holds the faces whose centroid lies within reach_i of its localization i (faces_within_reach),
+        instead of everything within `halo` of its tile's bounding box.  With reach_i = (nearest distance of i now) + margin the local
+        query stays the global one while no nearest distance has grown, and no centroid has moved, by more than the margin together --
+        a halo that pays for the mesh's movement, not for the height of the few localizations far above the surface."""
         pos = np.asarray(pos, np.float32)
         faces = np.asarray(faces, np.int32)
         nbr = np.asarray(nbr, np.int32)
@@ -492,7 +544,9 @@ class HaloPartition(object):
             else:
                 p = points[self.parts[r]]
                 box = (p.min(0), p.max(0)) if p.shape[0] else None
-            if box is not None:
+            if reach is not None and r in reach:
+                fmask = faces_within_reach(cent, points[self.parts[r]], np.asarray(reach[r], np.float64), voxel=reach_voxel)
+            elif box is not None:
                 lo, hi = box[0] - self.halo, box[1] + self.halo
                 fmask = ((cent >= lo) & (cent <= hi)).all(1)
             else:
@@ -593,8 +647,17 @@ class HaloScene(object):
     make_executor(local_mesh, local_points) -> executor (HipExecutor over a ShrinkwrapMeshConjGrad in production; the CPU tests pass
     an oracle-backed one)."""
 
-    def __init__(self, mesh, points, dist, halo, make_executor=None, native=None, torch_stream=None, comm=None):
+    def __init__(self, mesh, points, dist, halo, make_executor=None, native=None, torch_stream=None, comm=None, per_point=None, min_margin=None):
         self.mesh, self.points, self.dist, self.halo = mesh, np.ascontiguousarray(points, np.float32), dist, float(halo)
+        # per_point: shares cut with PER-LOCALIZATION halos -- a rank holds every face within (nearest distance now + margin) of each of
+        # its localizations instead of everything within `halo` of its tile's bounding box: the halo then pays for the mesh's movement
+        # (the margin: at most `halo`, shrunk to a few times the last block's movement as the fit converges, never below min_margin),
+        # not for the height of the few localizations far above the surface.  Default: on for the HIP executor.
+        self.per_point = (make_executor is None) if per_point is None else bool(per_point)
+        self.margin = float(halo)
+        self.min_margin = float(min_margin) if min_margin is not None else 0.05 * float(halo)
+        self._blocks_total = 0
+        self._last_shrink = -10 ** 9
         self.comm = comm                  # NativeComm over `native`: every collective of the run goes through the library's communicator
         if comm is not None and native is None:
             raise ValueError('HaloScene(comm=...) needs the NativeContext the communicator was created on (native=...)')
@@ -659,8 +722,25 @@ class HaloScene(object):
         nrm = np.ascontiguousarray(mesh.vertex_normals, np.float32)
         t1 = time.perf_counter()
         # every rank works out its OWN share only; who else holds a vertex (the boundary list) comes from one all-reduce of the counts
+        reach, d0 = None, None
+        if self.per_point:
+            from scipy.spatial import cKDTree
+            f = np.asarray(mesh.faces)
+            cent = ((pos[f[:, 0]] + pos[f[:, 1]]) + pos[f[:, 2]]) / np.float32(3.0)
+            d0 = None
+            cg_old = getattr(self.ex, 'cg', None) if self.ex is not None else None
+            if cg_old is not None and getattr(cg_old, 'loopcount', 0) > 0 and cg_old._points_f32.shape[0] == self._local_points.shape[0]:
+                # the distances of the last query on the device (one update old: ANY reference radius is valid -- the growth is measured
+                # against the same numbers the halos were cut with)
+                try:
+                    d0 = np.ascontiguousarray(cg_old.d[:, 0], np.float32)
+                except Exception:
+                    d0 = None
+            if d0 is None:
+                d0 = cKDTree(cent).query(self._local_points, workers=-1)[0].astype(np.float32)      # this rank's nearest distances now
+            reach = {self.rank: d0.astype(np.float64) * (1.0 + 1e-6) + self.margin}
         part = HaloPartition(pos, nrm, nbr, mesh.faces, self.points, self.world, self.halo, tiles=self._tiles, detail_ranks=(self.rank,),
-                             membership_ranks=(self.rank,))
+                             membership_ranks=(self.rank,), reach=reach, reach_voxel=0.5 * self.margin)
         if self.comm is not None:
             part.set_count(self.comm.all_reduce_host(np.ascontiguousarray(part.count, np.int64)).astype(part.count.dtype))
         else:
@@ -686,7 +766,11 @@ class HaloScene(object):
         self.ex.set_boundary(d['b_local'], d['b_slot'], part.boundary.size, d['owned'], gv, part.M)
         self._pos0 = pos.copy()                       # where the mesh was when the shares were cut (drift budget of the halo)
         if hasattr(self.ex, 'set_reference'):
-            self.ex.set_reference(self._pos0)
+            if self.per_point:
+                self.ex.set_reference(self._pos0, d0)
+            else:
+                self.ex.set_reference(self._pos0)
+        self._cut_margin = self.margin
         self._blocks_since_partition = 0
         self._pos0_t = None
         self._valid = mesh._vertices['halfedge'] != -1
@@ -775,9 +859,11 @@ class HaloScene(object):
         t1 = time.perf_counter()
         self._quantum = q if q > 0 else None
         drift = float(np.sqrt(max(d2, 0.0)))
-        if worst + drift > self.halo:
-            raise RuntimeError("halo mode: a localization is %.3g from its nearest face centroid and the mesh has moved %.3g since the shares were cut, "
-                               "beyond the halo radius %.3g: the sharded query is not guaranteed exact (increase `halo`)" % (worst, drift, self.halo))
+        budget = self._cut_margin if self.per_point else self.halo
+        if worst + drift > budget:
+            raise RuntimeError("halo mode: %s %.3g and the mesh has moved %.3g since the shares were cut, beyond the %s %.3g: the sharded query "
+                               "is not guaranteed exact (increase `halo`)" % ("a nearest distance has grown by" if self.per_point else "a localization's nearest face centroid is at",
+                                                                               worst, drift, "margin" if self.per_point else "halo radius", budget))
         posv = mesh._vertices['position']
         out = np.empty((newpos.shape[0], 3), np.float32)
         if hasattr(ex, 'host_copy_rows') and posv.dtype == np.float32 and posv.strides[1] == 4 and posv.strides[0] >= 12:
@@ -795,12 +881,43 @@ class HaloScene(object):
         self._last_step = step
         self._blocks_since_partition += 1
         self.max_dist, self.drift = worst, drift
-        if worst + drift + 1.5 * step > self.halo:    # (a fit slows down as it converges: C3 moves 26, 14, 9, 3, 2 ... nm per block of 5)
+        self._blocks_total += 1
+        if worst + drift + 1.5 * step > budget:       # (a fit slows down as it converges: C3 moves 26, 14, 9, 3, 2 ... nm per block of 5)
             self.last_partition = None                # cut new shares around the moved mesh before the next block
+            if self.per_point:                        # ... with a margin for what the next blocks will need (never more than `halo`)
+                self.margin = self._wanted_margin()
+        elif self.per_point and self._blocks_total >= 20 and self._blocks_since_partition >= 2 and self._blocks_total - self._last_shrink >= 10:
+            # the fit has slowed down: shares cut with a smaller margin hold fewer vertices (a cut costs ~0.1-0.2 s of host time: not often)
+            want = self._wanted_margin()
+            if want < 0.5 * self._cut_margin:
+                self.margin = want
+                self._last_shrink = self._blocks_total
+                self.last_partition = None
         t2 = time.perf_counter()
         self.host_ms['block_tail_collectives_and_copy'] = (t1 - t0) * 1e3
         self.host_ms['block_tail_host_mesh'] = (t2 - t1) * 1e3
         return out
+
+    def _wanted_margin(self):
+        """margin for shares cut now: a fit's movement roughly halves from block to block, so everything still to come is about one more
+        step of the last block's size; five of them leave room for the nearest distances that grow meanwhile and for the re-cut rule
+        (growth + drift + 1.5 steps must stay within the margin THROUGH the next block).  Three were measured too few: new shares after
+        every block of the fit's first twenty iterations, each followed by a cold query."""
+        return min(self.halo, max(self.min_margin, 5.0 * self._last_step))
+
+    def optimize_layout(self):
+        """One-off set-up a caller can take out of a timed region (bench.py, after its warm-up): shares cut NOW with the margin the fit
+        needs from here on (the first shares were cut with the whole `halo`, for a mesh that still moves by tens of nm per block), then the
+        library's own set-up (projection sort, cell tuner, work list)."""
+        if (self.per_point and self._blocks_total > 0 and not getattr(self, '_layout_cut', False)
+                and self._wanted_margin() < 0.8 * getattr(self, '_cut_margin', self.halo)):
+            self.margin = self._wanted_margin()
+            self.last_partition = None
+            self._layout_cut = True                 # (once: a second call -- after the new shares' first, cold, block -- is for the library's own set-up)
+        if self.last_partition is None:
+            self._setup()
+        if hasattr(self.ex, 'cg'):
+            self.ex.cg.optimize_layout()
 
     def refresh_normals(self, to_host=True):
         """vertex normals of the next block from the current positions, topology unchanged; restarts the optimiser's history (the

@@ -233,11 +233,15 @@ int nw_halo_unpack(nw_ctx *ctx, int what);
  * all-reduce(sum) per BLOCK gives every rank the whole mesh (the positions search() returns, mesh_conj_grad.py:288-292) */
 int nw_halo_gather_owned(nw_ctx *ctx, int what);
 /* end of a block of a sharded mesh (no reference counterpart): nw_halo_set_reference = where the WHOLE mesh was when the shares were cut
- * ((M_global,3) float32, host or device); nw_halo_block_stats fills NW_ARR_HALO_STATS from NW_ARR_HALO_FULL (after its all-reduce), that
+ * ((M_global,3) float32, host or device) and, optionally, d0 (n_d0 = N,) = this rank's nearest distances at that moment, caller order -- shares
+ * cut with PER-LOCALIZATION halos (every face within d0_i + margin of localization i is held): the logs' max_dist of such a rank is then the
+ * largest GROWTH of a nearest distance, max (d_i - d0_i), and the sharded query is exact while that growth + the mesh's drift stay within
+ * the margin (d0 = NULL: one halo radius for all, max_dist = the largest nearest distance).  nw_set_boundary / nw_set_mesh drop both.
+ * nw_halo_block_stats fills NW_ARR_HALO_STATS from NW_ARR_HALO_FULL (after its all-reduce), that
  * reference, the block's largest nearest distance (the caller has it from the iteration logs) and this rank's accumulator quantum -- the
  * three numbers the ranks agree on with ONE all-reduce(MAX) per block: is the sharded query still exact, how far has the mesh drifted,
  * which quantum do the integer accumulators of the next block share. */
-int nw_halo_set_reference(nw_ctx *ctx, const float *full);
+int nw_halo_set_reference(nw_ctx *ctx, const float *full, const float *d0, int64_t n_d0);
 int nw_halo_block_stats(nw_ctx *ctx, double max_dist);
 /* extent (largest bounding-box edge) of the WHOLE mesh, for a rank that holds a share of it: nw_refresh_normals takes the quantum of its
  * fixed-point normal sums from it instead of from the share's own box, so every holder of a vertex rounds its sum the same way and the

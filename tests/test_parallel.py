@@ -353,6 +353,88 @@ def test_halo_partition_invariants():
         assert np.array_equal(np.nonzero(held > 1)[0], part.boundary)
 
 
+def test_faces_within_reach_is_a_superset_of_the_exact_set():
+    """Per-localization halos: every centroid within reach_i of localization i must be taken (the classes and voxels may add some,
+    never lose one) -- radii spanning two orders of magnitude, points far outside the centroids' box, a single point, no point."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(11)
+    cent = rng.normal(0.0, 40.0, size=(20000, 3)).astype('f4')
+    tree = cKDTree(cent.astype('f8'))
+    for n, scale in ((3000, 1.0), (1, 1.0), (500, 30.0)):
+        pts = (rng.normal(0.0, 45.0, size=(n, 3)) * np.array([1.0, 1.0, scale])).astype('f4')
+        reach = np.exp(rng.uniform(np.log(0.3), np.log(40.0), size=n))
+        for voxel in (None, 0.5):
+            mask = parallel.faces_within_reach(cent, pts, reach, voxel=voxel)
+            exact = np.zeros(cent.shape[0], bool)
+            for lst in tree.query_ball_point(pts.astype('f8'), reach):
+                exact[lst] = True
+            assert not (exact & ~mask).any()
+            if voxel is not None and n == 3000:
+                assert mask.sum() <= 1.6 * exact.sum() + 50           # ... and not wastefully more
+    assert not parallel.faces_within_reach(cent, np.zeros((0, 3), 'f4'), np.zeros(0)).any()
+
+
+def test_per_localization_halos_hold_what_the_query_needs_and_far_fewer_vertices():
+    """Shares cut with reach_i = nearest distance + margin: (1) every face whose centroid lies within reach_i of a rank's localization is
+    among the rank's faces -- the local nearest-face query is the global one while growth + drift stay within the margin; (2) the
+    partition invariants hold; (3) the shares are much smaller than with one radius for all (which has to cover the localization
+    furthest from the surface)."""
+    from scipy.spatial import cKDTree
+    v, f = icosphere(5, 60.0)
+    mesh = TriMesh(v, f)
+    pts = sphere_cloud(20000, 60.0, 6.0, seed=4)
+    pts[::50] *= 1.5                                              # a few localizations far above the surface
+    cent = mesh.vertices[mesh.faces].mean(1)
+    tree = cKDTree(cent)
+    d0 = tree.query(pts)[0]
+    args = (mesh.vertices, mesh.vertex_normals, mesh.neighbor_vertex_table(), mesh.faces, pts)
+    for n in (2, 4, 8):
+        tiles = parallel.bisect_tiles(pts, n)
+        margin = 3.0
+        reach = {r: d0[tiles[0][r]] + margin for r in range(n)}
+        part = parallel.HaloPartition(*args, n, halo=0.0, tiles=tiles, reach=reach, reach_voxel=margin / 2)
+        box = parallel.HaloPartition(*args, n, halo=float(d0.max()) + margin, tiles=tiles)
+        owned_total = np.zeros(v.shape[0], int)
+        for r, d in enumerate(part.ranks):
+            gv = d['gv']
+            owned_total[gv[d['owned'].astype(bool)]] += 1
+            mine = np.zeros(mesh.faces.shape[0], bool)
+            key = {tuple(t) for t in np.sort(gv[d['faces']], 1)}
+            sub = tiles[0][r][::7]
+            for i, lst in zip(sub, tree.query_ball_point(pts[sub], d0[sub] + margin)):
+                assert all(tuple(np.sort(mesh.faces[k])) in key for k in lst)
+        assert (owned_total == 1).all()
+        held = sum(d['gv'].size for d in part.ranks)
+        held_box = sum(d['gv'].size for d in box.ranks)
+        assert held < 0.8 * held_box, (n, held, held_box)
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_partition_of_the_headline_mesh_at_full_size():
+    """BASELINE configs[2] at full size (10^6 localizations, 198 812 vertices), 8 ranks, the mesh on the cloud's surface (where a fit
+    spends its time), margin 5 nm: what the ranks hold together, how many vertices are shared, the largest share.  (Round 3, one halo
+    radius of 100 nm for all: 2.08 x the mesh, 70 % boundary vertices, largest share 2.09 x M/8.)"""
+    from scipy.spatial import cKDTree
+    from ch_shrinkwrap_amd import synth
+    cfg = synth.make_config('c3')
+    pts = cfg['points']
+    v0, f0 = cfg['surface']
+    mesh = TriMesh(v0, f0)
+    pos, faces = mesh.vertices, mesh.faces
+    cent = ((pos[faces[:, 0]] + pos[faces[:, 1]]) + pos[faces[:, 2]]) / np.float32(3.0)
+    d0 = cKDTree(cent).query(pts, workers=-1)[0]
+    tiles = parallel.bisect_tiles(pts, 8)
+    margin = 5.0
+    reach = {r: d0[tiles[0][r]] + margin for r in range(8)}
+    part = parallel.HaloPartition(pos, mesh.vertex_normals, mesh.neighbor_vertex_table(), faces, pts, 8, 0.0, tiles=tiles, reach=reach, reach_voxel=margin / 2)
+    M = pos.shape[0]
+    held = [d['gv'].size for d in part.ranks]
+    print('8 ranks of C3, margin %.0f nm: held %.3f x M, boundary %.1f %%, largest share %.3f x M/8' % (margin, sum(held) / M, 100.0 * part.boundary.size / M, max(held) / (M / 8)))
+    assert sum(held) / M <= 1.40
+    assert part.boundary.size / M <= 0.33
+    assert max(held) / (M / 8) <= 1.45
+
+
 def test_a_rank_that_works_out_only_its_own_share_agrees_with_the_full_partition():
     """HaloScene gives every rank its OWN share only (detail_ranks / membership_ranks) and all-reduces the holders' counts: the shares and
     the boundary list must be those of the partition computed in full on one process."""
