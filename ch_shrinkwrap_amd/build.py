@@ -51,7 +51,7 @@ def build_hip_library(force=False, verbose=False):
 HOST_LIB = os.path.join(HERE, 'libnw_remesh.so')
 HOST_SRC = os.path.join(HERE, 'csrc', 'remesh.cpp')
 HOST_DEPS = [HOST_SRC, os.path.join(os.path.dirname(HERE), 'include', 'nw_remesh.h')]
-HOST_FLAGS = ['-O2', '-std=c++14', '-fPIC', '-shared', '-fvisibility=hidden', '-ffp-contract=off', '-Wall']
+HOST_FLAGS = ['-O2', '-std=c++14', '-fPIC', '-shared', '-fvisibility=hidden', '-ffp-contract=off', '-Wall', '-pthread']
 
 
 def build_host_library(force=False, verbose=False):

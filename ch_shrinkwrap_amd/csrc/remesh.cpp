@@ -13,6 +13,9 @@
 #include <vector>
 #include <chrono>
 #include <cstdio>
+#include <thread>
+#include <atomic>
+#include <utility>
 
 #include "../../include/nw_remesh.h"
 
@@ -288,6 +291,13 @@ struct HalfEdgeMesh {
         const double q0 = dot(m0, navg), q1 = dot(m1, navg);
         if (!(q0 > 0) || !(q1 > 0)) return false;                           // non-convex quad
         if (q0 * q0 < 0.04 * norm2(m0) * norm2(navg) || q1 * q1 < 0.04 * norm2(m1) * norm2(navg)) return false;
+        // ... and of some area: with c or d (nearly) ON the line through the other and an end point -- the centre of a rhombus that an
+        // earlier split put on its diagonal -- the new diagonal would run through that vertex, a sliver of the right orientation and no area;
+        // it would be the next pass's longest edge, and its midpoint the vertex again (seen as zero-length edges beside frozen rims)
+        if (strict_rim) {                        // (pieces of a partitioned mesh only: the serial algorithm's output stays what it was)
+            const double amin = 0.01 * std::min(l0, l1);
+            if (norm2(m0) < amin || norm2(m1) < amin) return false;
+        }
         // f0 = (a->d = tn, d->c = h, c->a = hp), f1 = (d->b = tp, b->c = hn, c->d = t)
         const int f0 = face[h], f1 = face[t];
         vert[h] = c; vert[t] = d;
@@ -307,6 +317,7 @@ struct HalfEdgeMesh {
     bool alive(int h) const { return vert[h] >= 0; }
 
     int64_t split_cap = INT64_MAX;
+    bool strict_rim = false;
     void split_long_edges(double high2)
     {
         for (int pass = 0; pass < 8; ++pass) {
@@ -317,6 +328,12 @@ struct HalfEdgeMesh {
                 const int t = twin[h];
                 if (t < 0 || (int)h > t) continue;         // each interior edge once
                 if (boundary[from((int)h)] && boundary[vert[h]]) continue;
+                if (strict_rim) {
+                    // a PIECE of a larger mesh (remesh_partitioned): its rim is not a real boundary, and everything that touches a rim vertex
+                    // waits for the pass in which that vertex is interior (the collapses and flips wait anyway).  (Splitting the spokes of a
+                    // rim corner -- a rim vertex with two faces in the piece -- was seen to split the same edge over and over: coincident vertices.)
+                    if (boundary[from((int)h)] || boundary[vert[h]] || boundary[vert[next[h]]] || boundary[vert[next[t]]]) continue;
+                }
                 split((int)h);
             }
             if (n_split == before || n_split > split_cap) break;
@@ -382,7 +399,16 @@ struct HalfEdgeMesh {
 
 }  // namespace
 
-NWR_EXPORT int nwr_abi_version(void) { return 2; }
+NWR_EXPORT int nwr_abi_version(void) { return 3; }
+
+// key 0: 1 (default) = meshes of 40 000 faces and more are remeshed in pieces, on all cores (remesh_partitioned); 0 = always the serial
+// algorithm (what a caller wants whose OUTPUT must not depend on the library's version: the benchmark's mesh generator).  Returns the old value.
+static std::atomic<int> g_partition{1};
+NWR_EXPORT int nwr_configure(int key, int value)
+{
+    if (key != 0) return NWR_ERR_BADARG;
+    return g_partition.exchange(value ? 1 : 0);
+}
 
 NWR_EXPORT void nwr_free(void *p) { std::free(p); }
 
@@ -542,16 +568,15 @@ NWR_EXPORT int nwr_ring_tables(const void *halfedges, int64_t he_stride, int64_t
     return NWR_OK;
 }
 
-NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
-                          int n_iterations, float target_edge_length, float relax_lambda, int n_relax, int max_valence,
-                          float **out_vertices, int64_t *out_n_vertices, int32_t **out_faces, int64_t *out_n_faces,
-                          nwr_stats *stats)
+// The serial remesher on one (sub-)mesh.  seed: per-vertex flags -- only edges around flagged vertices are looked at by the collapse and
+// flip passes until an operation freshens more (NULL: every edge, the plain algorithm).  out_orig[v'] = the input vertex an output vertex
+// was, or -1 for a vertex a split created.  target_edge_length must be > 0 when the caller remeshes pieces of one mesh (the default,
+// the mean edge of the input, would differ from piece to piece).
+static int remesh_core(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
+                       int n_iterations, float target_edge_length, float relax_lambda, int n_relax, int max_valence, const unsigned char *seed,
+                       std::vector<float> &ov, std::vector<int32_t> &of, std::vector<int> *out_orig, nwr_stats *stats, double *mean_edge_in)
 {
-    if (!vertices || !faces || !out_vertices || !out_n_vertices || !out_faces || !out_n_faces) return NWR_ERR_BADARG;
-    if (n_vertices < 3 || n_faces < 1 || n_vertices > (1ll << 30) || n_faces > (1ll << 29) || n_iterations < 0 || n_relax < 0)
-        return NWR_ERR_BADARG;
-    *out_vertices = nullptr; *out_faces = nullptr; *out_n_vertices = 0; *out_n_faces = 0;
-    try {
+    {
         const bool verbose = std::getenv("NWR_VERBOSE") != nullptr;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -561,6 +586,12 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
         for (int64_t i = 0; i < 3 * n_vertices; ++i) if (!std::isfinite(vertices[i])) return NWR_ERR_BADARG;      // a non-finite vertex: its edges would be split for ever
         int rc = m.build(vertices, n_vertices, faces, n_faces);
         if (rc != NWR_OK) return rc;
+        m.strict_rim = out_orig != nullptr;          // (a piece of a partitioned mesh)
+        if (seed) {
+            std::fill(m.estamp.begin(), m.estamp.end(), -1);
+            m.cur_it = 1;
+            for (int64_t v = 0; v < n_vertices; ++v) if (seed[v]) m.mark((int)v);
+        }
         if (verbose) std::fprintf(stderr, "[nw_remesh] build %.1f ms\n", ms(t_start, now()));
         double L = target_edge_length, L_in = 1.0, L_med = 1.0;
         {
@@ -570,6 +601,7 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
             L_in = n ? s / n : 1.0;                 // mean edge length of the input (PYME's default target)
             if (n) { std::nth_element(len.begin(), len.begin() + n / 2, len.end()); L_med = len[n / 2]; }      // (robust against a few wild edges)
         }
+        if (mean_edge_in) *mean_edge_in = L_in;
         if (!(L > 0)) L = L_in;
         const double high = 4.0 / 3.0 * L, low = 4.0 / 5.0 * L;
         m.all_dirty = n_relax > 0;
@@ -619,8 +651,7 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
         std::vector<int> remap(m.pos.size(), -1);
         int64_t nf = 0;
         for (size_t f = 0; f < m.fhe.size(); ++f) nf += m.fhe[f] >= 0;
-        int32_t *of = (int32_t *)std::malloc(sizeof(int32_t) * 3 * (size_t)std::max<int64_t>(nf, 1));
-        if (!of) return NWR_ERR_NOMEM;
+        of.assign(3 * (size_t)nf, 0);
         std::vector<unsigned char> used(m.pos.size(), 0);
         int64_t k = 0;
         for (size_t f = 0; f < m.fhe.size(); ++f) {
@@ -633,11 +664,12 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
         }
         int64_t nv = 0;
         for (size_t v = 0; v < m.pos.size(); ++v) if (used[v]) remap[v] = (int)nv++;
-        float *ov = (float *)std::malloc(sizeof(float) * 3 * (size_t)std::max<int64_t>(nv, 1));
-        if (!ov) { std::free(of); return NWR_ERR_NOMEM; }
+        ov.assign(3 * (size_t)nv, 0.0f);
+        if (out_orig) out_orig->assign((size_t)nv, -1);
         for (size_t v = 0; v < m.pos.size(); ++v) {
             if (remap[v] < 0) continue;
             ov[3 * remap[v]] = (float)m.pos[v].x; ov[3 * remap[v] + 1] = (float)m.pos[v].y; ov[3 * remap[v] + 2] = (float)m.pos[v].z;
+            if (out_orig && (int64_t)v < n_vertices) (*out_orig)[remap[v]] = (int)v;
         }
         for (int64_t i = 0; i < 3 * nf; ++i) of[i] = remap[of[i]];
         if (stats) {
@@ -647,8 +679,292 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
             for (size_t v = 0; v < m.pos.size(); ++v) if (used[v]) mv = std::max(mv, m.val[v]);
             stats->mean_edge_length = n ? s / n : 0.0; stats->max_valence = mv; stats->reserved = 0;
         }
-        *out_vertices = ov; *out_n_vertices = nv; *out_faces = of; *out_n_faces = nf;
         if (verbose) std::fprintf(stderr, "[nw_remesh] total %.1f ms\n", ms(t_start, now()));
+        return NWR_OK;
+    }
+}
+
+// ---- the remesher over a partitioned mesh ------------------------------------------------------------------------------------
+// The algorithm above is a chain of local operations in half-edge order: serial, 0.15 s for 2 10^5 vertices, most of a fit's
+// block boundary.  The same operations run on pieces of the mesh at once:
+//   1. the faces are put in Morton order of their centroids and cut into NWR_REGIONS runs of equal length (the cut depends on the mesh
+//      alone, not on the number of threads); every run is a sub-mesh whose rim -- the edges it shares with other runs -- is an open
+//      boundary, which the remesher never touches (vertices on unmatched edges are frozen): the runs are remeshed independently, on
+//      as many threads as there are, and spliced back in run order;
+//   2. what the frozen rims kept from being done is done in a second pass over the SEAM ZONE alone: the faces within NWR_SEAM_RINGS
+//      rings of a rim vertex, again a sub-mesh with a frozen rim of its own (which lies inside the runs, where pass 1 was free).
+// Every edge has been free in one of the two passes.  The result is a valid output of the same algorithm -- not the serial one's
+// (the order of the operations differs), and independent of the thread count.  Without relaxation only (n_relax = 0: what the fit's
+// block boundary asks for): relaxation moves every vertex in every iteration, rims included.
+#define NWR_REGIONS 16
+#define NWR_SEAM_RINGS 3
+#define NWR_PARALLEL_MIN_FACES 40000
+
+struct Piece {
+    std::vector<int> faces_in;           // ids of the mesh's faces that make up the piece
+    std::vector<int> l2g;                // local vertex -> vertex of the mesh
+    std::vector<float> ov;               // the remeshed piece
+    std::vector<int32_t> of;
+    std::vector<int> orig;               // output vertex -> local input vertex, -1 = new
+    nwr_stats st{};
+    int rc = NWR_OK;
+};
+
+static void piece_run(Piece &p, const std::vector<float> &V, const std::vector<int32_t> &F, std::vector<int> &g2l_scratch, int n_iterations, float L, int max_valence,
+                      const unsigned char *seed_global)
+{
+    // local numbering in first-seen order
+    std::vector<float> lv;
+    std::vector<int32_t> lf(3 * p.faces_in.size());
+    std::vector<unsigned char> lseed;
+    p.l2g.clear();
+    for (size_t i = 0; i < p.faces_in.size(); ++i)
+        for (int k = 0; k < 3; ++k) {
+            const int g = F[3 * (size_t)p.faces_in[i] + k];
+            int l = g2l_scratch[g];
+            if (l < 0) {
+                l = (int)p.l2g.size();
+                g2l_scratch[g] = l;
+                p.l2g.push_back(g);
+                lv.push_back(V[3 * (size_t)g]); lv.push_back(V[3 * (size_t)g + 1]); lv.push_back(V[3 * (size_t)g + 2]);
+                if (seed_global) lseed.push_back(seed_global[g]);
+            }
+            lf[3 * i + k] = l;
+        }
+    for (int g : p.l2g) g2l_scratch[g] = -1;          // leave the scratch map clean for the next piece of this thread
+    if (p.l2g.size() < 3 || p.faces_in.empty()) { p.rc = NWR_OK; p.ov.clear(); p.of.clear(); p.orig.clear(); return; }
+    p.rc = remesh_core(lv.data(), (int64_t)p.l2g.size(), lf.data(), (int64_t)p.faces_in.size(), n_iterations, L, 0.0f, 0, max_valence,
+                       seed_global ? lseed.data() : nullptr, p.ov, p.of, &p.orig, &p.st, nullptr);
+}
+
+// replace the faces of the pieces (disjoint sets) by their remeshed versions: original vertices keep their ids, new ones are appended in
+// piece order; faces: the untouched ones in their order, then the pieces' in piece order
+static void splice(std::vector<float> &V, std::vector<int32_t> &F, std::vector<Piece> &pieces)
+{
+    const size_t nf = F.size() / 3;
+    std::vector<unsigned char> gone(nf, 0);
+    for (auto &p : pieces) for (int f : p.faces_in) gone[f] = 1;
+    std::vector<int32_t> F2;
+    F2.reserve(F.size() + F.size() / 4);
+    for (size_t f = 0; f < nf; ++f) if (!gone[f]) { F2.push_back(F[3 * f]); F2.push_back(F[3 * f + 1]); F2.push_back(F[3 * f + 2]); }
+    for (auto &p : pieces) {
+        std::vector<int> o2g(p.orig.size());
+        for (size_t v = 0; v < p.orig.size(); ++v) {
+            if (p.orig[v] >= 0) o2g[v] = p.l2g[p.orig[v]];
+            else {
+                o2g[v] = (int)(V.size() / 3);
+                V.push_back(p.ov[3 * v]); V.push_back(p.ov[3 * v + 1]); V.push_back(p.ov[3 * v + 2]);
+            }
+        }
+        for (size_t i = 0; i < p.of.size(); ++i) F2.push_back(o2g[p.of[i]]);
+    }
+    F.swap(F2);
+}
+
+static unsigned spread10(unsigned v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+static int n_threads()
+{
+    if (const char *e = std::getenv("NW_REMESH_THREADS")) return std::max(1, std::atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hc ? hc : 1u, 16u));
+}
+
+static int remesh_partitioned(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces, int n_iterations, float L, int max_valence,
+                              std::vector<float> &ov, std::vector<int32_t> &of, nwr_stats *stats)
+{
+    const bool verbose = std::getenv("NWR_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
+    std::vector<float> V(vertices, vertices + 3 * n_vertices);
+    std::vector<int32_t> F(faces, faces + 3 * n_faces);
+    // Morton order of the faces' centroids over the mesh's bounding cube
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t v = 0; v < n_vertices; ++v) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], V[3 * v + k]); hi[k] = std::max(hi[k], V[3 * v + k]); }
+    const double ext = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-30});
+    std::vector<std::pair<unsigned, int>> key((size_t)n_faces);
+    for (int64_t f = 0; f < n_faces; ++f) {
+        unsigned q[3];
+        for (int k = 0; k < 3; ++k) {
+            const double c = ((double)V[3 * (size_t)F[3 * f] + k] + V[3 * (size_t)F[3 * f + 1] + k] + V[3 * (size_t)F[3 * f + 2] + k]) / 3.0;
+            q[k] = (unsigned)std::min(1023.0, std::max(0.0, (c - lo[k]) / ext * 1024.0));
+        }
+        key[f] = {spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2), (int)f};
+    }
+    {
+        // stable LSD radix sort of the 30-bit keys, three passes of 10 bits (faces of equal key keep their order: as std::sort of the
+        // (key, face) pairs would leave them -- a third of its time)
+        std::vector<std::pair<unsigned, int>> tmp(key.size());
+        for (int pass = 0; pass < 3; ++pass) {
+            const int sh = 10 * pass;
+            size_t cnt[1025] = {0};
+            for (const auto &e : key) cnt[((e.first >> sh) & 1023u) + 1] += 1;
+            for (int b = 0; b < 1024; ++b) cnt[b + 1] += cnt[b];
+            for (const auto &e : key) tmp[cnt[(e.first >> sh) & 1023u]++] = e;
+            key.swap(tmp);
+        }
+    }
+    std::vector<Piece> pieces(NWR_REGIONS);
+    for (int r = 0; r < NWR_REGIONS; ++r) {
+        const int64_t a = n_faces * r / NWR_REGIONS, b = n_faces * (r + 1) / NWR_REGIONS;
+        pieces[r].faces_in.reserve((size_t)(b - a));
+        for (int64_t i = a; i < b; ++i) pieces[r].faces_in.push_back(key[i].second);
+        std::sort(pieces[r].faces_in.begin(), pieces[r].faces_in.end());          // (the mesh's own face order inside a run)
+    }
+    // vertices on a rim: used by faces of more than one run
+    std::vector<int> vrun((size_t)n_vertices, -1);
+    std::vector<unsigned char> rim((size_t)n_vertices, 0);
+    for (int r = 0; r < NWR_REGIONS; ++r)
+        for (int f : pieces[r].faces_in)
+            for (int k = 0; k < 3; ++k) {
+                const int v = F[3 * (size_t)f + k];
+                if (vrun[v] < 0) vrun[v] = r;
+                else if (vrun[v] != r) rim[v] = 1;
+            }
+    const auto t1 = now();
+    // pass 1: the runs, independently
+    const int T = std::min(n_threads(), NWR_REGIONS);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                std::vector<int> g2l((size_t)n_vertices, -1);
+                for (int r = t; r < NWR_REGIONS; r += T) piece_run(pieces[r], V, F, g2l, n_iterations, L, max_valence, nullptr);
+            });
+        for (auto &x : th) x.join();
+    }
+    nwr_stats tot{};
+    for (auto &p : pieces) {
+        if (p.rc != NWR_OK) return p.rc;
+        tot.n_split += p.st.n_split; tot.n_collapse += p.st.n_collapse; tot.n_flip += p.st.n_flip;
+    }
+    splice(V, F, pieces);
+    const auto t2 = now();
+    // pass 2: the seam zone = faces within NWR_SEAM_RINGS rings of a rim vertex (rim vertices kept their ids: they were frozen)
+    {
+        const size_t nv = V.size() / 3, nf = F.size() / 3;
+        std::vector<unsigned char> zone(nv, 0), fz(nf, 0);
+        for (int64_t v = 0; v < n_vertices; ++v) zone[v] = rim[v];
+        for (int ring = 0; ring < NWR_SEAM_RINGS; ++ring) {
+            for (size_t f = 0; f < nf; ++f) if (!fz[f] && (zone[F[3 * f]] || zone[F[3 * f + 1]] || zone[F[3 * f + 2]])) fz[f] = 2;
+            for (size_t f = 0; f < nf; ++f) if (fz[f] == 2) { zone[F[3 * f]] = zone[F[3 * f + 1]] = zone[F[3 * f + 2]] = 1; fz[f] = 1; }
+        }
+        std::vector<Piece> seam(1);
+        for (size_t f = 0; f < nf; ++f) if (fz[f]) seam[0].faces_in.push_back((int)f);
+        if (!seam[0].faces_in.empty() && !std::getenv("NWR_NO_SEAM")) {
+            std::vector<int> g2l(nv, -1);
+            std::vector<unsigned char> seed(nv, 0);
+            for (int64_t v = 0; v < n_vertices; ++v) seed[v] = rim[v];
+            piece_run(seam[0], V, F, g2l, n_iterations, L, max_valence, seed.data());
+            if (seam[0].rc != NWR_OK) return seam[0].rc;
+            tot.n_split += seam[0].st.n_split; tot.n_collapse += seam[0].st.n_collapse; tot.n_flip += seam[0].st.n_flip;
+            splice(V, F, seam);
+        }
+    }
+    const auto t3 = now();
+    // compact (vertices no face refers to any more: collapsed away inside a piece), relative order kept
+    {
+        const size_t nv = V.size() / 3;
+        std::vector<int> remap(nv, -1);
+        std::vector<unsigned char> used(nv, 0);
+        for (int32_t v : F) used[v] = 1;
+        int64_t n = 0;
+        for (size_t v = 0; v < nv; ++v) if (used[v]) remap[v] = (int)n++;
+        ov.assign(3 * (size_t)n, 0.0f);
+        for (size_t v = 0; v < nv; ++v) if (remap[v] >= 0) { ov[3 * remap[v]] = V[3 * v]; ov[3 * remap[v] + 1] = V[3 * v + 1]; ov[3 * remap[v] + 2] = V[3 * v + 2]; }
+        of.resize(F.size());
+        for (size_t i = 0; i < F.size(); ++i) of[i] = remap[F[i]];
+    }
+    if (stats) {
+        *stats = tot;
+        // mean edge length and largest degree of the result
+        const size_t nv = ov.size() / 3;
+        std::vector<int> deg(nv, 0);
+        double s = 0; int64_t n = 0;
+        for (size_t f = 0; f + 2 < of.size(); f += 3)
+            for (int k = 0; k < 3; ++k) {
+                const int a = of[f + k], b = of[f + (k + 1) % 3];
+                const double dx = (double)ov[3 * a] - ov[3 * b], dy = (double)ov[3 * a + 1] - ov[3 * b + 1], dz = (double)ov[3 * a + 2] - ov[3 * b + 2];
+                s += std::sqrt(dx * dx + dy * dy + dz * dz); ++n;
+                deg[a] += 1;
+            }
+        stats->mean_edge_length = n ? s / n : 0.0;
+        stats->max_valence = nv ? *std::max_element(deg.begin(), deg.end()) : 0;
+        stats->reserved = 0;
+    }
+    if (verbose) std::fprintf(stderr, "[nw_remesh] partitioned: order + runs %.1f ms, pass 1 (%d threads) %.1f ms, seam zone %.1f ms, compaction %.1f ms\n", ms(t0, t1), T, ms(t1, t2),
+                              ms(t2, t3), ms(t3, now()));
+    return NWR_OK;
+}
+
+NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
+                          int n_iterations, float target_edge_length, float relax_lambda, int n_relax, int max_valence,
+                          float **out_vertices, int64_t *out_n_vertices, int32_t **out_faces, int64_t *out_n_faces,
+                          nwr_stats *stats)
+{
+    if (!vertices || !faces || !out_vertices || !out_n_vertices || !out_faces || !out_n_faces) return NWR_ERR_BADARG;
+    if (n_vertices < 3 || n_faces < 1 || n_vertices > (1ll << 30) || n_faces > (1ll << 29) || n_iterations < 0 || n_relax < 0)
+        return NWR_ERR_BADARG;
+    *out_vertices = nullptr; *out_faces = nullptr; *out_n_vertices = 0; *out_n_faces = 0;
+    try {
+        std::vector<float> ov;
+        std::vector<int32_t> of;
+        int rc;
+        static const bool part_env = !(std::getenv("NW_REMESH_PARTITION") && std::atoi(std::getenv("NW_REMESH_PARTITION")) == 0);
+        const bool part_on = part_env && g_partition.load() != 0;
+        if (part_on && n_relax == 0 && n_iterations > 0 && n_faces >= NWR_PARALLEL_MIN_FACES) {
+            for (int64_t i = 0; i < 3 * n_vertices; ++i) if (!std::isfinite(vertices[i])) return NWR_ERR_BADARG;
+            for (int64_t i = 0; i < 3 * n_faces; ++i) if (faces[i] < 0 || faces[i] >= n_vertices) return NWR_ERR_BADARG;
+            float L = target_edge_length;
+            if (!(L > 0)) {                          // PYME's default: the mean edge length of the input -- of the WHOLE input
+                double s = 0;
+                for (int64_t f = 0; f < n_faces; ++f)
+                    for (int k = 0; k < 3; ++k) {
+                        const int a = faces[3 * f + k], b = faces[3 * f + (k + 1) % 3];
+                        const double dx = (double)vertices[3 * a] - vertices[3 * b], dy = (double)vertices[3 * a + 1] - vertices[3 * b + 1], dz = (double)vertices[3 * a + 2] - vertices[3 * b + 2];
+                        s += std::sqrt(dx * dx + dy * dy + dz * dz);
+                    }
+                L = (float)(s / (3.0 * (double)n_faces));
+            }
+            // (a non-manifold input is refused like the serial path does: the twin table of the whole mesh)
+            {
+                std::vector<int> twin(3 * (size_t)n_faces);
+                rc = match_twins(faces, n_faces, n_vertices, twin.data());
+                if (rc != NWR_OK) return rc;
+            }
+            rc = remesh_partitioned(vertices, n_vertices, faces, n_faces, n_iterations, L, max_valence, ov, of, stats);
+            if (rc == NWR_OK) {
+                // safety net: an edge of (nearly) no length in the result -- never seen since the rims wait for their pass -- and the
+                // serial algorithm takes over
+                const double tiny2 = 1e-12 * (double)L * (double)L;
+                bool bad = false;
+                for (size_t f = 0; f + 2 < of.size() && !bad; f += 3)
+                    for (int k = 0; k < 3; ++k) {
+                        const int a = of[f + k], b = of[f + (k + 1) % 3];
+                        const double dx = (double)ov[3 * a] - ov[3 * b], dy = (double)ov[3 * a + 1] - ov[3 * b + 1], dz = (double)ov[3 * a + 2] - ov[3 * b + 2];
+                        if (!(dx * dx + dy * dy + dz * dz > tiny2)) { bad = true; break; }
+                    }
+                if (bad) rc = remesh_core(vertices, n_vertices, faces, n_faces, n_iterations, target_edge_length, relax_lambda, n_relax, max_valence, nullptr, ov, of, nullptr, stats, nullptr);
+            }
+        } else {
+            rc = remesh_core(vertices, n_vertices, faces, n_faces, n_iterations, target_edge_length, relax_lambda, n_relax, max_valence, nullptr, ov, of, nullptr, stats, nullptr);
+        }
+        if (rc != NWR_OK) return rc;
+        float *pv = (float *)std::malloc(sizeof(float) * std::max<size_t>(ov.size(), 3));
+        int32_t *pf = (int32_t *)std::malloc(sizeof(int32_t) * std::max<size_t>(of.size(), 3));
+        if (!pv || !pf) { std::free(pv); std::free(pf); return NWR_ERR_NOMEM; }
+        std::memcpy(pv, ov.data(), sizeof(float) * ov.size());
+        std::memcpy(pf, of.data(), sizeof(int32_t) * of.size());
+        *out_vertices = pv; *out_n_vertices = (int64_t)(ov.size() / 3); *out_faces = pf; *out_n_faces = (int64_t)(of.size() / 3);
         return NWR_OK;
     } catch (const std::bad_alloc &) {
         return NWR_ERR_NOMEM;

@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libnw_remesh.so')
-SYMBOLS = ['nwr_abi_version', 'nwr_remesh', 'nwr_free', 'nwr_halfedge_twins', 'nwr_mesh_geometry', 'nwr_build_topology', 'nwr_ring_tables']
+SYMBOLS = ['nwr_abi_version', 'nwr_configure', 'nwr_remesh', 'nwr_free', 'nwr_halfedge_twins', 'nwr_mesh_geometry', 'nwr_build_topology', 'nwr_ring_tables']
 ERRORS = {-1: 'bad argument (sizes, indices or a non-finite vertex)', -2: 'the mesh is not an oriented 2-manifold', -3: 'out of memory',
           -4: 'runaway: far more splits than the target length can explain (degenerate input)'}
 
@@ -52,15 +52,27 @@ def load():
         L.nwr_ring_tables.restype = ctypes.c_int
         L.nwr_ring_tables.argtypes = [ctypes.c_void_p] + [ctypes.c_int64] * 5 + [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
                                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        if L.nwr_abi_version() != 2:
+        L.nwr_configure.restype = ctypes.c_int
+        L.nwr_configure.argtypes = [ctypes.c_int, ctypes.c_int]
+        if L.nwr_abi_version() != 3:
             raise RuntimeError('libnw_remesh.so ABI version mismatch')
         _lib = L
     return _lib
 
 
-def remesh(vertices, faces, n=5, target_edge_length=-1, l=0.5, n_relax=10, max_valence=16, return_stats=False):
-    """Returns (vertices float32 (V,3), faces int32 (F,3)) of the remeshed surface."""
+def remesh(vertices, faces, n=5, target_edge_length=-1, l=0.5, n_relax=10, max_valence=16, return_stats=False, serial=False):
+    """Returns (vertices float32 (V,3), faces int32 (F,3)) of the remeshed surface.
+
+    Meshes of 40 000 faces and more are remeshed in pieces on all cores when n_relax == 0 (a valid result of the same algorithm,
+    independent of the number of threads, but not the serial algorithm's arrays); serial=True keeps to the serial algorithm (whose
+    output only changes when the algorithm does: the benchmark's mesh generator uses it)."""
     L = load()
+    if serial:
+        old = L.nwr_configure(0, 0)
+        try:
+            return remesh(vertices, faces, n, target_edge_length, l, n_relax, max_valence, return_stats, serial=False)
+        finally:
+            L.nwr_configure(0, old)
     v = np.ascontiguousarray(vertices, np.float32)
     f = np.ascontiguousarray(faces, np.int32)
     if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3:

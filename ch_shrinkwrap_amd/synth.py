@@ -397,7 +397,7 @@ def _c4_start_mesh(sdf, cell):
     v, f = isosurface_mesh(sdf, (-1500, -1500, -420), (1400, 900, 420), cell, level=20.0, slack=60.0)
     e = np.concatenate([v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 1]], v[f[:, 0]] - v[f[:, 2]]]).astype('f8')
     target = float(np.sqrt((e * e).sum(1)).mean())
-    v2, f2 = _remesh.remesh(v, f, 3, target, 0.5, 0)
+    v2, f2 = _remesh.remesh(v, f, 3, target, 0.5, 0, serial=True)      # (serial: the benchmark's start mesh must not change with the library's threading)
     if not 0.5 * f.shape[0] < f2.shape[0] < 2 * f.shape[0]:
         raise RuntimeError('synth c4: remeshing the start surface at its mean edge length %.3f turned %d faces into %d' % (target, f.shape[0], f2.shape[0]))
     return v2, f2

@@ -39,6 +39,10 @@ typedef struct nwr_stats {
 } nwr_stats;
 
 int nwr_abi_version(void);
+/* key 0: 1 (default) = meshes of 40 000 faces and more are remeshed in pieces on all cores when n_relax == 0 (16 Morton runs of the faces
+ * with frozen rims, then the seam zone: a valid result of the same algorithm, independent of the number of threads -- NW_REMESH_THREADS --
+ * but not the serial algorithm's arrays); 0 = always the serial algorithm.  Returns the previous value. */
+int nwr_configure(int key, int value);
 
 /* vertices: float[3*n_vertices]; faces: int32[3*n_faces] (counter-clockwise).  target_edge_length < 0 -> the mean edge
  * length of the input (PYME's default).  max_valence: collapses/flips never raise a vertex degree above it (the
