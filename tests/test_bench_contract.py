@@ -50,7 +50,8 @@ def test_two_ranks_started_by_plain_python_print_one_json_line(mode):
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j['n_gpus'] == 2 and j['steps'] == 10 and j['warmup'] == 5 and j['warmup_executed'] == 10
+    # (a sharded mesh gets new shares at layout time: one more untimed block for the library's own set-up on the new sub-mesh)
+    assert j['n_gpus'] == 2 and j['steps'] == 10 and j['warmup'] == 5 and j['warmup_executed'] == (15 if mode == 'halo' else 10)
     assert j['scaling'] == ('strong' if mode == 'halo' else 'weak') and j['config']['mode'] == mode
     assert j['rccl']['backend'] == 'gloo' and j['rccl']['world_size_seen'] == 2 and len(j['rccl']['devices']) == 2
     c = j['collectives']
@@ -58,7 +59,7 @@ def test_two_ranks_started_by_plain_python_print_one_json_line(mode):
     assert j['value'] > 0 and j['roofline']['launches'] >= 2
     if mode == 'halo':
         h = j['halo']
-        assert h['boundary_vertices'] > 0 and h['max_nn_distance_nm'] + h['drift_since_partition_nm'] <= h['radius_nm']
+        assert h['per_localization_halos'] and h['boundary_vertices'] > 0 and h['max_nn_distance_nm'] + h['drift_since_partition_nm'] <= h['margin_nm'] <= h['radius_nm']
         assert j['config']['vertices_per_gpu'] < j['config']['localizations_per_gpu']       # a share, not the whole mesh
         # one mesh: value counts its vertices once
         assert abs(j['value'] - float(j['config']['workload'].split(' vertices')[0].split(', ')[-1]) * 1e3 / j['ms_per_step']) <= 1e-6 * j['value']

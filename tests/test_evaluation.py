@@ -101,14 +101,50 @@ def test_c1_fixed_topology_converges_to_the_sampling_floor():
     assert q['mse_rms'] <= 5.0 and q['mse01'] <= 25.0 and q['mse10'] <= 25.0
 
 
+def _recipe_fit_fixed(cfg, **kw):
+    """the same fit with the topology held fixed (no remesher installed)"""
+    from ch_shrinkwrap_amd.membrane_mesh import ShrinkwrapMembrane
+
+    class Surf(object):
+        vertices, faces = cfg['vertices'], cfg['faces']
+    pts = cfg['points']
+    table = {'x': pts[:, 0], 'y': pts[:, 1], 'z': pts[:, 2], 'error_x': cfg['sigma'][:, 0], 'error_y': cfg['sigma'][:, 1], 'error_z': cfg['sigma'][:, 2]}
+    mod = ShrinkwrapMembrane(**kw)
+    mod.remesher = None
+    return mod.execute({'surf': Surf, 'filtered_localizations': table})
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('name,scale,limit', [('c2', 1.0, 9.0), ('c4', 0.02, 13.0)])
-def test_recipe_fit_with_the_builtin_remesher(name, scale, limit):
+@pytest.mark.parametrize('name,scale,floor', [('c2', 1.0, None), ('c4', 0.02, 5.0)])
+def test_recipe_fit_left_to_converge(name, scale, floor):
+    """The recipe fit with the builtin remesher, given the iterations it needs (159 instead of the module's default 39; the start surface
+    is 20 nm off, the reference's own recipes start from an isosurface of the cloud): the remesher -- the one component whose parity
+    cannot be pinned (PYME's is not in the reference tree) -- must not cost the fit anything against the same fit on the FIXED start
+    topology (within 1.3 x in the reference's metric), and where the fit converges it must reach sigma / 2.
+    Observed (tools/experiments/r04_convergence.py): C4 x 0.02: 11.2 / 6.1 / 3.2 / 2.9 nm after 39 / 79 / 159 / 319 iterations (fixed topology:
+    7.5 / 4.1 / 3.2 / 3.2); C2, a tube of 50 nm radius under curvature_weight 20: 8.1 / 7.8 / 7.8 / 7.9 nm (fixed: 6.8 / 6.6 / 6.8 / 7.1) --
+    it does not get better with more iterations on either topology: the bias of the regulariser on a thin tube, not the remesher."""
+    from ch_shrinkwrap_amd import synth
+    cfg = synth.make_config(name, scale=scale, seed=0)
+    truth = synth.truth_cloud(cfg)
+    kw = dict(max_iters=159, remesh_frequency=5, curvature_weight=20.0, neck_first_iter=-1)
+    q = E.fit_quality(_recipe_fit(cfg, **kw), truth)
+    qf = E.fit_quality(_recipe_fit_fixed(cfg, **kw), truth)
+    print(name, 'remeshed', q, 'fixed topology', qf)
+    assert q['mse_rms'] <= 1.3 * qf['mse_rms']
+    if floor is not None:
+        assert q['mse_rms'] <= floor and qf['mse_rms'] <= floor
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('name,scale', [('c2', 1.0), ('c4', 0.02)])
+def test_recipe_fit_with_the_builtin_remesher(name, scale):
     """The recipe module's default fit -- 39 iterations, remeshed every 5 by this package's own remesher -- from the +20 nm start surface:
-    the reference's metric must fall from ~20-27 nm to the order of the localization error (C2: 6.8 nm observed, C4 x 0.02: 11.2 nm;
-    39 iterations do not converge a fit that starts 20 nm off -- the reference's own recipes start from an isosurface of the cloud --
-    so the bound is sigma-sized, not the sampling floor) and the remeshed surface must be a clean closed mesh."""
+    39 iterations do not converge a fit that starts 20 nm off (C2: 8.1 nm, C4 x 0.02: 11.2 nm observed: reported, not thresholds -- see
+    test_recipe_fit_left_to_converge for the statement about quality); what IS asserted: the metric falls well below the start's and the
+    surface after seven remeshing passes is a clean closed mesh."""
     from ch_shrinkwrap_amd import synth
     cfg = synth.make_config(name, scale=scale, seed=0)
     truth = synth.truth_cloud(cfg)
@@ -117,7 +153,7 @@ def test_recipe_fit_with_the_builtin_remesher(name, scale, limit):
     q = E.fit_quality(mesh, truth)
     print(name, 'start', q0, 'fitted', q, 'vertices', mesh.vertices.shape[0])
     assert q0['mse_rms'] >= 20.0
-    assert q['mse_rms'] <= limit and q['mse_rms'] <= 0.6 * q0['mse_rms']
+    assert q['mse_rms'] <= 0.6 * q0['mse_rms']
     assert len(mesh.block_log) == 7 and np.isfinite(mesh.vertices).all()
     # closed 2-manifold after seven remeshing passes: every edge shared by exactly two faces
     f = mesh.faces

@@ -304,7 +304,7 @@ def test_sharded_mesh_entry_points_check_their_arguments():
         cg._native.check(L.nw_halo_block_stats(h, 1.0))
     ref = v.copy()
     ref[17] += np.array([3.0, -4.0, 12.0], 'f4')                      # one vertex 13 nm away from where it was
-    cg._native.check(L.nw_halo_set_reference(h, nw.ptr(ref)))
+    cg._native.check(L.nw_halo_set_reference(h, nw.ptr(ref), None, 0))
     cg._native.check(L.nw_halo_block_stats(h, 42.5))
     stats = np.empty(4, np.float32)
     cg._native.check(L.nw_get(h, nw.NW_ARR_HALO_STATS, nw.ptr(stats), stats.nbytes))

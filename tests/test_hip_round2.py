@@ -88,7 +88,7 @@ def test_c3_full_size_three_blocks_against_oracle():
         print('C3 full size, block %d: vertex RMS vs oracle %.3e, %d of %d nearest faces differ in its last iteration' % (blk, rms, mism, pts.shape[0]))
         assert cg.loopcount == 5 and r.loopcount == 5
         assert rms <= 1e-4, 'block %d' % blk
-        assert mism <= 2000, 'block %d' % blk                  # near-ties flipped by 1e-7-level position drift (47 after the first block)
+        assert mism <= (150, 750, 1200)[blk], 'block %d' % blk    # near-ties flipped by 1e-7-level position drift: three times the observed 47 / 249 / 393
         assert np.allclose(np.array(cg.tests, 'f8'), np.array(r.tests, 'f8'), rtol=1e-3, atol=1e-6), 'block %d' % blk
         assert np.allclose(np.array(cg.ress, 'f8'), np.array(r.ress, 'f8'), rtol=2e-4), 'block %d' % blk
     print('C3 full size, 15 iterations in 3 blocks: worst vertex RMS vs oracle %.3e of the bbox diagonal' % worst)
