@@ -20,11 +20,12 @@ NW_FLAG_COMM_TILES, NW_FLAG_COMM_REPLICATED, NW_FLAG_COMM_HALO = 16, 32, 64
 NW_N_SCALARS = 32
 
 # every symbol include/nanowrap.h declares (tests/test_abi.py checks the exports against the header)
+NW_INFO_POINT_SCALARS, NW_INFO_SCALARS, NW_INFO_SCALAR_STRIDE = 0, 1, 2
 SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set_stream', 'nw_synchronize',
-           'nw_set_points', 'nw_set_mesh', 'nw_set_normals', 'nw_set_positions', 'nw_refresh_normals', 'nw_reset_history', 'nw_search', 'nw_search_begin',
-           'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_n_point_scalars', 'nw_n_scalars', 'nw_scalar_stride',
-           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug_nn_stats', 'nw_debug_items', 'nw_set_data', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back', 'nw_set_owned',
-           'nw_set_boundary', 'nw_halo_pack', 'nw_halo_unpack', 'nw_halo_gather_owned', 'nw_set_extent_hint', 'nw_host_copy_rows',
+           'nw_set_points', 'nw_set_mesh', 'nw_refresh_normals', 'nw_reset_history', 'nw_search', 'nw_search_begin',
+           'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_info',
+           'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug', 'nw_set_data', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back',
+           'nw_set_boundary', 'nw_halo_rows', 'nw_halo_gather_owned', 'nw_host_copy_rows',
            'nw_comm_unique_id', 'nw_comm_init', 'nw_comm_all_reduce', 'nw_halo_set_reference', 'nw_halo_block_stats']
 
 
@@ -58,9 +59,7 @@ def load():
     L.nw_synchronize.argtypes = [vp]
     L.nw_set_points.argtypes = [vp, vp, i64, vp, f32, i32, vp, f32]
     L.nw_set_mesh.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32]
-    L.nw_set_normals.argtypes = [vp, vp]
-    L.nw_set_positions.argtypes = [vp, vp]
-    L.nw_refresh_normals.argtypes = [vp, vp]
+    L.nw_refresh_normals.argtypes = [vp, vp, ctypes.c_double]
     L.nw_reset_history.argtypes = [vp]
     L.nw_search.argtypes = [vp, vp, i32, i32, u32, vp, ctypes.POINTER(IterLog), ctypes.POINTER(i32)]
     L.nw_search_begin.argtypes = [vp, vp, i32, i32, u32]
@@ -68,20 +67,15 @@ def load():
     L.nw_iter_directions.argtypes = [vp]
     L.nw_iter_update.argtypes = [vp]
     L.nw_search_end.argtypes = [vp, vp, ctypes.POINTER(IterLog), ctypes.POINTER(i32)]
-    L.nw_n_point_scalars.argtypes = []
-    L.nw_n_scalars.argtypes = []
-    L.nw_scalar_stride.argtypes = []
+    L.nw_info.argtypes = [i32]
     L.nw_apply_A.argtypes = [vp, vp, vp]
     L.nw_apply_At.argtypes = [vp, vp, vp]
     L.nw_get.argtypes = [vp, i32, vp, i64]
     L.nw_write_back.argtypes = [vp, vp, vp, i64]
     L.nw_set_write_back.argtypes = [vp, vp, i64]
-    L.nw_set_owned.argtypes = [vp, vp]
     L.nw_set_boundary.argtypes = [vp, vp, vp, i64, i64, vp, vp, i64]
-    L.nw_halo_pack.argtypes = [vp, i32]
-    L.nw_halo_unpack.argtypes = [vp, i32]
+    L.nw_halo_rows.argtypes = [vp, i32, i32]
     L.nw_halo_gather_owned.argtypes = [vp, i32]
-    L.nw_set_extent_hint.argtypes = [vp, ctypes.c_double]
     L.nw_host_copy_rows.argtypes = [vp, vp, i64, vp, vp, i64, vp]
     L.nw_comm_unique_id.argtypes = [vp, i64]
     L.nw_comm_init.argtypes = [vp, vp, i64, i32, i32]
@@ -94,8 +88,7 @@ def load():
     L.nw_curvature.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32] + [vp] * 12
     L.nw_set_profiling.argtypes = [vp, i32]
     L.nw_stage_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
-    L.nw_debug_nn_stats.argtypes = [vp, ctypes.POINTER(i64)]
-    L.nw_debug_items.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.nw_debug.argtypes = [vp, i32, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.nw_optimize_layout.argtypes = [vp]
     L.nw_accumulator_quantum.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     for s in SYMBOLS:

@@ -197,7 +197,7 @@ struct nw_ctx {
     double scene_ext = 1.0;           // extent of localizations + mesh at the last grid build
     double quantum_override = 0.0;    // > 0: nw_accumulator_quantum fixed it (multi-GPU: every rank must use the same)
     double acc_quantum = 1.0;         // fixed-point quantum of the LDS scatter accumulators (k_attract): 2^-36 of the cloud extent
-    double extent_hint = 0.0;         // > 0: extent of the WHOLE mesh (a rank of a sharded mesh; nw_set_extent_hint)
+    double extent_hint = 0.0;         // > 0: extent of the WHOLE mesh (a rank of a sharded mesh; nw_refresh_normals)
     double local_quantum = 1.0;       // what this ctx would choose for its own localizations and weights (nw_search_begin computes it every block)
     double cell_tune = 1.0;           // multiplier on the cell-size rule (tune_grid)
     bool tuned = false;
@@ -217,7 +217,7 @@ struct nw_ctx {
     DevBuf<int> aux_i;
     DevBuf<float> aux_f, aux_f2, aux_f3;
     DevBuf<double> aux_d;
-    DevBuf<unsigned long long> nn_stats;   // developer counters of the NN query (nw_debug_nn_stats); null unless enabled
+    DevBuf<unsigned long long> nn_stats;   // developer counters of the NN query (nw_debug, what = 0); null unless enabled
     DevBuf<unsigned> proj_key;        // projection keys of the last completed query (second sort, see k_projection_keys)
     DevBuf<int> proj_idx;
     bool proj_ready = false, proj_sorted = false;
@@ -576,9 +576,15 @@ int alloc_work(nw_ctx *ctx)
 
 // =============================================================================================================
 NW_EXPORT int nw_abi_version(void) { return NW_ABI_VERSION; }
-NW_EXPORT int nw_n_point_scalars(void) { return SC_NPOINT; }
-NW_EXPORT int nw_n_scalars(void) { return SC_MAXD; }      // the SUMMED slots (what ranks all-reduce); the max-distance slot behind them stays local
-NW_EXPORT int nw_scalar_stride(void) { return NW_SPARTS; }
+NW_EXPORT int nw_info(int what)
+{
+    switch (what) {
+    case NW_INFO_POINT_SCALARS: return SC_NPOINT;
+    case NW_INFO_SCALARS: return SC_MAXD;                     // the SUMMED slots (what ranks all-reduce); the max-distance slot behind them stays local
+    case NW_INFO_SCALAR_STRIDE: return NW_SPARTS;
+    default: return NW_ERR_BADARG;
+    }
+}
 
 NW_EXPORT int nw_create(int device, nw_ctx **out)
 {
@@ -913,7 +919,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     ctx->have_mesh = true;
     NW_TRY(sort_faces(ctx));
     if (nrm) NW_HIP(hipMemcpyAsync(ctx->nrm.p, nrm, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
-    else NW_TRY(nw_refresh_normals(ctx, nullptr));         // area-weighted vertex normals from positions + faces on the device
+    else NW_TRY(nw_refresh_normals(ctx, nullptr, 0.0));         // area-weighted vertex normals from positions + faces on the device
     if (topo_change) { ctx->grid_valid = false; }
     ctx->face_warm = false;                               // face ids of another topology are no starting guess
     if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 2) fprintf(stderr, "[nanowrap] warm start dropped (%s)\n", __func__);
@@ -929,9 +935,9 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     return NW_OK;
 }
 
-NW_EXPORT int nw_set_owned(nw_ctx *ctx, const uint8_t *owned)
+static int nw_set_owned(nw_ctx *ctx, const uint8_t *owned)
 {
-    if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_owned: mesh not set");
+    if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: mesh not set");
     ctx->have_owned = owned != nullptr;
     if (owned) {
         NW_HIP(ctx->owned.ensure(ctx->M));
@@ -1025,19 +1031,12 @@ static int halo_unpack(nw_ctx *ctx, int what)
     return NW_OK;
 }
 
-NW_EXPORT int nw_halo_pack(nw_ctx *ctx, int what)
+NW_EXPORT int nw_halo_rows(nw_ctx *ctx, int what, int unpack)
 {
-    if (!ctx || !ctx->have_boundary) return fail(ctx, NW_ERR_BADARG, "nw_halo_pack: no boundary set (nw_set_boundary)");
-    if (what != NW_ARR_VACC && what != NW_ARR_POS && what != NW_ARR_NRM) return fail(ctx, NW_ERR_BADARG, "nw_halo_pack: accumulator, positions or normals");
-    if (what == NW_ARR_VACC && !ctx->vacc.p) return fail(ctx, NW_ERR_BADARG, "nw_halo_pack: no accumulator yet");
-    return halo_pack(ctx, what);
-}
-
-NW_EXPORT int nw_halo_unpack(nw_ctx *ctx, int what)
-{
-    if (!ctx || !ctx->have_boundary) return fail(ctx, NW_ERR_BADARG, "nw_halo_unpack: no boundary set (nw_set_boundary)");
-    if (what != NW_ARR_VACC && what != NW_ARR_POS && what != NW_ARR_NRM) return fail(ctx, NW_ERR_BADARG, "nw_halo_unpack: accumulator, positions or normals");
-    if (what == NW_ARR_VACC && !ctx->vacc.p) return fail(ctx, NW_ERR_BADARG, "nw_halo_unpack: no accumulator yet");
+    if (!ctx || !ctx->have_boundary) return fail(ctx, NW_ERR_BADARG, "nw_halo_rows: no boundary set (nw_set_boundary)");
+    if (what != NW_ARR_VACC && what != NW_ARR_POS && what != NW_ARR_NRM) return fail(ctx, NW_ERR_BADARG, "nw_halo_rows: accumulator, positions or normals");
+    if (what == NW_ARR_VACC && !ctx->vacc.p) return fail(ctx, NW_ERR_BADARG, "nw_halo_rows: no accumulator yet");
+    if (!unpack) return halo_pack(ctx, what);
     if (what == NW_ARR_POS) ctx->pos_unpack_pending = false;
     return halo_unpack(ctx, what);
 }
@@ -1086,16 +1085,9 @@ NW_EXPORT int nw_halo_gather_owned(nw_ctx *ctx, int what)
     return NW_OK;
 }
 
-NW_EXPORT int nw_set_normals(nw_ctx *ctx, const float *nrm)
+NW_EXPORT int nw_refresh_normals(nw_ctx *ctx, float *nrm_out, double whole_mesh_extent)
 {
-    if (!ctx || !nrm || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_normals: mesh not set");
-    NW_HIP(hipMemcpyAsync(ctx->nrm.p, nrm, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
-    NW_HIP(hipStreamSynchronize(ctx->stream));
-    return NW_OK;
-}
-
-NW_EXPORT int nw_refresh_normals(nw_ctx *ctx, float *nrm_out)
-{
+    if (ctx) ctx->extent_hint = (whole_mesh_extent > 0 && std::isfinite(whole_mesh_extent)) ? whole_mesh_extent : 0.0;
     if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_refresh_normals: mesh not set");
     NW_HIP(hipSetDevice(ctx->device));
     if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_refresh_normals inside a search");
@@ -1124,13 +1116,6 @@ NW_EXPORT int nw_refresh_normals(nw_ctx *ctx, float *nrm_out)
 // Extent of the whole mesh for a rank that holds a share of it: nw_refresh_normals derives the quantum of its fixed-point normal sums
 // from the mesh's bounding box, and ranks whose shares have different boxes would round the same vertex's sum differently.  ext <= 0:
 // back to the local box.
-NW_EXPORT int nw_set_extent_hint(nw_ctx *ctx, double ext)
-{
-    if (!ctx) return NW_ERR_BADARG;
-    ctx->extent_hint = (ext > 0 && std::isfinite(ext)) ? ext : 0.0;
-    return NW_OK;
-}
-
 NW_EXPORT int nw_reset_history(nw_ctx *ctx)
 {
     if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_reset_history: mesh not set");
@@ -1140,15 +1125,6 @@ NW_EXPORT int nw_reset_history(nw_ctx *ctx)
     NW_HIP(hipMemcpyAsync(ctx->state.p, &st, sizeof(st), hipMemcpyHostToDevice, ctx->stream));
     NW_HIP(hipStreamSynchronize(ctx->stream));
     ctx->global_iter = 0;
-    return NW_OK;
-}
-
-NW_EXPORT int nw_set_positions(nw_ctx *ctx, const float *pos)
-{
-    if (!ctx || !pos || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_positions: mesh not set");
-    NW_HIP(hipMemcpyAsync(ctx->pos.p, pos, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
-    NW_HIP(hipMemcpyAsync(ctx->meshpos.p, pos, 3 * ctx->M * sizeof(float), hipMemcpyDefault, ctx->stream));
-    NW_HIP(hipStreamSynchronize(ctx->stream));
     return NW_OK;
 }
 
@@ -2170,7 +2146,7 @@ NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nb
 // developer aid: the work list of the NN query and the duration the last query measured for every item (s_memtime ticks / 16;
 // zeros once the list has been ordered).  out_items: int32[2 * cap] = {first localization (sorted order), count}; returns the number
 // of items through *n.
-NW_EXPORT int nw_debug_items(nw_ctx *ctx, int32_t *out_items, uint32_t *out_cost, int cap, int *n)
+static int debug_items(nw_ctx *ctx, int32_t *out_items, uint32_t *out_cost, int cap, int *n)
 {
     if (!ctx || !n) return NW_ERR_BADARG;
     *n = ctx->nitems;
@@ -2186,7 +2162,7 @@ NW_EXPORT int nw_debug_items(nw_ctx *ctx, int32_t *out_items, uint32_t *out_cost
 // developer aid (not part of the drop-in surface): counters of the NN query accumulated since the last call.
 // out[0..7] = candidates evaluated (x64 lanes each), non-empty rows listed, rows visited, cells tested, cells visited, box rows,
 // rounds, small runs; out[8] = work items.  The first call switches the counting on.
-NW_EXPORT int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out)
+static int debug_nn_stats(nw_ctx *ctx, int64_t *out)
 {
     if (!ctx || !out) return NW_ERR_BADARG;
     if (!ctx->nn_stats.p) {
@@ -2206,6 +2182,16 @@ NW_EXPORT int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out)
     }
     out[NWS_COUNT] = ctx->nitems;
     return NW_OK;
+}
+
+// developer aids behind one entry point (not part of the drop-in surface): what = 0: counters of the NN query since the last call
+// (a = int64[NWS_COUNT + 1]; the first call switches the counting on); what = 1: the query's work list (a = int32 {p0, n}[cap], b =
+// uint32 cost[cap] (2 cap with NW_ITEM_TIMES), *n = items in the list)
+NW_EXPORT int nw_debug(nw_ctx *ctx, int what, void *a, void *b, int cap, int *n)
+{
+    if (what == 0) return debug_nn_stats(ctx, (int64_t *)a);
+    if (what == 1) return debug_items(ctx, (int32_t *)a, (uint32_t *)b, cap, n);
+    return NW_ERR_BADARG;
 }
 
 // Quantum of the fixed-point A^T accumulator (NW_ARR_VACC = int64 counts of this quantum).  *q > 0 on entry fixes it for all later

@@ -272,7 +272,7 @@ __device__ __forceinline__ int nw_wave_max_i(int v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-// developer counters of one launch (nw_debug_nn_stats): candidates evaluated, rows listed / visited, cells tested / visited, ...
+// developer counters of one launch (nw_debug, what = 0): candidates evaluated, rows listed / visited, cells tested / visited, ...
 enum { NWS_CAND = 0, NWS_ROWS_NONEMPTY, NWS_ROWS_PASS, NWS_CELLS_TESTED, NWS_CELLS_PASS, NWS_BOX_ROWS, NWS_ROUNDS, NWS_T_WAVE_MAX, NWS_T_STREAM, NWS_T_WAVE, NWS_T_PRO, NWS_T_TAIL, NWS_COUNT };   // T_*: s_memtime ticks / 16 (PRO: before the walk, TAIL: after it)
 #define NWS_COPIES 1024             // sets of counters the waves spread their atomics over (one set: 17 000 same-address atomics took 3 ms per launch)
 struct NwStats { int v[NWS_COUNT]; bool timed; };
@@ -494,7 +494,7 @@ __device__ __forceinline__ int nw_fixup_point(const NwGrid &g, float Px, float P
     return bf;
 }
 
-// STATS: the developer counters of nw_debug_nn_stats (compiled out of the production variant: they cost registers)
+// STATS: the developer counters of nw_debug, what = 0 (compiled out of the production variant: they cost registers)
 template <bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_nn_wave(NwGrid g, const NwItem *__restrict__ items, int nitems, const float4 *__restrict__ pts,
                                                  const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,

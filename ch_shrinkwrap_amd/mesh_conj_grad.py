@@ -406,7 +406,7 @@ class ShrinkwrapMeshConjGrad(object):
         """Block-boundary refresh for an unchanged topology (_membrane_mesh.pyx:1524-1527) on the device: vertex normals are
         recomputed from the device-resident positions, kept in HBM for the next block and written to mesh.vertex_normals."""
         nrm = np.empty((self.M, 3), np.float32)
-        self._native.check(self._L.nw_refresh_normals(self._h, nw.ptr(nrm)))
+        self._native.check(self._L.nw_refresh_normals(self._h, nw.ptr(nrm), 0.0))
         self.mesh._vertices['normal'][:] = nrm
         return nrm
 
@@ -438,7 +438,7 @@ class ShrinkwrapMeshConjGrad(object):
     def nn_stats(self):
         """developer counters of the nearest-face query since the previous call (first call: switches them on)"""
         out = (ctypes.c_int64 * 13)()
-        self._native.check(self._L.nw_debug_nn_stats(self._h, out))
+        self._native.check(self._L.nw_debug(self._h, 0, out, None, 0, None))
         names = ['candidates', 'rows_nonempty', 'rows_visited', 'cells_tested', 'cells_visited', 'box_rows', 'rounds', 'max_wave_cycles_16', 'stream_cycles_16', 'wave_cycles_16',
                  'prologue_cycles_16', 'tail_cycles_16', 'items']
         return dict(zip(names, [int(v) for v in out]))

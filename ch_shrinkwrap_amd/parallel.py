@@ -97,9 +97,9 @@ class HipExecutor(object):
     def __init__(self, cg):
         self.cg = cg
         self.L, self.h, self.native = cg._L, cg._h, cg._native
-        stride = self.L.nw_scalar_stride()          # doubles per slot (its ordered partial sums, k_reduce_scalars)
-        self.n_point_scalars = self.L.nw_n_point_scalars() * stride
-        self.n_scalars = self.L.nw_n_scalars() * stride
+        stride = self.L.nw_info(nw.NW_INFO_SCALAR_STRIDE)          # doubles per slot (its ordered partial sums, k_reduce_scalars)
+        self.n_point_scalars = self.L.nw_info(nw.NW_INFO_POINT_SCALARS) * stride
+        self.n_scalars = self.L.nw_info(nw.NW_INFO_SCALARS) * stride
         self._views = {}
         self.write_back = True                      # end(): copy the rank's (M,3) result to the host mesh (a sharded mesh gathers the whole mesh instead)
         self.max_dist = 0.0
@@ -143,7 +143,7 @@ class HipExecutor(object):
         return self._views[key]
 
     def scalars(self, count):
-        # the 24 sums of the current iteration (first nw_n_point_scalars(): point side)
+        # the sums of the current iteration (first NW_INFO_POINT_SCALARS slots: point side + the status slot)
         return self._view(nw.NW_ARR_SCALARS, count, '<f8')
 
     def vertex_accumulator(self):
@@ -193,12 +193,11 @@ class HipExecutor(object):
     def refresh_normals_local(self, extent):
         """block-boundary refresh (_membrane_mesh.pyx:1524-1527) of this rank's share on the device; the owners' normals of the boundary
         vertices are left in boundary_rows() for the all-reduce, take_normals() then gives every holder the owner's"""
-        self.native.check(self.L.nw_set_extent_hint(self.h, float(extent)))
-        self.native.check(self.L.nw_refresh_normals(self.h, None))
-        self.native.check(self.L.nw_halo_pack(self.h, nw.NW_ARR_NRM))
+        self.native.check(self.L.nw_refresh_normals(self.h, None, float(extent)))
+        self.native.check(self.L.nw_halo_rows(self.h, nw.NW_ARR_NRM, 0))
 
     def take_normals(self):
-        self.native.check(self.L.nw_halo_unpack(self.h, nw.NW_ARR_NRM))
+        self.native.check(self.L.nw_halo_rows(self.h, nw.NW_ARR_NRM, 1))
         self.native.check(self.L.nw_reset_history(self.h))          # a new optimiser per block (_membrane_mesh.pyx:1510)
         self.cg.tests, self.cg.ress, self.cg.prefs = [], [], []
 

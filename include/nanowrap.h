@@ -94,15 +94,15 @@ typedef enum nw_array {
     NW_ARR_MESHPOS = 9,     /* (M, 3)  f32  mesh._vertices['position'] as written back at :289                   */
     NW_ARR_VACC = 10,       /* (M, 4)  i64  device-only: per-vertex fixed-point accumulator {A^T res, sum w} in units of nw_accumulator_quantum
                                (xyz) / 2^-40 (w): exact, order-independent sums (multi-GPU all-reduce of integers) */
-    NW_ARR_SCALARS = 11,    /* f64 device-only: normal-equation partial sums of the current iteration (multi-GPU all-reduce), see nw_scalar_stride */
+    NW_ARR_SCALARS = 11,    /* f64 device-only: normal-equation partial sums of the current iteration (multi-GPU all-reduce), see nw_info */
     NW_ARR_NBR = 12,        /* (M, NB) i32  1-ring vertex ids, -1 padded (as given to, or built by, nw_set_mesh)          */
-    NW_ARR_NRM = 13,        /* (M, 3)  f32  vertex normals in use (nw_set_mesh / nw_set_normals / nw_refresh_normals)     */
+    NW_ARR_NRM = 13,        /* (M, 3)  f32  vertex normals in use (nw_set_mesh / nw_refresh_normals)     */
     NW_ARR_VALID = 14,      /* (M,)    u8   valid flags (only when given to, or built by, nw_set_mesh)                   */
     NW_ARR_HALO_ACC = 15,   /* (n_slots, 4) i64  device-only, sharded mesh: this rank's accumulator rows of the boundary vertices, one row per
                                entry of the GLOBAL boundary list (zero where the rank does not hold the vertex): all-reduce(sum) between
                                nw_iter_attract and nw_iter_directions (nw_set_boundary) */
     NW_ARR_HALO_ROWS = 16,  /* (n_slots, 3) f32  device-only: rows of the boundary vertices this rank OWNS (new positions after nw_iter_update;
-                               normals after nw_halo_pack(NW_ARR_NRM)), zero elsewhere: all-reduce(sum) = the owner's row on every rank */
+                               normals after nw_halo_rows(NW_ARR_NRM, 0)), zero elsewhere: all-reduce(sum) = the owner's row on every rank */
     NW_ARR_HALO_FULL = 17,  /* (M_global, 3) f32 device-only: nw_halo_gather_owned -- the owners' rows of the whole mesh */
     NW_ARR_HALO_STATS = 18  /* (4,) f32 device-only: nw_halo_block_stats -- {largest nearest distance, accumulator quantum, max drift^2, 0}: all-reduce(MAX) */
 } nw_array;
@@ -142,12 +142,13 @@ int nw_set_data(nw_ctx *ctx, const float *data);
  * more than n_nbr neighbours is an error (the reference's table has 20 slots, membrane_mesh_utils.h:29). */
 int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const int32_t *nbr, const uint8_t *valid,
                 const int32_t *faces, int64_t n_vertices, int64_t n_faces, int n_nbr);
-/* cheap refresh between blocks with unchanged topology (_membrane_mesh.pyx:1524-1527) */
-int nw_set_normals(nw_ctx *ctx, const float *nrm);
-int nw_set_positions(nw_ctx *ctx, const float *pos);
-/* The same refresh done ON the device for an unchanged topology: area-weighted vertex normals recomputed from the current
- * device-resident positions (no upload); nrm_out (M,3) receives a copy unless NULL. */
-int nw_refresh_normals(nw_ctx *ctx, float *nrm_out);
+/* The refresh between blocks with unchanged topology (_membrane_mesh.pyx:1524-1527) done ON the device: area-weighted vertex normals
+ * recomputed from the current device-resident positions (no upload); nrm_out (M,3) receives a copy unless NULL.  (Positions or normals
+ * edited on the host go through nw_set_mesh: the same topology costs an upload, nothing else.)
+ * whole_mesh_extent > 0: the largest bounding-box edge of the WHOLE mesh, for a rank that holds a share of it -- the quantum of the
+ * fixed-point normal sums is then taken from it instead of from the share's own box, so every holder of a vertex rounds its sum the same
+ * way and the normals are bit-identical to a single-process run; <= 0: this mesh's own box. */
+int nw_refresh_normals(nw_ctx *ctx, float *nrm_out, double whole_mesh_extent);
 /* Start a new optimiser on the resident mesh + localizations: what constructing a new ShrinkwrapMeshConjGrad per block does
  * to the logs and the stop-condition history (_membrane_mesh.pyx:1510, conj_grad.py:35-39), without re-uploading anything. */
 int nw_reset_history(nw_ctx *ctx);
@@ -163,7 +164,7 @@ int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_
  *   nw_iter_attract  : grid build, exact NN, weights, residual, A^T scatter -> NW_ARR_VACC partial sums
  *   -- all-reduce(sum) NW_ARR_VACC over ranks --
  *   nw_iter_directions: curvature prior, S0/S1, vertex dot products, A.S_k and point dot products -> NW_ARR_SCALARS
- *   -- all-reduce(sum) the first nw_n_point_scalars() entries of NW_ARR_SCALARS over ranks --
+ *   -- all-reduce(sum) the first nw_info(NW_INFO_POINT_SCALARS) slots of NW_ARR_SCALARS over ranks --
  *   nw_iter_update   : <=3x3 solve, f += S c, write-back, log record
  * nw_search_begin/_end bracket the iterations of one search() call. */
 int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int num_iters, uint32_t flags);
@@ -171,12 +172,14 @@ int nw_iter_attract(nw_ctx *ctx);
 int nw_iter_directions(nw_ctx *ctx);
 int nw_iter_update(nw_ctx *ctx);
 int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *loopcount);
-int nw_n_point_scalars(void);
-/* NW_ARR_SCALARS layout: slot k occupies nw_scalar_stride() consecutive doubles (its ordered partial sums; the consumer adds
- * them in order, so the result is deterministic); all-reduce the first nw_n_point_scalars()*nw_scalar_stride() doubles (a shared mesh)
- * or nw_n_scalars()*nw_scalar_stride() (disjoint tiles, one global subspace solve) between nw_iter_directions and nw_iter_update. */
-int nw_n_scalars(void);
-int nw_scalar_stride(void);
+/* NW_ARR_SCALARS layout: slot k occupies nw_info(NW_INFO_SCALAR_STRIDE) consecutive doubles (its ordered partial sums; the consumer adds
+ * them in order, so the result is deterministic); all-reduce the first NW_INFO_POINT_SCALARS x stride doubles (a shared mesh: the point-side
+ * sums and the status slot) or NW_INFO_SCALARS x stride (disjoint tiles, one global subspace solve) between nw_iter_directions and
+ * nw_iter_update. */
+#define NW_INFO_POINT_SCALARS 0
+#define NW_INFO_SCALARS 1
+#define NW_INFO_SCALAR_STRIDE 2
+int nw_info(int what);
 
 /* ---- operators & state read-back ------------------------------------------------------------------------- */
 /* y = A x   (Afunc, mesh_conj_grad.py:518-551)  x: (3M,) -> y: (3N,), with the cached weight matrix */
@@ -199,7 +202,7 @@ int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *cont
  * (nw_destroy does too).  From then on nw_search with ONE of the NW_FLAG_COMM_* flags runs a block's collectives itself: ncclAllReduce
  * on the ctx's own stream between the phases, recorded into the block's hipGraph like every kernel launch --
  *   NW_FLAG_COMM_TILES       disjoint tiles (every rank owns its localizations AND the mesh components inside its tile): the normal-equation
- *                            sums only (nw_n_scalars() x nw_scalar_stride() doubles): one global <=3x3 solve, conj_grad.py:202-219;
+ *                            sums only (nw_info(NW_INFO_SCALARS) x nw_info(NW_INFO_SCALAR_STRIDE) doubles): one global <=3x3 solve, conj_grad.py:202-219;
  *   NW_FLAG_COMM_REPLICATED  mesh replicated, localizations sharded: the per-vertex accumulator (M x 4 int64) and the point-side sums;
  *   NW_FLAG_COMM_HALO        one mesh sharded with nw_set_boundary: the accumulator's boundary rows, the sums, the owners' new boundary rows.
  * Every rank must call nw_search with the same flags, num_iters and lams.  A status raised on one rank (NaN, ...) travels with the sums:
@@ -210,14 +213,11 @@ int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *cont
 int nw_comm_unique_id(uint8_t *out, int64_t nbytes);
 int nw_comm_init(nw_ctx *ctx, const uint8_t *unique_id, int64_t nbytes, int rank, int nranks);
 int nw_comm_all_reduce(nw_ctx *ctx, void *buf, int64_t count, int dtype, int op);
-/* Sharded mesh ('halo' mode): owned[M] = 1 for the vertices this rank owns, 0 for the copies of vertices owned by
- * another rank.  The vertex-side normal-equation sums (S^T S, S.prefs, |prefs|^2) then run over the owned vertices only, so that the
- * all-reduce over ranks counts every vertex once.  NULL = every vertex is owned (default).  Reset by nw_set_mesh. */
-int nw_set_owned(nw_ctx *ctx, const uint8_t *owned);
 /* Sharded mesh, complete form (SURVEY.md section 8e "all-reduce on the boundary-vertex rows only"; no reference counterpart -- the reference is
  * one process, conj_grad.py:202-219 solves ONE system for the whole mesh, which the all-reduced sums reproduce).  b_local[n_local] = local ids
  * of the vertices this rank holds that are held by another rank as well; b_slot[n_local] = their rows in the global boundary list of n_slots
- * entries (the same list on every rank); owned[M] as nw_set_owned; gv[M] = global id of every local vertex, n_global = vertices of the whole
+ * entries (the same list on every rank); owned[M] = 1 for the vertices this rank owns, 0 for its copies of vertices another rank owns (the
+ * vertex-side normal-equation sums then run over the owned vertices only: the all-reduce counts every vertex once; NULL = all owned); gv[M] = global id of every local vertex, n_global = vertices of the whole
  * mesh.  After this call the split-phase iteration fills / takes the exchange buffers itself and the caller only all-reduces them:
  *   nw_iter_attract -> all-reduce NW_ARR_HALO_ACC (int64 sum) -> nw_iter_directions -> all-reduce NW_ARR_SCALARS -> nw_iter_update ->
  *   all-reduce NW_ARR_HALO_ROWS (f32 sum of owner-only rows); the next nw_iter_attract / nw_search_end takes the owners' positions.
@@ -225,10 +225,10 @@ int nw_set_owned(nw_ctx *ctx, const uint8_t *owned);
 int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t *b_slot, int64_t n_local, int64_t n_slots, const uint8_t *owned,
                     const int32_t *gv, int64_t n_global);
 /* the exchange buffers by hand: what = NW_ARR_VACC (-> / <- NW_ARR_HALO_ACC), NW_ARR_POS or NW_ARR_NRM (owner-only rows -> / <- NW_ARR_HALO_ROWS;
- * positions are taken into NW_ARR_POS and NW_ARR_MESHPOS).  Needed by a caller only for the vertex normals after nw_refresh_normals (a rank
- * does not hold every face of the vertices at the rim of its share: the owner's normal is the mesh's, _membrane_mesh.pyx:1524-1527). */
-int nw_halo_pack(nw_ctx *ctx, int what);
-int nw_halo_unpack(nw_ctx *ctx, int what);
+ * positions are taken into NW_ARR_POS and NW_ARR_MESHPOS); unpack = 0 fills the buffer from this rank's rows, 1 takes the (all-reduced) buffer.
+ * Needed by a caller only for the vertex normals after nw_refresh_normals (a rank does not hold every face of the vertices at the rim of its
+ * share: the owner's normal is the mesh's, _membrane_mesh.pyx:1524-1527). */
+int nw_halo_rows(nw_ctx *ctx, int what, int unpack);
 /* NW_ARR_HALO_FULL <- the rows (what = NW_ARR_POS or NW_ARR_NRM) of the vertices this rank owns at their global ids, zero elsewhere: one
  * all-reduce(sum) per BLOCK gives every rank the whole mesh (the positions search() returns, mesh_conj_grad.py:288-292) */
 int nw_halo_gather_owned(nw_ctx *ctx, int what);
@@ -243,10 +243,6 @@ int nw_halo_gather_owned(nw_ctx *ctx, int what);
  * which quantum do the integer accumulators of the next block share. */
 int nw_halo_set_reference(nw_ctx *ctx, const float *full, const float *d0, int64_t n_d0);
 int nw_halo_block_stats(nw_ctx *ctx, double max_dist);
-/* extent (largest bounding-box edge) of the WHOLE mesh, for a rank that holds a share of it: nw_refresh_normals takes the quantum of its
- * fixed-point normal sums from it instead of from the share's own box, so every holder of a vertex rounds its sum the same way and the
- * normals are bit-identical to a single-process run.  ext <= 0: back to the local box. */
-int nw_set_extent_hint(nw_ctx *ctx, double ext);
 
 /* registers the strided vertex records (mesh._vertices['position'] rows, `row_stride_bytes` apart) that nw_search / nw_search_end
  * fill together with `pos_out` at the end of every search (valid vertices only, mesh_conj_grad.py:288-289); NULL switches it off */
@@ -269,7 +265,7 @@ int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, float *out)
  * skip_prob folded into the valid flags of nw_set_mesh: a vertex the reference would skip (:962, `r2() < skip_prob`; never > 0 on the
  * live path) is an unused slot for this call -- its H, K, dH, dK, dE_neighbors, E, pE, dEdN read 0 and its k0, k1, e0, e1 rows keep
  * what the caller's arrays held.  Works on the ctx's CURRENT device-resident mesh positions, the
- * normals of nw_set_mesh / nw_set_normals and the neighbour table of nw_set_mesh (walk stops at the first -1, as the
+ * normals of nw_set_mesh / nw_refresh_normals and the neighbour table of nw_set_mesh (walk stops at the first -1, as the
  * reference's does).  nbr_next (M,NB) i32 = halfedges[halfedges[neighbors[j]].next].vertex, nbr_area (M,NB) f32 =
  * faces[halfedges[neighbors[j]].face].area.  jitter: (M,3) float64 in [0,1) standing for the reference's rand() stream
  * (:1017), or NULL for a deterministic hash of (vertex, axis).  Outputs (host or device): k0,k1,H,K,dH,dK,E,pE,
@@ -304,16 +300,16 @@ int nw_optimize_layout(nw_ctx *ctx);
  * the override: ranks all-reduce it again for every block. */
 int nw_accumulator_quantum(nw_ctx *ctx, double *q);
 
-/* developer aid, no reference counterpart: counters of the exact nearest-face query accumulated since the previous call (the first
- * call switches the counting on; the counting variant of the kernel is a few per cent slower).  out[13]: candidate evaluations per wave
- * summed, non-empty rows listed, rows visited, cells tested, cells visited, rows of the boxes, rounds, slowest wave, and the waves' time
- * (s_memtime ticks / 16) in the candidate stream / in all / before the walk / after it; out[12] = work items. */
-int nw_debug_nn_stats(nw_ctx *ctx, int64_t *out);
-/* developer aid: work list of the NN query ({first localization in sorted order, count} per item) and the duration (s_memtime ticks / 16)
- * the last query measured for each item; zeros once the list has been ordered (heavy first, light last).  With NW_ITEM_TIMES set in the
- * environment the timing stays on, durations are in 10 ns ticks of the clock all XCDs share, and out_cost must hold 2 * cap entries: the
- * second `cap` receive when each item started -- the launch's time line (tools/nn_costs.py). */
-int nw_debug_items(nw_ctx *ctx, int32_t *out_items, uint32_t *out_cost, int cap, int *n);
+/* developer aids, no reference counterpart (one entry point):
+ * what = 0: counters of the exact nearest-face query accumulated since the previous call (the first call switches the counting on; the
+ *   counting variant of the kernel is a few per cent slower).  a = int64 out[13]: candidate evaluations per wave summed, non-empty rows listed,
+ *   rows visited, cells tested, cells visited, rows of the boxes, rounds, slowest wave, and the waves' time (s_memtime ticks / 16) in the
+ *   candidate stream / in all / before the walk / after it; out[12] = work items.  b, cap, n unused.
+ * what = 1: the work list of the query -- a = int32 {first localization in sorted order, count}[cap], b = uint32 cost[cap] (duration in
+ *   s_memtime ticks / 16 the last query measured for each item; zeros once the list has been ordered: heavy first, light last), *n = items in
+ *   the list.  With NW_ITEM_TIMES set in the environment the timing stays on, durations are in 10 ns ticks of the clock all XCDs share, and b
+ *   must hold 2 * cap entries: the second `cap` receive when each item started -- the launch's time line (tools/nn_costs.py). */
+int nw_debug(nw_ctx *ctx, int what, void *a, void *b, int cap, int *n);
 
 #ifdef __cplusplus
 }

@@ -280,7 +280,7 @@ def test_sharded_mesh_entry_points_check_their_arguments():
     owned = np.ones(M, np.uint8)
     gv = i32(np.arange(M))
     with pytest.raises(ValueError):                                   # no boundary yet
-        cg._native.check(L.nw_halo_pack(h, nw.NW_ARR_POS))
+        cg._native.check(L.nw_halo_rows(h, nw.NW_ARR_POS, 0))
     for bl, bs, ns in ((i32([M]), i32([0]), 4), (i32([3]), i32([4]), 4), (i32([3, 5]), i32([1, 1]), 4)):      # vertex out of range / slot out of range / slot twice
         with pytest.raises(ValueError):
             cg._native.check(L.nw_set_boundary(h, nw.ptr(bl), nw.ptr(bs), bl.size, ns, nw.ptr(owned), nw.ptr(gv), M))

@@ -1,5 +1,5 @@
 """Developer probe: distribution of the per-item duration of the nearest-face query (s_memtime ticks of the production kernel,
-nw_debug_items) a few warm queries into a fit.  NW_ITEM_ORDER=0 keeps the timing on.  usage: python tools/nn_costs.py [config] [scale]"""
+nw_debug what = 1) a few warm queries into a fit.  NW_ITEM_ORDER=0 keeps the timing on.  usage: python tools/nn_costs.py [config] [scale]"""
 import os, sys, ctypes
 os.environ.setdefault('NW_ITEM_TIMES', '1')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +27,7 @@ for b in range(3):
     items = np.zeros((cap, 2), np.int32)
     cost = np.zeros(2 * cap, np.uint32)
     n_items = ctypes.c_int(0)
-    cg._native.check(cg._L.nw_debug_items(cg._h, items.ctypes.data_as(ctypes.c_void_p), cost.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n_items)))
+    cg._native.check(cg._L.nw_debug(cg._h, 1, items.ctypes.data_as(ctypes.c_void_p), cost.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n_items)))
     k = n_items.value
     cst = cost[:k].astype(np.float64)
     print('block %d: nn %.1f us/query; %d items; item ticks: mean %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f; share of the total in the slowest 1%%: %.2f, slowest 10%%: %.2f' % (

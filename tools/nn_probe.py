@@ -1,5 +1,5 @@
 """Developer probe of the nearest-face query on the headline workload: per-iteration query time (HIP events, profiling level 1) and the
-walk counters and phase shares of nw_debug_nn_stats.
+walk counters and phase shares of nw_debug (what = 0).
 usage: python tools/nn_probe.py [config] [scale] [blocks]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
