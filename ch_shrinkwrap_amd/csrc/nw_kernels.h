@@ -385,8 +385,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
     }
 }
 
-// K4b as a launch of its own (the multi-GPU phases and NW_FUSE_ATTRACT=0; the single-GPU iteration runs the step in the tail of the
-// query kernel): one thread per localization, nw_attract_point (nw_attract.h), the workgroup's 256 localizations share one table.
+// K4b: the attraction step, one thread per localization (nw_attract_point, nw_attract.h), the workgroup's 256 localizations share one
+// table.  (Running it in the tail of the query kernel was measured in round 3 and not kept: tools/experiments/r03_notes.md.)
 #define NW_HT 512          // slots of the per-workgroup table: 18 KB of LDS, 8 workgroups per CU (1024 slots: 36 KB, 4 per CU, 10 us slower)
 #define NW_HT_BITS 9
 #define NW_ATTRACT_PPT 1      // (2: 39.7 us against 36.5 -- the two dependent load chains of a thread do not overlap)

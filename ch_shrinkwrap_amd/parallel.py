@@ -627,21 +627,28 @@ class ArrayMesh(object):
         pass
 
 
+class HaloExceeded(RuntimeError):
+    """a block of a sharded mesh ran beyond what its shares guarantee (HaloScene.search cuts new shares and runs it again, once)"""
+
+
 class HaloScene(object):
     """Front end of the 'halo' mode: every rank holds the whole mesh on the HOST (it is small: 24 bytes per vertex) and its own share of
     everything on the DEVICE, and keeps it there:
 
       * the tiles of the cloud are cut once (they do not depend on the mesh), a rank's localizations are uploaded once;
       * the partition of the mesh (HaloPartition: shares, owners, boundary list), the rank's sub-mesh on the device and the optimiser
-        over it are built once per topology -- and again when the mesh has moved by more than a quarter of the halo radius since, or
+        over it are built once per topology -- and again when the mesh has moved too far for the margin the shares were cut with, or
         after mesh_changed() (a remesh);
       * search() = one block on the resident state: run_search(..., 'halo') and then ONE all-reduce of the owners' rows, float32 on the
         device, that gives every rank the whole new mesh (copied to the host mesh like search() does, mesh_conj_grad.py:288-289);
       * refresh_normals() = the block-boundary refresh (_membrane_mesh.pyx:1524-1527) for an unchanged topology on the device: every rank
         refreshes its share, the owners' normals of the boundary vertices go round, the optimiser history restarts.
 
-    The sharded nearest-face query is exact as long as max nearest distance + displacement since the partition <= halo; checked after
-    every block, the run raises otherwise.
+    The sharded nearest-face query is exact as long as (growth of any nearest distance since the shares were cut) + (drift of the mesh
+    since then) stays within the margin the shares were cut with (per-localization halos; with one radius for all: largest nearest
+    distance + drift <= halo); checked after every block -- a block that went beyond runs again on new shares (search()), and new shares
+    are cut BEFORE a block whenever another block like the last one could go beyond (margin = five times the last block's movement,
+    never more than `halo`).
 
     make_executor(local_mesh, local_points) -> executor (HipExecutor over a ShrinkwrapMeshConjGrad in production; the CPU tests pass
     an oracle-backed one)."""
@@ -807,6 +814,21 @@ class HaloScene(object):
 
     # -- one block ----------------------------------------------------------------------------------------------------------------
     def search(self, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
+        """One block.  The sharded query is only known to have been exact AFTER the block (the growth of the nearest distances and the
+        drift of the mesh against the margin the shares were cut with): if it was not, the host mesh still holds the positions of the
+        block's start -- new shares are cut from it with the whole `halo` as margin and the block runs once more; only a block that fails
+        on fresh shares raises."""
+        try:
+            return self._search_once(lams, num_iters, sigma_inv, weights, pos, last_step)
+        except HaloExceeded:
+            if self._blocks_since_partition == 0 and self._cut_margin >= self.halo:
+                raise
+            self.margin = self.halo
+            self.last_partition = None
+            self.redone_blocks = getattr(self, 'redone_blocks', 0) + 1
+            return self._search_once(lams, num_iters, sigma_inv, weights, pos, last_step)
+
+    def _search_once(self, lams, num_iters, sigma_inv, weights=None, pos=False, last_step=True):
         import time
         if self.last_partition is None:
             self._setup()
@@ -860,7 +882,7 @@ class HaloScene(object):
         drift = float(np.sqrt(max(d2, 0.0)))
         budget = self._cut_margin if self.per_point else self.halo
         if worst + drift > budget:
-            raise RuntimeError("halo mode: %s %.3g and the mesh has moved %.3g since the shares were cut, beyond the %s %.3g: the sharded query "
+            raise HaloExceeded("halo mode: %s %.3g and the mesh has moved %.3g since the shares were cut, beyond the %s %.3g: the sharded query "
                                "is not guaranteed exact (increase `halo`)" % ("a nearest distance has grown by" if self.per_point else "a localization's nearest face centroid is at",
                                                                                worst, drift, "margin" if self.per_point else "halo radius", budget))
         posv = mesh._vertices['position']

@@ -3,7 +3,7 @@
   <tag>_bench.json                       the bench line of the same round (no profiler attached)
   <tag>_pmc_and_trace_summary.json       per-kernel HBM traffic from the FETCH_SIZE / WRITE_SIZE passes + average durations
   <tag>_sq_counters.json                 per-kernel SQ counters (mean per dispatch)
-  r03_pmc_traffic.json                   what bench.py reports as roofline.traffic (tagged there as file-sourced)
+  r04_pmc_traffic.json                   what bench.py reports as roofline.traffic (tagged there as file-sourced)
 HBM bytes per launch: both counters are in KiB; gfx950's FETCH_SIZE counts exactly half of a WIDE coalesced read (16 B per lane) and other
 access widths are uncalibrated (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).  So the doubling is applied only to
 the kernel whose loads are 16 B per lane -- k_nn_wave: float4 localizations, float4 centroids -- and every kernel gets both bounds:
@@ -97,7 +97,7 @@ out['_note'] = ('HBM bytes per launch from separate rocprofv3 --pmc passes: (2*F
                 'bound is in _bounds); mean of the timed iterations of bench.py --steps 10 --warmup 10; profiles/' + tag + '_*')
 out['_bounds'] = {k: [traffic[k]['hbm_bytes_lower'], traffic[k]['hbm_bytes_upper']] for k in traffic}
 out['_source_tag'] = tag
-json.dump(out, open(os.path.join(dst, 'r03_pmc_traffic.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(dst, 'r04_pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
 for k in ('k_nn_wave', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_reduce_scalars', 'k_prior_directions', 'k_solve_update', 'k_face_centroids', 'k_scan_tile_sums', 'k_scan_final', 'k_centroid_scatter'):
     if k in dur:
