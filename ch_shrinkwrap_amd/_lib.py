@@ -100,6 +100,28 @@ def load():
     return L
 
 
+_hip = None
+
+
+def pinned_empty(shape, dtype):
+    """ndarray over page-locked host memory (hipHostMalloc): a device-to-host copy into it is a plain DMA, not a staged one.  The memory lives
+    as long as the process (block-sized buffers allocated once per scene).  Falls back to ordinary memory if the HIP runtime cannot be loaded."""
+    global _hip
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    try:
+        if _hip is None:
+            _hip = ctypes.CDLL('libamdhip64.so')
+            _hip.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+            _hip.hipHostMalloc.restype = ctypes.c_int
+        p = ctypes.c_void_p()
+        if _hip.hipHostMalloc(ctypes.byref(p), max(n, 1), 0) != 0 or not p.value:
+            raise OSError('hipHostMalloc failed')
+        buf = (ctypes.c_char * max(n, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    except Exception:
+        return np.empty(shape, dtype)
+
+
 def ptr(a):
     """host ndarray (C-contiguous) or raw integer device pointer -> c_void_p"""
     if a is None:

@@ -238,6 +238,9 @@ struct nw_ctx {
     bool have_halo_d0 = false;
     int64_t halo_d0_n = 0;
     DevBuf<float> halo_stats;         // {largest nearest distance, quantum, max drift^2, 0}: one MAX all-reduce per block
+    void *pin_full = nullptr;         // pinned: the whole mesh (3 M_global floats) + the 4 statistics, staged by the tail of a sharded nw_search block
+    size_t pin_full_bytes = 0;
+    bool full_staged = false;         // pin_full holds the result of the last block (until the next search begins)
     bool have_halo_ref = false;
     int64_t hb_n = 0, hb_nslot = 0, M_global = 0;
     bool have_boundary = false;
@@ -609,6 +612,7 @@ NW_EXPORT int nw_create(int device, nw_ctx **out)
 NW_EXPORT void nw_destroy(nw_ctx *ctx)
 {
     if (ctx && ctx->comm) (void)nw_comm_init(ctx, nullptr, 0, 0, 0);
+    if (ctx && ctx->pin_full) { (void)hipHostFree(ctx->pin_full); ctx->pin_full = nullptr; }
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -1067,7 +1071,7 @@ NW_EXPORT int nw_halo_block_stats(nw_ctx *ctx, double max_dist)
     NW_HIP(hipMemsetAsync(ctx->halo_stats.p, 0, 4 * sizeof(float), ctx->stream));
     const int blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (ctx->M_global + NW_BLOCK - 1) / NW_BLOCK));
     hipLaunchKernelGGL(k_halo_block_stats, dim3(blocks), dim3(NW_BLOCK), 0, ctx->stream, ctx->M_global, ctx->halo_full.p, ctx->halo_ref.p, (float)max_dist,
-                       (float)ctx->local_quantum, ctx->halo_stats.p);
+                       (float)ctx->local_quantum, ctx->halo_stats.p, (const NwIterLogDev *)nullptr, 0);
     NW_HIP(hipGetLastError());
     return NW_OK;
 }
@@ -1347,6 +1351,7 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     ctx->acc_quantum = ctx->quantum_override > 0 ? ctx->quantum_override : ctx->local_quantum;
     ctx->w_quantum = std::ldexp(1.0, -40);
     ctx->lam0 = lams[0];
+    ctx->full_staged = false;
     ctx->comm_mode = flags & (NW_FLAG_COMM_TILES | NW_FLAG_COMM_REPLICATED | NW_FLAG_COMM_HALO);
     ctx->search_flags = flags & ~(NW_FLAG_RESULT_TO_HOST | NW_FLAG_COMM_TILES | NW_FLAG_COMM_REPLICATED | NW_FLAG_COMM_HALO);
     ctx->direct_out = false;
@@ -1821,6 +1826,32 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         const int r = run_iteration(ctx);
         if (r != NW_OK) { ctx->in_search = false; return r; }
     }
+    if ((cmode & NW_FLAG_COMM_HALO) && ctx->have_boundary && ctx->have_halo_ref && num_iters > 0) {
+        // The tail of a sharded block, enqueued behind its last iteration (no host round trip in between): the owners' rows of the whole
+        // mesh go round, then the three numbers the ranks agree on per block (exactness of the sharded query, drift, next quantum), and
+        // both land in pinned host memory -- nw_search_end's one synchronisation covers them (nw_host_copy_rows with src = NULL and
+        // nw_get(NW_ARR_HALO_STATS) then read the staged copies).
+        if (ctx->pos_unpack_pending) { ctx->pos_unpack_pending = false; NW_TRY(halo_unpack(ctx, NW_ARR_POS)); }
+        const size_t fb = (size_t)3 * ctx->M_global * sizeof(float);
+        if (ctx->pin_full_bytes < fb + 16) {
+            if (ctx->pin_full) (void)hipHostFree(ctx->pin_full);
+            ctx->pin_full = nullptr; ctx->pin_full_bytes = 0;
+            NW_HIP(hipHostMalloc(&ctx->pin_full, fb + 16, hipHostMallocDefault));
+            ctx->pin_full_bytes = fb + 16;
+        }
+        NW_HIP(hipMemsetAsync(ctx->halo_full.p, 0, fb, ctx->stream));
+        hipLaunchKernelGGL(k_halo_gather_owned, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->hb_gv.p, ctx->owned.p, ctx->pos.p, ctx->halo_full.p);
+        NW_TRY(comm_all_reduce_dev(ctx, ctx->halo_full.p, (size_t)3 * ctx->M_global, ncclFloat, ncclSum));
+        NW_HIP(hipMemsetAsync(ctx->halo_stats.p, 0, 4 * sizeof(float), ctx->stream));
+        const int sblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (ctx->M_global + NW_BLOCK - 1) / NW_BLOCK));
+        hipLaunchKernelGGL(k_halo_block_stats, dim3(sblocks), dim3(NW_BLOCK), 0, ctx->stream, ctx->M_global, ctx->halo_full.p, ctx->halo_ref.p, 0.0f,
+                           (float)ctx->local_quantum, ctx->halo_stats.p, (const NwIterLogDev *)ctx->logs.p, num_iters);
+        NW_HIP(hipGetLastError());
+        NW_TRY(comm_all_reduce_dev(ctx, ctx->halo_stats.p, 4, ncclFloat, ncclMax));
+        NW_HIP(hipMemcpyAsync(ctx->pin_full, ctx->halo_full.p, fb, hipMemcpyDeviceToHost, ctx->stream));
+        NW_HIP(hipMemcpyAsync((char *)ctx->pin_full + fb, ctx->halo_stats.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->full_staged = true;
+    }
     const auto t2 = std::chrono::steady_clock::now();
     if (trace_blocks) (void)hipEventRecord(tb1, ctx->stream);
     const int rc = nw_search_end(ctx, pos_out, log, loopcount);
@@ -1898,6 +1929,10 @@ NW_EXPORT int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes)
     const void *src = nullptr;
     int64_t need = 0;
     int width = 0;                       // >0: per-point array that must be un-permuted
+    if (what == NW_ARR_HALO_STATS && ctx->full_staged && nbytes >= 16) {      // the staged copy of a sharded block's tail: no device round trip
+        memcpy(dst, (const char *)ctx->pin_full + (size_t)3 * ctx->M_global * sizeof(float), 16);
+        return NW_OK;
+    }
     switch (what) {
     case NW_ARR_RES: src = ctx->res.p; width = 3; break;
     case NW_ARR_VIDX: src = ctx->vidx.p; width = 3; break;
@@ -2020,7 +2055,11 @@ NW_EXPORT int nw_write_back(nw_ctx *ctx, float *contiguous, void *rows, int64_t 
 // (only where valid[v] != 0 if `valid` is given).  No device work.
 NW_EXPORT int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *contiguous, void *rows, int64_t row_stride_bytes, const uint8_t *valid)
 {
-    if (!ctx || !src || n_rows < 0) return NW_ERR_BADARG;
+    if (!ctx || n_rows < 0) return NW_ERR_BADARG;
+    if (!src) {          // the whole mesh a sharded nw_search block left in pinned memory (its tail; nw_search_end has synchronised)
+        if (!ctx->full_staged || n_rows != ctx->M_global) return fail(ctx, NW_ERR_BADARG, "nw_host_copy_rows: no staged result of a sharded block (nw_search with NW_FLAG_COMM_HALO)");
+        src = (const float *)ctx->pin_full;
+    }
     if (rows && row_stride_bytes < 12) return fail(ctx, NW_ERR_BADARG, "nw_host_copy_rows: bad stride");
     if (!ctx->pool) {
         int T = 8;

@@ -1000,8 +1000,10 @@ __global__ __launch_bounds__(NW_BLOCK) void k_halo_gather_owned(int M, const int
 // rank's accumulator quantum, max over the WHOLE mesh of |full - ref|^2} as float32 (a power-of-two quantum is exact in float32), for one
 // MAX all-reduce over the ranks.  `full` = the whole mesh after the all-reduce of the owners' rows, `ref` = where the mesh was when the
 // shares were cut.  stats[2] must be zero before the launch (non-negative floats order like unsigned integers: atomicMax on the bits).
+// logs != NULL: max_dist is taken from the block's own iteration records on the device (the largest of the executed iterations) instead of
+// from the host -- the block's tail is then enqueued behind its last iteration without waiting for the logs (nw_search on a sharded mesh)
 __global__ __launch_bounds__(NW_BLOCK) void k_halo_block_stats(int64_t n_global, const float *__restrict__ full, const float *__restrict__ ref, float max_dist, float quantum,
-                                                              float *__restrict__ stats)
+                                                              float *__restrict__ stats, const NwIterLogDev *__restrict__ logs, int nlogs)
 {
     float m = 0.0f;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_global; v += (int64_t)gridDim.x * blockDim.x) {
@@ -1012,7 +1014,10 @@ __global__ __launch_bounds__(NW_BLOCK) void k_halo_block_stats(int64_t n_global,
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned *>(stats) + 2, __float_as_uint(m));
-    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = max_dist; stats[1] = quantum; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (logs) { max_dist = 0.0f; for (int i = 0; i < nlogs; ++i) if (logs[i].executed) max_dist = fmaxf(max_dist, (float)logs[i].max_dist); }
+        stats[0] = max_dist; stats[1] = quantum;
+    }
 }
 
 // ---- block-boundary geometry refresh (the reference's `self.face_normals; self.vertex_neighbors` after a block,

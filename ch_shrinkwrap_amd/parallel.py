@@ -839,19 +839,14 @@ class HaloScene(object):
             # the library's communicator and stream: the block, then the owners' rows of the whole mesh and the block's statistics go round
             run_search(ex, None, 'halo', self._local_points, lams, num_iters, self._local(sigma_inv), self._local(weights), pos, last_step,
                        quantum=self._quantum)
+            # (the block's tail -- the owners' rows of the whole mesh and the block's statistics going round, both staged in pinned host
+            # memory -- ran inside nw_search, behind the last iteration: what is left is host work)
             t0 = time.perf_counter()
             L, h, chk = ex.L, ex.h, ex.native.check
-            chk(L.nw_halo_gather_owned(h, nw.NW_ARR_POS))
-            self.comm.all_reduce_device(nw.NW_ARR_HALO_FULL, 3 * ex.n_global, np.float32)
-            chk(L.nw_halo_block_stats(h, float(ex.max_dist)))
-            self.comm.all_reduce_device(nw.NW_ARR_HALO_STATS, 4, np.float32, NativeComm.MAX)
-            if self._host_full is None or self._host_full.shape[0] != ex.n_global:
-                self._host_full = np.empty((ex.n_global, 3), np.float32)
-            newpos = self._host_full
-            chk(L.nw_get(h, nw.NW_ARR_HALO_FULL, nw.ptr(newpos), newpos.nbytes))
             st4 = np.zeros(4, np.float32)
             chk(L.nw_get(h, nw.NW_ARR_HALO_STATS, nw.ptr(st4), st4.nbytes))
             worst, q, d2 = float(st4[0]), float(st4[1]), float(st4[2])
+            newpos = None                                     # (the staged mesh: copied out by the library's host threads below)
             return self._finish_block(ex, mesh, newpos, worst, q, d2, t0)
         import torch
         with self._stream():
@@ -886,8 +881,22 @@ class HaloScene(object):
                                "is not guaranteed exact (increase `halo`)" % ("a nearest distance has grown by" if self.per_point else "a localization's nearest face centroid is at",
                                                                                worst, drift, "margin" if self.per_point else "halo radius", budget))
         posv = mesh._vertices['position']
-        out = np.empty((newpos.shape[0], 3), np.float32)
-        if hasattr(ex, 'host_copy_rows') and posv.dtype == np.float32 and posv.strides[1] == 4 and posv.strides[0] >= 12:
+        n_rows = ex.n_global if newpos is None else newpos.shape[0]
+        # the (M,3) result: a fresh 2.4 MB array costs ~600 page faults per block -- two buffers take turns (the caller holds at most the
+        # previous block's result when the next one is written; keep a copy of anything older)
+        pool = getattr(self, '_out_pool', None)
+        if pool is None or pool[0].shape[0] != n_rows:
+            pool = self._out_pool = [np.empty((n_rows, 3), np.float32) for _ in range(2)]
+            self._out_turn = 0
+        self._out_turn ^= 1
+        out = pool[self._out_turn]
+        if newpos is None:
+            direct = posv.dtype == np.float32 and posv.strides[1] == 4 and posv.strides[0] >= 12
+            ex.native.check(ex.L.nw_host_copy_rows(ex.h, None, n_rows, nw.ptr(out), ctypes.c_void_p(posv.ctypes.data) if direct else None, posv.strides[0] if direct else 0,
+                                                   None if self._all_valid else nw.ptr(self._valid_u8)))
+            if not direct:
+                posv[self._valid] = out[self._valid]
+        elif hasattr(ex, 'host_copy_rows') and posv.dtype == np.float32 and posv.strides[1] == 4 and posv.strides[0] >= 12:
             ex.host_copy_rows(newpos, out, posv, None if self._all_valid else self._valid_u8)      # the library's copy threads
         else:
             out[:] = newpos
@@ -930,8 +939,8 @@ class HaloScene(object):
         """One-off set-up a caller can take out of a timed region (bench.py, after its warm-up): shares cut NOW with the margin the fit
         needs from here on (the first shares were cut with the whole `halo`, for a mesh that still moves by tens of nm per block), then the
         library's own set-up (projection sort, cell tuner, work list)."""
-        if (self.per_point and self._blocks_total > 0 and not getattr(self, '_layout_cut', False)
-                and self._wanted_margin() < 0.8 * getattr(self, '_cut_margin', self.halo)):
+        if self.per_point and self._blocks_since_partition > 0 and not getattr(self, '_layout_cut', False):
+            # (also when the margin stays what it was: the drift and the growth the margin pays for are counted from the cut)
             self.margin = self._wanted_margin()
             self.last_partition = None
             self._layout_cut = True                 # (once: a second call -- after the new shares' first, cold, block -- is for the library's own set-up)
