@@ -1423,17 +1423,19 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
         static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;   // 0 slabs, 1 round-robin, 2 interleaved runs (default)
         static const bool no_outliers = getenv("NW_NO_OUTLIERS") != nullptr;      // developer knob
         static const bool item_times = getenv("NW_ITEM_TIMES") != nullptr;        // developer aid: nw_debug_items also returns when every item started
+        static const float outl_f = getenv("NW_OUTL_F") ? (float)atof(getenv("NW_OUTL_F")) : 6.25f;          // developer knobs: which lanes a wave sets aside (nw_nn.h "Outliers")
+        static const int outl_max = getenv("NW_OUTL_MAX") ? atoi(getenv("NW_OUTL_MAX")) : NW_OUTLIERS;
         static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
         const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;   // one wave = one work item
         const int nbp = nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
 if (ctx->nn_stats.p) {
             hipLaunchKernelGGL(k_nn_wave<true>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (item_times ? 64 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr);
+                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max);
         } else {
             hipLaunchKernelGGL(k_nn_wave<false>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (item_times ? 64 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr);
+                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max);
         }
         if (ctx->face_warm && !ctx->items_by_cost) ctx->item_cost_valid = true;      // (a cold query's costs say little about the warm ones)
         ctx->face_warm = true;

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                  const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,
                                                  int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
                                                  NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats,
-                                                 unsigned *__restrict__ item_cost, const int *__restrict__ face_orig)
+                                                 unsigned *__restrict__ item_cost, const int *__restrict__ face_orig, float outl_f, int outl_max)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ NwWaveLds s_wave[4];
@@ -568,8 +568,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
         const float mean = nw_readlane_f(sum, 0) / (float)item.n;
-        const unsigned long long m = __ballot(active && prev >= 0 && r2 > 6.25f * mean && r2 * cullk > 2.25f);
-        if (__popcll(m) <= NW_OUTLIERS) outl_mask = m;
+        const unsigned long long m = __ballot(active && prev >= 0 && r2 > outl_f * mean && r2 * cullk > 2.25f);
+        if (__popcll(m) <= outl_max) outl_mask = m;
     }
     const bool wact = active && !((outl_mask >> lane) & 1ull);         // takes part in the walk
     // wave origin = mean of the walk's localizations (idle and outlier lanes stand in for the first of them), bias K = largest
