@@ -86,6 +86,13 @@ class OracleExecutor(object):
         self.nrm = nrm
         self.pos0 = self.f.reshape(-1, 3).copy()             # a new optimiser starts from the mesh's positions
 
+    d0 = None
+
+    def set_reference(self, full_positions, d0=None):
+        """per-localization halos (same contract as parallel.HipExecutor.set_reference): with d0 the block's statistic is the largest
+        GROWTH of a nearest distance over the one the shares were cut with"""
+        self.d0 = None if d0 is None else np.asarray(d0, np.float32)
+
     def new_tensor(self, values):
         return torch.tensor(values, dtype=torch.float64)
 
@@ -118,7 +125,7 @@ class OracleExecutor(object):
         d3 = np.repeat(dmean, 3)
         res = (res * (1.0 / (d3 * self.sigma_inv / 2.0 + 1))).astype('f4')
         self.wm, self.res = (v_idx, w), res
-        self.max_dist = max(self.max_dist, float(dmean.max()))
+        self.max_dist = max(self.max_dist, float(dmean.max() if self.d0 is None else (dmean.astype('f4') - self.d0).max()))
         va = np.zeros((self.M, 4), 'f4')
         va[:, :3] = O.apply_At(res, v_idx, w, self.M).reshape(-1, 3)
         va[:, 3] = O.apply_At(np.ones_like(res), v_idx, w, self.M).reshape(-1, 3)[:, 0]
@@ -227,7 +234,7 @@ def _worker(rank, world, port, mode, q):
             mine = parts[rank]
             ex = OracleExecutor(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts[mine])
             out = parallel.run_search(ex, dist, 'replicated', pts[mine], [7.0], 4, 1.0 / sigma[mine].ravel())
-        elif mode in ('halo', 'halo_tight'):
+        elif mode in ('halo', 'halo_tight', 'halo_reach'):
             (v, f, pts, sigma), = _scene(False)
             mesh = TriMesh(v, f)
 
@@ -238,12 +245,17 @@ def _worker(rank, world, port, mode, q):
                 return OracleExecutor(lm.vertices.copy(), lm.vertex_normals.copy(), np.ascontiguousarray(nb, np.int32), lm.faces, local_points)
             # 'halo': a radius with room for the fit's movement -> both blocks on the shares cut at the start;
             # 'halo_tight': largest nearest distance + movement comes close to the radius after the first block -> new shares are cut
-            scene = parallel.HaloScene(mesh, pts, dist, halo=50.0 if mode == 'halo' else 35.0, make_executor=make)
+            # 'halo_reach': per-localization halos (every face within a localization's own nearest distance + margin)
+            # (its margin pays for growth + drift only: 9 nm is 'tight' for this fit -- new shares after the first block)
+            scene = parallel.HaloScene(mesh, pts, dist, halo={'halo': 50.0, 'halo_tight': 35.0, 'halo_reach': 9.0}[mode], make_executor=make,
+                                       per_point=(mode == 'halo_reach'), min_margin=4.0)
             s_inv = 1.0 / sigma.ravel()
             scene.search([7.0], 4, s_inv)
+            first = (scene.max_dist, scene.drift)
             scene.refresh_normals()                           # second block on the RESIDENT shares: new normals, same partition
             out = scene.search([7.0], 3, s_inv)
-            assert scene.repartitions == (1 if mode == 'halo' else 2), (scene.repartitions, scene.max_dist, scene.drift)
+            assert scene.repartitions == {'halo': 1, 'halo_tight': 2, 'halo_reach': 2}[mode], (scene.repartitions, first, scene.max_dist, scene.drift)
+            assert getattr(scene, 'redone_blocks', 0) == 0
             part = scene.last_partition
             d = part.ranks[rank]                        # (a rank works out its own share only; the boundary list comes from the all-reduced counts)
             assert all('gv' not in o for r, o in enumerate(part.ranks) if r != rank)
@@ -305,7 +317,7 @@ def test_tiles_two_vesicles_gloo():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('mode', ['halo', 'halo_tight'])
+@pytest.mark.parametrize('mode', ['halo', 'halo_tight', 'halo_reach'])
 def test_halo_sharded_mesh_gloo(mode):
     from oracle import nanowrap_oracle as O
     res = _run(mode)
