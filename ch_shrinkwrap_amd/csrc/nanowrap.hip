@@ -204,6 +204,7 @@ struct nw_ctx {
     int blocks_done = 0;              // completed search() calls since the localizations were set
     double force_h = 0.0;             // > 0: build_grid uses exactly this cell (nw_tune_grid probes)
     DevBuf<int> ccount, cstart, scan_tmp;
+    DevBuf<int> ctile;              // sums of the cell histogram per scan tile, kept by k_face_centroids, zero between iterations
     DevBuf<float> data_in, dat;       // search(data != points): the residual's target in the caller's / the sorted order (nw_set_data)
     bool have_data = false;
     DevBuf<NwItem> items;             // work list of the NN query: runs of <= 64 Morton-consecutive localizations
@@ -317,12 +318,18 @@ int fail(nw_ctx *c, int code, const std::string &msg)
 
 inline int nblk(int64_t n, int b = NW_BLOCK) { return (int)((n + b - 1) / b); }
 
-int scan_exclusive(nw_ctx *ctx, int *in, int n, int *out, bool zero_input = false)
+// tile_sums: the raw tile sums are already there (the histogram's producer kept them, k_face_centroids) -- no first pass
+int scan_exclusive(nw_ctx *ctx, int *in, int n, int *out, bool zero_input = false, int *tile_sums = nullptr)
 {
     const int nb = (n + NW_SCAN_TILE - 1) / NW_SCAN_TILE;
+    const bool two_pass = nb <= 4096;          // every workgroup of the last pass adds the earlier tile sums itself
+    if (tile_sums && two_pass) {
+        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, in, n, tile_sums, out, zero_input ? 1 : 0, 1);
+        NW_HIP(hipGetLastError());
+        return NW_OK;
+    }
     NW_HIP(ctx->scan_tmp.ensure((size_t)nb + 1));
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, in, n, ctx->scan_tmp.p);
-    const bool two_pass = nb <= 4096;          // every workgroup of the last pass adds the earlier tile sums itself
     if (!two_pass) hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, ctx->stream, ctx->scan_tmp.p, nb);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(NW_BLOCK), 0, ctx->stream, in, n, ctx->scan_tmp.p, out, zero_input ? 1 : 0, two_pass ? 1 : 0);
     NW_HIP(hipGetLastError());
@@ -495,6 +502,8 @@ int build_grid(nw_ctx *ctx, double mean_dist)
     NW_HIP(ctx->cstart.ensure(nc + 1));
     NW_HIP(ctx->scan_tmp.ensure(nc / NW_SCAN_TILE + 2));      // (no allocation inside a captured block)
     NW_HIP(hipMemsetAsync(ctx->ccount.p, 0, nc * sizeof(int), ctx->stream));
+    NW_HIP(ctx->ctile.ensure(nc / NW_SCAN_TILE + 2));
+    NW_HIP(hipMemsetAsync(ctx->ctile.p, 0, (nc / NW_SCAN_TILE + 2) * sizeof(int), ctx->stream));
     // work list: Morton blocks of about NW_ITEM_BLOCK_CELLS cells per edge
     const double block_cells = getenv("NW_ITEM_BLOCK_CELLS") ? atof(getenv("NW_ITEM_BLOCK_CELLS")) : 4.0;
     int level = (int)std::lround(std::log2(std::max(block_cells * h / (double)ctx->morton_unit, 1.0)));
@@ -618,7 +627,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pts_in.release(); ctx->sinv_in.release(); ctx->w_in.release(); ctx->wsum.release();
     ctx->pts.release(); ctx->perm.release(); ctx->mkey.release(); ctx->proj_key.release(); ctx->proj_idx.release(); ctx->sinv.release(); ctx->wnorm.release(); ctx->mask.release();
-    ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->items.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
+    ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->ctile.release(); ctx->items.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->owned.release(); ctx->d_small.release();
     ctx->hb_local.release(); ctx->hb_slot.release(); ctx->hb_slot2local.release(); ctx->hb_gv.release(); ctx->halo_acc.release(); ctx->halo_rows.release(); ctx->halo_full.release(); ctx->halo_ref.release(); ctx->halo_stats.release();
@@ -1412,11 +1421,13 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
     const NwGrid g = ctx->grid;
     if (parts & QP_GRID) {
         StageScope s(ctx, ST_GRID);
+        static const bool tile_fuse = !(getenv("NW_TILE_FUSE") && atoi(getenv("NW_TILE_FUSE")) == 0);      // developer knob: 0 = the scan's own first pass
+        int *tiles = tile_fuse ? ctx->ctile.p : nullptr;
         hipLaunchKernelGGL(k_face_centroids, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pos.p, ctx->faces.p, (int)F,
-                           ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->ccount.p, ctx->ambig_count.p, ctx->state.p, it);
-        NW_TRY(scan_exclusive(ctx, ctx->ccount.p, g.ncell, ctx->cstart.p, true));      // also re-zeroes the histogram
+                           ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->ccount.p, tiles, ctx->ambig_count.p, ctx->state.p, it);
+        NW_TRY(scan_exclusive(ctx, ctx->ccount.p, g.ncell, ctx->cstart.p, true, tiles));      // also re-zeroes the histogram
         hipLaunchKernelGGL(k_centroid_scatter, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, (int)F, ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->cstart.p,
-                           ctx->cent.p, ctx->state.p, it);
+                           ctx->cent.p, ctx->state.p, it, ctx->ctile.p, (g.ncell + NW_SCAN_TILE - 1) / NW_SCAN_TILE);
     }
     if (parts & QP_NN) {
         StageScope s(ctx, ST_NN, it == ctx->search_iters - 1);      // level 4 samples the block's LAST iteration (the one launched from the host)
@@ -1629,7 +1640,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 4 ? 256 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0) | (ctx->have_boundary ? 512 : 0) | (ctx->vacc_dirty ? 1024 : 0));
     mixp(ctx->direct_out ? ctx->pin : nullptr);
     mixp(ctx->have_data ? ctx->dat.p : nullptr);
-    const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
+    const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->ctile.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
                           ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p,

@@ -310,15 +310,20 @@ __global__ void k_nbr_transpose(const int *__restrict__ nbr, int M, int NB, int 
 // (mesh_conj_grad.py:443).  The rank of a face inside its cell (needed by the scatter) comes from the histogram's returning
 // atomic; 4e5 returning global atomics cost ~20 us, so the 256 faces of a workgroup -- neighbours on the surface for any
 // reasonably ordered mesh -- are first counted per cell in an LDS hash table (integer LDS atomics), and only one global
-// atomic per (workgroup, distinct cell) reserves the range.
+// atomic per (workgroup, distinct cell) reserves the range.  The same flush adds the workgroup's count to the SCAN TILE the cell
+// belongs to (`tile_sums`, a fire-and-forget atomic): the scan's first pass (k_scan_tile_sums, a launch that re-reads the whole
+// histogram) is not needed; k_centroid_scatter leaves the tile sums zeroed for the next iteration.
 #define NW_FC_HT 512
+#define NW_FC_TT 64        // scan tiles a workgroup's cells may lie in before its tile counts go to memory one by one
 __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const float *__restrict__ pos, const int *__restrict__ faces, int F,
                                                             float4 *__restrict__ cent_tmp, int *__restrict__ fcell, int *__restrict__ frank, int *__restrict__ count,
-                                                            int *__restrict__ ambig_count, NwDevState *__restrict__ st, int it)
+                                                            int *__restrict__ tile_sums, int *__restrict__ ambig_count, NwDevState *__restrict__ st, int it)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ int s_key[NW_FC_HT], s_cnt[NW_FC_HT];
+    __shared__ int s_tkey[NW_FC_TT], s_tcnt[NW_FC_TT];
     for (int t = threadIdx.x; t < NW_FC_HT; t += NW_BLOCK) { s_key[t] = -1; s_cnt[t] = 0; }
+    if (threadIdx.x < NW_FC_TT) { s_tkey[threadIdx.x] = -1; s_tcnt[threadIdx.x] = 0; }
     __syncthreads();
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f == 0) *ambig_count = 0;
@@ -346,8 +351,22 @@ __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const flo
     __syncthreads();
     for (int t = threadIdx.x; t < NW_FC_HT; t += NW_BLOCK) {
         const int key = s_key[t];
-        if (key >= 0) s_cnt[t] = atomicAdd(&count[key], s_cnt[t]);      // base of this workgroup's faces in the cell
+        if (key >= 0) {
+            const int c = s_cnt[t];
+            // (per tile first in LDS: a workgroup's cells lie in a handful of tiles, and same-address global atomics run one after the other)
+            const int tile = key / NW_SCAN_TILE;
+            int ts = tile & (NW_FC_TT - 1), probes = 0;
+            for (; tile_sums;) {
+                const int old = atomicCAS(&s_tkey[ts], -1, tile);
+                if (old == -1 || old == tile) { atomicAdd(&s_tcnt[ts], c); break; }
+                if (++probes == NW_FC_TT) { atomicAdd(&tile_sums[tile], c); break; }
+                ts = (ts + 1) & (NW_FC_TT - 1);
+            }
+            s_cnt[t] = atomicAdd(&count[key], c);                       // base of this workgroup's faces in the cell
+        }
     }
+    __syncthreads();
+    if (tile_sums && threadIdx.x < NW_FC_TT && s_tkey[threadIdx.x] >= 0) atomicAdd(&tile_sums[s_tkey[threadIdx.x]], s_tcnt[threadIdx.x]);
     __syncthreads();
     if (f < F) frank[f] = s_cnt[slot] + local;
 }
@@ -355,10 +374,11 @@ __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const flo
 // K3: scatter centroids into cell order
 __global__ __launch_bounds__(NW_BLOCK) void k_centroid_scatter(int F, const float4 *__restrict__ cent_tmp, const int *__restrict__ fcell, const int *__restrict__ frank,
                                                               const int *__restrict__ start, float4 *__restrict__ cent,
-                                                              const NwDevState *__restrict__ st, int it)
+                                                              const NwDevState *__restrict__ st, int it, int *__restrict__ tile_sums, int ntiles)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int t = f; t < ntiles; t += (int)(gridDim.x * blockDim.x)) tile_sums[t] = 0;      // consumed by the scan: zero for the next k_face_centroids
     if (f >= F) return;
     cent[start[fcell[f]] + frank[f]] = cent_tmp[f];
 }
