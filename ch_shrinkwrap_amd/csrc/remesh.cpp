@@ -16,6 +16,7 @@
 #include <thread>
 #include <atomic>
 #include <utility>
+#include <climits>
 
 #include "../../include/nw_remesh.h"
 
@@ -33,6 +34,27 @@ inline double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z
 inline V3 cross(const V3 &a, const V3 &b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline double norm2(const V3 &a) { return dot(a, a); }
 
+int n_threads()
+{
+    if (const char *e = std::getenv("NW_REMESH_THREADS")) return std::max(1, std::atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hc ? hc : 1u, 16u));
+}
+
+// fn(lo, hi) over [0, n) cut into contiguous chunks, one per thread (the calling thread takes the first).  Only for loops whose iterations
+// write disjoint outputs: the result does not depend on the number of threads.
+template <class Fn>
+void parallel_for(int64_t n, int64_t min_chunk, Fn fn)
+{
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads(), n / std::max<int64_t>(min_chunk, 1)));
+    if (T <= 1) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    for (int t = 1; t < T; ++t) th.emplace_back([=] { fn(n * t / T, n * (t + 1) / T); });
+    fn((int64_t)0, n / T);
+    for (auto &x : th) x.join();
+}
+
 // twin[3f+k] = the half-edge running the other way along edge (faces[f][k], faces[f][k+1]), -1 on a boundary.  Linear time:
 // the half-edges are bucketed by their origin vertex, and the twin of a->b is looked up among the handful leaving b.
 int match_twins(const int32_t *faces, int64_t nf, int64_t nv, int *twin)
@@ -47,24 +69,32 @@ int match_twins(const int32_t *faces, int64_t nf, int64_t nv, int *twin)
     }
     // target vertex of every half-edge, laid out next to the bucket entries (one sequential read per candidate)
     std::vector<int> tgt(nh), out_tgt(nh);
-    for (int64_t f = 0; f < nf; ++f) { tgt[3 * f] = faces[3 * f + 1]; tgt[3 * f + 1] = faces[3 * f + 2]; tgt[3 * f + 2] = faces[3 * f]; }
-    for (int64_t i = 0; i < nh; ++i) out_tgt[i] = tgt[out[i]];
-    for (int64_t h = 0; h < nh; ++h) {
-        const int a = faces[h], b = tgt[h];
-        int t = -1;
-        for (int i = first[b]; i < first[b + 1]; ++i) if (out_tgt[i] == a) { if (t >= 0) return NWR_ERR_NONMANIFOLD; t = out[i]; }
-        twin[h] = t;
-    }
+    parallel_for(nf, 1 << 15, [&](int64_t lo, int64_t hi) {
+        for (int64_t f = lo; f < hi; ++f) { tgt[3 * f] = faces[3 * f + 1]; tgt[3 * f + 1] = faces[3 * f + 2]; tgt[3 * f + 2] = faces[3 * f]; }
+    });
+    parallel_for(nh, 1 << 16, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) out_tgt[i] = tgt[out[i]]; });
+    std::atomic<int> bad{0};
+    parallel_for(nh, 1 << 16, [&](int64_t lo, int64_t hi) {
+        for (int64_t h = lo; h < hi; ++h) {
+            const int a = faces[h], b = tgt[h];
+            int t = -1;
+            for (int i = first[b]; i < first[b + 1]; ++i) if (out_tgt[i] == a) { if (t >= 0) bad.store(1, std::memory_order_relaxed); t = out[i]; }
+            twin[h] = t;
+        }
+    });
+    if (bad.load()) return NWR_ERR_NONMANIFOLD;
     // the same directed edge twice: both copies found the same twin, which can point back at only one of them; an unmatched
     // duplicate pair shows up among the half-edges leaving their origin
-    for (int64_t h = 0; h < nh; ++h) {
-        if (twin[h] >= 0) { if (twin[twin[h]] != (int)h) return NWR_ERR_NONMANIFOLD; continue; }
-        const int a = faces[h], b = tgt[h];
-        int same = 0;
-        for (int i = first[a]; i < first[a + 1]; ++i) same += (out_tgt[i] == b);
-        if (same != 1) return NWR_ERR_NONMANIFOLD;
-    }
-    return NWR_OK;
+    parallel_for(nh, 1 << 16, [&](int64_t lo, int64_t hi) {
+        for (int64_t h = lo; h < hi; ++h) {
+            if (twin[h] >= 0) { if (twin[twin[h]] != (int)h) bad.store(1, std::memory_order_relaxed); continue; }
+            const int a = faces[h], b = tgt[h];
+            int same = 0;
+            for (int i = first[a]; i < first[a + 1]; ++i) same += (out_tgt[i] == b);
+            if (same != 1) bad.store(1, std::memory_order_relaxed);
+        }
+    });
+    return bad.load() ? NWR_ERR_NONMANIFOLD : NWR_OK;
 }
 
 struct HalfEdgeMesh {
@@ -399,7 +429,7 @@ struct HalfEdgeMesh {
 
 }  // namespace
 
-NWR_EXPORT int nwr_abi_version(void) { return 3; }
+NWR_EXPORT int nwr_abi_version(void) { return 4; }
 
 // key 0: 1 (default) = meshes of 40 000 faces and more are remeshed in pieces, on all cores (remesh_partitioned); 0 = always the serial
 // algorithm (what a caller wants whose OUTPUT must not depend on the library's version: the benchmark's mesh generator).  Returns the old value.
@@ -427,16 +457,22 @@ NWR_EXPORT int nwr_halfedge_twins(const int32_t *faces, int64_t n_faces, int64_t
 // trimesh.TriMesh.update_geometry does in NumPy (float32 products and differences rounded individually, three-term sums left
 // to right, vertex normals accumulated in float64 corner-major), so that both paths give bit-identical arrays.
 NWR_EXPORT int nwr_mesh_geometry(const void *positions, int64_t pos_stride_bytes, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
-                                 float *face_normal, float *face_area, float *halfedge_length, float *vertex_normal)
+                                 void *face_normal_out, int64_t fn_stride, void *face_area_out, int64_t fa_stride, void *halfedge_length_out, int64_t hl_stride,
+                                 void *vertex_normal_out, int64_t vn_stride)
 {
-    if (!positions || !faces || !face_normal || !face_area || !halfedge_length || n_vertices < 1 || n_faces < 1 || pos_stride_bytes < 12)
+    if (!positions || !faces || !face_normal_out || !face_area_out || !halfedge_length_out || n_vertices < 1 || n_faces < 1 || pos_stride_bytes < 12 ||
+        fn_stride < 12 || fa_stride < 4 || hl_stride < 4 || (vertex_normal_out && vn_stride < 12))
         return NWR_ERR_BADARG;
+    // (outputs go straight into the caller's records: a face's normal fn_stride bytes after the previous face's, and so on)
+    char *fnb = (char *)face_normal_out, *fab = (char *)face_area_out, *hlb = (char *)halfedge_length_out, *vnb = (char *)vertex_normal_out;
+    const bool vertex_normal = vertex_normal_out != nullptr;
     const char *base = (const char *)positions;
     auto P = [&](int v) { return (const float *)(base + (int64_t)v * pos_stride_bytes); };
     for (int64_t i = 0; i < 3 * n_faces; ++i) if (faces[i] < 0 || faces[i] >= n_vertices) return NWR_ERR_BADARG;
     try {
         std::vector<float> cr(vertex_normal ? 3 * (size_t)n_faces : 0);
-        for (int64_t f = 0; f < n_faces; ++f) {
+        parallel_for(n_faces, 1 << 14, [&](int64_t f_lo, int64_t f_hi) {
+        for (int64_t f = f_lo; f < f_hi; ++f) {
             const float *p0 = P(faces[3 * f]), *p1 = P(faces[3 * f + 1]), *p2 = P(faces[3 * f + 2]);
             const float a0 = p1[0] - p0[0], a1 = p1[1] - p0[1], a2 = p1[2] - p0[2];
             const float b0 = p2[0] - p0[0], b1 = p2[1] - p0[1], b2 = p2[2] - p0[2];
@@ -449,35 +485,43 @@ NWR_EXPORT int nwr_mesh_geometry(const void *positions, int64_t pos_stride_bytes
             if (!std::isfinite(n0)) n0 = 0;
             if (!std::isfinite(n1)) n1 = 0;
             if (!std::isfinite(n2)) n2 = 0;
-            face_normal[3 * f] = n0; face_normal[3 * f + 1] = n1; face_normal[3 * f + 2] = n2;
-            face_area[f] = 0.5f * n;
+            float *fno = (float *)(fnb + f * fn_stride);
+            fno[0] = n0; fno[1] = n1; fno[2] = n2;
+            *(float *)(fab + f * fa_stride) = 0.5f * n;
             if (vertex_normal) { cr[3 * f] = c0; cr[3 * f + 1] = c1; cr[3 * f + 2] = c2; }
             for (int k = 0; k < 3; ++k) {
                 const float *o = P(faces[3 * f + k]), *d = P(faces[3 * f + (k + 1) % 3]);
                 const float e0 = d[0] - o[0], e1 = d[1] - o[1], e2 = d[2] - o[2];
                 volatile float r0 = e0 * e0, r1 = e1 * e1, r2 = e2 * e2;
                 volatile float t01 = r0 + r1;
-                halfedge_length[3 * f + k] = std::sqrt((float)(t01 + r2));
+                *(float *)(hlb + (3 * f + k) * hl_stride) = std::sqrt((float)(t01 + r2));
             }
         }
+        });
         if (vertex_normal) {
+            // (every thread owns a range of vertices and walks all corners in the serial order -- corner-major, faces ascending --
+            // adding only what lands in its range: the sums are those of the serial loop, bit for bit, whatever the thread count)
             std::vector<double> vn(3 * (size_t)n_vertices, 0.0);
-            for (int corner = 0; corner < 3; ++corner)
-                for (int64_t f = 0; f < n_faces; ++f) {
-                    const int v = faces[3 * f + corner];
-                    vn[3 * (size_t)v] += (double)cr[3 * f]; vn[3 * (size_t)v + 1] += (double)cr[3 * f + 1]; vn[3 * (size_t)v + 2] += (double)cr[3 * f + 2];
+            parallel_for(n_vertices, 1 << 14, [&](int64_t v_lo, int64_t v_hi) {
+                for (int corner = 0; corner < 3; ++corner)
+                    for (int64_t f = 0; f < n_faces; ++f) {
+                        const int v = faces[3 * f + corner];
+                        if (v < v_lo || v >= v_hi) continue;
+                        vn[3 * (size_t)v] += (double)cr[3 * f]; vn[3 * (size_t)v + 1] += (double)cr[3 * f + 1]; vn[3 * (size_t)v + 2] += (double)cr[3 * f + 2];
+                    }
+                for (int64_t v = v_lo; v < v_hi; ++v) {
+                    const double x = vn[3 * v], y = vn[3 * v + 1], z = vn[3 * v + 2];
+                    volatile double xx = x * x, yy = y * y, zz = z * z;
+                    volatile double sxy = xx + yy;
+                    const double l = std::sqrt((double)(sxy + zz));
+                    double u0 = x / l, u1 = y / l, u2 = z / l;
+                    if (!std::isfinite(u0)) u0 = 0;
+                    if (!std::isfinite(u1)) u1 = 0;
+                    if (!std::isfinite(u2)) u2 = 0;
+                    float *vno = (float *)(vnb + v * vn_stride);
+                    vno[0] = (float)u0; vno[1] = (float)u1; vno[2] = (float)u2;
                 }
-            for (int64_t v = 0; v < n_vertices; ++v) {
-                const double x = vn[3 * v], y = vn[3 * v + 1], z = vn[3 * v + 2];
-                volatile double xx = x * x, yy = y * y, zz = z * z;
-                volatile double sxy = xx + yy;
-                const double l = std::sqrt((double)(sxy + zz));
-                double u0 = x / l, u1 = y / l, u2 = z / l;
-                if (!std::isfinite(u0)) u0 = 0;
-                if (!std::isfinite(u1)) u1 = 0;
-                if (!std::isfinite(u2)) u2 = 0;
-                vertex_normal[3 * v] = (float)u0; vertex_normal[3 * v + 1] = (float)u1; vertex_normal[3 * v + 2] = (float)u2;
-            }
+            });
         }
         return NWR_OK;
     } catch (const std::bad_alloc &) {
@@ -505,34 +549,38 @@ NWR_EXPORT int nwr_build_topology(const int32_t *faces, int64_t n_faces, int64_t
         if (rc != NWR_OK) return rc;
         char *hb = (char *)halfedges, *vb = (char *)vertices;
         auto H = [&](int64_t h, int64_t off) -> int32_t & { return *(int32_t *)(hb + h * he_stride + off); };
-        for (int64_t f = 0; f < n_faces; ++f)
-            for (int k = 0; k < 3; ++k) {
-                const int64_t h = 3 * f + k;
-                H(h, off_vertex) = faces[3 * f + (k + 1) % 3];
-                H(h, off_face) = (int32_t)f;
-                H(h, off_twin) = twin[h];
-                H(h, off_next) = (int32_t)(3 * f + (k + 1) % 3);
-                H(h, off_prev) = (int32_t)(3 * f + (k + 2) % 3);
-                origin[h] = faces[h];
-            }
+        parallel_for(n_faces, 1 << 14, [&](int64_t f_lo, int64_t f_hi) {
+            for (int64_t f = f_lo; f < f_hi; ++f)
+                for (int k = 0; k < 3; ++k) {
+                    const int64_t h = 3 * f + k;
+                    H(h, off_vertex) = faces[3 * f + (k + 1) % 3];
+                    H(h, off_face) = (int32_t)f;
+                    H(h, off_twin) = twin[h];
+                    H(h, off_next) = (int32_t)(3 * f + (k + 1) % 3);
+                    H(h, off_prev) = (int32_t)(3 * f + (k + 2) % 3);
+                    origin[h] = faces[h];
+                }
+        });
         std::vector<int> start(n_vertex_slots, -1);
         for (int64_t h = nh - 1; h >= 0; --h) start[faces[h]] = (int)h;                  // lowest index wins
         for (int64_t h = 0; h < nh; ++h) if (twin[h] < 0) start[faces[h]] = (int)h;       // boundary: the last one wins
-        for (int64_t v = 0; v < n_vertex_slots; ++v) {
-            int32_t *nb = (int32_t *)(vb + v * v_stride + off_neighbors);
-            for (int s = 0; s < neighbor_size; ++s) nb[s] = -1;
-            const int s0 = start[v];
-            *(int32_t *)(vb + v * v_stride + off_halfedge) = s0;
-            int n = 0, cur = s0;
-            while (cur >= 0 && n < neighbor_size) {
-                nb[n++] = cur;
-                const int k = cur % 3, p = cur - k + (k + 2) % 3;
-                const int nx = twin[p];
-                if (nx < 0 || nx == s0) break;
-                cur = nx;
+        parallel_for(n_vertex_slots, 1 << 13, [&](int64_t v_lo, int64_t v_hi) {
+            for (int64_t v = v_lo; v < v_hi; ++v) {
+                int32_t *nb = (int32_t *)(vb + v * v_stride + off_neighbors);
+                for (int s = 0; s < neighbor_size; ++s) nb[s] = -1;
+                const int s0 = start[v];
+                *(int32_t *)(vb + v * v_stride + off_halfedge) = s0;
+                int n = 0, cur = s0;
+                while (cur >= 0 && n < neighbor_size) {
+                    nb[n++] = cur;
+                    const int k = cur % 3, p = cur - k + (k + 2) % 3;
+                    const int nx = twin[p];
+                    if (nx < 0 || nx == s0) break;
+                    cur = nx;
+                }
+                *(int32_t *)(vb + v * v_stride + off_valence) = n;
             }
-            *(int32_t *)(vb + v * v_stride + off_valence) = n;
-        }
+        });
         return NWR_OK;
     } catch (const std::bad_alloc &) {
         return NWR_ERR_NOMEM;
@@ -549,22 +597,24 @@ NWR_EXPORT int nwr_ring_tables(const void *halfedges, int64_t he_stride, int64_t
     if (!halfedges || !vertices || n_halfedges < 3 || n_vertex_slots < 1 || neighbor_size < 1 || (ring_area && !face_area)) return NWR_ERR_BADARG;
     const char *hb = (const char *)halfedges, *vb = (const char *)vertices, *fb = (const char *)face_area;
     auto H = [&](int64_t h, int64_t off) { return *(const int32_t *)(hb + h * he_stride + off); };
-    for (int64_t v = 0; v < n_vertex_slots; ++v) {
-        const int32_t *nb = (const int32_t *)(vb + v * v_stride + off_neighbors);
-        for (int s = 0; s < neighbor_size; ++s) {
-            const int h = nb[s];
-            const int64_t o = v * neighbor_size + s;
-            if (h < 0 || h >= n_halfedges) {
-                if (ring_vertex) ring_vertex[o] = -1;
-                if (ring_next_vertex) ring_next_vertex[o] = -1;
-                if (ring_area) ring_area[o] = 0.0f;
-                continue;
+    parallel_for(n_vertex_slots, 1 << 13, [&](int64_t v_lo, int64_t v_hi) {
+        for (int64_t v = v_lo; v < v_hi; ++v) {
+            const int32_t *nb = (const int32_t *)(vb + v * v_stride + off_neighbors);
+            for (int s = 0; s < neighbor_size; ++s) {
+                const int h = nb[s];
+                const int64_t o = v * neighbor_size + s;
+                if (h < 0 || h >= n_halfedges) {
+                    if (ring_vertex) ring_vertex[o] = -1;
+                    if (ring_next_vertex) ring_next_vertex[o] = -1;
+                    if (ring_area) ring_area[o] = 0.0f;
+                    continue;
+                }
+                if (ring_vertex) ring_vertex[o] = H(h, off_vertex);
+                if (ring_next_vertex) ring_next_vertex[o] = H(H(h, off_next), off_vertex);
+                if (ring_area) ring_area[o] = *(const float *)(fb + (int64_t)H(h, off_face) * fa_stride);
             }
-            if (ring_vertex) ring_vertex[o] = H(h, off_vertex);
-            if (ring_next_vertex) ring_next_vertex[o] = H(H(h, off_next), off_vertex);
-            if (ring_area) ring_area[o] = *(const float *)(fb + (int64_t)H(h, off_face) * fa_stride);
         }
-    }
+    });
     return NWR_OK;
 }
 
@@ -771,15 +821,103 @@ static unsigned spread10(unsigned v)
     return v;
 }
 
-static int n_threads()
+// What frozen rims kept from being done: the zone of faces within NWR_SEAM_RINGS rings of the `seeds` (the rim vertices of the pass before)
+// is remeshed as a sub-mesh of its own -- its outer edge is an open boundary, i.e. frozen, and lies where the pass before was free; only
+// edges around the seeds are looked at until an operation freshens more.
+// face_run (pass 2 only): the run of pass 1 every face belongs to.  The zone of a 16-run partition is a network of strips, a third of
+// the mesh: it is cut where three runs meet -- every strip (the faces that grew from the rim between runs a and b) is a piece of its own,
+// the strips are remeshed at once, and what THEIR frozen ends kept from being done (patches around the junctions) is a last, small, seam
+// pass.  (Morton runs of the zone do not do: a run of a strip network is a scatter of fragments with as much rim as the zone had.)
+static int seam_pass(std::vector<float> &V, std::vector<int32_t> &F, const std::vector<unsigned char> &seeds, const std::vector<int> *face_run,
+                     int n_iterations, float L, int max_valence, nwr_stats &tot)
 {
-    if (const char *e = std::getenv("NW_REMESH_THREADS")) return std::max(1, std::atoi(e));
-    const unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(hc ? hc : 1u, 16u));
+    const bool verbose = std::getenv("NWR_VERBOSE") != nullptr;
+    const size_t nv = V.size() / 3, nf = F.size() / 3;
+    // label of a seed = the two lowest runs among its faces (the strip it belongs to); without face_run everything is strip 0
+    std::vector<int> vlab(nv, -1);
+    if (face_run) {
+        std::vector<int> p1(nv, INT32_MAX), p2(nv, INT32_MAX);
+        for (size_t f = 0; f < nf; ++f)
+            for (int k = 0; k < 3; ++k) {
+                const int v = F[3 * f + k];
+                if (!seeds[v]) continue;
+                const int r = (*face_run)[f];
+                if (r == p1[v] || r == p2[v]) continue;
+                if (r < p1[v]) { p2[v] = p1[v]; p1[v] = r; }
+                else if (r < p2[v]) p2[v] = r;
+            }
+        for (size_t v = 0; v < nv; ++v) if (seeds[v]) vlab[v] = p1[v] * NWR_REGIONS + (p2[v] == INT32_MAX ? p1[v] : p2[v]);
+    } else {
+        for (size_t v = 0; v < nv; ++v) if (seeds[v]) vlab[v] = 0;
+    }
+    // the zone grows ring by ring; a face takes the lowest label among its labelled vertices, its other vertices take the face's
+    std::vector<int> flab(nf, -1);
+    std::vector<int> fresh;
+    for (int ring = 0; ring < NWR_SEAM_RINGS; ++ring) {
+        fresh.clear();
+        for (size_t f = 0; f < nf; ++f) {
+            if (flab[f] >= 0) continue;
+            int lab = INT32_MAX;
+            for (int k = 0; k < 3; ++k) { const int l = vlab[F[3 * f + k]]; if (l >= 0 && l < lab) lab = l; }
+            if (lab != INT32_MAX) { flab[f] = lab; fresh.push_back((int)f); }
+        }
+        for (int f : fresh)
+            for (int k = 0; k < 3; ++k) { int &l = vlab[F[3 * (size_t)f + k]]; if (l < 0) l = flab[f]; }
+    }
+    const int nlab = face_run ? NWR_REGIONS * NWR_REGIONS : 1;
+    std::vector<int> cnt(nlab, 0);
+    size_t nz = 0;
+    for (size_t f = 0; f < nf; ++f) if (flab[f] >= 0) { cnt[flab[f]] += 1; ++nz; }
+    if (nz == 0) return NWR_OK;
+    std::vector<int> slot(nlab, -1);
+    int npieces = 0;
+    for (int l = 0; l < nlab; ++l) if (cnt[l] > 0) slot[l] = npieces++;
+    std::vector<Piece> pieces(npieces);
+    for (int l = 0; l < nlab; ++l) if (cnt[l] > 0) pieces[slot[l]].faces_in.reserve(cnt[l]);
+    for (size_t f = 0; f < nf; ++f) if (flab[f] >= 0) pieces[slot[flab[f]]].faces_in.push_back((int)f);
+    // the strips' frozen ends: vertices that faces of two strips share
+    std::vector<unsigned char> ends(nv, 0);
+    size_t nends = 0;
+    if (npieces > 1) {
+        std::vector<int> vstrip(nv, -1);
+        for (size_t f = 0; f < nf; ++f) {
+            if (flab[f] < 0) continue;
+            for (int k = 0; k < 3; ++k) {
+                const int v = F[3 * f + k];
+                if (vstrip[v] < 0) vstrip[v] = flab[f];
+                else if (vstrip[v] != flab[f] && !ends[v]) { ends[v] = 1; ++nends; }
+            }
+        }
+    }
+    if (verbose) {
+        size_t ns = 0;
+        for (unsigned char c : seeds) ns += c;
+        std::fprintf(stderr, "[nw_remesh] seam pass: %zu seeds, zone of %zu faces (of %zu) in %d strips, %zu vertices at their ends\n", ns, nz, nf, npieces, nends);
+    }
+    {
+        const int T = std::min(n_threads(), npieces);
+        std::atomic<int> next{0};
+        std::vector<std::thread> th;
+        auto work = [&] {
+            std::vector<int> g2l(nv, -1);
+            for (int i = next.fetch_add(1); i < npieces; i = next.fetch_add(1)) piece_run(pieces[i], V, F, g2l, n_iterations, L, max_valence, seeds.data());
+        };
+        for (int t = 1; t < T; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    for (auto &p : pieces) {
+        if (p.rc != NWR_OK) return p.rc;
+        tot.n_split += p.st.n_split; tot.n_collapse += p.st.n_collapse; tot.n_flip += p.st.n_flip;
+    }
+    splice(V, F, pieces);
+    if (nends == 0) return NWR_OK;
+    ends.resize(V.size() / 3, 0);                             // (frozen: they kept their ids; what the strips created is no seed)
+    return seam_pass(V, F, ends, nullptr, n_iterations, L, max_valence, tot);
 }
 
 static int remesh_partitioned(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces, int n_iterations, float L, int max_valence,
-                              std::vector<float> &ov, std::vector<int32_t> &of, nwr_stats *stats)
+                              std::vector<float> &ov, std::vector<int32_t> &of, nwr_stats *stats, double *min_edge2)
 {
     const bool verbose = std::getenv("NWR_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -792,14 +930,16 @@ static int remesh_partitioned(const float *vertices, int64_t n_vertices, const i
     for (int64_t v = 0; v < n_vertices; ++v) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], V[3 * v + k]); hi[k] = std::max(hi[k], V[3 * v + k]); }
     const double ext = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-30});
     std::vector<std::pair<unsigned, int>> key((size_t)n_faces);
-    for (int64_t f = 0; f < n_faces; ++f) {
-        unsigned q[3];
-        for (int k = 0; k < 3; ++k) {
-            const double c = ((double)V[3 * (size_t)F[3 * f] + k] + V[3 * (size_t)F[3 * f + 1] + k] + V[3 * (size_t)F[3 * f + 2] + k]) / 3.0;
-            q[k] = (unsigned)std::min(1023.0, std::max(0.0, (c - lo[k]) / ext * 1024.0));
+    parallel_for(n_faces, 1 << 14, [&](int64_t f_lo, int64_t f_hi) {
+        for (int64_t f = f_lo; f < f_hi; ++f) {
+            unsigned q[3];
+            for (int k = 0; k < 3; ++k) {
+                const double c = ((double)V[3 * (size_t)F[3 * f] + k] + V[3 * (size_t)F[3 * f + 1] + k] + V[3 * (size_t)F[3 * f + 2] + k]) / 3.0;
+                q[k] = (unsigned)std::min(1023.0, std::max(0.0, (c - lo[k]) / ext * 1024.0));
+            }
+            key[f] = {spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2), (int)f};
         }
-        key[f] = {spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2), (int)f};
-    }
+    });
     {
         // stable LSD radix sort of the 30-bit keys, three passes of 10 bits (faces of equal key keep their order: as std::sort of the
         // (key, face) pairs would leave them -- a third of its time)
@@ -814,12 +954,14 @@ static int remesh_partitioned(const float *vertices, int64_t n_vertices, const i
         }
     }
     std::vector<Piece> pieces(NWR_REGIONS);
-    for (int r = 0; r < NWR_REGIONS; ++r) {
-        const int64_t a = n_faces * r / NWR_REGIONS, b = n_faces * (r + 1) / NWR_REGIONS;
-        pieces[r].faces_in.reserve((size_t)(b - a));
-        for (int64_t i = a; i < b; ++i) pieces[r].faces_in.push_back(key[i].second);
-        std::sort(pieces[r].faces_in.begin(), pieces[r].faces_in.end());          // (the mesh's own face order inside a run)
-    }
+    parallel_for(NWR_REGIONS, 1, [&](int64_t r_lo, int64_t r_hi) {
+        for (int64_t r = r_lo; r < r_hi; ++r) {
+            const int64_t a = n_faces * r / NWR_REGIONS, b = n_faces * (r + 1) / NWR_REGIONS;
+            pieces[r].faces_in.reserve((size_t)(b - a));
+            for (int64_t i = a; i < b; ++i) pieces[r].faces_in.push_back(key[i].second);
+            std::sort(pieces[r].faces_in.begin(), pieces[r].faces_in.end());          // (the mesh's own face order inside a run)
+        }
+    });
     // vertices on a rim: used by faces of more than one run
     std::vector<int> vrun((size_t)n_vertices, -1);
     std::vector<unsigned char> rim((size_t)n_vertices, 0);
@@ -850,25 +992,14 @@ static int remesh_partitioned(const float *vertices, int64_t n_vertices, const i
     splice(V, F, pieces);
     const auto t2 = now();
     // pass 2: the seam zone = faces within NWR_SEAM_RINGS rings of a rim vertex (rim vertices kept their ids: they were frozen)
-    {
-        const size_t nv = V.size() / 3, nf = F.size() / 3;
-        std::vector<unsigned char> zone(nv, 0), fz(nf, 0);
-        for (int64_t v = 0; v < n_vertices; ++v) zone[v] = rim[v];
-        for (int ring = 0; ring < NWR_SEAM_RINGS; ++ring) {
-            for (size_t f = 0; f < nf; ++f) if (!fz[f] && (zone[F[3 * f]] || zone[F[3 * f + 1]] || zone[F[3 * f + 2]])) fz[f] = 2;
-            for (size_t f = 0; f < nf; ++f) if (fz[f] == 2) { zone[F[3 * f]] = zone[F[3 * f + 1]] = zone[F[3 * f + 2]] = 1; fz[f] = 1; }
-        }
-        std::vector<Piece> seam(1);
-        for (size_t f = 0; f < nf; ++f) if (fz[f]) seam[0].faces_in.push_back((int)f);
-        if (!seam[0].faces_in.empty() && !std::getenv("NWR_NO_SEAM")) {
-            std::vector<int> g2l(nv, -1);
-            std::vector<unsigned char> seed(nv, 0);
-            for (int64_t v = 0; v < n_vertices; ++v) seed[v] = rim[v];
-            piece_run(seam[0], V, F, g2l, n_iterations, L, max_valence, seed.data());
-            if (seam[0].rc != NWR_OK) return seam[0].rc;
-            tot.n_split += seam[0].st.n_split; tot.n_collapse += seam[0].st.n_collapse; tot.n_flip += seam[0].st.n_flip;
-            splice(V, F, seam);
-        }
+    if (!std::getenv("NWR_NO_SEAM")) {
+        std::vector<unsigned char> seeds(V.size() / 3, 0);
+        for (int64_t v = 0; v < n_vertices; ++v) seeds[v] = rim[v];
+        std::vector<int> face_run(F.size() / 3);              // (pass 1 covered every face: the spliced faces are the runs', in run order)
+        size_t o = 0;
+        for (int r = 0; r < NWR_REGIONS; ++r) for (size_t i = 0; i < pieces[r].of.size() / 3; ++i) face_run[o++] = r;
+        const int rc = seam_pass(V, F, seeds, &face_run, n_iterations, L, max_valence, tot);
+        if (rc != NWR_OK) return rc;
     }
     const auto t3 = now();
     // compact (vertices no face refers to any more: collapsed away inside a piece), relative order kept
@@ -879,27 +1010,44 @@ static int remesh_partitioned(const float *vertices, int64_t n_vertices, const i
         for (int32_t v : F) used[v] = 1;
         int64_t n = 0;
         for (size_t v = 0; v < nv; ++v) if (used[v]) remap[v] = (int)n++;
-        ov.assign(3 * (size_t)n, 0.0f);
-        for (size_t v = 0; v < nv; ++v) if (remap[v] >= 0) { ov[3 * remap[v]] = V[3 * v]; ov[3 * remap[v] + 1] = V[3 * v + 1]; ov[3 * remap[v] + 2] = V[3 * v + 2]; }
+        ov.resize(3 * (size_t)n);
+        parallel_for((int64_t)nv, 1 << 15, [&](int64_t lo_, int64_t hi_) {
+            for (int64_t v = lo_; v < hi_; ++v) if (remap[v] >= 0) { ov[3 * (size_t)remap[v]] = V[3 * v]; ov[3 * (size_t)remap[v] + 1] = V[3 * v + 1]; ov[3 * (size_t)remap[v] + 2] = V[3 * v + 2]; }
+        });
         of.resize(F.size());
-        for (size_t i = 0; i < F.size(); ++i) of[i] = remap[F[i]];
+        parallel_for((int64_t)F.size(), 1 << 16, [&](int64_t lo_, int64_t hi_) { for (int64_t i = lo_; i < hi_; ++i) of[i] = remap[F[i]]; });
     }
-    if (stats) {
-        *stats = tot;
-        // mean edge length and largest degree of the result
-        const size_t nv = ov.size() / 3;
+    {
+        // mean edge length, largest degree and shortest edge of the result: chunks of faces of a FIXED size on all threads, the chunks' sums
+        // added in chunk order (the same number whatever the thread count)
+        const size_t nv = ov.size() / 3, nfo = of.size() / 3;
+        const size_t CH = 32768, nch = (nfo + CH - 1) / CH;
         std::vector<int> deg(nv, 0);
-        double s = 0; int64_t n = 0;
-        for (size_t f = 0; f + 2 < of.size(); f += 3)
-            for (int k = 0; k < 3; ++k) {
-                const int a = of[f + k], b = of[f + (k + 1) % 3];
-                const double dx = (double)ov[3 * a] - ov[3 * b], dy = (double)ov[3 * a + 1] - ov[3 * b + 1], dz = (double)ov[3 * a + 2] - ov[3 * b + 2];
-                s += std::sqrt(dx * dx + dy * dy + dz * dz); ++n;
-                deg[a] += 1;
+        std::vector<double> psum(nch, 0.0), pmin(nch, INFINITY);
+        parallel_for((int64_t)nch, 1, [&](int64_t c_lo, int64_t c_hi) {
+            for (int64_t c = c_lo; c < c_hi; ++c) {
+                double s = 0, mn = INFINITY;
+                for (size_t f = (size_t)c * CH; f < std::min(nfo, (size_t)(c + 1) * CH); ++f)
+                    for (int k = 0; k < 3; ++k) {
+                        const int a = of[3 * f + k], b = of[3 * f + (k + 1) % 3];
+                        const double dx = (double)ov[3 * a] - ov[3 * b], dy = (double)ov[3 * a + 1] - ov[3 * b + 1], dz = (double)ov[3 * a + 2] - ov[3 * b + 2];
+                        const double d2 = dx * dx + dy * dy + dz * dz;
+                        s += std::sqrt(d2);
+                        mn = d2 < mn || !(d2 == d2) ? d2 : mn;
+                        __atomic_fetch_add(&deg[a], 1, __ATOMIC_RELAXED);
+                    }
+                psum[c] = s; pmin[c] = mn;
             }
-        stats->mean_edge_length = n ? s / n : 0.0;
-        stats->max_valence = nv ? *std::max_element(deg.begin(), deg.end()) : 0;
-        stats->reserved = 0;
+        });
+        double s = 0, mn = INFINITY;
+        for (size_t c = 0; c < nch; ++c) { s += psum[c]; if (!(pmin[c] >= mn)) mn = pmin[c]; }
+        if (min_edge2) *min_edge2 = mn;
+        if (stats) {
+            *stats = tot;
+            stats->mean_edge_length = nfo ? s / (3.0 * (double)nfo) : 0.0;
+            stats->max_valence = nv ? *std::max_element(deg.begin(), deg.end()) : 0;
+            stats->reserved = 0;
+        }
     }
     if (verbose) std::fprintf(stderr, "[nw_remesh] partitioned: order + runs %.1f ms, pass 1 (%d threads) %.1f ms, seam zone %.1f ms, compaction %.1f ms\n", ms(t0, t1), T, ms(t1, t2),
                               ms(t2, t3), ms(t3, now()));
@@ -941,19 +1089,13 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
                 rc = match_twins(faces, n_faces, n_vertices, twin.data());
                 if (rc != NWR_OK) return rc;
             }
-            rc = remesh_partitioned(vertices, n_vertices, faces, n_faces, n_iterations, L, max_valence, ov, of, stats);
-            if (rc == NWR_OK) {
-                // safety net: an edge of (nearly) no length in the result -- never seen since the rims wait for their pass -- and the
-                // serial algorithm takes over
-                const double tiny2 = 1e-12 * (double)L * (double)L;
-                bool bad = false;
-                for (size_t f = 0; f + 2 < of.size() && !bad; f += 3)
-                    for (int k = 0; k < 3; ++k) {
-                        const int a = of[f + k], b = of[f + (k + 1) % 3];
-                        const double dx = (double)ov[3 * a] - ov[3 * b], dy = (double)ov[3 * a + 1] - ov[3 * b + 1], dz = (double)ov[3 * a + 2] - ov[3 * b + 2];
-                        if (!(dx * dx + dy * dy + dz * dz > tiny2)) { bad = true; break; }
-                    }
-                if (bad) rc = remesh_core(vertices, n_vertices, faces, n_faces, n_iterations, target_edge_length, relax_lambda, n_relax, max_valence, nullptr, ov, of, nullptr, stats, nullptr);
+            double min_edge2 = INFINITY;
+            rc = remesh_partitioned(vertices, n_vertices, faces, n_faces, n_iterations, L, max_valence, ov, of, stats, &min_edge2);
+            // safety net: an edge of (nearly) no length in the result -- never seen since the rims wait for their pass -- and the
+            // serial algorithm takes over
+            if (rc == NWR_OK && !(min_edge2 > 1e-12 * (double)L * (double)L)) {
+                if (std::getenv("NWR_VERBOSE")) std::fprintf(stderr, "[nw_remesh] an edge of no length in the partitioned result: the serial algorithm takes over\n");
+                rc = remesh_core(vertices, n_vertices, faces, n_faces, n_iterations, target_edge_length, relax_lambda, n_relax, max_valence, nullptr, ov, of, nullptr, stats, nullptr);
             }
         } else {
             rc = remesh_core(vertices, n_vertices, faces, n_faces, n_iterations, target_edge_length, relax_lambda, n_relax, max_valence, nullptr, ov, of, nullptr, stats, nullptr);

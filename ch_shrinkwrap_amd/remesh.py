@@ -43,7 +43,7 @@ def load():
         L.nwr_halfedge_twins.restype = ctypes.c_int
         L.nwr_halfedge_twins.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
         L.nwr_mesh_geometry.restype = ctypes.c_int
-        L.nwr_mesh_geometry.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4
+        L.nwr_mesh_geometry.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p, ctypes.c_int64] * 4
         L.nwr_free.restype = None
         L.nwr_free.argtypes = [ctypes.c_void_p]
         L.nwr_build_topology.restype = ctypes.c_int
@@ -54,7 +54,7 @@ def load():
                                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.nwr_configure.restype = ctypes.c_int
         L.nwr_configure.argtypes = [ctypes.c_int, ctypes.c_int]
-        if L.nwr_abi_version() != 3:
+        if L.nwr_abi_version() != 4:
             raise RuntimeError('libnw_remesh.so ABI version mismatch')
         _lib = L
     return _lib
@@ -146,21 +146,24 @@ def ring_tables(halfedges, vertices, faces_rec=None, ring_vertex=True, ring_next
     return rv, rn, ra
 
 
-def mesh_geometry(positions, faces, vertex_normals=True):
+def mesh_geometry(positions, faces, vertex_normals=True, out=None):
     """(face normals (F,3), face areas (F,), half-edge lengths (3F,), vertex normals (V,3) or None) of a mesh whose
-    positions are a float32 (V,3) array, possibly a strided view into vertex records."""
+    positions are a float32 (V,3) array, possibly a strided view into vertex records.  out = (fn, fa, hl, vn): float32 arrays -- packed or
+    fields of record arrays -- the library writes into directly (vn may be None)."""
     L = load()
     pos = positions
     if pos.dtype != np.float32 or pos.ndim != 2 or pos.shape[1] != 3 or pos.strides[1] != 4 or pos.strides[0] < 12:
         pos = np.ascontiguousarray(positions, np.float32)
     f = np.ascontiguousarray(faces, np.int32)
     V, F = pos.shape[0], f.shape[0]
-    fn = np.empty((F, 3), np.float32)
-    fa = np.empty(F, np.float32)
-    hl = np.empty(3 * F, np.float32)
-    vn = np.empty((V, 3), np.float32) if vertex_normals else None
-    rc = L.nwr_mesh_geometry(pos.ctypes.data, pos.strides[0], V, f.ctypes.data, F, fn.ctypes.data, fa.ctypes.data, hl.ctypes.data,
-                             vn.ctypes.data if vn is not None else None)
+    if out is None:
+        out = (np.empty((F, 3), np.float32), np.empty(F, np.float32), np.empty(3 * F, np.float32), np.empty((V, 3), np.float32) if vertex_normals else None)
+    fn, fa, hl, vn = out
+    for a, shape in ((fn, (F, 3)), (fa, (F,)), (hl, (3 * F,)), (vn, (V, 3))):
+        if a is not None and (a.dtype != np.float32 or a.shape != shape or (a.ndim == 2 and a.strides[1] != 4)):
+            raise ValueError('mesh_geometry: an output array of the wrong type or shape')
+    rc = L.nwr_mesh_geometry(pos.ctypes.data, pos.strides[0], V, f.ctypes.data, F, fn.ctypes.data, fn.strides[0], fa.ctypes.data, fa.strides[0],
+                             hl.ctypes.data, hl.strides[0], vn.ctypes.data if vn is not None else None, vn.strides[0] if vn is not None else 0)
     if rc != 0:
         raise RuntimeError('nwr_mesh_geometry: %s' % ERRORS.get(rc, 'error %d' % rc))
     return fn, fa, hl, vn
@@ -169,8 +172,11 @@ def mesh_geometry(positions, faces, vertex_normals=True):
 def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):
     """`MembraneMesh.remesher` hook: remesh the valid part of `mesh` and rebuild its half-edge tables in place."""
     valid = mesh._vertices['halfedge'] != -1
-    remap = np.cumsum(valid) - 1
-    v = mesh._vertices['position'][valid]
-    f = remap[mesh.faces]
+    if valid.all():                                   # (the usual case: no spare or deleted vertex slots -- nothing to renumber)
+        v, f = mesh._vertices['position'], mesh.faces
+    else:
+        remap = np.cumsum(valid) - 1
+        v = mesh._vertices['position'][valid]
+        f = remap[mesh.faces]
     nv, nf = remesh(v, f, n, target_edge_length, l, n_relax)
     mesh._topology_changed(nv, nf)

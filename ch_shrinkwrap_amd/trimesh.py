@@ -246,12 +246,9 @@ class TriMesh(object):
         if not getattr(self, '_numpy_geometry', False):
             try:                                              # native, bit-identical to the NumPy definition below
                 from .remesh import mesh_geometry
-                fn, fa, hl, vn = mesh_geometry(pos, f, vertex_normals)
-                self._faces['normal'] = fn
-                self._faces['area'] = fa
-                self._halfedges['length'] = hl
-                if vertex_normals:
-                    self._vertices['normal'] = vn
+                # (written straight into the records' fields: no staging arrays)
+                mesh_geometry(pos, f, vertex_normals, out=(self._faces['normal'], self._faces['area'], self._halfedges['length'],
+                                                           self._vertices['normal'] if vertex_normals else None))
                 return
             except (RuntimeError, ValueError):                # an input the library rejects: NumPy definition below
                 pass

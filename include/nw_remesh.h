@@ -66,9 +66,12 @@ int nwr_halfedge_twins(const int32_t *faces, int64_t n_faces, int64_t n_vertices
  * substrate's TriMesh.update_geometry): unit face normals (F,3), face areas (F,), half-edge lengths (3F,: half-edge 3f+k runs
  * from faces[f][k] to faces[f][(k+1)%3]) and, if vertex_normal is not NULL, area-weighted unit vertex normals (V,3).
  * `positions` points at the first vertex's xyz (float32), consecutive vertices pos_stride_bytes apart (120 for PYME's vertex_t,
- * 12 for a packed array).  Bit-identical to the NumPy definition it replaces. */
+ * 12 for a packed array).  The outputs are float32 fields written in place: element i of an output lies i * its stride (bytes) after
+ * the pointer -- 12 / 4 / 4 / 12 for packed arrays, the record size for a field of PYME's face_t / halfedge_t / vertex_t records (ABI 4:
+ * no staging copies).  Bit-identical to the NumPy definition it replaces, for any number of host threads. */
 int nwr_mesh_geometry(const void *positions, int64_t pos_stride_bytes, int64_t n_vertices, const int32_t *faces, int64_t n_faces,
-                      float *face_normal, float *face_area, float *halfedge_length, float *vertex_normal /* may be NULL */);
+                      void *face_normal, int64_t fn_stride_bytes, void *face_area, int64_t fa_stride_bytes,
+                      void *halfedge_length, int64_t hl_stride_bytes, void *vertex_normal /* may be NULL */, int64_t vn_stride_bytes);
 
 /* Half-edge tables and 1-rings written straight into the caller's records (structured arrays in PYME's layout: half-edge records
  * he_stride bytes apart with int32 fields at the given byte offsets, vertex records likewise): what a half-edge substrate

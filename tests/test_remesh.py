@@ -37,7 +37,7 @@ def test_library_exports_header_symbols():
     assert names == sorted(R.SYMBOLS)
     for n in names:
         assert hasattr(L, n)
-    assert R.load().nwr_abi_version() == 3
+    assert R.load().nwr_abi_version() == 4
     assert ctypes.sizeof(R.Stats) == 3 * 8 + 8 + 2 * 4
 
 
@@ -103,8 +103,8 @@ def test_genus_two_network_and_degenerate_input():
     assert set(np.unique(cn)) <= {1, 2} and (cn == 1).any()
 
 
-@pytest.mark.parametrize('case', ['icosphere', 'network', 'open_with_spare_slots'])
-def test_native_geometry_refresh_is_bit_identical_to_the_numpy_definition(case):
+@pytest.mark.parametrize('case', ['icosphere', 'network', 'open_with_spare_slots', 'large_on_all_cores'])
+def test_native_geometry_refresh_is_bit_identical_to_the_numpy_definition(case, monkeypatch):
     """nwr_mesh_geometry / nwr_halfedge_twins against the NumPy code they replace in trimesh.TriMesh (the definition the
     optimiser's golden inputs were produced with): face normals, areas, half-edge lengths, vertex normals, twins."""
     from ch_shrinkwrap_amd import trimesh as T
@@ -113,7 +113,11 @@ def test_native_geometry_refresh_is_bit_identical_to_the_numpy_definition(case):
         c = synth.make_config('c4', scale=0.02, seed=5)
         v, f, extra = c['vertices'], c['faces'], 0
     else:
-        v, f = icosphere(3, 73.0)
+        # 'large_on_all_cores': 327 680 faces -- the native loops run on several threads (every thread its own range of faces / vertices,
+        # the vertex normals summed in the serial order inside each range)
+        v, f = icosphere(7 if case == 'large_on_all_cores' else 3, 73.0)
+        if case == 'large_on_all_cores':
+            monkeypatch.setenv('NW_REMESH_THREADS', '8')
         v = (v * np.array([1.0, 0.6, 1.7], 'f4') + np.array([1e3, -2e3, 5e2], 'f4')).astype('f4')
         extra = 0
         if case == 'open_with_spare_slots':
@@ -137,8 +141,8 @@ def test_native_geometry_refresh_is_bit_identical_to_the_numpy_definition(case):
     assert np.array_equal(a._halfedges['twin'], np.where(key[cand] == rkey, cand, -1))
 
 
-@pytest.mark.parametrize('case', ['icosphere', 'network', 'open_with_spare_slots', 'remeshed'])
-def test_native_topology_is_identical_to_the_numpy_definition(case):
+@pytest.mark.parametrize('case', ['icosphere', 'network', 'open_with_spare_slots', 'remeshed', 'large_on_all_cores'])
+def test_native_topology_is_identical_to_the_numpy_definition(case, monkeypatch):
     """nwr_build_topology / nwr_ring_tables against the NumPy code they replace (trimesh._build_halfedges, TriMesh._build_rings,
     neighbor_vertex_table, MembraneMesh._neighbor_tables): every half-edge field, ring start, ring order, valence, and the per-slot
     tables -- closed, open (boundary fans) and freshly remeshed (ids in creation order) meshes, with unused vertex slots."""
@@ -149,7 +153,9 @@ def test_native_topology_is_identical_to_the_numpy_definition(case):
         c = synth.make_config('c4', scale=0.02, seed=5)
         v, f = c['vertices'], c['faces']
     else:
-        v, f = icosphere(3, 73.0)
+        v, f = icosphere(7 if case == 'large_on_all_cores' else 3, 73.0)
+        if case == 'large_on_all_cores':
+            monkeypatch.setenv('NW_REMESH_THREADS', '8')
         v = (v * np.array([1.0, 0.6, 1.7], 'f4')).astype('f4')
         if case == 'open_with_spare_slots':
             f = f[v[f].mean(1)[:, 2] > 0]
