@@ -273,7 +273,7 @@ __device__ __forceinline__ int nw_wave_max_i(int v)
 }
 
 // developer counters of one launch (nw_debug, what = 0): candidates evaluated, rows listed / visited, cells tested / visited, ...
-enum { NWS_CAND = 0, NWS_ROWS_NONEMPTY, NWS_ROWS_PASS, NWS_CELLS_TESTED, NWS_CELLS_PASS, NWS_BOX_ROWS, NWS_ROUNDS, NWS_T_WAVE_MAX, NWS_T_STREAM, NWS_T_WAVE, NWS_T_PRO, NWS_T_TAIL, NWS_COUNT };   // T_*: s_memtime ticks / 16 (PRO: before the walk, TAIL: after it)
+enum { NWS_CAND = 0, NWS_ROWS_NONEMPTY, NWS_ROWS_PASS, NWS_CELLS_TESTED, NWS_CELLS_PASS, NWS_BOX_ROWS, NWS_ROUNDS, NWS_T_WAVE_MAX, NWS_T_STREAM, NWS_T_WAVE, NWS_T_PRO, NWS_T_TAIL, NWS_LANE_CELLS, NWS_LANE_CELLS_MAX, NWS_LANE_CAND, NWS_LANE_CAND_MAX, NWS_COUNT };   // LANE_*: cells / candidates of the collected ranges that the lane's OWN ball reaches, summed over the lanes; *_MAX: the wave's largest lane, summed over the waves   // T_*: s_memtime ticks / 16 (PRO: before the walk, TAIL: after it)
 #define NWS_COPIES 1024             // sets of counters the waves spread their atomics over (one set: 17 000 same-address atomics took 3 ms per launch)
 struct NwStats { int v[NWS_COUNT]; bool timed; };
 
@@ -605,6 +605,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const int cx = nw_clampi((int)floorf(L.ux), 0, g.gx - 1), cy = nw_clampi((int)floorf(L.uy), 0, g.gy - 1), cz = nw_clampi((int)floorf(L.uz), 0, g.gz - 1);
     int Exl = 0, Exh = -1, Eyl = 0, Eyh = -1, Ezl = 0, Ezh = -1;         // visited box (cells), empty
     int margin = 1, rounds = 0;
+    int lane_cells = 0, lane_cand = 0;                                   // (STATS only)
     if (STATS) S.v[NWS_T_PRO] += (int)((__builtin_amdgcn_s_memtime() - t_wave) >> 4);
     for (;;) {
         // ---- the box this round must cover: the lanes' balls (finite b1) or their own cell +- margin (nothing seen yet)
@@ -683,7 +684,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     t &= t - 1u;
                     const float dx = nw_slab_d(L.ax, L.bx, xj + (float)k);
                     if (STATS) S.v[NWS_CELLS_TESTED] += 1;
-                    if (__any(fmaf(dx, dx, dyz2) <= r2u)) { pm |= 1u << k; if (STATS) S.v[NWS_CELLS_PASS] += 1; }
+                    const bool mine = fmaf(dx, dx, dyz2) <= r2u;
+                    if (STATS && mine) { lane_cells += 1; lane_cand += nw_pick(cs, k + 1, j) - nw_pick(cs, k, j); }
+                    if (__any(mine)) { pm |= 1u << k; if (STATS) S.v[NWS_CELLS_PASS] += 1; }
                 }
                 // runs of surviving cells (empty or culled-empty cells in between join for free) -> candidate ranges
                 const unsigned joinable = pm | ~mj;
@@ -750,6 +753,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         item_cost[wi] = (unsigned)min((unsigned long long)0xffffffffu, (__builtin_amdgcn_s_memtime() - t_wave) >> 4);
         // developer aid (NW_ITEM_TIMES): start and duration of every item in 10 ns ticks, for the launch's time line (tools/nn_costs.py)
         if (warm & 64) { item_cost[nitems + wi] = (unsigned)t_real; item_cost[wi] = (unsigned)(wall_clock64() - t_real); }
+    }
+    if (STATS) {
+        int cs_ = lane_cells, cm_ = lane_cells, ns_ = lane_cand, nm_ = lane_cand;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cs_ += __shfl_xor(cs_, off, 64); ns_ += __shfl_xor(ns_, off, 64);
+            cm_ = max(cm_, __shfl_xor(cm_, off, 64)); nm_ = max(nm_, __shfl_xor(nm_, off, 64));
+        }
+        S.v[NWS_LANE_CELLS] = cs_; S.v[NWS_LANE_CELLS_MAX] = cm_; S.v[NWS_LANE_CAND] = ns_; S.v[NWS_LANE_CAND_MAX] = nm_;
     }
     if (STATS && stats && lane == 0) {
         S.v[NWS_ROUNDS] = rounds;

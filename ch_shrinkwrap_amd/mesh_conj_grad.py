@@ -437,10 +437,10 @@ class ShrinkwrapMeshConjGrad(object):
 
     def nn_stats(self):
         """developer counters of the nearest-face query since the previous call (first call: switches them on)"""
-        out = (ctypes.c_int64 * 13)()
+        out = (ctypes.c_int64 * 17)()
         self._native.check(self._L.nw_debug(self._h, 0, out, None, 0, None))
         names = ['candidates', 'rows_nonempty', 'rows_visited', 'cells_tested', 'cells_visited', 'box_rows', 'rounds', 'max_wave_cycles_16', 'stream_cycles_16', 'wave_cycles_16',
-                 'prologue_cycles_16', 'tail_cycles_16', 'items']
+                 'prologue_cycles_16', 'tail_cycles_16', 'lane_cells', 'lane_cells_max', 'lane_candidates', 'lane_candidates_max', 'items']
         return dict(zip(names, [int(v) for v in out]))
 
     def stage_ms(self, only=None):

@@ -302,9 +302,11 @@ int nw_accumulator_quantum(nw_ctx *ctx, double *q);
 
 /* developer aids, no reference counterpart (one entry point):
  * what = 0: counters of the exact nearest-face query accumulated since the previous call (the first call switches the counting on; the
- *   counting variant of the kernel is a few per cent slower).  a = int64 out[13]: candidate evaluations per wave summed, non-empty rows listed,
- *   rows visited, cells tested, cells visited, rows of the boxes, rounds, slowest wave, and the waves' time (s_memtime ticks / 16) in the
- *   candidate stream / in all / before the walk / after it; out[12] = work items.  b, cap, n unused.
+ *   counting variant of the kernel is a few per cent slower).  a = int64 out[17]: candidate evaluations per wave summed, non-empty rows listed,
+ *   rows visited, cells tested, cells visited, rows of the boxes, rounds, slowest wave, the waves' time (s_memtime ticks / 16) in the
+ *   candidate stream / in all / before the walk / after it, then what a lane's OWN ball reaches of the cells its wave tested: cells summed
+ *   over the lanes, the wave's largest lane summed over the waves, and the same two for the candidates in those cells; out[16] = work
+ *   items.  b, cap, n unused.
  * what = 1: the work list of the query -- a = int32 {first localization in sorted order, count}[cap], b = uint32 cost[cap] (duration in
  *   s_memtime ticks / 16 the last query measured for each item; zeros once the list has been ordered: heavy first, light last), *n = items in
  *   the list.  With NW_ITEM_TIMES set in the environment the timing stays on, durations are in 10 ns ticks of the clock all XCDs share, and b

@@ -41,3 +41,6 @@ for b in range(min(blocks, 3)):
     print('         per wave: segments with centroids %.1f, of them a ball reaches %.1f; cells tested %.1f, reached %.1f; box rows %.1f, rounds %.2f' % (
         st.get('rows_nonempty', 0) / (5.0 * items), st.get('rows_visited', 0) / (5.0 * items), st['cells_tested'] / (5.0 * items), st.get('cells_visited', 0) / (5.0 * items),
         st.get('box_rows', 0) / (5.0 * items), st.get('rounds', 0) / (5.0 * items)), flush=True)
+    print('         per LANE (its own ball against the cells): cells reached %.2f (largest lane of a wave %.1f), their candidates %.1f (largest lane %.1f)' % (
+        st.get('lane_cells', 0) / (5.0 * items * 59.0), st.get('lane_cells_max', 0) / (5.0 * items), st.get('lane_candidates', 0) / (5.0 * items * 59.0),
+        st.get('lane_candidates_max', 0) / (5.0 * items)), flush=True)
