@@ -117,6 +117,7 @@ def parse_args(argv=None):
     ap.add_argument('--mode', default='tiles', choices=('tiles', 'halo'),
                     help='N > 1: tiles = one vesicle per rank (BASELINE configs[4], weak scaling); halo = ONE mesh sharded over the ranks (strong scaling)')
     ap.add_argument('--halo', type=float, default=60.0, help='--mode halo: margin (nm) of the first shares -- every rank holds the faces within (nearest distance + margin) of each of its localizations; budget for the growth of a nearest distance + the drift of the mesh until new shares are cut (bench.py cuts them again, with three times the last block\'s movement, after its warm-up)')
+    ap.add_argument('--exchange', choices=['peers', 'dense'], default='peers', help="--mode halo: how the boundary rows go round -- 'peers': between the ranks that share them (the copies' partial sums to the vertex's owner, its sum and new position back); 'dense': two all-reduces over the global list of boundary vertices")
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the workload (debug only; the reported config says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph-pass', action='store_true', help='skip the extra un-instrumented (graph-replay) pass (profiling runs)')
@@ -261,7 +262,7 @@ def run_rank(args):
     native = NativeContext(local_rank, None) if native_comm else None
     comm = parallel.NativeComm(native, dist) if native_comm else None
     if halo:
-        scene = parallel.HaloScene(mesh, pts, dist, halo=args.halo, torch_stream=tstream, native=native, comm=comm)
+        scene = parallel.HaloScene(mesh, pts, dist, halo=args.halo, torch_stream=tstream, native=native, comm=comm, exchange=args.exchange)
         scene.set_profiling(0)
         cg_of = lambda: scene.ex.cg                     # (a re-partition builds a new optimiser over the new share)
     else:
@@ -459,8 +460,10 @@ def run_rank(args):
                                       'note': 'rank 0, event-bracketed all-reduces of %d extra iterations after the timed region' % n_extra}
             if halo:
                 out['halo'] = {'radius_nm': args.halo, 'per_localization_halos': bool(scene.per_point), 'margin_nm': float(getattr(scene, '_cut_margin', args.halo)),
-                               'exchange_bytes_per_iteration': int(scene.ex.n_boundary) * (32 + 12) + 28 * 32 * 8,
-                               'boundary_vertices': scene.ex.n_boundary, 'repartitions_in_timed_region': reparts,
+                               'exchange': args.exchange,
+                               'exchange_bytes': int(scene.exchange_bytes) + 28 * 32 * 8,
+                               'exchange_bytes_note': ('bytes rank 0 SENDS per iteration: 32 B for every copy it holds of a vertex another rank owns (partial accumulator row to the owner), 44 B for every copy another rank holds of a vertex it owns (the sum and the new position back), + the 7 KB of normal-equation sums' if args.exchange == 'peers' else 'bytes of the two dense buffers every rank all-reduces per iteration (44 B per boundary vertex of the whole mesh) + the 7 KB of normal-equation sums'),
+                               'boundary_vertices': int(scene.boundary_vertices), 'repartitions_in_timed_region': reparts,
                                'max_nn_distance_nm': scene.max_dist, 'drift_since_partition_nm': scene.drift,
                                'host_ms_per_block': host_ms,
                                'vertices_held_over_owned': float(Ml) * world / max(M, 1)}

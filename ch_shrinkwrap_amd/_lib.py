@@ -16,7 +16,7 @@ NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP, NW_FLAG_WFUNC, NW_FLAG_RESULT_TO_HOST 
 NW_FLAG_COMM_TILES, NW_FLAG_COMM_REPLICATED, NW_FLAG_COMM_HALO = 16, 32, 64
 (NW_ARR_S, NW_ARR_RES, NW_ARR_VIDX, NW_ARR_W, NW_ARR_DIST, NW_ARR_FACE, NW_ARR_POS, NW_ARR_FDEF, NW_ARR_PI,
  NW_ARR_MESHPOS, NW_ARR_VACC, NW_ARR_SCALARS, NW_ARR_NBR, NW_ARR_NRM, NW_ARR_VALID, NW_ARR_HALO_ACC, NW_ARR_HALO_ROWS,
- NW_ARR_HALO_FULL, NW_ARR_HALO_STATS) = range(19)
+ NW_ARR_HALO_FULL, NW_ARR_HALO_STATS, NW_ARR_PEER_SEND, NW_ARR_PEER_RECV) = range(21)
 NW_N_SCALARS = 32
 
 # every symbol include/nanowrap.h declares (tests/test_abi.py checks the exports against the header)
@@ -73,7 +73,7 @@ def load():
     L.nw_get.argtypes = [vp, i32, vp, i64]
     L.nw_write_back.argtypes = [vp, vp, vp, i64]
     L.nw_set_write_back.argtypes = [vp, vp, i64]
-    L.nw_set_boundary.argtypes = [vp, vp, vp, i64, i64, vp, vp, i64]
+    L.nw_set_boundary.argtypes = [vp, vp, vp, i64, i64, vp, vp, i64, ctypes.c_int32, vp, vp, vp, vp, vp]
     L.nw_halo_rows.argtypes = [vp, i32, i32]
     L.nw_halo_gather_owned.argtypes = [vp, i32]
     L.nw_host_copy_rows.argtypes = [vp, vp, i64, vp, vp, i64, vp]
@@ -94,7 +94,7 @@ def load():
     for s in SYMBOLS:
         if s not in ('nw_destroy', 'nw_last_error'):
             getattr(L, s).restype = i32
-    if L.nw_abi_version() != 4:
+    if L.nw_abi_version() != 5:
         raise RuntimeError('libnanowrap_hip.so ABI version mismatch')
     _lib = L
     return L

@@ -38,6 +38,10 @@ struct NwRccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
     bool load()
@@ -50,6 +54,10 @@ struct NwRccl {
         CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
         AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        Send = (decltype(Send))dlsym(lib, "ncclSend");
+        Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
         if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce) { err = "RCCL: a symbol is missing"; (void)dlclose(lib); lib = nullptr; return false; }
         return true;
@@ -246,6 +254,16 @@ struct nw_ctx {
     int64_t hb_n = 0, hb_nslot = 0, M_global = 0;
     bool have_boundary = false;
     bool pos_unpack_pending = false;  // the owners' new boundary positions are in halo_rows (all-reduced by the caller), not yet taken
+    // owner-wise exchange of the boundary rows (nw_set_boundary with peers): rows = (peer, vertex) pairs, peer after peer.  `ghost` rows:
+    // this rank's copies of vertices the peer owns; `owned` rows: vertices this rank owns that the peer holds a copy of.  A copy's partial
+    // accumulator row goes to the owner, the owner's sum and, after the update, its new position come back: three neighbour exchanges per
+    // iteration instead of two all-reduces over the dense global boundary list.
+    bool have_peers = false;
+    std::vector<int> px_rank;
+    std::vector<int64_t> px_goff, px_ooff;        // [n_peers + 1]
+    DevBuf<int> px_ghost, px_owned;               // local vertex ids, by peer
+    DevBuf<long long> px_send, px_recv;           // max(ghost rows, owned rows) x 4 int64 (the float32 rows of positions / normals use the front)
+    int64_t px_ng = 0, px_no = 0;
     int maxdeg = 0;
     DevBuf<int> d_small;              // small int scratch (maxdeg, flags)
 
@@ -630,7 +648,7 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->ccount.release(); ctx->cstart.release(); ctx->scan_tmp.release(); ctx->ctile.release(); ctx->items.release(); ctx->nn_stats.release(); ctx->aux_i.release(); ctx->aux_f.release(); ctx->aux_f2.release(); ctx->aux_f3.release(); ctx->aux_d.release();
     ctx->pos.release(); ctx->meshpos.release(); ctx->nrm.release(); ctx->nbr.release(); ctx->nbr_t.release(); ctx->faces.release();
     ctx->valid.release(); ctx->owned.release(); ctx->d_small.release();
-    ctx->hb_local.release(); ctx->hb_slot.release(); ctx->hb_slot2local.release(); ctx->hb_gv.release(); ctx->halo_acc.release(); ctx->halo_rows.release(); ctx->halo_full.release(); ctx->halo_ref.release(); ctx->halo_stats.release();
+    ctx->px_ghost.release(); ctx->px_owned.release(); ctx->px_send.release(); ctx->px_recv.release(); ctx->hb_local.release(); ctx->hb_slot.release(); ctx->hb_slot2local.release(); ctx->hb_gv.release(); ctx->halo_acc.release(); ctx->halo_rows.release(); ctx->halo_full.release(); ctx->halo_ref.release(); ctx->halo_stats.release();
     ctx->ambig_list.release(); ctx->ambig_count.release(); ctx->cent_tmp.release(); ctx->cent.release(); ctx->fcell.release(); ctx->frank.release(); ctx->face.release(); ctx->vidx.release();
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->wv.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
@@ -937,7 +955,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     ctx->face_warm = false;                               // face ids of another topology are no starting guess
     if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 2) fprintf(stderr, "[nanowrap] warm start dropped (%s)\n", __func__);
     ctx->have_owned = false;
-    ctx->have_boundary = false; ctx->pos_unpack_pending = false;      // (a sharding belongs to the mesh it was made for)
+    ctx->have_boundary = false; ctx->have_peers = false; ctx->pos_unpack_pending = false;      // (a sharding belongs to the mesh it was made for)
     // a new mesh object = a new optimiser in the reference (_membrane_mesh.pyx:1510): history restarts
     NwDevState st{};
     st.stop_at = 0x7fffffff;
@@ -969,12 +987,13 @@ static int nw_set_owned(nw_ctx *ctx, const uint8_t *owned)
 //   the next nw_iter_attract / nw_search_end takes the owners' rows (positions and mesh positions) first.
 // n_local == 0 with n_slots == 0 is a valid sharding (no shared vertex); b_local == NULL with n_slots < 0 clears it.
 NW_EXPORT int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t *b_slot, int64_t n_local, int64_t n_slots, const uint8_t *owned,
-                              const int32_t *gv, int64_t n_global)
+                              const int32_t *gv, int64_t n_global, int32_t n_peers, const int32_t *peer_rank, const int64_t *ghost_off,
+                              const int32_t *ghost_local, const int64_t *owned_off, const int32_t *owned_local)
 {
     if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: mesh not set");
     if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary inside a search");
     NW_HIP(hipSetDevice(ctx->device));
-    if (n_slots < 0) { ctx->have_boundary = false; ctx->pos_unpack_pending = false; return nw_set_owned(ctx, nullptr); }
+    if (n_slots < 0) { ctx->have_boundary = false; ctx->have_peers = false; ctx->pos_unpack_pending = false; return nw_set_owned(ctx, nullptr); }
     if (n_local < 0 || n_local > ctx->M || n_local > n_slots || (n_local > 0 && (!b_local || !b_slot)) || !owned || !gv || n_global <= 0 || n_global > 0x7fffffff / 4)
         return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: bad array/size");
     // validate on the host (a bad index would fault a kernel): local ids inside the mesh, slots inside the list, each slot at most once
@@ -1016,8 +1035,74 @@ NW_EXPORT int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t
     NW_HIP(hipMemsetAsync(ctx->halo_rows.p, 0, (size_t)3 * std::max<int64_t>(n_slots, 1) * sizeof(float), ctx->stream));
     ctx->hb_n = n_local; ctx->hb_nslot = n_slots; ctx->M_global = n_global;
     NW_TRY(nw_set_owned(ctx, owned));
+    // owner-wise exchange: the (peer, vertex) rows, validated on the host like the dense list (a bad index would fault a kernel; a count
+    // that differs from the peer's would hang the exchange -- the peers' lists come from the same all-reduced holder masks, parallel.py)
+    ctx->have_peers = false;
+    if (n_peers >= 0 && peer_rank && ghost_off && owned_off) {
+        if (n_peers > 4096) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: too many peers");
+        const int64_t ng = ghost_off[n_peers], no = owned_off[n_peers];
+        if (ghost_off[0] != 0 || owned_off[0] != 0 || ng < 0 || no < 0 || ng > ctx->M || no > (int64_t)n_peers * ctx->M || (ng > 0 && !ghost_local) || (no > 0 && !owned_local))
+            return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: bad peer offsets");
+        std::vector<uint8_t> ho((size_t)ctx->M);
+        if (hipMemcpy(ho.data(), owned, (size_t)ctx->M, hipMemcpyDefault) != hipSuccess) return fail(ctx, NW_ERR_HIP, "nw_set_boundary: cannot read `owned`");
+        for (int p = 0; p < n_peers; ++p) {
+            if (ghost_off[p + 1] < ghost_off[p] || owned_off[p + 1] < owned_off[p] || peer_rank[p] < 0) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: bad peer offsets");
+            for (int q = 0; q < p; ++q) if (peer_rank[q] == peer_rank[p]) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: a peer listed twice");
+        }
+        std::vector<uint8_t> seen((size_t)ctx->M, 0);
+        for (int64_t k = 0; k < ng; ++k) {
+            const int l = ghost_local[k];
+            if (l < 0 || l >= ctx->M || ho[l] || seen[l]) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: a ghost row that is out of range, owned here, or listed twice");
+            seen[l] = 1;
+        }
+        for (int64_t k = 0; k < no; ++k) {
+            const int l = owned_local[k];
+            if (l < 0 || l >= ctx->M || !ho[l]) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: an owned row that is out of range or not owned here");
+        }
+        NW_HIP(ctx->px_ghost.ensure((size_t)std::max<int64_t>(ng, 1)));
+        NW_HIP(ctx->px_owned.ensure((size_t)std::max<int64_t>(no, 1)));
+        if (ng > 0) NW_HIP(hipMemcpy(ctx->px_ghost.p, ghost_local, (size_t)ng * sizeof(int), hipMemcpyHostToDevice));
+        if (no > 0) NW_HIP(hipMemcpy(ctx->px_owned.p, owned_local, (size_t)no * sizeof(int), hipMemcpyHostToDevice));
+        const size_t rows = (size_t)std::max<int64_t>(std::max(ng, no), 1);
+        NW_HIP(ctx->px_send.ensure(4 * rows));
+        NW_HIP(ctx->px_recv.ensure(4 * rows));
+        NW_HIP(hipMemset(ctx->px_send.p, 0, 4 * rows * sizeof(long long)));
+        NW_HIP(hipMemset(ctx->px_recv.p, 0, 4 * rows * sizeof(long long)));
+        ctx->px_rank.assign(peer_rank, peer_rank + n_peers);
+        ctx->px_goff.assign(ghost_off, ghost_off + n_peers + 1);
+        ctx->px_ooff.assign(owned_off, owned_off + n_peers + 1);
+        ctx->px_ng = ng; ctx->px_no = no;
+        ctx->have_peers = true;
+    }
     ctx->have_boundary = true;
     ctx->pos_unpack_pending = false;
+    return NW_OK;
+}
+
+// owner-wise exchange, the steps around the transfers (the iteration phases call them; the transfers are the caller's -- split-phase -- or
+// px_exchange's -- nw_search with a communicator):
+//   accumulator  0: the copies' partial rows -> send          [exchange: ghost rows out, owned rows in]
+//                1: received partial rows added to the owners' rows; the owners' sums -> send   [exchange: owned rows out, ghost rows in]
+//                2: the owners' sums taken by the copies
+//   positions / normals  0: the owners' rows -> send          [exchange: owned rows out, ghost rows in]     1: taken by the copies
+static int px_stage(nw_ctx *ctx, int what, int stage)
+{
+    const int ng = (int)ctx->px_ng, no = (int)ctx->px_no;
+    if (what == NW_ARR_VACC) {
+        if (stage == 0) { if (ng > 0) hipLaunchKernelGGL(k_halo_pack_acc, dim3(nblk(ng)), dim3(NW_BLOCK), 0, ctx->stream, ng, ctx->px_ghost.p, ctx->vacc.p, ctx->px_send.p); }
+        else if (stage == 1) {
+            if (no > 0) {
+                hipLaunchKernelGGL(k_px_add_acc, dim3(nblk(no)), dim3(NW_BLOCK), 0, ctx->stream, no, ctx->px_owned.p, ctx->px_recv.p, ctx->vacc.p);
+                hipLaunchKernelGGL(k_halo_pack_acc, dim3(nblk(no)), dim3(NW_BLOCK), 0, ctx->stream, no, ctx->px_owned.p, ctx->vacc.p, ctx->px_send.p);
+            }
+        } else if (ng > 0) hipLaunchKernelGGL(k_px_take_acc, dim3(nblk(ng)), dim3(NW_BLOCK), 0, ctx->stream, ng, ctx->px_ghost.p, ctx->px_recv.p, ctx->vacc.p);
+    } else {
+        float *rows = what == NW_ARR_NRM ? ctx->nrm.p : ctx->pos.p;
+        if (stage == 0) { if (no > 0) hipLaunchKernelGGL(k_px_pack_rows, dim3(nblk(no)), dim3(NW_BLOCK), 0, ctx->stream, no, ctx->px_owned.p, rows, (float *)ctx->px_send.p); }
+        else if (ng > 0) hipLaunchKernelGGL(k_px_take_rows, dim3(nblk(ng)), dim3(NW_BLOCK), 0, ctx->stream, ng, ctx->px_ghost.p, (const float *)ctx->px_recv.p, rows,
+                                            what == NW_ARR_NRM ? (float *)nullptr : ctx->meshpos.p);
+    }
+    NW_HIP(hipGetLastError());
     return NW_OK;
 }
 
@@ -1025,6 +1110,7 @@ NW_EXPORT int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t
 // nw_refresh_normals): what = NW_ARR_VACC -> NW_ARR_HALO_ACC; NW_ARR_POS / NW_ARR_NRM -> NW_ARR_HALO_ROWS (owner-only rows)
 static int halo_pack(nw_ctx *ctx, int what)
 {
+    if (ctx->have_peers) return px_stage(ctx, what, 0);
     const int ns = (int)ctx->hb_nslot;
     if (ns <= 0) return NW_OK;
     if (what == NW_ARR_VACC) hipLaunchKernelGGL(k_halo_pack_acc, dim3(nblk(ns)), dim3(NW_BLOCK), 0, ctx->stream, ns, ctx->hb_slot2local.p, ctx->vacc.p, ctx->halo_acc.p);
@@ -1035,6 +1121,7 @@ static int halo_pack(nw_ctx *ctx, int what)
 
 static int halo_unpack(nw_ctx *ctx, int what)
 {
+    if (ctx->have_peers) return px_stage(ctx, what, what == NW_ARR_VACC ? 2 : 1);
     const int n = (int)ctx->hb_n;
     if (n <= 0) return NW_OK;
     if (what == NW_ARR_VACC) hipLaunchKernelGGL(k_halo_unpack_acc, dim3(nblk(n)), dim3(NW_BLOCK), 0, ctx->stream, n, ctx->hb_local.p, ctx->hb_slot.p, ctx->halo_acc.p, ctx->vacc.p);
@@ -1049,6 +1136,11 @@ NW_EXPORT int nw_halo_rows(nw_ctx *ctx, int what, int unpack)
     if (!ctx || !ctx->have_boundary) return fail(ctx, NW_ERR_BADARG, "nw_halo_rows: no boundary set (nw_set_boundary)");
     if (what != NW_ARR_VACC && what != NW_ARR_POS && what != NW_ARR_NRM) return fail(ctx, NW_ERR_BADARG, "nw_halo_rows: accumulator, positions or normals");
     if (what == NW_ARR_VACC && !ctx->vacc.p) return fail(ctx, NW_ERR_BADARG, "nw_halo_rows: no accumulator yet");
+    if (ctx->have_peers) {                                  // `unpack` = the step (px_stage)
+        if (unpack < 0 || unpack > (what == NW_ARR_VACC ? 2 : 1)) return fail(ctx, NW_ERR_BADARG, "nw_halo_rows: no such step of the owner-wise exchange");
+        if (what == NW_ARR_POS && unpack == 1) ctx->pos_unpack_pending = false;
+        return px_stage(ctx, what, unpack);
+    }
     if (!unpack) return halo_pack(ctx, what);
     if (what == NW_ARR_POS) ctx->pos_unpack_pending = false;
     return halo_unpack(ctx, what);
@@ -1644,7 +1736,10 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
                           ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p,
-                          ctx->hb_local.p, ctx->hb_slot.p, ctx->hb_slot2local.p, ctx->halo_acc.p, ctx->halo_rows.p, ctx->face_sorted ? ctx->face_orig.p : nullptr};
+                          ctx->hb_local.p, ctx->hb_slot.p, ctx->hb_slot2local.p, ctx->halo_acc.p, ctx->halo_rows.p, ctx->face_sorted ? ctx->face_orig.p : nullptr,
+                          ctx->have_peers ? ctx->px_ghost.p : nullptr, ctx->have_peers ? ctx->px_owned.p : nullptr, ctx->have_peers ? ctx->px_send.p : nullptr,
+                          ctx->have_peers ? ctx->px_recv.p : nullptr};
+    if (ctx->have_peers) { mix((uint64_t)ctx->px_ng); mix((uint64_t)ctx->px_no); for (size_t p = 0; p < ctx->px_rank.size(); ++p) { mix((uint64_t)ctx->px_rank[p]); mix((uint64_t)ctx->px_goff[p + 1]); mix((uint64_t)ctx->px_ooff[p + 1]); } }
     mix((uint64_t)ctx->hb_n); mix((uint64_t)ctx->hb_nslot); mix((uint64_t)(uintptr_t)ctx->stream);
     mix((uint64_t)(uintptr_t)ctx->comm); mix((uint64_t)ctx->comm_mode); mixp((ctx->have_boundary && ctx->have_halo_d0) ? ctx->halo_d0.p : nullptr);
     for (const void *p : ptrs) mixp(p);
@@ -1703,6 +1798,28 @@ static int comm_all_reduce_dev(nw_ctx *ctx, void *buf, size_t count, ncclDataTyp
     return NW_OK;
 }
 
+// one neighbour exchange of the owner-wise scheme: every peer's segment of px_send goes out, its segment of px_recv comes in (grouped
+// ncclSend / ncclRecv: one launch).  send_owned: the owned rows go out and the ghost rows come in (else the other way round).
+static int px_exchange(nw_ctx *ctx, bool send_owned, int elems_per_row, ncclDataType_t dt, size_t elem_bytes)
+{
+    if (!ctx->comm) return fail(ctx, NW_ERR_BADARG, "no communicator (nw_comm_init)");
+    if (ctx->px_rank.empty()) return NW_OK;
+    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(ctx, NW_ERR_HIP, "RCCL: ncclSend / ncclRecv / ncclGroup* missing");
+    const std::vector<int64_t> &so = send_owned ? ctx->px_ooff : ctx->px_goff, &ro = send_owned ? ctx->px_goff : ctx->px_ooff;
+    ncclResult_t r = g_rccl.GroupStart();
+    for (size_t p = 0; p < ctx->px_rank.size() && r == ncclSuccess; ++p) {
+        const int peer = ctx->px_rank[p];
+        if (peer >= ctx->comm_ranks || peer == ctx->comm_rank) { (void)g_rccl.GroupEnd(); return fail(ctx, NW_ERR_BADARG, "owner-wise exchange: a peer outside the communicator"); }
+        const size_t ns = (size_t)(so[p + 1] - so[p]) * elems_per_row, nr = (size_t)(ro[p + 1] - ro[p]) * elems_per_row;
+        if (ns > 0) r = g_rccl.Send((const char *)ctx->px_send.p + (size_t)so[p] * elems_per_row * elem_bytes, ns, dt, peer, ctx->comm, ctx->stream);
+        if (nr > 0 && r == ncclSuccess) r = g_rccl.Recv((char *)ctx->px_recv.p + (size_t)ro[p] * elems_per_row * elem_bytes, nr, dt, peer, ctx->comm, ctx->stream);
+    }
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) return fail(ctx, NW_ERR_HIP, std::string("ncclSend/ncclRecv: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+    return NW_OK;
+}
+
 // what goes round between the phases of one iteration (ch_shrinkwrap_amd/parallel.py run_search is the same protocol
 // over an external process group):
 //   after the attraction step   'replicated': the whole per-vertex accumulator (M x 4 int64);  'halo': its boundary rows (n_slots x 4 int64)
@@ -1712,6 +1829,12 @@ static int comm_after_attract(nw_ctx *ctx)
 {
     if (!ctx->comm || !ctx->comm_mode) return NW_OK;
     if (ctx->comm_mode & NW_FLAG_COMM_REPLICATED) return comm_all_reduce_dev(ctx, ctx->vacc.p, (size_t)4 * ctx->M, ncclInt64, ncclSum);
+    if ((ctx->comm_mode & NW_FLAG_COMM_HALO) && ctx->have_boundary && ctx->have_peers) {
+        // the copies' partial rows to the owners, the owners' sums back (the attraction step packed, the directions step takes)
+        NW_TRY(px_exchange(ctx, false, 4, ncclInt64, 8));
+        NW_TRY(px_stage(ctx, NW_ARR_VACC, 1));
+        return px_exchange(ctx, true, 4, ncclInt64, 8);
+    }
     if ((ctx->comm_mode & NW_FLAG_COMM_HALO) && ctx->have_boundary && ctx->hb_nslot > 0) return comm_all_reduce_dev(ctx, ctx->halo_acc.p, (size_t)4 * ctx->hb_nslot, ncclInt64, ncclSum);
     return NW_OK;
 }
@@ -1724,6 +1847,7 @@ static int comm_after_directions(nw_ctx *ctx)
 static int comm_after_update(nw_ctx *ctx)
 {
     if (!ctx->comm || !ctx->comm_mode) return NW_OK;
+    if ((ctx->comm_mode & NW_FLAG_COMM_HALO) && ctx->have_boundary && ctx->have_peers) return px_exchange(ctx, true, 3, ncclFloat, 4);
     if ((ctx->comm_mode & NW_FLAG_COMM_HALO) && ctx->have_boundary && ctx->hb_nslot > 0) return comm_all_reduce_dev(ctx, ctx->halo_rows.p, (size_t)3 * ctx->hb_nslot, ncclFloat, ncclSum);
     return NW_OK;
 }
@@ -1773,12 +1897,21 @@ NW_EXPORT int nw_comm_init(nw_ctx *ctx, const uint8_t *unique_id, int64_t nbytes
 
 NW_EXPORT int nw_comm_all_reduce(nw_ctx *ctx, void *buf, int64_t count, int dtype, int op)
 {
+    static const ncclDataType_t dts[4] = {ncclFloat, ncclDouble, ncclInt64, ncclInt32};
+    static const size_t sz[4] = {4, 8, 8, 4};
+    if (ctx && !buf && (op == 2 || op == 3) && dtype >= 0 && dtype <= 3 && count > 0 && count <= 4) {
+        // the neighbour exchange of a sharded mesh's peers outside a block (the owners' normals after a refresh): `count` elements per row
+        // of NW_ARR_PEER_SEND go out, NW_ARR_PEER_RECV comes in; op 2 = the owned rows out / the ghost rows in, 3 = the other way round
+        if (!ctx->comm) return fail(ctx, NW_ERR_BADARG, "nw_comm_all_reduce: no communicator (nw_comm_init)");
+        if (!ctx->have_boundary || !ctx->have_peers) return fail(ctx, NW_ERR_BADARG, "nw_comm_all_reduce: no peers (nw_set_boundary)");
+        if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "neighbour exchange by hand inside a search");
+        NW_HIP(hipSetDevice(ctx->device));
+        return px_exchange(ctx, op == 2, (int)count, dts[dtype], sz[dtype]);
+    }
     if (!ctx || !buf || count < 0 || dtype < 0 || dtype > 3 || op < 0 || op > 1) return fail(ctx, NW_ERR_BADARG, "nw_comm_all_reduce: buffer, count >= 0, dtype 0..3 (f32, f64, i64, i32), op 0 (sum) / 1 (max)");
     if (!ctx->comm) return fail(ctx, NW_ERR_BADARG, "nw_comm_all_reduce: no communicator (nw_comm_init)");
     if (ctx->in_search && ctx->capturing) return fail(ctx, NW_ERR_BADARG, "nw_comm_all_reduce while a block is being recorded");
     NW_HIP(hipSetDevice(ctx->device));
-    static const ncclDataType_t dts[4] = {ncclFloat, ncclDouble, ncclInt64, ncclInt32};
-    static const size_t sz[4] = {4, 8, 8, 4};
     hipPointerAttribute_t attr;
     const bool on_device = hipPointerGetAttributes(&attr, buf) == hipSuccess && attr.type == hipMemoryTypeDevice;
     (void)hipGetLastError();
@@ -1799,7 +1932,7 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t cmode = flags & (NW_FLAG_COMM_TILES | NW_FLAG_COMM_REPLICATED | NW_FLAG_COMM_HALO);
     if (ctx && cmode && !ctx->comm) return fail(ctx, NW_ERR_BADARG, "nw_search: NW_FLAG_COMM_* without a communicator (nw_comm_init)");
-    if (ctx && ctx->have_boundary && ctx->hb_nslot > 0 && !(cmode & NW_FLAG_COMM_HALO))
+    if (ctx && ctx->have_boundary && (ctx->hb_nslot > 0 || (ctx->have_peers && ctx->px_ng + ctx->px_no > 0)) && !(cmode & NW_FLAG_COMM_HALO))
         return fail(ctx, NW_ERR_BADARG, "nw_search on a sharded mesh: the boundary rows must go round between the phases (NW_FLAG_COMM_HALO with a communicator, or nw_search_begin / nw_iter_* / nw_search_end with the caller's collectives)");
     NW_TRY(nw_search_begin(ctx, lams, n_lams, num_iters, flags));
     const auto t1 = std::chrono::steady_clock::now();
@@ -1927,6 +2060,8 @@ NW_EXPORT int nw_device_ptr(nw_ctx *ctx, int what, void **ptr, int64_t *nbytes)
     case NW_ARR_HALO_ROWS: p = ctx->have_boundary ? ctx->halo_rows.p : nullptr; nb = 3 * ctx->hb_nslot * 4; break;
     case NW_ARR_HALO_FULL: p = ctx->have_boundary ? ctx->halo_full.p : nullptr; nb = 3 * ctx->M_global * 4; break;
     case NW_ARR_HALO_STATS: p = ctx->have_boundary ? ctx->halo_stats.p : nullptr; nb = 4 * 4; break;
+    case NW_ARR_PEER_SEND: p = (ctx->have_boundary && ctx->have_peers) ? ctx->px_send.p : nullptr; nb = 4 * std::max(ctx->px_ng, ctx->px_no) * 8; break;
+    case NW_ARR_PEER_RECV: p = (ctx->have_boundary && ctx->have_peers) ? ctx->px_recv.p : nullptr; nb = 4 * std::max(ctx->px_ng, ctx->px_no) * 8; break;
     default: return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array is not device-addressable in caller order");
     }
     if (!p) return fail(ctx, NW_ERR_BADARG, "nw_device_ptr: array not allocated yet");

@@ -1005,6 +1005,49 @@ __global__ __launch_bounds__(NW_BLOCK) void k_halo_unpack_rows(int n, const int 
     }
 }
 
+// ---- owner-wise exchange (nw_set_boundary with peers): rows of the exchange buffers are (peer, vertex) pairs, laid out peer after peer ----
+// the partial sums a peer's copies collected for vertices this rank owns: added to the owner's rows (integers: any order gives the same sum;
+// a vertex held by several peers has a row per peer)
+__global__ __launch_bounds__(NW_BLOCK) void k_px_add_acc(int n, const int *__restrict__ ids, const long long *__restrict__ buf, long long *__restrict__ vacc)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t l = ids[k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) atomicAdd(reinterpret_cast<unsigned long long *>(vacc + 4 * l + c), (unsigned long long)buf[4 * (int64_t)k + c]);
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_px_take_acc(int n, const int *__restrict__ ids, const long long *__restrict__ buf, long long *__restrict__ vacc)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t l = ids[k];
+    *reinterpret_cast<longlong2 *>(vacc + 4 * l) = *reinterpret_cast<const longlong2 *>(buf + 4 * (int64_t)k);
+    *reinterpret_cast<longlong2 *>(vacc + 4 * l + 2) = *reinterpret_cast<const longlong2 *>(buf + 4 * (int64_t)k + 2);
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_px_pack_rows(int n, const int *__restrict__ ids, const float *__restrict__ rows, float *__restrict__ buf)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t l = ids[k];
+    buf[3 * (int64_t)k] = rows[3 * l]; buf[3 * (int64_t)k + 1] = rows[3 * l + 1]; buf[3 * (int64_t)k + 2] = rows[3 * l + 2];
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_px_take_rows(int n, const int *__restrict__ ids, const float *__restrict__ buf, float *__restrict__ dst,
+                                                          float *__restrict__ dst2 /* second copy (mesh positions) or NULL */)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t l = ids[k];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = buf[3 * (int64_t)k + c];
+        dst[3 * l + c] = v;
+        if (dst2) dst2[3 * l + c] = v;
+    }
+}
+
 // the owners' rows of a (M_local,3) array into the (M_global,3) array that one all-reduce per block turns into the whole mesh
 // (`full` zeroed beforehand; gv = global id of every local vertex)
 __global__ __launch_bounds__(NW_BLOCK) void k_halo_gather_owned(int M, const int *__restrict__ gv, const unsigned char *__restrict__ owned, const float *__restrict__ rows,

@@ -75,6 +75,11 @@ class NativeComm(object):
         self.native.check(self.L.nw_device_ptr(self.h, what, ctypes.byref(p), ctypes.byref(nb)))
         self.native.check(self.L.nw_comm_all_reduce(self.h, p, int(count), self._DT[np.dtype(dtype)], int(op)))
 
+    def exchange(self, elems_per_row, dtype, owned_out=True):
+        """one neighbour exchange of a sharded mesh's peers outside a block (nw_set_boundary with peers): NW_ARR_PEER_SEND goes out,
+        NW_ARR_PEER_RECV comes in; asynchronous on the ctx's stream"""
+        self.native.check(self.L.nw_comm_all_reduce(self.h, None, int(elems_per_row), self._DT[np.dtype(dtype)], 2 if owned_out else 3))
+
     def close(self):
         self.native.check(self.L.nw_comm_init(self.h, None, 0, 0, 0))
 
@@ -151,16 +156,49 @@ class HipExecutor(object):
         return self._view(nw.NW_ARR_VACC, 4 * self.cg.M, '<i8')
 
     # -- 'halo' mode: boundary rows <-> one dense buffer over the global boundary list (packed / taken inside the phases) ------------
-    def set_boundary(self, b_local, b_slot, n_boundary, owned_local, gv, n_global):
+    def set_boundary(self, b_local, b_slot, n_boundary, owned_local, gv, n_global, peers=None):
         """b_local: local ids of this rank's vertices that are boundary vertices; b_slot: their rows in the global boundary
-        list (length n_boundary); owned_local: uint8 (M_local) ownership flags; gv: global id of every local vertex."""
-        bl = np.ascontiguousarray(b_local, dtype=np.int32)
-        bs = np.ascontiguousarray(b_slot, dtype=np.int32)
+        list (length n_boundary); owned_local: uint8 (M_local) ownership flags; gv: global id of every local vertex.
+        peers = (peer_rank, ghost_off, ghost_local, owned_off, owned_local) (HaloPartition.set_holders): the boundary rows then go
+        between the ranks that share them (owner-wise exchange) and the dense list is not used."""
         ow = np.ascontiguousarray(owned_local, dtype=np.uint8)
         g = np.ascontiguousarray(gv, dtype=np.int32)
-        self.native.check(self.L.nw_set_boundary(self.h, nw.ptr(bl), nw.ptr(bs), bl.size, int(n_boundary), nw.ptr(ow), nw.ptr(g), int(n_global)))
-        self.n_boundary, self.n_global = int(n_boundary), int(n_global)
+        self.peers = None
+        if peers is not None:
+            pr, go, gl, oo, ol = peers
+            pr = np.ascontiguousarray(pr, np.int32)
+            go, oo = np.ascontiguousarray(go, np.int64), np.ascontiguousarray(oo, np.int64)
+            gl, ol = np.ascontiguousarray(gl, np.int32), np.ascontiguousarray(ol, np.int32)
+            self.native.check(self.L.nw_set_boundary(self.h, None, None, 0, 0, nw.ptr(ow), nw.ptr(g), int(n_global),
+                                                     pr.size, nw.ptr(pr), nw.ptr(go), nw.ptr(gl), nw.ptr(oo), nw.ptr(ol)))
+            self.peers = (pr, go, oo)
+            self.n_boundary = 0
+        else:
+            bl = np.ascontiguousarray(b_local, dtype=np.int32)
+            bs = np.ascontiguousarray(b_slot, dtype=np.int32)
+            self.native.check(self.L.nw_set_boundary(self.h, nw.ptr(bl), nw.ptr(bs), bl.size, int(n_boundary), nw.ptr(ow), nw.ptr(g), int(n_global),
+                                                     -1, None, None, None, None, None))
+            self.n_boundary = int(n_boundary)
+        self.n_global = int(n_global)
         self._views = {}
+
+    # -- owner-wise exchange: the segments of the library's send / receive buffers, peer by peer ---------------------------------------
+    def peer_segments(self, kind):
+        """[(peer rank, tensor to send, tensor to receive into)] of one neighbour exchange.  kind: 'acc_to_owners' (the copies' partial
+        accumulator rows out, rows for the owned vertices in), 'acc_to_copies' (the owners' sums out / in), 'rows_to_copies' (the owners'
+        float32 rows -- positions after update(), normals after refresh_normals_local() -- out / in)"""
+        pr, go, oo = self.peers
+        rows = int(max(go[-1], oo[-1], 1))
+        if kind == 'rows_to_copies':
+            e, snd, rcv = 3, self._view(nw.NW_ARR_PEER_SEND, 3 * rows, '<f4'), self._view(nw.NW_ARR_PEER_RECV, 3 * rows, '<f4')
+        else:
+            e, snd, rcv = 4, self._view(nw.NW_ARR_PEER_SEND, 4 * rows, '<i8'), self._view(nw.NW_ARR_PEER_RECV, 4 * rows, '<i8')
+        so, ro = (go, oo) if kind == 'acc_to_owners' else (oo, go)
+        return [(int(pr[k]), snd[e * int(so[k]):e * int(so[k + 1])], rcv[e * int(ro[k]):e * int(ro[k + 1])]) for k in range(pr.size)]
+
+    def peer_step(self, what, step):
+        """a step of the owner-wise exchange by hand (nw_halo_rows): the one between the two accumulator exchanges is the caller's"""
+        self.native.check(self.L.nw_halo_rows(self.h, {'acc': nw.NW_ARR_VACC, 'pos': nw.NW_ARR_POS, 'nrm': nw.NW_ARR_NRM}[what], int(step)))
 
     def boundary_accumulator(self):
         """(n_boundary, 4) int64: this rank's partial sums of the boundary vertices it holds (filled by attract())"""
@@ -287,22 +325,62 @@ def run_search(ex, dist, mode, data, lams, num_iters, sigma_inv, weights=None, p
             with timer:
                 dist.all_reduce(t)
 
+    peers = mode == 'halo' and getattr(ex, 'peers', None) is not None
+
     def iteration():
         ex.attract()                                         # 'halo': leaves this rank's partial sums of the boundary vertices packed
         if mode == 'replicated':
             all_reduce(ex.vertex_accumulator())
+        elif peers:
+            peer_exchange(dist, ex, 'acc_to_owners', timer)  # the copies' partial rows to the vertices' owners ...
+            ex.peer_step('acc', 1)                           # ... added there ...
+            peer_exchange(dist, ex, 'acc_to_copies', timer)  # ... and the sums back to the copies (directions() takes them)
         elif mode == 'halo' and ex.n_boundary > 0:
             all_reduce(ex.boundary_accumulator())            # (|B|, 4) int64
         ex.directions()                                      # 'halo': takes the summed boundary rows first
         all_reduce(ex.scalars(n_red))
         ex.update()                                          # 'halo': leaves the new positions of the boundary vertices it OWNS packed
-        if mode == 'halo' and ex.n_boundary > 0:
+        if peers:
+            peer_exchange(dist, ex, 'rows_to_copies', timer)
+        elif mode == 'halo' and ex.n_boundary > 0:
             all_reduce(ex.boundary_rows())                   # (|B|, 3): owner-only non-zero rows -> every holder takes the owner's value
 
     for _ in range(int(num_iters)):
         iteration()
     ex.blocks_run = getattr(ex, 'blocks_run', 0) + 1
     return ex.end()                                          # (the last update's rows are taken here)
+
+
+def peer_exchange(dist, ex, kind, timer=None):
+    """One neighbour exchange of the owner-wise scheme over an external process group: every peer's segment goes out and comes in as
+    point-to-point messages (batch_isend_irecv).  Device buffers are staged through the host when the group cannot send them (gloo)."""
+    import torch
+    segs = ex.peer_segments(kind)
+    if not segs:
+        return
+    stage = bool(segs[0][1].is_cuda) and str(dist.get_backend()) != 'nccl'
+    ops, taken = [], []
+    for peer, snd, rcv in segs:
+        if snd.numel():
+            ops.append(dist.P2POp(dist.isend, snd.cpu() if stage else snd, peer))
+        if rcv.numel():
+            buf = torch.empty(rcv.shape, dtype=rcv.dtype) if stage else rcv
+            ops.append(dist.P2POp(dist.irecv, buf, peer))
+            taken.append((rcv, buf))
+    if not ops:
+        return
+
+    def go():
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if stage:
+            for rcv, buf in taken:
+                rcv.copy_(buf)
+    if timer is None:
+        go()
+    else:
+        with timer:
+            go()
 
 
 def _run_search_native(ex, mode, data, lams, num_iters, sigma_inv, weights, pos, last_step, quantum):
@@ -529,7 +607,10 @@ class HaloPartition(object):
         self.owner = classify(pos)
         cent = ((pos[faces[:, 0]] + pos[faces[:, 1]]) + pos[faces[:, 2]]) / np.float32(3.0)
         fowner = self.owner[faces]                                  # (F, 3): owners of a face's vertices
+        if self.n_ranks > 62:
+            raise ValueError('HaloPartition: at most 62 ranks (the holders of a vertex are kept as the bits of an int64)')
         count = np.zeros(M, np.int32)
+        holders = np.zeros(M, np.int64)                              # bit r: rank r holds the vertex (as one of its own, a copy, or a ring ghost)
         self.ranks = []
         nbr_ok = nbr >= 0
         nbr_safe = np.where(nbr_ok, nbr, 0)
@@ -562,6 +643,7 @@ class HaloPartition(object):
             inW &= ~inV
             count += inV
             count += inW
+            holders |= (inV | inW).astype(np.int64) << r
             if detail_ranks is not None and r not in detail_ranks:
                 self.ranks.append(dict(pidx=self.parts[r]))
                 continue
@@ -581,9 +663,10 @@ class HaloPartition(object):
             self.ranks.append(dict(pidx=self.parts[r], gv=gv, nV=int(gV.size), faces=g2l[faces[fsel]].astype(np.int32),
                                    nbr=nbr_l, valid=valid, owned=owned))
         self.count = count
+        self.holders = holders
         self.boundary = None
         if membership_ranks is None:
-            self.set_count(count)
+            self.set_holders(holders)
 
     def set_count(self, count):
         """count[v] = number of ranks holding vertex v (summed over the ranks) -> the boundary list and every detailed rank's rows in it"""
@@ -597,6 +680,54 @@ class HaloPartition(object):
             s = slot[d['gv']]
             d['b_local'] = np.nonzero(s >= 0)[0]
             d['b_slot'] = s[s >= 0]
+
+
+    def set_holders(self, holders):
+        """holders[v] = the ranks holding vertex v as bits of an int64 (a process that computed its own membership only: the SUM over the
+        ranks -- the bits are disjoint).  -> the boundary list (set_count) and, for every detailed rank, the rows of the OWNER-WISE
+        exchange: `peers` = (peer ranks, ghost_off, ghost_local, owned_off, owned_local) -- for peer q the local ids of this rank's copies
+        of vertices q owns, and of the vertices this rank owns that q holds, both in ascending global id: rank r's ghost segment for q
+        and q's owned segment for r list the same vertices in the same order (both follow from the same masks and the same owner map)."""
+        holders = np.asarray(holders, np.int64)
+        self.holders = holders
+        count = np.zeros(self.M, np.int32)
+        for r in range(self.n_ranks):
+            count += ((holders >> r) & 1).astype(np.int32)
+        self.set_count(count)
+        for r, d in enumerate(self.ranks):
+            if 'gv' not in d:
+                continue
+            gv = d['gv']
+            owned = np.asarray(d['owned'], bool)
+            own_of = self.owner[gv]
+            gl = np.nonzero(~owned)[0]
+            gl = gl[np.lexsort((gv[gl], own_of[gl]))]                      # by owner, ascending global id inside
+            g_owner = own_of[gl]
+            ol = np.nonzero(owned)[0]
+            ol = ol[np.argsort(gv[ol], kind='stable')]
+            others = holders[gv[ol]] & ~(np.int64(1) << r)
+            peers, go, oo, gparts, oparts = [], [0], [0], [], []
+            for q in range(self.n_ranks):
+                if q == r:
+                    continue
+                gq = gl[g_owner == q]
+                oq = ol[((others >> q) & 1) == 1]
+                if gq.size == 0 and oq.size == 0:
+                    continue
+                peers.append(q)
+                gparts.append(gq)
+                oparts.append(oq)
+                go.append(go[-1] + gq.size)
+                oo.append(oo[-1] + oq.size)
+            d['peers'] = (np.asarray(peers, np.int32), np.asarray(go, np.int64),
+                          np.concatenate(gparts).astype(np.int32) if gparts else np.zeros(0, np.int32),
+                          np.asarray(oo, np.int64), np.concatenate(oparts).astype(np.int32) if oparts else np.zeros(0, np.int32))
+
+    @staticmethod
+    def exchange_bytes(peers):
+        """bytes one rank SENDS per iteration with the owner-wise exchange: its copies' partial accumulator rows (32 B) to their owners,
+        and for every copy another rank holds of a vertex it owns the sum (32 B) and the new position (12 B)"""
+        return int(peers[1][-1]) * 32 + int(peers[3][-1]) * 44
 
 
 class ArrayMesh(object):
@@ -653,13 +784,19 @@ class HaloScene(object):
     make_executor(local_mesh, local_points) -> executor (HipExecutor over a ShrinkwrapMeshConjGrad in production; the CPU tests pass
     an oracle-backed one)."""
 
-    def __init__(self, mesh, points, dist, halo, make_executor=None, native=None, torch_stream=None, comm=None, per_point=None, min_margin=None):
+    def __init__(self, mesh, points, dist, halo, make_executor=None, native=None, torch_stream=None, comm=None, per_point=None, min_margin=None,
+                 exchange='peers'):
         self.mesh, self.points, self.dist, self.halo = mesh, np.ascontiguousarray(points, np.float32), dist, float(halo)
         # per_point: shares cut with PER-LOCALIZATION halos -- a rank holds every face within (nearest distance now + margin) of each of
         # its localizations instead of everything within `halo` of its tile's bounding box: the halo then pays for the mesh's movement
         # (the margin: at most `halo`, shrunk to a few times the last block's movement as the fit converges, never below min_margin),
         # not for the height of the few localizations far above the surface.  Default: on for the HIP executor.
         self.per_point = (make_executor is None) if per_point is None else bool(per_point)
+        # exchange: 'peers' = the boundary rows go between the ranks that share them (owner-wise: copies' partial sums to the owner, the
+        # owner's sum and new position back); 'dense' = two all-reduces per iteration over the global list of boundary vertices
+        if exchange not in ('peers', 'dense'):
+            raise ValueError("exchange must be 'peers' or 'dense'")
+        self.exchange = exchange
         self.margin = float(halo)
         self.min_margin = float(min_margin) if min_margin is not None else 0.05 * float(halo)
         self._blocks_total = 0
@@ -747,15 +884,16 @@ class HaloScene(object):
             reach = {self.rank: d0.astype(np.float64) * (1.0 + 1e-6) + self.margin}
         part = HaloPartition(pos, nrm, nbr, mesh.faces, self.points, self.world, self.halo, tiles=self._tiles, detail_ranks=(self.rank,),
                              membership_ranks=(self.rank,), reach=reach, reach_voxel=0.5 * self.margin)
+        # who else holds a vertex: the ranks' holder bits (disjoint) summed
         if self.comm is not None:
-            part.set_count(self.comm.all_reduce_host(np.ascontiguousarray(part.count, np.int64)).astype(part.count.dtype))
+            part.set_holders(self.comm.all_reduce_host(np.ascontiguousarray(part.holders, np.int64)))
         else:
             import torch
-            cnt = torch.from_numpy(part.count)
+            hold = torch.from_numpy(part.holders)
             if self.make_executor is None:
-                cnt = cnt.cuda()
-            self.dist.all_reduce(cnt)
-            part.set_count(cnt.cpu().numpy())
+                hold = hold.cuda()
+            self.dist.all_reduce(hold)
+            part.set_holders(hold.cpu().numpy())
         t2 = time.perf_counter()
         self.last_partition = part
         d = part.ranks[self.rank]
@@ -769,7 +907,12 @@ class HaloScene(object):
             setattr(self.ex, k, v)
         if old is not None and hasattr(old, 'cg') and hasattr(self.ex, 'cg') and hasattr(old.cg, 'stage_ms_total') and getattr(self, '_profiling', None):
             self.ex.cg.stage_ms_total = old.cg.stage_ms_total          # HIP-event totals run on across a re-partition (bench.py reads them at the end)
-        self.ex.set_boundary(d['b_local'], d['b_slot'], part.boundary.size, d['owned'], gv, part.M)
+        if self.exchange == 'peers':
+            self.ex.set_boundary(d['b_local'], d['b_slot'], part.boundary.size, d['owned'], gv, part.M, peers=d['peers'])
+        else:
+            self.ex.set_boundary(d['b_local'], d['b_slot'], part.boundary.size, d['owned'], gv, part.M)
+        self.exchange_bytes = HaloPartition.exchange_bytes(d['peers']) if self.exchange == 'peers' else int(part.boundary.size) * 44
+        self.boundary_vertices = int(part.boundary.size)
         self._pos0 = pos.copy()                       # where the mesh was when the shares were cut (drift budget of the halo)
         if hasattr(self.ex, 'set_reference'):
             if self.per_point:
@@ -959,7 +1102,9 @@ class HaloScene(object):
         if self.comm is not None:
             p = self.mesh._vertices['position']
             ex.refresh_normals_local(float((p.max(0).astype(np.float64) - p.min(0).astype(np.float64)).max()))
-            if ex.n_boundary > 0:
+            if getattr(ex, 'peers', None) is not None:
+                self.comm.exchange(3, np.float32, owned_out=True)      # the owners' normals to the copies
+            elif ex.n_boundary > 0:
                 self.comm.all_reduce_device(nw.NW_ARR_HALO_ROWS, 3 * ex.n_boundary, np.float32)
             ex.take_normals()
             if to_host:
@@ -974,7 +1119,9 @@ class HaloScene(object):
                 p = self.mesh._vertices['position']
                 ext = float((p.max(0).astype(np.float64) - p.min(0).astype(np.float64)).max())
                 ex.refresh_normals_local(ext)
-                if ex.n_boundary > 0:
+                if getattr(ex, 'peers', None) is not None:
+                    peer_exchange(self.dist, ex, 'rows_to_copies')
+                elif ex.n_boundary > 0:
                     self.dist.all_reduce(ex.boundary_rows())
                 ex.take_normals()
                 if to_host:

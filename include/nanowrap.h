@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NW_ABI_VERSION 4
+#define NW_ABI_VERSION 5
 
 typedef struct nw_ctx nw_ctx;
 
@@ -104,7 +104,9 @@ typedef enum nw_array {
     NW_ARR_HALO_ROWS = 16,  /* (n_slots, 3) f32  device-only: rows of the boundary vertices this rank OWNS (new positions after nw_iter_update;
                                normals after nw_halo_rows(NW_ARR_NRM, 0)), zero elsewhere: all-reduce(sum) = the owner's row on every rank */
     NW_ARR_HALO_FULL = 17,  /* (M_global, 3) f32 device-only: nw_halo_gather_owned -- the owners' rows of the whole mesh */
-    NW_ARR_HALO_STATS = 18  /* (4,) f32 device-only: nw_halo_block_stats -- {largest nearest distance, accumulator quantum, max drift^2, 0}: all-reduce(MAX) */
+    NW_ARR_HALO_STATS = 18, /* (4,) f32 device-only: nw_halo_block_stats -- {largest nearest distance, accumulator quantum, max drift^2, 0}: all-reduce(MAX) */
+    NW_ARR_PEER_SEND = 19,  /* device-only, nw_set_boundary with peers: the rows going out in the next neighbour exchange, peer after peer ((rows, 4) i64 for */
+    NW_ARR_PEER_RECV = 20   /*   the accumulator, (rows, 3) f32 at the front of the same buffer for positions / normals), and the rows that came in */
 } nw_array;
 
 #define NW_N_SCALARS 32
@@ -209,7 +211,9 @@ int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *cont
  * the other ranks stop in the same iteration with NW_ERR_REMOTE.
  * nw_comm_all_reduce: the set-up and block-boundary collectives of such a run (weight means, quanta, the whole mesh of a sharded run) on the
  * same communicator and stream.  buf: device pointer (in place, asynchronous on the ctx's stream) or host pointer (staged, blocking);
- * dtype 0 float32, 1 float64, 2 int64, 3 int32; op 0 sum, 1 max. */
+ * dtype 0 float32, 1 float64, 2 int64, 3 int32; op 0 sum, 1 max.  buf = NULL with op 2 / 3: one neighbour exchange of a sharded mesh's peers
+ * outside a block (nw_set_boundary with peers; the owners' normals after nw_refresh_normals): `count` (1..4) elements of `dtype` per row of
+ * NW_ARR_PEER_SEND go out and NW_ARR_PEER_RECV comes in -- op 2: owned rows out, ghost rows in; op 3: ghost rows out, owned rows in. */
 int nw_comm_unique_id(uint8_t *out, int64_t nbytes);
 int nw_comm_init(nw_ctx *ctx, const uint8_t *unique_id, int64_t nbytes, int rank, int nranks);
 int nw_comm_all_reduce(nw_ctx *ctx, void *buf, int64_t count, int dtype, int op);
@@ -223,9 +227,23 @@ int nw_comm_all_reduce(nw_ctx *ctx, void *buf, int64_t count, int dtype, int op)
  *   all-reduce NW_ARR_HALO_ROWS (f32 sum of owner-only rows); the next nw_iter_attract / nw_search_end takes the owners' positions.
  * nw_search runs such a mesh only with a communicator and NW_FLAG_COMM_HALO.  n_slots < 0 clears the sharding; nw_set_mesh clears it too. */
 int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t *b_slot, int64_t n_local, int64_t n_slots, const uint8_t *owned,
-                    const int32_t *gv, int64_t n_global);
+                    const int32_t *gv, int64_t n_global, int32_t n_peers, const int32_t *peer_rank, const int64_t *ghost_off,
+                    const int32_t *ghost_local, const int64_t *owned_off, const int32_t *owned_local);
+/* Owner-wise exchange (ABI 5; peer_rank = NULL: the dense list above goes round).  The ranks this one shares vertices with, and for
+ * peer p: ghost_local[ghost_off[p] .. ghost_off[p+1]) = local ids of this rank's COPIES of vertices peer p owns, owned_local[owned_off[p] ..
+ * owned_off[p+1]) = local ids of the vertices this rank OWNS that peer p holds a copy of -- both in ascending global id, so that this rank's
+ * ghost segment for p lists the same vertices in the same order as p's owned segment for this rank.  Per iteration, instead of the two
+ * all-reduces over the dense list:  copies' partial accumulator rows -> owners (added);  owners' sums -> copies;  after the update the
+ * owners' new positions -> copies.  Three neighbour exchanges of (rows x 32 B), (rows x 32 B), (rows x 12 B) between ranks that share
+ * vertices, nothing to anyone else.  nw_search (communicator + NW_FLAG_COMM_HALO) runs them itself: grouped ncclSend / ncclRecv on the
+ * ctx's stream, recorded in the block's hipGraph.  Split-phase callers move NW_ARR_PEER_SEND -> the peers' NW_ARR_PEER_RECV themselves:
+ *   nw_iter_attract [ghost segments out, owned segments in] nw_halo_rows(NW_ARR_VACC, 1) [owned out, ghost in] nw_iter_directions
+ *   ... nw_iter_update [owned out, ghost in]; the next nw_iter_attract / nw_search_end takes the owners' positions. */
 /* the exchange buffers by hand: what = NW_ARR_VACC (-> / <- NW_ARR_HALO_ACC), NW_ARR_POS or NW_ARR_NRM (owner-only rows -> / <- NW_ARR_HALO_ROWS;
  * positions are taken into NW_ARR_POS and NW_ARR_MESHPOS); unpack = 0 fills the buffer from this rank's rows, 1 takes the (all-reduced) buffer.
+ * With peers `unpack` is the step of the owner-wise exchange: accumulator 0 = copies' rows -> NW_ARR_PEER_SEND, 1 = NW_ARR_PEER_RECV added
+ * to the owners' rows and their sums -> NW_ARR_PEER_SEND, 2 = NW_ARR_PEER_RECV taken by the copies; positions / normals 0 = owners' rows ->
+ * NW_ARR_PEER_SEND, 1 = NW_ARR_PEER_RECV taken by the copies.
  * Needed by a caller only for the vertex normals after nw_refresh_normals (a rank does not hold every face of the vertices at the rim of its
  * share: the owner's normal is the mesh's, _membrane_mesh.pyx:1524-1527). */
 int nw_halo_rows(nw_ctx *ctx, int what, int unpack);

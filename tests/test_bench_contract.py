@@ -55,11 +55,11 @@ def test_two_ranks_started_by_plain_python_print_one_json_line(mode):
     assert j['scaling'] == ('strong' if mode == 'halo' else 'weak') and j['config']['mode'] == mode
     assert j['rccl']['backend'] == 'gloo' and j['rccl']['world_size_seen'] == 2 and len(j['rccl']['devices']) == 2
     c = j['collectives']
-    assert c['per_iter'] == (3 if mode == 'halo' else 1) and 0 < c['share_of_device_time'] < 1
+    assert c['per_iter'] == (4 if mode == 'halo' else 1) and 0 < c['share_of_device_time'] < 1       # 'halo': three neighbour exchanges + the sums
     assert j['value'] > 0 and j['roofline']['launches'] >= 2
     if mode == 'halo':
         h = j['halo']
-        assert h['per_localization_halos'] and h['boundary_vertices'] > 0 and h['max_nn_distance_nm'] + h['drift_since_partition_nm'] <= h['margin_nm'] <= h['radius_nm']
+        assert h['per_localization_halos'] and h['boundary_vertices'] > 0 and h['exchange'] == 'peers' and 7168 < h['exchange_bytes'] < 44 * h['boundary_vertices'] + 7168 and h['max_nn_distance_nm'] + h['drift_since_partition_nm'] <= h['margin_nm'] <= h['radius_nm']
         assert j['config']['vertices_per_gpu'] < j['config']['localizations_per_gpu']       # a share, not the whole mesh
         # one mesh: value counts its vertices once
         assert abs(j['value'] - float(j['config']['workload'].split(' vertices')[0].split(', ')[-1]) * 1e3 / j['ms_per_step']) <= 1e-6 * j['value']

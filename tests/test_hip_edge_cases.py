@@ -283,10 +283,52 @@ def test_sharded_mesh_entry_points_check_their_arguments():
         cg._native.check(L.nw_halo_rows(h, nw.NW_ARR_POS, 0))
     for bl, bs, ns in ((i32([M]), i32([0]), 4), (i32([3]), i32([4]), 4), (i32([3, 5]), i32([1, 1]), 4)):      # vertex out of range / slot out of range / slot twice
         with pytest.raises(ValueError):
-            cg._native.check(L.nw_set_boundary(h, nw.ptr(bl), nw.ptr(bs), bl.size, ns, nw.ptr(owned), nw.ptr(gv), M))
+            cg._native.check(L.nw_set_boundary(h, nw.ptr(bl), nw.ptr(bs), bl.size, ns, nw.ptr(owned), nw.ptr(gv), M, -1, None, None, None, None, None))
     with pytest.raises(ValueError):                                   # global id out of range
-        cg._native.check(L.nw_set_boundary(h, nw.ptr(i32([3])), nw.ptr(i32([0])), 1, 4, nw.ptr(owned), nw.ptr(i32(np.arange(M) + 1)), M))
-    cg._native.check(L.nw_set_boundary(h, nw.ptr(i32([3, 7])), nw.ptr(i32([2, 0])), 2, 4, nw.ptr(owned), nw.ptr(gv), M))
+        cg._native.check(L.nw_set_boundary(h, nw.ptr(i32([3])), nw.ptr(i32([0])), 1, 4, nw.ptr(owned), nw.ptr(i32(np.arange(M) + 1)), M, -1, None, None, None, None, None))
+    # owner-wise exchange: peers' rows are checked too -- a copy must not be owned here, an owned row must be, no peer twice, offsets in order
+    i64 = lambda a: np.ascontiguousarray(a, np.int64)
+    own2 = owned.copy()
+    own2[[3, 7]] = 0                                                  # two copies of vertices rank 1 owns; vertex 9 is held by rank 1 too
+    good = (1, i32([1]), i64([0, 2]), i32([3, 7]), i64([0, 1]), i32([9]))
+    bad = [(1, i32([1]), i64([0, 2]), i32([3, 9]), i64([0, 1]), i32([9])),      # a ghost row that is owned here
+           (1, i32([1]), i64([0, 2]), i32([3, 7]), i64([0, 1]), i32([7])),      # an owned row that is not
+           (1, i32([1]), i64([0, 2]), i32([3, 3]), i64([0, 1]), i32([9])),      # a copy listed twice
+           (1, i32([1]), i64([0, 2]), i32([3, M]), i64([0, 1]), i32([9])),      # out of range
+           (2, i32([1, 1]), i64([0, 1, 2]), i32([3, 7]), i64([0, 1, 1]), i32([9])),   # a peer twice
+           (1, i32([1]), i64([1, 2]), i32([3, 7]), i64([0, 1]), i32([9]))]      # offsets do not start at 0
+    for npeer, pr, go, gl, oo, ol in bad:
+        with pytest.raises(ValueError):
+            cg._native.check(L.nw_set_boundary(h, None, None, 0, 0, nw.ptr(own2), nw.ptr(gv), M, npeer, nw.ptr(pr), nw.ptr(go), nw.ptr(gl), nw.ptr(oo), nw.ptr(ol)))
+    npeer, pr, go, gl, oo, ol = good
+    cg._native.check(L.nw_set_boundary(h, None, None, 0, 0, nw.ptr(own2), nw.ptr(gv), M, npeer, nw.ptr(pr), nw.ptr(go), nw.ptr(gl), nw.ptr(oo), nw.ptr(ol)))
+    p, nb = ctypes.c_void_p(), ctypes.c_int64()
+    cg._native.check(L.nw_device_ptr(h, nw.NW_ARR_PEER_SEND, ctypes.byref(p), ctypes.byref(nb)))
+    assert p.value and nb.value == 2 * 4 * 8                          # max(2 ghost rows, 1 owned row) x 4 int64
+    with pytest.raises(ValueError):                                   # shared vertices: not without the exchange
+        cg.search(pts, lams=[5.0], num_iters=1, sigma_inv=0.2)
+    with pytest.raises(ValueError):                                   # the owner-wise exchange has steps 0..1 for positions
+        cg._native.check(L.nw_halo_rows(h, nw.NW_ARR_POS, 2))
+    # positions by hand: the owner's row of vertex 9 goes out; rows coming in are taken by the copies 3 and 7 (positions and mesh positions)
+    cg._native.check(L.nw_halo_rows(h, nw.NW_ARR_POS, 0))
+    import torch
+    from ch_shrinkwrap_amd.parallel import _DevArray
+    send = torch.as_tensor(_DevArray(p.value, (6,), '<f4'), device='cuda')
+    assert np.array_equal(send[:3].cpu().numpy(), v[9])
+    cg._native.check(L.nw_device_ptr(h, nw.NW_ARR_PEER_RECV, ctypes.byref(p), ctypes.byref(nb)))
+    recv = torch.as_tensor(_DevArray(p.value, (6,), '<f4'), device='cuda')
+    recv.copy_(torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0]))
+    torch.cuda.synchronize()
+    cg._native.check(L.nw_halo_rows(h, nw.NW_ARR_POS, 1))
+    pm, nbm = ctypes.c_void_p(), ctypes.c_int64()
+    for arr in (nw.NW_ARR_MESHPOS, nw.NW_ARR_POS):
+        cg._native.check(L.nw_device_ptr(h, arr, ctypes.byref(pm), ctypes.byref(nbm)))
+        got = torch.as_tensor(_DevArray(pm.value, (M, 3), '<f4'), device='cuda').cpu().numpy()
+        assert np.array_equal(got[3], [1, 2, 3]) and np.array_equal(got[7], [4, 5, 6]) and np.array_equal(got[9], v[9])
+    recv.copy_(torch.from_numpy(np.concatenate([v[3], v[7]]).astype('f4')))          # (and back, for the checks below)
+    torch.cuda.synchronize()
+    cg._native.check(L.nw_halo_rows(h, nw.NW_ARR_POS, 1))
+    cg._native.check(L.nw_set_boundary(h, nw.ptr(i32([3, 7])), nw.ptr(i32([2, 0])), 2, 4, nw.ptr(owned), nw.ptr(gv), M, -1, None, None, None, None, None))
     p, nb = ctypes.c_void_p(), ctypes.c_int64()
     cg._native.check(L.nw_device_ptr(h, nw.NW_ARR_HALO_ACC, ctypes.byref(p), ctypes.byref(nb)))
     assert p.value and nb.value == 4 * 4 * 8
@@ -310,7 +352,7 @@ def test_sharded_mesh_entry_points_check_their_arguments():
     cg._native.check(L.nw_get(h, nw.NW_ARR_HALO_STATS, nw.ptr(stats), stats.nbytes))
     d = (v[17].astype('f4') - ref[17]).astype('f4')
     assert stats[0] == np.float32(42.5) and stats[2] == np.float32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) and abs(float(stats[2]) - 169.0) < 1e-2 and stats[3] == 0
-    cg._native.check(L.nw_set_boundary(h, None, None, 0, -1, None, None, 0))         # cleared: nw_search works again
+    cg._native.check(L.nw_set_boundary(h, None, None, 0, -1, None, None, 0, -1, None, None, None, None, None))         # cleared: nw_search works again
     out = cg.search(pts, lams=[5.0], num_iters=1, sigma_inv=0.2)
     assert np.isfinite(out).all()
     # host half of the write-back

@@ -42,13 +42,36 @@ class OracleExecutor(object):
     # -- 'halo' mode hooks (same contract as parallel.HipExecutor: the phases pack / take the boundary rows themselves) ---------------
     n_boundary = 0
 
-    def set_boundary(self, b_local, b_slot, n_boundary, owned_local, gv, n_global):
+    peers = None
+
+    def set_boundary(self, b_local, b_slot, n_boundary, owned_local, gv, n_global, peers=None):
         self.b_local, self.b_slot, self.n_boundary = np.asarray(b_local), torch.from_numpy(np.asarray(b_slot)), int(n_boundary)
         self.own3 = np.repeat(np.asarray(owned_local, bool), 3)
         self.owned = np.asarray(owned_local, bool)
         self.b_owned = self.owned[self.b_local]
         self.gv, self.n_global = np.asarray(gv), int(n_global)
         self.halo = True
+        self.peers = None
+        if peers is not None:                                  # owner-wise exchange (same contract as parallel.HipExecutor)
+            pr, go, gl, oo, ol = [np.asarray(a) for a in peers]
+            self.peers = (pr, go, oo)
+            self.px_ghost, self.px_owned = torch.from_numpy(gl.astype(np.int64)), torch.from_numpy(ol.astype(np.int64))
+            rows = int(max(go[-1], oo[-1], 1))
+            self.px_send, self.px_recv = torch.zeros((rows, 4), dtype=torch.float32), torch.zeros((rows, 4), dtype=torch.float32)
+            self.px_send3, self.px_recv3 = torch.zeros((rows, 3), dtype=torch.float32), torch.zeros((rows, 3), dtype=torch.float32)
+            self.n_boundary = 0
+
+    def peer_segments(self, kind):
+        pr, go, oo = self.peers
+        snd, rcv = (self.px_send3, self.px_recv3) if kind == 'rows_to_copies' else (self.px_send, self.px_recv)
+        so, ro = (go, oo) if kind == 'acc_to_owners' else (oo, go)
+        return [(int(pr[k]), snd[int(so[k]):int(so[k + 1])], rcv[int(ro[k]):int(ro[k + 1])]) for k in range(pr.size)]
+
+    def peer_step(self, what, step):
+        assert what == 'acc' and step == 1
+        no = self.px_owned.numel()
+        self.vacc.view(-1, 4).index_add_(0, self.px_owned, self.px_recv[:no])       # the copies' partial sums, added to the owner's rows
+        self.px_send[:no] = self.vacc.view(-1, 4)[self.px_owned]
 
     def boundary_accumulator(self):
         return self.buf_acc
@@ -57,13 +80,23 @@ class OracleExecutor(object):
         return self.buf_rows
 
     def _pack_acc(self):
+        if self.peers is not None:
+            self.px_send[:self.px_ghost.numel()] = self.vacc.view(-1, 4)[self.px_ghost]
+            return
         self.buf_acc = torch.zeros((self.n_boundary, 4), dtype=torch.float32)
         self.buf_acc[self.b_slot] = self.vacc.view(-1, 4)[self.b_local]
 
     def _take_acc(self):
+        if self.peers is not None:
+            self.vacc.view(-1, 4)[self.px_ghost] = self.px_recv[:self.px_ghost.numel()]
+            return
         self.vacc.view(-1, 4)[self.b_local] = self.buf_acc[self.b_slot]
 
     def _pack_rows(self):
+        if self.peers is not None:
+            self.px_send3[:self.px_owned.numel()] = torch.from_numpy(self.f.reshape(-1, 3)[self.px_owned.numpy()].astype('f4'))
+            self.rows_pending = True
+            return
         self.buf_rows = torch.zeros((self.n_boundary, 3), dtype=torch.float32)
         rows = self.f.reshape(-1, 3)[self.b_local] * self.b_owned[:, None]
         self.buf_rows[self.b_slot] = torch.from_numpy(rows.astype('f4'))
@@ -72,7 +105,10 @@ class OracleExecutor(object):
     def _take_rows(self):
         if getattr(self, 'rows_pending', False):
             f = self.f.reshape(-1, 3)
-            f[self.b_local] = self.buf_rows[self.b_slot].numpy()
+            if self.peers is not None:
+                f[self.px_ghost.numpy()] = self.px_recv3[:self.px_ghost.numel()].numpy()
+            else:
+                f[self.b_local] = self.buf_rows[self.b_slot].numpy()
             self.f = f.ravel()
             self.rows_pending = False
 
@@ -248,7 +284,8 @@ def _worker(rank, world, port, mode, q):
             # 'halo_reach': per-localization halos (every face within a localization's own nearest distance + margin)
             # (its margin pays for growth + drift only: 9 nm is 'tight' for this fit -- new shares after the first block)
             scene = parallel.HaloScene(mesh, pts, dist, halo={'halo': 50.0, 'halo_tight': 35.0, 'halo_reach': 9.0}[mode], make_executor=make,
-                                       per_point=(mode == 'halo_reach'), min_margin=4.0)
+                                       per_point=(mode == 'halo_reach'), min_margin=4.0,
+                                       exchange='dense' if mode == 'halo' else 'peers')       # both transports of the boundary rows
             s_inv = 1.0 / sigma.ravel()
             scene.search([7.0], 4, s_inv)
             first = (scene.max_dist, scene.drift)
@@ -445,6 +482,13 @@ def test_eight_rank_partition_of_the_headline_mesh_at_full_size():
     assert sum(held) / M <= 1.40
     assert part.boundary.size / M <= 0.33
     assert max(held) / (M / 8) <= 1.45
+    # owner-wise exchange: what a rank sends per iteration (32 B per copy it holds, 44 B per copy others hold of its vertices) against the
+    # two dense buffers every rank would all-reduce (44 B per boundary vertex of the whole mesh)
+    sent = [parallel.HaloPartition.exchange_bytes(d['peers']) for d in part.ranks]
+    npeers = [d['peers'][0].size for d in part.ranks]
+    print('   exchange per rank and iteration: %.2f MB on average, %.2f MB at most (dense list: %.2f MB); %d-%d peers per rank' % (
+        np.mean(sent) / 1e6, max(sent) / 1e6, 44 * part.boundary.size / 1e6, min(npeers), max(npeers)))
+    assert max(sent) <= 0.8e6 and np.mean(sent) <= 0.25 * 44 * part.boundary.size
 
 
 def test_a_rank_that_works_out_only_its_own_share_agrees_with_the_full_partition():
@@ -458,15 +502,32 @@ def test_a_rank_that_works_out_only_its_own_share_agrees_with_the_full_partition
         tiles = parallel.bisect_tiles(pts, n)
         full = parallel.HaloPartition(*args, n, halo=20.0, tiles=tiles)
         own = [parallel.HaloPartition(*args, n, halo=20.0, tiles=tiles, detail_ranks=(r,), membership_ranks=(r,)) for r in range(n)]
-        count = sum(p.count for p in own)                         # what the all-reduce does
-        assert np.array_equal(count, full.count)
+        holders = sum(p.holders for p in own)                     # what the all-reduce does (the ranks' bits are disjoint)
+        assert np.array_equal(holders, full.holders)
         for r, p in enumerate(own):
             assert p.boundary is None
-            p.set_count(count)
-            assert np.array_equal(p.boundary, full.boundary)
+            p.set_holders(holders)
+            assert np.array_equal(p.count, full.count) and np.array_equal(p.boundary, full.boundary)
             assert all('gv' not in d for q, d in enumerate(p.ranks) if q != r)
             for k, a in full.ranks[r].items():
-                assert np.array_equal(p.ranks[r][k], a), (n, r, k)
+                if k == 'peers':
+                    assert all(np.array_equal(x, y) for x, y in zip(p.ranks[r][k], a)), (n, r, k)
+                else:
+                    assert np.array_equal(p.ranks[r][k], a), (n, r, k)
+        # the owner-wise exchange: rank r's ghost segment for q and q's owned segment for r are the same vertices in the same order;
+        # every copy of a vertex appears once, with the vertex's owner; the segments are in ascending global id
+        seg = {}
+        for r, d in enumerate(full.ranks):
+            pr, go, gl, oo, ol = d['peers']
+            gv = d['gv']
+            assert np.unique(gl).size == gl.size == int((np.asarray(d['owned']) == 0).sum())          # every copy once
+            for k, q in enumerate(pr):
+                g, o = gv[gl[go[k]:go[k + 1]]], gv[ol[oo[k]:oo[k + 1]]]
+                assert (np.diff(g) > 0).all() and (np.diff(o) > 0).all()
+                assert (full.owner[g] == q).all() and (full.owner[o] == r).all()
+                seg[(r, int(q))] = (g, o)
+        for (r, q), (g, o) in seg.items():
+            assert (q, r) in seg and np.array_equal(g, seg[(q, r)][1]) and np.array_equal(o, seg[(q, r)][0]), (n, r, q)
 
 
 def test_partition_by_tiles_is_a_partition():
@@ -622,12 +683,19 @@ def _gpu_worker(rank, world, port, mode, q):
         else:
             (v, f, pts, sigma), = _scene(False)
             mesh = TriMesh(v, f)
-            scene = parallel.HaloScene(mesh, pts, dist, halo=50.0, torch_stream=ts)
+            # 'halo': the boundary rows go between the two ranks that share them (owner-wise exchange, the default); 'halo_dense': two
+            # all-reduces over the global list of boundary vertices
+            scene = parallel.HaloScene(mesh, pts, dist, halo=50.0, torch_stream=ts, exchange='dense' if mode == 'halo_dense' else 'peers')
             s_inv = 1.0 / sigma.ravel()
             out = scene.search([7.0], 4, s_inv)
             scene.refresh_normals()                           # on the device: shares stay resident, owners' normals go round
             out = scene.search([7.0], 3, s_inv)
             assert scene.repartitions == 1
+            assert (scene.ex.peers is None) == (mode == 'halo_dense')
+            if mode == 'halo':                                # every copy sends 32 B and gets 44 B back: less than the dense list's 44 B per boundary vertex
+                pr, go, oo = scene.ex.peers
+                assert list(pr) == [1 - rank] and go[-1] > 0 and oo[-1] > 0
+                assert scene.exchange_bytes == 32 * int(go[-1]) + 44 * int(oo[-1]) < 44 * scene.last_partition.boundary.size
             assert np.array_equal(out, mesh._vertices['position'])
         q.put((rank, out))
     finally:
@@ -636,7 +704,7 @@ def _gpu_worker(rank, world, port, mode, q):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('mode', ['tiles', 'replicated', 'halo'])
+@pytest.mark.parametrize('mode', ['tiles', 'replicated', 'halo', 'halo_dense'])
 def test_hip_executor_two_ranks_share_one_gpu(mode):
     """The N > 1 HIP path on hardware: two fresh processes, both on cuda:0, run HipExecutor (split-phase C-ABI, device buffers viewed
     by torch, collectives between the phases) in every mode; the result must equal the single-process nw_search fit of the same
@@ -665,7 +733,7 @@ def test_hip_executor_two_ranks_share_one_gpu(mode):
     mesh = TriMesh(V, F)
     cg = ShrinkwrapMeshConjGrad(mesh, P)
     cg.search(P, lams=[7.0], num_iters=4, sigma_inv=1.0 / S.ravel())
-    if mode == 'halo':
+    if mode in ('halo', 'halo_dense'):
         cg.refresh_normals()                             # the single-process form of the same block boundary, on the device
         cg = ShrinkwrapMeshConjGrad(mesh, P, native=cg._native, reuse_device_mesh=True)      # a new optimiser per block
     ref = cg.search(P, lams=[7.0], num_iters=3, sigma_inv=1.0 / S.ravel())
