@@ -230,6 +230,9 @@ def run_rank(args):
         os.environ.setdefault('WORLD_SIZE', '1')
     if multi:
         if backend == 'nccl':
+            # (the library records its blocks with their collectives: no buffer registration at capture time -- RCCL reads its parameters
+            # once per process, so the default has to be there before torch's process group creates the first communicator)
+            os.environ.setdefault('NCCL_GRAPH_REGISTER', '0')
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)

@@ -1886,6 +1886,10 @@ NW_EXPORT int nw_comm_init(nw_ctx *ctx, const uint8_t *unique_id, int64_t nbytes
     }
     if (nranks <= 0) return NW_OK;
     if (!unique_id || nbytes < (int64_t)sizeof(ncclUniqueId) || rank < 0 || rank >= nranks) return fail(ctx, NW_ERR_BADARG, "nw_comm_init: unique id (nw_comm_unique_id of rank 0), 0 <= rank < nranks");
+    // blocks are recorded with their collectives: no buffer registration at capture time (it would be a hand-shake between ranks that
+    // record and ranks that replay; the library's buffers are ordinary device memory).  Only a default, and only seen by an RCCL that has
+    // not read its parameters yet -- a process that initialises torch's process group first sets it there (bench.py does)
+    (void)setenv("NCCL_GRAPH_REGISTER", "0", 0);
     if (!g_rccl.load()) return fail(ctx, NW_ERR_HIP, g_rccl.err);
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
