@@ -270,7 +270,9 @@ def _worker(rank, world, port, mode, q):
             mine = parts[rank]
             ex = OracleExecutor(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts[mine])
             out = parallel.run_search(ex, dist, 'replicated', pts[mine], [7.0], 4, 1.0 / sigma[mine].ravel())
-        elif mode in ('halo', 'halo_tight', 'halo_reach'):
+        elif mode in ('halo', 'halo_tight', 'halo_reach', 'halo_reach3'):
+            three = mode == 'halo_reach3'                     # three ranks: a rank has two peers, vertices near the cuts' meeting line have two copies
+            mode = 'halo_reach' if three else mode
             (v, f, pts, sigma), = _scene(False)
             mesh = TriMesh(v, f)
 
@@ -291,11 +293,17 @@ def _worker(rank, world, port, mode, q):
             first = (scene.max_dist, scene.drift)
             scene.refresh_normals()                           # second block on the RESIDENT shares: new normals, same partition
             out = scene.search([7.0], 3, s_inv)
-            assert scene.repartitions == {'halo': 1, 'halo_tight': 2, 'halo_reach': 2}[mode], (scene.repartitions, first, scene.max_dist, scene.drift)
+            if not three:
+                assert scene.repartitions == {'halo': 1, 'halo_tight': 2, 'halo_reach': 2}[mode], (scene.repartitions, first, scene.max_dist, scene.drift)
             assert getattr(scene, 'redone_blocks', 0) == 0
             part = scene.last_partition
             d = part.ranks[rank]                        # (a rank works out its own share only; the boundary list comes from the all-reduced counts)
             assert all('gv' not in o for r, o in enumerate(part.ranks) if r != rank)
+            if three:                                   # both other ranks are peers, and some owned vertex is held by both of them
+                pr, go, gl, oo, ol = d['peers']
+                assert sorted(pr) == [r for r in range(3) if r != rank]
+                q.put((rank, (out, part.boundary.size, int(d['nV']), int(d['owned'].sum()), int(ol.size - np.unique(ol).size))))
+                return
             q.put((rank, (out, part.boundary.size, int(d['nV']), int(d['owned'].sum()))))
             return
         else:
@@ -308,14 +316,14 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-def _run(mode):
+def _run(mode, world=2):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = dict(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -351,6 +359,25 @@ def test_tiles_two_vesicles_gloo():
     m1 = TriMesh(v1, f1)
     ind = O.search(m1.vertices.copy(), m1.vertex_normals.copy(), m1.neighbor_vertex_table(), m1.faces, p1, [7.0], 4, 1.0 / s1.ravel())
     assert rel_rms(res[0], ind.positions) > 1e-5
+
+
+@pytest.mark.timeout(300)
+def test_halo_sharded_mesh_three_ranks_owner_wise_gloo():
+    """Three ranks: every rank exchanges with two peers, and vertices where the tiles meet are held by all three -- the owner's row of such
+    a vertex takes two partial sums and goes back twice."""
+    from oracle import nanowrap_oracle as O
+    res = _run('halo_reach3', world=3)
+    (v, f, pts, sigma), = _scene(False)
+    mesh = TriMesh(v, f)
+    ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, [7.0], 4, 1.0 / sigma.ravel())
+    mesh._vertices['position'][:] = ref.positions.astype('f4')
+    mesh.update_geometry()
+    ref = O.search(mesh.vertices.copy(), mesh.vertex_normals.copy(), mesh.neighbor_vertex_table(), mesh.faces, pts, [7.0], 3, 1.0 / sigma.ravel())
+    outs = [res[r][0] for r in range(3)]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert rel_rms(outs[0], ref.positions) <= 1e-5
+    assert sum(res[r][3] for r in range(3)) == v.shape[0]         # every vertex owned once
+    assert sum(res[r][4] for r in range(3)) > 0                   # some owned vertex has copies on both other ranks
 
 
 @pytest.mark.timeout(300)
@@ -685,13 +712,15 @@ def _gpu_worker(rank, world, port, mode, q):
             mesh = TriMesh(v, f)
             # 'halo': the boundary rows go between the two ranks that share them (owner-wise exchange, the default); 'halo_dense': two
             # all-reduces over the global list of boundary vertices
-            scene = parallel.HaloScene(mesh, pts, dist, halo=50.0, torch_stream=ts, exchange='dense' if mode == 'halo_dense' else 'peers')
+            scene = parallel.HaloScene(mesh, pts, dist, halo=50.0 if world == 2 else 12.0, torch_stream=ts, exchange='dense' if mode == 'halo_dense' else 'peers')
             s_inv = 1.0 / sigma.ravel()
             out = scene.search([7.0], 4, s_inv)
             scene.refresh_normals()                           # on the device: shares stay resident, owners' normals go round
             out = scene.search([7.0], 3, s_inv)
-            assert scene.repartitions == 1
+            assert scene.repartitions == 1 or world == 3
             assert (scene.ex.peers is None) == (mode == 'halo_dense')
+            if mode == 'halo3':                               # three ranks: two peers each
+                assert sorted(scene.ex.peers[0]) == [r for r in range(3) if r != rank]
             if mode == 'halo':                                # every copy sends 32 B and gets 44 B back: less than the dense list's 44 B per boundary vertex
                 pr, go, oo = scene.ex.peers
                 assert list(pr) == [1 - rank] and go[-1] > 0 and oo[-1] > 0
@@ -704,7 +733,7 @@ def _gpu_worker(rank, world, port, mode, q):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('mode', ['tiles', 'replicated', 'halo', 'halo_dense'])
+@pytest.mark.parametrize('mode', ['tiles', 'replicated', 'halo', 'halo_dense', 'halo3'])
 def test_hip_executor_two_ranks_share_one_gpu(mode):
     """The N > 1 HIP path on hardware: two fresh processes, both on cuda:0, run HipExecutor (split-phase C-ABI, device buffers viewed
     by torch, collectives between the phases) in every mode; the result must equal the single-process nw_search fit of the same
@@ -713,10 +742,11 @@ def test_hip_executor_two_ranks_share_one_gpu(mode):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    world = 3 if mode == 'halo3' else 2          # 'halo3': three ranks on cuda:0 -- two peers each, vertices with two copies (owner-wise exchange)
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=400) for _ in range(2))
+    res = dict(q.get(timeout=400) for _ in range(world))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -728,12 +758,12 @@ def test_hip_executor_two_ranks_share_one_gpu(mode):
         got = np.concatenate([res[0], res[1]], 0)
     else:
         (V, F, P, S), = _scene(False)
-        assert np.array_equal(res[0], res[1])
+        assert all(np.array_equal(res[0], res[r]) for r in range(1, world))
         got = res[0]
     mesh = TriMesh(V, F)
     cg = ShrinkwrapMeshConjGrad(mesh, P)
     cg.search(P, lams=[7.0], num_iters=4, sigma_inv=1.0 / S.ravel())
-    if mode in ('halo', 'halo_dense'):
+    if mode in ('halo', 'halo_dense', 'halo3'):
         cg.refresh_normals()                             # the single-process form of the same block boundary, on the device
         cg = ShrinkwrapMeshConjGrad(mesh, P, native=cg._native, reuse_device_mesh=True)      # a new optimiser per block
     ref = cg.search(P, lams=[7.0], num_iters=3, sigma_inv=1.0 / S.ravel())
