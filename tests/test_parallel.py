@@ -486,13 +486,17 @@ def test_per_localization_halos_hold_what_the_query_needs_and_far_fewer_vertices
 
 
 @pytest.mark.timeout(900)
-def test_eight_rank_partition_of_the_headline_mesh_at_full_size():
-    """BASELINE configs[2] at full size (10^6 localizations, 198 812 vertices), 8 ranks, the mesh on the cloud's surface (where a fit
-    spends its time), margin 5 nm: what the ranks hold together, how many vertices are shared, the largest share.  (Round 3, one halo
-    radius of 100 nm for all: 2.08 x the mesh, 70 % boundary vertices, largest share 2.09 x M/8.)"""
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('name', ['c3', 'c4'])
+def test_eight_rank_partition_of_the_headline_mesh_at_full_size(name):
+    """BASELINE configs[2] (C3: 10^6 localizations, 198 812 vertices) and configs[3] (C4: 5 10^6 localizations, 809 955 vertices) at full
+    size, 8 ranks, the mesh on the cloud's surface (where a fit spends its time), margin 5 nm: what the ranks hold together, how many
+    vertices are shared, the largest share, and what a rank sends per iteration.  (Round 3, one halo radius of 100 nm for all: C3 2.08 x
+    the mesh, 70 % boundary vertices, largest share 2.09 x M/8; C4 1.79 / 65 % / 2.24.)  C4's largest share stays at 1.5: its tiles
+    balance the localizations, and the network's sheets carry more vertices per localization than its tubes."""
     from scipy.spatial import cKDTree
     from ch_shrinkwrap_amd import synth
-    cfg = synth.make_config('c3')
+    cfg = synth.make_config(name)
     pts = cfg['points']
     v0, f0 = cfg['surface']
     mesh = TriMesh(v0, f0)
@@ -505,17 +509,20 @@ def test_eight_rank_partition_of_the_headline_mesh_at_full_size():
     part = parallel.HaloPartition(pos, mesh.vertex_normals, mesh.neighbor_vertex_table(), faces, pts, 8, 0.0, tiles=tiles, reach=reach, reach_voxel=margin / 2)
     M = pos.shape[0]
     held = [d['gv'].size for d in part.ranks]
-    print('8 ranks of C3, margin %.0f nm: held %.3f x M, boundary %.1f %%, largest share %.3f x M/8' % (margin, sum(held) / M, 100.0 * part.boundary.size / M, max(held) / (M / 8)))
-    assert sum(held) / M <= 1.40
-    assert part.boundary.size / M <= 0.33
-    assert max(held) / (M / 8) <= 1.45
+    print('8 ranks of %s, margin %.0f nm: held %.3f x M, boundary %.1f %%, largest share %.3f x M/8' % (name, margin, sum(held) / M, 100.0 * part.boundary.size / M, max(held) / (M / 8)))
+    limit = {'c3': (1.40, 0.33, 1.45), 'c4': (1.35, 0.32, 1.55)}[name]
+    assert sum(held) / M <= limit[0]
+    assert part.boundary.size / M <= limit[1]
+    assert max(held) / (M / 8) <= limit[2]
     # owner-wise exchange: what a rank sends per iteration (32 B per copy it holds, 44 B per copy others hold of its vertices) against the
     # two dense buffers every rank would all-reduce (44 B per boundary vertex of the whole mesh)
     sent = [parallel.HaloPartition.exchange_bytes(d['peers']) for d in part.ranks]
     npeers = [d['peers'][0].size for d in part.ranks]
     print('   exchange per rank and iteration: %.2f MB on average, %.2f MB at most (dense list: %.2f MB); %d-%d peers per rank' % (
         np.mean(sent) / 1e6, max(sent) / 1e6, 44 * part.boundary.size / 1e6, min(npeers), max(npeers)))
-    assert max(sent) <= 0.8e6 and np.mean(sent) <= 0.25 * 44 * part.boundary.size
+    assert np.mean(sent) <= 0.26 * 44 * part.boundary.size and max(sent) <= 0.36 * 44 * part.boundary.size
+    if name == 'c3':
+        assert max(sent) <= 0.8e6
 
 
 def test_a_rank_that_works_out_only_its_own_share_agrees_with_the_full_partition():
