@@ -172,6 +172,7 @@ struct nw_ctx {
     int comm_rank = 0, comm_ranks = 1;
     uint32_t comm_mode = 0;                // NW_FLAG_COMM_* of the current search
     DevBuf<unsigned char> comm_scratch;    // staging of host buffers given to nw_comm_all_reduce
+    std::vector<uint64_t> comm_patterns;   // communication patterns (mode, sizes, peers) that have run one block outside a capture (nw_search)
     bool direct_out = false;         // nw_search: the last update of the block writes its result into the pinned staging buffer itself
     BlockGraph graphs[4];
     int graph_next = 0;
@@ -1883,6 +1884,7 @@ NW_EXPORT int nw_comm_init(nw_ctx *ctx, const uint8_t *unique_id, int64_t nbytes
         for (auto &gph : ctx->graphs) if (gph.exec) { (void)hipGraphExecDestroy(gph.exec); gph.exec = nullptr; }      // recorded blocks hold the communicator's kernels
         (void)g_rccl.CommDestroy(ctx->comm);
         ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_ranks = 1;
+        ctx->comm_patterns.clear();
     }
     if (nranks <= 0) return NW_OK;
     if (!unique_id || nbytes < (int64_t)sizeof(ncclUniqueId) || rank < 0 || rank >= nranks) return fail(ctx, NW_ERR_BADARG, "nw_comm_init: unique id (nw_comm_unique_id of rank 0), 0 <= rank < nranks");
@@ -1961,7 +1963,24 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     if (trace_blocks) { if (!tb0) { (void)hipEventCreate(&tb0); (void)hipEventCreate(&tb1); } (void)hipEventRecord(tb0, ctx->stream); }
     // level 4: the graph holds everything before the last iteration, which is launched below (its query kernel between two events)
     const bool head = ctx->profiling == 4 && num_iters > 1;
-    nw_ctx::BlockGraph *slot = block_graph(ctx, num_iters, head);
+    // With more than one rank the FIRST block of a communication pattern (mode, sizes, set of peers) is launched directly: RCCL sets up
+    // channels and peer connections when an operation first needs them -- host-side hand-shakes and allocations that have no place inside a
+    // stream capture.  Every later block of the pattern is recorded / replayed.  (The pattern is the same on all ranks of a block except for
+    // the peer lists, which change together when new shares are cut.)
+    bool eager_first = false;
+    if (ctx->comm && ctx->comm_ranks > 1 && cmode) {
+        uint64_t pat = 1469598103934665603ull;
+        auto mixp = [&](uint64_t v) { pat ^= v; pat *= 1099511628211ull; };
+        mixp(cmode); mixp((uint64_t)(uintptr_t)ctx->comm); mixp((uint64_t)ctx->M);
+        mixp((uint64_t)((cmode & NW_FLAG_COMM_HALO) ? (ctx->have_peers ? 2 : 1) : 0)); mixp((uint64_t)ctx->hb_nslot);
+        if ((cmode & NW_FLAG_COMM_HALO) && ctx->have_peers) for (int r : ctx->px_rank) mixp((uint64_t)r + 1);
+        if (std::find(ctx->comm_patterns.begin(), ctx->comm_patterns.end(), pat) == ctx->comm_patterns.end()) {
+            eager_first = true;
+            if (ctx->comm_patterns.size() >= 64) ctx->comm_patterns.clear();
+            ctx->comm_patterns.push_back(pat);
+        }
+    }
+    nw_ctx::BlockGraph *slot = eager_first ? nullptr : block_graph(ctx, num_iters, head);
     if (slot) {
         if (hipGraphLaunch(slot->exec, ctx->stream) == hipSuccess) {
             const int n_done = head ? num_iters - 1 : num_iters;

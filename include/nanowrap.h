@@ -207,6 +207,8 @@ int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, float *cont
  *                            sums only (nw_info(NW_INFO_SCALARS) x nw_info(NW_INFO_SCALAR_STRIDE) doubles): one global <=3x3 solve, conj_grad.py:202-219;
  *   NW_FLAG_COMM_REPLICATED  mesh replicated, localizations sharded: the per-vertex accumulator (M x 4 int64) and the point-side sums;
  *   NW_FLAG_COMM_HALO        one mesh sharded with nw_set_boundary: the accumulator's boundary rows, the sums, the owners' new boundary rows.
+ * With more than one rank the first block of a communication pattern (mode, sizes, peers) is launched directly -- RCCL connects channels and
+ * peers at first use, which cannot happen inside a stream capture -- and the blocks after it are recorded / replayed.
  * Every rank must call nw_search with the same flags, num_iters and lams.  A status raised on one rank (NaN, ...) travels with the sums:
  * the other ranks stop in the same iteration with NW_ERR_REMOTE.
  * nw_comm_all_reduce: the set-up and block-boundary collectives of such a run (weight means, quanta, the whole mesh of a sharded run) on the
