@@ -16,16 +16,19 @@ localization cloud, because A is row-separable -- each localization touches the 
 
   mode 'halo'        ONE mesh, sharded (BASELINE.json north_star "all-reduce on the boundary-vertex forces
                      only"): space is cut into tiles by recursive bisection of the localization cloud; a rank holds the
-                     localizations of its tile, the faces whose centroid lies within one search radius H of the tile, their
-                     vertices (on which it runs the complete iteration) and one more ring of ghost vertices (positions and
-                     normals only, for the curvature prior).  A vertex is OWNED by the tile that contains it.  Per iteration:
-                       (1) all-reduce(sum) of the rows of the fixed-point accumulator {A^T res, sum w} that belong to BOUNDARY
-                           vertices -- vertices present on more than one rank -- packed into one dense buffer;
+                     localizations of its tile, the faces whose centroid lies within (nearest distance + margin) of each of its
+                     localizations (or within one radius H of the tile), their vertices (on which it runs the complete iteration)
+                     and one more ring of ghost vertices (positions and normals only, for the curvature prior).  A vertex is OWNED
+                     by the tile that contains it.  Per iteration, for the vertices more than one rank holds:
+                       (1) the rows of the fixed-point accumulator {A^T res, sum w}: the copies' partial sums go to the vertex's
+                           owner, which adds them and sends the sum back to the copies (owner-wise exchange between the ranks that
+                           share vertices; exchange='dense': one all-reduce over the global list of such vertices);
                        (2) all-reduce(sum) of the normal-equation scalars (vertex-side sums run over owned vertices only);
-                       (3) the owners' new positions of the boundary vertices, same buffer shape, owner-only non-zero rows.
+                       (3) the owners' new positions to the copies (dense: owner-only non-zero rows, all-reduced).
                      Every rank solves the same <=3x3 system; integer accumulators make the shared rows bit-identical everywhere.
-                     The nearest-face query stays exact as long as no localization is further than H from its nearest centroid
-                     (checked every iteration from the device-side maximum).
+                     The nearest-face query stays exact while (growth of any nearest distance + drift of the mesh) since the
+                     shares were cut stays within the margin (one radius: largest nearest distance + drift within H), checked on
+                     the device after every block.
 
 Who issues the collectives.  In production the LIBRARY does: every rank joins an RCCL communicator of its own nw_ctx (NativeComm ->
 nw_comm_init) and a block is ONE nw_search call with an NW_FLAG_COMM_* flag -- phases and ncclAllReduce on the ctx's own stream,
@@ -589,8 +592,9 @@ class HaloPartition(object):
     def __init__(self, pos, nrm, nbr, faces, points, n_ranks, halo, tiles=None, detail_ranks=None, membership_ranks=None, reach=None, reach_voxel=None):
         """detail_ranks: the ranks whose share is worked out in full (index maps, local faces, local ring table); None = all.
         membership_ranks: the ranks whose MEMBERSHIP (which vertices they hold) is computed here; None = all.  Who else holds a vertex
-        decides the boundary list, which all ranks must agree on: a process that computes only its own membership leaves `count`
-        partial and must call set_count() with the sum over the ranks (one all-reduce of M int32) before using `boundary`.
+        decides the boundary list and the peers' rows, which all ranks must agree on: a process that computes only its own membership
+        leaves `holders` partial and must call set_holders() with the sum over the ranks (one all-reduce of M int64: the ranks' bits are
+        disjoint) before using `boundary` / `peers`.
 
         reach: {rank: (n_r,) array} -- PER-LOCALIZATION radii for the ranks whose membership is computed here (in the order of
         parts[rank]): the rank then holds the faces whose centroid lies within reach_i of its localization i (faces_within_reach),
@@ -864,7 +868,7 @@ class HaloScene(object):
         pos = np.ascontiguousarray(mesh._vertices['position'], np.float32)
         nrm = np.ascontiguousarray(mesh.vertex_normals, np.float32)
         t1 = time.perf_counter()
-        # every rank works out its OWN share only; who else holds a vertex (the boundary list) comes from one all-reduce of the counts
+        # every rank works out its OWN share only; who else holds a vertex (boundary list, peers' rows) comes from one all-reduce of the holder bits
         reach, d0 = None, None
         if self.per_point:
             from scipy.spatial import cKDTree
