@@ -198,34 +198,49 @@ def test_degenerate_input_is_refused_not_refined_for_ever():
     assert time.time() - t0 < 20.0
 
 
-def test_partitioned_remesher_is_independent_of_the_thread_count_and_as_good_as_the_serial_one(monkeypatch):
-    """Above 40 000 faces the remesher works on 16 Morton runs of the faces at once (frozen rims), then on the seam zone: the cut depends
-    on the mesh alone, so one thread and eight must give the same arrays; the result is a closed 2-manifold of the input's genus with
-    the serial algorithm's edge statistics (not its arrays: the order of the operations differs)."""
+@pytest.mark.parametrize('case', ['ellipsoid', 'network'])
+def test_partitioned_remesher_is_independent_of_the_thread_count_and_as_good_as_the_serial_one(case):
+    """Above 40 000 faces the remesher works on 16 Morton runs of the faces at once (frozen rims), then on the strips along their seams at
+    once, then on the patches around the strips' ends: the cuts depend on the mesh alone, so one thread and eight must give the same
+    arrays; the result is a closed 2-manifold of the input's genus with the serial algorithm's edge statistics (not its arrays: the order
+    of the operations differs), and the serial algorithm never had to take over (no edge of no length).  'network': the genus-2 tube /
+    sheet network of BASELINE configs[3] (thin tubes: runs and strips that wrap around)."""
     import subprocess, sys, json, textwrap
-    from ch_shrinkwrap_amd.trimesh import icosphere
     code = textwrap.dedent('''
         import sys, json, zlib, numpy as np
         sys.path.insert(0, %r)
         from ch_shrinkwrap_amd.trimesh import icosphere, TriMesh
-        from ch_shrinkwrap_amd import remesh
-        v, f = icosphere(6, 100.0)                       # 40 962 vertices, 81 920 faces, edge ~3.1
-        v = (v * np.array([1.0, 0.7, 1.4], 'f4')).astype('f4')
-        ov, of = remesh.remesh(v, f, n=5, target_edge_length=2.2, l=0.5, n_relax=0)[:2]
+        from ch_shrinkwrap_amd import remesh, synth
+        if %r == 'network':
+            sdf = lambda p: 2.0 * synth.sdf_er_sim2(np.asarray(p, 'f8') * 0.5)
+            v, f = synth._c4_start_mesh(sdf, 2.96 / np.sqrt(0.06))      # ~50 000 vertices, mean edge ~11
+            target = 9.5
+        else:
+            v, f = icosphere(6, 100.0)                       # 40 962 vertices, 81 920 faces, edge ~3.1
+            v = (v * np.array([1.0, 0.7, 1.4], 'f4')).astype('f4')
+            target = 2.2
+        ov, of = remesh.remesh(v, f, n=5, target_edge_length=target, l=0.5, n_relax=0)[:2]
         m = TriMesh(ov, of)
+        assert (m._halfedges['twin'] >= 0).all()             # closed
         e = np.linalg.norm(ov[of] - ov[np.roll(of, -1, 1)], axis=2)
-        print(json.dumps(dict(nv=int(ov.shape[0]), nf=int(of.shape[0]), crc=[zlib.crc32(ov.tobytes()), zlib.crc32(of.tobytes())],
+        print(json.dumps(dict(nv=int(ov.shape[0]), nf=int(of.shape[0]), nf_in=int(f.shape[0]), crc=[zlib.crc32(ov.tobytes()), zlib.crc32(of.tobytes())],
                               mean=float(e.mean()), mn=float(e.min()), mx=float(e.max()), deg=int(np.bincount(of.ravel()).max()))))
-    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ''') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), case)
     res = {}
     for tag, env in (('t1', {'NW_REMESH_THREADS': '1'}), ('t8', {'NW_REMESH_THREADS': '8'}), ('serial', {'NW_REMESH_PARTITION': '0'})):
-        e = dict(os.environ); e.update(env)
+        e = dict(os.environ); e.update(env); e['NWR_VERBOSE'] = '1'
         p = subprocess.run([sys.executable, '-c', code], env=e, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         res[tag] = json.loads(p.stdout.strip().splitlines()[-1])
+        assert 'takes over' not in p.stderr
+        if tag != 'serial':
+            assert 'seam pass' in p.stderr and 'strips' in p.stderr        # (the partitioned path did run)
     assert res['t1'] == res['t8']
     a, s = res['t8'], res['serial']
-    assert a['nv'] - a['nf'] // 2 == 2 and a['nf'] % 2 == 0                   # closed, genus 0
+    assert a['nf_in'] >= 40000
+    genus = {'ellipsoid': 0, 'network': 2}[case]
+    assert a['nv'] - a['nf'] // 2 == 2 - 2 * genus and a['nf'] % 2 == 0          # closed, the input's genus
+    assert s['nv'] - s['nf'] // 2 == 2 - 2 * genus
     assert abs(a['nv'] - s['nv']) <= 0.02 * s['nv']
     assert abs(a['mean'] - s['mean']) <= 0.02 * s['mean']
     assert a['mx'] <= 1.15 * s['mx'] and a['mn'] >= 0.5 * s['mn'] and a['deg'] <= 16
