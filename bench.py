@@ -465,7 +465,7 @@ def run_rank(args):
                 out['halo'] = {'radius_nm': args.halo, 'per_localization_halos': bool(scene.per_point), 'margin_nm': float(getattr(scene, '_cut_margin', args.halo)),
                                'exchange': args.exchange,
                                'exchange_bytes': int(scene.exchange_bytes) + 28 * 32 * 8,
-                               'exchange_bytes_note': ('bytes rank 0 SENDS per iteration: 32 B for every copy it holds of a vertex another rank owns (partial accumulator row to the owner), 44 B for every copy another rank holds of a vertex it owns (the sum and the new position back), + the 7 KB of normal-equation sums' if args.exchange == 'peers' else 'bytes of the two dense buffers every rank all-reduces per iteration (44 B per boundary vertex of the whole mesh) + the 7 KB of normal-equation sums'),
+                               'exchange_bytes_note': ('bytes rank 0 SENDS per iteration: 32 B for every copy it holds of a vertex another rank owns (partial accumulator row to the owner), 28 B for every copy another rank holds of a vertex it owns (the sum as four float32 and the new position back), + the 7 KB of normal-equation sums' if args.exchange == 'peers' else 'bytes of the two dense buffers every rank all-reduces per iteration (44 B per boundary vertex of the whole mesh) + the 7 KB of normal-equation sums'),
                                'boundary_vertices': int(scene.boundary_vertices), 'repartitions_in_timed_region': reparts,
                                'max_nn_distance_nm': scene.max_dist, 'drift_since_partition_nm': scene.drift,
                                'host_ms_per_block': host_ms,

@@ -1082,9 +1082,10 @@ NW_EXPORT int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t
 
 // owner-wise exchange, the steps around the transfers (the iteration phases call them; the transfers are the caller's -- split-phase -- or
 // px_exchange's -- nw_search with a communicator):
-//   accumulator  0: the copies' partial rows -> send          [exchange: ghost rows out, owned rows in]
-//                1: received partial rows added to the owners' rows; the owners' sums -> send   [exchange: owned rows out, ghost rows in]
-//                2: the owners' sums taken by the copies
+//   accumulator  0: the copies' partial rows (4 int64) -> send                          [exchange: ghost rows out, owned rows in]
+//                1: received partial rows added to the owners' rows; the owners' sums, as the 4 float32 the kernels convert them
+//                   to, -> send                                                        [exchange: owned rows out, ghost rows in]
+//                2: the owners' sums taken by the copies (stored as the integers that convert to exactly those floats)
 //   positions / normals  0: the owners' rows -> send          [exchange: owned rows out, ghost rows in]     1: taken by the copies
 static int px_stage(nw_ctx *ctx, int what, int stage)
 {
@@ -1094,9 +1095,11 @@ static int px_stage(nw_ctx *ctx, int what, int stage)
         else if (stage == 1) {
             if (no > 0) {
                 hipLaunchKernelGGL(k_px_add_acc, dim3(nblk(no)), dim3(NW_BLOCK), 0, ctx->stream, no, ctx->px_owned.p, ctx->px_recv.p, ctx->vacc.p);
-                hipLaunchKernelGGL(k_halo_pack_acc, dim3(nblk(no)), dim3(NW_BLOCK), 0, ctx->stream, no, ctx->px_owned.p, ctx->vacc.p, ctx->px_send.p);
+                hipLaunchKernelGGL(k_px_pack_acc_f32, dim3(nblk(no)), dim3(NW_BLOCK), 0, ctx->stream, no, ctx->px_owned.p, ctx->vacc.p, ctx->acc_quantum, ctx->w_quantum,
+                                   (float4 *)ctx->px_send.p);
             }
-        } else if (ng > 0) hipLaunchKernelGGL(k_px_take_acc, dim3(nblk(ng)), dim3(NW_BLOCK), 0, ctx->stream, ng, ctx->px_ghost.p, ctx->px_recv.p, ctx->vacc.p);
+        } else if (ng > 0) hipLaunchKernelGGL(k_px_take_acc_f32, dim3(nblk(ng)), dim3(NW_BLOCK), 0, ctx->stream, ng, ctx->px_ghost.p, (const float4 *)ctx->px_recv.p,
+                                              1.0 / ctx->acc_quantum, 1.0 / ctx->w_quantum, ctx->vacc.p);
     } else {
         float *rows = what == NW_ARR_NRM ? ctx->nrm.p : ctx->pos.p;
         if (stage == 0) { if (no > 0) hipLaunchKernelGGL(k_px_pack_rows, dim3(nblk(no)), dim3(NW_BLOCK), 0, ctx->stream, no, ctx->px_owned.p, rows, (float *)ctx->px_send.p); }
@@ -1834,7 +1837,7 @@ static int comm_after_attract(nw_ctx *ctx)
         // the copies' partial rows to the owners, the owners' sums back (the attraction step packed, the directions step takes)
         NW_TRY(px_exchange(ctx, false, 4, ncclInt64, 8));
         NW_TRY(px_stage(ctx, NW_ARR_VACC, 1));
-        return px_exchange(ctx, true, 4, ncclInt64, 8);
+        return px_exchange(ctx, true, 4, ncclFloat, 4);          // (the sums as the four float32 they are converted to: 16 B a row)
     }
     if ((ctx->comm_mode & NW_FLAG_COMM_HALO) && ctx->have_boundary && ctx->hb_nslot > 0) return comm_all_reduce_dev(ctx, ctx->halo_acc.p, (size_t)4 * ctx->hb_nslot, ncclInt64, ncclSum);
     return NW_OK;

@@ -1026,6 +1026,28 @@ __global__ __launch_bounds__(NW_BLOCK) void k_px_take_acc(int n, const int *__re
     *reinterpret_cast<longlong2 *>(vacc + 4 * l + 2) = *reinterpret_cast<const longlong2 *>(buf + 4 * (int64_t)k + 2);
 }
 
+// The owners' SUMS go back as the four float32 the kernels convert an accumulator row to ((float)(sum * quantum): 16 B instead of 32).
+// The copy stores the integer that converts to exactly that float: the quanta are powers of two, so f / q is an integer (a sum rounded
+// to 24 bits is still a multiple of the quantum) and (float)((double)(f / q) * q) == f -- every holder computes with the same numbers.
+__global__ __launch_bounds__(NW_BLOCK) void k_px_pack_acc_f32(int n, const int *__restrict__ ids, const long long *__restrict__ vacc, double q, double qw, float4 *__restrict__ buf)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t l = ids[k];
+    const longlong2 a01 = *reinterpret_cast<const longlong2 *>(vacc + 4 * l), a23 = *reinterpret_cast<const longlong2 *>(vacc + 4 * l + 2);
+    buf[k] = make_float4((float)((double)a01.x * q), (float)((double)a01.y * q), (float)((double)a23.x * q), (float)((double)a23.y * qw));
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_px_take_acc_f32(int n, const int *__restrict__ ids, const float4 *__restrict__ buf, double inv_q, double inv_qw, long long *__restrict__ vacc)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t l = ids[k];
+    const float4 f = buf[k];
+    *reinterpret_cast<longlong2 *>(vacc + 4 * l) = make_longlong2((long long)((double)f.x * inv_q), (long long)((double)f.y * inv_q));
+    *reinterpret_cast<longlong2 *>(vacc + 4 * l + 2) = make_longlong2((long long)((double)f.z * inv_q), (long long)((double)f.w * inv_qw));
+}
+
 __global__ __launch_bounds__(NW_BLOCK) void k_px_pack_rows(int n, const int *__restrict__ ids, const float *__restrict__ rows, float *__restrict__ buf)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

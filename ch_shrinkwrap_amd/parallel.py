@@ -194,6 +194,8 @@ class HipExecutor(object):
         rows = int(max(go[-1], oo[-1], 1))
         if kind == 'rows_to_copies':
             e, snd, rcv = 3, self._view(nw.NW_ARR_PEER_SEND, 3 * rows, '<f4'), self._view(nw.NW_ARR_PEER_RECV, 3 * rows, '<f4')
+        elif kind == 'acc_to_copies':                         # the sums go back as the four float32 the kernels convert them to
+            e, snd, rcv = 4, self._view(nw.NW_ARR_PEER_SEND, 4 * rows, '<f4'), self._view(nw.NW_ARR_PEER_RECV, 4 * rows, '<f4')
         else:
             e, snd, rcv = 4, self._view(nw.NW_ARR_PEER_SEND, 4 * rows, '<i8'), self._view(nw.NW_ARR_PEER_RECV, 4 * rows, '<i8')
         so, ro = (go, oo) if kind == 'acc_to_owners' else (oo, go)
@@ -730,8 +732,8 @@ class HaloPartition(object):
     @staticmethod
     def exchange_bytes(peers):
         """bytes one rank SENDS per iteration with the owner-wise exchange: its copies' partial accumulator rows (32 B) to their owners,
-        and for every copy another rank holds of a vertex it owns the sum (32 B) and the new position (12 B)"""
-        return int(peers[1][-1]) * 32 + int(peers[3][-1]) * 44
+        and for every copy another rank holds of a vertex it owns the sum (16 B: four float32) and the new position (12 B)"""
+        return int(peers[1][-1]) * 32 + int(peers[3][-1]) * 28
 
 
 class ArrayMesh(object):

@@ -106,7 +106,7 @@ typedef enum nw_array {
     NW_ARR_HALO_FULL = 17,  /* (M_global, 3) f32 device-only: nw_halo_gather_owned -- the owners' rows of the whole mesh */
     NW_ARR_HALO_STATS = 18, /* (4,) f32 device-only: nw_halo_block_stats -- {largest nearest distance, accumulator quantum, max drift^2, 0}: all-reduce(MAX) */
     NW_ARR_PEER_SEND = 19,  /* device-only, nw_set_boundary with peers: the rows going out in the next neighbour exchange, peer after peer ((rows, 4) i64 for */
-    NW_ARR_PEER_RECV = 20   /*   the accumulator, (rows, 3) f32 at the front of the same buffer for positions / normals), and the rows that came in */
+    NW_ARR_PEER_RECV = 20   /*   partial accumulator rows, (rows, 4) f32 for the sums going back, (rows, 3) f32 for positions / normals, all at the front of the same buffer), and the rows that came in */
 } nw_array;
 
 #define NW_N_SCALARS 32
@@ -235,16 +235,17 @@ int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t *b_slot, 
  * peer p: ghost_local[ghost_off[p] .. ghost_off[p+1]) = local ids of this rank's COPIES of vertices peer p owns, owned_local[owned_off[p] ..
  * owned_off[p+1]) = local ids of the vertices this rank OWNS that peer p holds a copy of -- both in ascending global id, so that this rank's
  * ghost segment for p lists the same vertices in the same order as p's owned segment for this rank.  Per iteration, instead of the two
- * all-reduces over the dense list:  copies' partial accumulator rows -> owners (added);  owners' sums -> copies;  after the update the
- * owners' new positions -> copies.  Three neighbour exchanges of (rows x 32 B), (rows x 32 B), (rows x 12 B) between ranks that share
- * vertices, nothing to anyone else.  nw_search (communicator + NW_FLAG_COMM_HALO) runs them itself: grouped ncclSend / ncclRecv on the
+ * all-reduces over the dense list:  copies' partial accumulator rows -> owners (added);  owners' sums -> copies (as the four float32
+ * the kernels convert a row to: the quanta are powers of two, the copy stores the integer that converts to the same float);  after the
+ * update the owners' new positions -> copies.  Three neighbour exchanges of (rows x 32 B), (rows x 16 B), (rows x 12 B) between ranks
+ * that share vertices, nothing to anyone else.  nw_search (communicator + NW_FLAG_COMM_HALO) runs them itself: grouped ncclSend / ncclRecv on the
  * ctx's stream, recorded in the block's hipGraph.  Split-phase callers move NW_ARR_PEER_SEND -> the peers' NW_ARR_PEER_RECV themselves:
  *   nw_iter_attract [ghost segments out, owned segments in] nw_halo_rows(NW_ARR_VACC, 1) [owned out, ghost in] nw_iter_directions
  *   ... nw_iter_update [owned out, ghost in]; the next nw_iter_attract / nw_search_end takes the owners' positions. */
 /* the exchange buffers by hand: what = NW_ARR_VACC (-> / <- NW_ARR_HALO_ACC), NW_ARR_POS or NW_ARR_NRM (owner-only rows -> / <- NW_ARR_HALO_ROWS;
  * positions are taken into NW_ARR_POS and NW_ARR_MESHPOS); unpack = 0 fills the buffer from this rank's rows, 1 takes the (all-reduced) buffer.
- * With peers `unpack` is the step of the owner-wise exchange: accumulator 0 = copies' rows -> NW_ARR_PEER_SEND, 1 = NW_ARR_PEER_RECV added
- * to the owners' rows and their sums -> NW_ARR_PEER_SEND, 2 = NW_ARR_PEER_RECV taken by the copies; positions / normals 0 = owners' rows ->
+ * With peers `unpack` is the step of the owner-wise exchange: accumulator 0 = copies' rows (4 int64) -> NW_ARR_PEER_SEND, 1 = NW_ARR_PEER_RECV added
+ * to the owners' rows and their sums (4 float32) -> NW_ARR_PEER_SEND, 2 = NW_ARR_PEER_RECV taken by the copies; positions / normals 0 = owners' rows ->
  * NW_ARR_PEER_SEND, 1 = NW_ARR_PEER_RECV taken by the copies.
  * Needed by a caller only for the vertex normals after nw_refresh_normals (a rank does not hold every face of the vertices at the rim of its
  * share: the owner's normal is the mesh's, _membrane_mesh.pyx:1524-1527). */
