@@ -492,8 +492,9 @@ def test_eight_rank_partition_of_the_headline_mesh_at_full_size(name):
     """BASELINE configs[2] (C3: 10^6 localizations, 198 812 vertices) and configs[3] (C4: 5 10^6 localizations, 809 955 vertices) at full
     size, 8 ranks, the mesh on the cloud's surface (where a fit spends its time), margin 5 nm: what the ranks hold together, how many
     vertices are shared, the largest share, and what a rank sends per iteration.  (Round 3, one halo radius of 100 nm for all: C3 2.08 x
-    the mesh, 70 % boundary vertices, largest share 2.09 x M/8; C4 1.79 / 65 % / 2.24.)  C4's largest share stays at 1.5: its tiles
-    balance the localizations, and the network's sheets carry more vertices per localization than its tubes."""
+    the mesh, 70 % boundary vertices, largest share 2.09 x M/8; C4 1.79 / 65 % / 2.24.)  The tiles' cuts go across the axis on which the
+    fewest localizations lie near the plane: the same cuts as across the longest axis for C3's vesicle, much shorter ones through C4's
+    network (1.30 / 29 % / 1.49 with cuts across the longest axis)."""
     from scipy.spatial import cKDTree
     from ch_shrinkwrap_amd import synth
     cfg = synth.make_config(name)
@@ -503,14 +504,14 @@ def test_eight_rank_partition_of_the_headline_mesh_at_full_size(name):
     pos, faces = mesh.vertices, mesh.faces
     cent = ((pos[faces[:, 0]] + pos[faces[:, 1]]) + pos[faces[:, 2]]) / np.float32(3.0)
     d0 = cKDTree(cent).query(pts, workers=-1)[0]
-    tiles = parallel.bisect_tiles(pts, 8)
+    tiles = parallel.bisect_tiles(pts, 8, thin_cuts=parallel.THIN_CUTS_NM)          # (HaloScene's choice)
     margin = 5.0
     reach = {r: d0[tiles[0][r]] + margin for r in range(8)}
     part = parallel.HaloPartition(pos, mesh.vertex_normals, mesh.neighbor_vertex_table(), faces, pts, 8, 0.0, tiles=tiles, reach=reach, reach_voxel=margin / 4)      # (HaloScene's choice)
     M = pos.shape[0]
     held = [d['gv'].size for d in part.ranks]
     print('8 ranks of %s, margin %.0f nm: held %.3f x M, boundary %.1f %%, largest share %.3f x M/8' % (name, margin, sum(held) / M, 100.0 * part.boundary.size / M, max(held) / (M / 8)))
-    limit = {'c3': (1.35, 0.30, 1.40), 'c4': (1.35, 0.30, 1.55)}[name]          # (VERDICT r03 #3 asked for 1.35 / 30 % / 1.4: C4's largest share misses)
+    limit = (1.35, 0.30, 1.40)                                                 # (what VERDICT r03 #3 asked for)
     assert sum(held) / M <= limit[0]
     assert part.boundary.size / M <= limit[1]
     assert max(held) / (M / 8) <= limit[2]
@@ -520,7 +521,7 @@ def test_eight_rank_partition_of_the_headline_mesh_at_full_size(name):
     npeers = [d['peers'][0].size for d in part.ranks]
     print('   exchange per rank and iteration: %.2f MB on average, %.2f MB at most (dense list: %.2f MB); %d-%d peers per rank' % (
         np.mean(sent) / 1e6, max(sent) / 1e6, 44 * part.boundary.size / 1e6, min(npeers), max(npeers)))
-    assert np.mean(sent) <= 0.21 * 44 * part.boundary.size and max(sent) <= 0.29 * 44 * part.boundary.size
+    assert np.mean(sent) <= 0.21 * 44 * part.boundary.size and max(sent) <= 0.31 * 44 * part.boundary.size
     if name == 'c3':
         assert max(sent) <= 0.6e6
 
@@ -562,6 +563,22 @@ def test_a_rank_that_works_out_only_its_own_share_agrees_with_the_full_partition
                 seg[(r, int(q))] = (g, o)
         for (r, q), (g, o) in seg.items():
             assert (q, r) in seg and np.array_equal(g, seg[(q, r)][1]) and np.array_equal(o, seg[(q, r)][0]), (n, r, q)
+
+
+@pytest.mark.parametrize('thin', [None, 25.0])
+def test_bisect_tiles_cuts_space_consistently(thin):
+    """the tiles partition the localizations in balanced counts, and classify() puts every localization into its own tile -- with cuts across
+    the longest axis and with the shortest cuts (HaloScene's)"""
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([sphere_cloud(4000, 50.0, 5.0, seed=2), sphere_cloud(3000, 30.0, 4.0, seed=3) + np.array([140.0, 10.0, 0.0], 'f4'),
+                          (rng.normal(size=(2000, 3)) * np.array([60.0, 4.0, 4.0]) + np.array([70.0, 0.0, 0.0])).astype('f4')]).astype('f4')
+    for n in (1, 2, 3, 5, 8):
+        parts, classify = parallel.bisect_tiles(pts, n, thin_cuts=thin)
+        assert len(parts) == n and np.array_equal(np.sort(np.concatenate(parts)), np.arange(pts.shape[0]))
+        assert max(p.size for p in parts) - min(p.size for p in parts) <= 2
+        owner = classify(pts)
+        for r, p in enumerate(parts):
+            assert (owner[p] == r).all(), (n, r)
 
 
 def test_partition_by_tiles_is_a_partition():
