@@ -800,8 +800,9 @@ class HaloScene(object):
     The sharded nearest-face query is exact as long as (growth of any nearest distance since the shares were cut) + (drift of the mesh
     since then) stays within the margin the shares were cut with (per-localization halos; with one radius for all: largest nearest
     distance + drift <= halo); checked after every block -- a block that went beyond runs again on new shares (search()), and new shares
-    are cut BEFORE a block whenever another block like the last one could go beyond (margin = five times the last block's movement,
-    never more than `halo`).
+    are cut BEFORE a block whenever another block like the last one could go beyond, with a margin of at least five times the last
+    block's movement and TWICE the margin that has just run out (cutting shares costs hundreds of blocks' worth of time: the cuts of a
+    long fit must be few), never more than `halo`; optimize_layout() cuts once with the small margin a short timed run needs.
 
     make_executor(local_mesh, local_points) -> executor (HipExecutor over a ShrinkwrapMeshConjGrad in production; the CPU tests pass
     an oracle-backed one)."""
@@ -811,7 +812,7 @@ class HaloScene(object):
         self.mesh, self.points, self.dist, self.halo = mesh, np.ascontiguousarray(points, np.float32), dist, float(halo)
         # per_point: shares cut with PER-LOCALIZATION halos -- a rank holds every face within (nearest distance now + margin) of each of
         # its localizations instead of everything within `halo` of its tile's bounding box: the halo then pays for the mesh's movement
-        # (the margin: at most `halo`, shrunk to a few times the last block's movement as the fit converges, never below min_margin),
+        # (the margin: at most `halo`, a few times the last block's movement where a caller asks for the set-up, doubled whenever it runs out),
         # not for the height of the few localizations far above the surface.  Default: on for the HIP executor.
         self.per_point = (make_executor is None) if per_point is None else bool(per_point)
         # exchange: 'peers' = the boundary rows go between the ranks that share them (owner-wise: copies' partial sums to the owner, the
@@ -1081,13 +1082,17 @@ class HaloScene(object):
         self._blocks_total += 1
         if worst + drift + 1.5 * step > budget:       # (a fit slows down as it converges: C3 moves 26, 14, 9, 3, 2 ... nm per block of 5)
             self.last_partition = None                # cut new shares around the moved mesh before the next block
-            if self.per_point:                        # ... with a margin for what the next blocks will need (never more than `halo`)
-                self.margin = self._wanted_margin()
-        elif self.per_point and self._blocks_total >= 20 and self._blocks_since_partition >= 2 and self._blocks_total - self._last_shrink >= 10:
-            # the fit has slowed down: shares cut with a smaller margin hold fewer vertices (a cut costs ~0.1-0.2 s of host time: not often)
-            want = self._wanted_margin()
+            if self.per_point:
+                # ... with a margin for what the next blocks will need, and TWICE the margin that has just run out: cutting shares costs
+                # 0.1-0.5 s of host time, hundreds of blocks' worth of device time, and late in a fit growth + drift still rise by 1-2 nm
+                # per block (some vertices keep sliding) -- a margin of a few steps was used up every two or three blocks (measured: 19
+                # cuts in 60 blocks, 10 s for 0.1 s of iterations).  Doubling makes the cuts of a long fit few; never more than `halo`.
+                self.margin = min(self.halo, max(self._wanted_margin(), 2.0 * self._cut_margin))
+        elif self.per_point and self._blocks_since_partition >= 100 and self._blocks_total - self._last_shrink >= 100:
+            # the shares have lasted a hundred blocks with room to spare: a smaller margin holds fewer vertices (never less than half)
+            want = max(self._wanted_margin(), 2.0 * (worst + drift))
             if want < 0.5 * self._cut_margin:
-                self.margin = want
+                self.margin = max(want, 0.5 * self._cut_margin)
                 self._last_shrink = self._blocks_total
                 self.last_partition = None
         t2 = time.perf_counter()
