@@ -81,6 +81,32 @@ def test_rccl_path_replays_blocks_with_their_collectives(mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_started_by_the_drivers_launcher_print_one_json_line():
+    """The driver's own command for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` (RANK / LOCAL_RANK / WORLD_SIZE come from the launcher; bench.py must not start
+    ranks of its own).  Two gloo ranks sharing cuda:0 here (NW_BENCH_BACKEND=gloo: RCCL refuses duplicate devices)."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env['NW_BENCH_BACKEND'] = 'gloo'
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '5', '--scale', '0.05'],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800, universal_newlines=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]                          # rank 0 only
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 10 and j['scaling'] == 'weak' and j['config']['mode'] == 'tiles'
+    assert j['rccl']['world_size_seen'] == 2 and j['value'] > 0 and 'roofline' in j
+
+
+@pytest.mark.gpu
 def test_one_json_line_with_roofline_and_cpu_baseline():
     p = _run(['--gpus', '1', '--steps', '10', '--warmup', '5', '--scale', '0.05', '--cpu-iters', '2'])
     assert p.returncode == 0, p.stderr[-2000:]
