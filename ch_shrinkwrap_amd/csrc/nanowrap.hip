@@ -2256,8 +2256,12 @@ NW_EXPORT int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, f
                 if (!valid || valid[v]) memcpy(dst + v * row_stride_bytes, src + 3 * v, 12);
         }
     };
+    static const bool verbose3 = getenv("NW_VERBOSE") != nullptr && atoi(getenv("NW_VERBOSE")) >= 3;
+    const auto tc0 = std::chrono::steady_clock::now();
     if (T == 1) work(0);
     else ctx->pool->run(work);
+    if (verbose3) fprintf(stderr, "[nanowrap] host_copy_rows: %lld rows on %d threads, %ld us\n", (long long)n_rows, T,
+                          (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tc0).count());
     return NW_OK;
 }
 
