@@ -1176,7 +1176,7 @@ NW_EXPORT int nw_halo_block_stats(nw_ctx *ctx, double max_dist)
     NW_HIP(hipMemsetAsync(ctx->halo_stats.p, 0, 4 * sizeof(float), ctx->stream));
     const int blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (ctx->M_global + NW_BLOCK - 1) / NW_BLOCK));
     hipLaunchKernelGGL(k_halo_block_stats, dim3(blocks), dim3(NW_BLOCK), 0, ctx->stream, ctx->M_global, ctx->halo_full.p, ctx->halo_ref.p, (float)max_dist,
-                       (float)ctx->local_quantum, ctx->halo_stats.p, (const NwIterLogDev *)nullptr, 0);
+                       (float)ctx->local_quantum, ctx->halo_stats.p, (const NwIterLogDev *)nullptr, 0, (float *)nullptr);
     NW_HIP(hipGetLastError());
     return NW_OK;
 }
@@ -2016,11 +2016,12 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         NW_TRY(comm_all_reduce_dev(ctx, ctx->halo_full.p, (size_t)3 * ctx->M_global, ncclFloat, ncclSum));
         NW_HIP(hipMemsetAsync(ctx->halo_stats.p, 0, 4 * sizeof(float), ctx->stream));
         const int sblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (ctx->M_global + NW_BLOCK - 1) / NW_BLOCK));
+        static const bool tail_direct = !(getenv("NW_HALO_TAIL_DIRECT") && atoi(getenv("NW_HALO_TAIL_DIRECT")) == 0);      // developer knob: 0 = a device-to-host copy behind the kernel
         hipLaunchKernelGGL(k_halo_block_stats, dim3(sblocks), dim3(NW_BLOCK), 0, ctx->stream, ctx->M_global, ctx->halo_full.p, ctx->halo_ref.p, 0.0f,
-                           (float)ctx->local_quantum, ctx->halo_stats.p, (const NwIterLogDev *)ctx->logs.p, num_iters);
+                           (float)ctx->local_quantum, ctx->halo_stats.p, (const NwIterLogDev *)ctx->logs.p, num_iters, tail_direct ? (float *)ctx->pin_full : (float *)nullptr);
         NW_HIP(hipGetLastError());
         NW_TRY(comm_all_reduce_dev(ctx, ctx->halo_stats.p, 4, ncclFloat, ncclMax));
-        NW_HIP(hipMemcpyAsync(ctx->pin_full, ctx->halo_full.p, fb, hipMemcpyDeviceToHost, ctx->stream));
+        if (!tail_direct) NW_HIP(hipMemcpyAsync(ctx->pin_full, ctx->halo_full.p, fb, hipMemcpyDeviceToHost, ctx->stream));
         NW_HIP(hipMemcpyAsync((char *)ctx->pin_full + fb, ctx->halo_stats.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         ctx->full_staged = true;
     }

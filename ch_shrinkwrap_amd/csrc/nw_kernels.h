@@ -1087,12 +1087,16 @@ __global__ __launch_bounds__(NW_BLOCK) void k_halo_gather_owned(int M, const int
 // shares were cut.  stats[2] must be zero before the launch (non-negative floats order like unsigned integers: atomicMax on the bits).
 // logs != NULL: max_dist is taken from the block's own iteration records on the device (the largest of the executed iterations) instead of
 // from the host -- the block's tail is then enqueued behind its last iteration without waiting for the logs (nw_search on a sharded mesh)
+// host_out (pinned host memory or NULL): the whole mesh is written there on the way -- the PCIe writes overlap this kernel's reads instead
+// of a device-to-host copy queued behind it (the same trade as the single-GPU block's last update kernel, DESIGN section 3 "Block tail")
 __global__ __launch_bounds__(NW_BLOCK) void k_halo_block_stats(int64_t n_global, const float *__restrict__ full, const float *__restrict__ ref, float max_dist, float quantum,
-                                                              float *__restrict__ stats, const NwIterLogDev *__restrict__ logs, int nlogs)
+                                                              float *__restrict__ stats, const NwIterLogDev *__restrict__ logs, int nlogs, float *__restrict__ host_out)
 {
     float m = 0.0f;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_global; v += (int64_t)gridDim.x * blockDim.x) {
-        const float dx = full[3 * v] - ref[3 * v], dy = full[3 * v + 1] - ref[3 * v + 1], dz = full[3 * v + 2] - ref[3 * v + 2];
+        const float fx = full[3 * v], fy = full[3 * v + 1], fz = full[3 * v + 2];
+        if (host_out) { host_out[3 * v] = fx; host_out[3 * v + 1] = fy; host_out[3 * v + 2] = fz; }
+        const float dx = fx - ref[3 * v], dy = fy - ref[3 * v + 1], dz = fz - ref[3 * v + 2];
         const float d2 = dx * dx + dy * dy + dz * dz;
         m = d2 > m ? d2 : m;                               // (a NaN never wins: the block's NaN status is raised elsewhere)
     }
