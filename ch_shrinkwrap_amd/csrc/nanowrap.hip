@@ -1664,7 +1664,10 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
             const auto tw0 = std::chrono::steady_clock::now();
             NW_HIP(hipStreamSynchronize(ctx->stream));
             const bool last_ran = ctx->search_done > 0 && ctx->search_done == ctx->search_iters && host[ctx->search_done - 1].executed;
+            const auto tcp0 = std::chrono::steady_clock::now();
             if (last_ran) copy_out_staged(ctx, pos_out, ctx->wb_rows, ctx->wb_stride);
+            if (last_ran && getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
+                fprintf(stderr, "[nanowrap] search_end: copy-out of the staged result alone %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tcp0).count());
             else NW_TRY(write_back_impl(ctx, pos_out, ctx->wb_rows, ctx->wb_stride));
             if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
                 fprintf(stderr, "[nanowrap] search_end: wait + copy-out of the staged result %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw0).count());
@@ -2162,13 +2165,14 @@ static int ensure_staging(nw_ctx *ctx)
 }
 
 // the staging buffer already holds the result (written by the block's last kernel, stream synchronised): copy it out with the host threads
+static int64_t rows_per_copy_thread() { static const int64_t v = getenv("NW_HOST_ROWS_PER_THREAD") ? std::max<int64_t>(1000, atoll(getenv("NW_HOST_ROWS_PER_THREAD"))) : 25000; return v; }      // developer knob
 static void copy_out_staged(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes)
 {
     const int64_t M = ctx->M;
     const float *stage = (const float *)ctx->pin;
     const bool masked = rows && ctx->have_valid;
     const unsigned char *vstage = masked ? ctx->valid_host.data() : nullptr;
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, M / 25000));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, M / rows_per_copy_thread()));
     auto work = [&](int t) {
         if (t >= T) return;
         const int64_t v0 = M * t / T, v1 = M * (t + 1) / T;
@@ -2246,7 +2250,7 @@ NW_EXPORT int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, f
         ctx->wb_events.resize(ctx->pool->n);
         for (auto &e : ctx->wb_events) NW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, n_rows / 25000));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, n_rows / rows_per_copy_thread()));
     auto work = [&](int t) {
         if (t >= T) return;
         const int64_t v0 = n_rows * t / T, v1 = n_rows * (t + 1) / T;
