@@ -780,6 +780,29 @@ class ArrayMesh(object):
         pass
 
 
+def margin_after_block(worst, drift, step, budget, cut_margin, halo, min_margin, per_point, blocks_on_shares, blocks_since_shrink):
+    """New shares before the next block, and with which margin?  -> (cut, margin or None).  worst = largest growth of a nearest distance
+    (or the largest nearest distance) since the shares were cut, drift = the mesh's largest movement since then, step = the drift the last
+    block added, budget = what the shares were cut for.
+      * cut as soon as another block like the last one (one and a half times its movement, for room) could go beyond the budget -- a fit
+        slows down as it converges (C3 moves 26, 14, 9, 3, 2 ... nm per block of 5); the margin of the new shares is at least five steps
+        (a fit's movement roughly halves from block to block; three were measured too few) and TWICE the margin that has just run out:
+        cutting shares costs 0.1-0.5 s of host time, hundreds of blocks' worth of device time, and late in a fit growth + drift still rise
+        by 1-2 nm per block -- a margin of a few steps was used up every two or three blocks (19 cuts in 60 blocks, 10 s for 0.1 s of
+        iterations).  Doubling makes the cuts of a long fit few; never more than `halo`;
+      * shares that have lasted a hundred blocks with room to spare are cut again with a smaller margin (fewer vertices held), never less
+        than half."""
+    if worst + drift + 1.5 * step > budget:
+        if not per_point:
+            return True, None
+        return True, min(halo, max(min_margin, 5.0 * step, 2.0 * cut_margin))
+    if per_point and blocks_on_shares >= 100 and blocks_since_shrink >= 100:
+        want = max(min_margin, 5.0 * step, 2.0 * (worst + drift))
+        if want < 0.5 * cut_margin:
+            return True, max(want, 0.5 * cut_margin)
+    return False, None
+
+
 class HaloExceeded(RuntimeError):
     """a block of a sharded mesh ran beyond what its shares guarantee (HaloScene.search cuts new shares and runs it again, once)"""
 
@@ -1080,21 +1103,14 @@ class HaloScene(object):
         self._blocks_since_partition += 1
         self.max_dist, self.drift = worst, drift
         self._blocks_total += 1
-        if worst + drift + 1.5 * step > budget:       # (a fit slows down as it converges: C3 moves 26, 14, 9, 3, 2 ... nm per block of 5)
+        cut, margin = margin_after_block(worst, drift, step, budget, self._cut_margin, self.halo, self.min_margin, self.per_point,
+                                         self._blocks_since_partition, self._blocks_total - self._last_shrink)
+        if cut:
             self.last_partition = None                # cut new shares around the moved mesh before the next block
-            if self.per_point:
-                # ... with a margin for what the next blocks will need, and TWICE the margin that has just run out: cutting shares costs
-                # 0.1-0.5 s of host time, hundreds of blocks' worth of device time, and late in a fit growth + drift still rise by 1-2 nm
-                # per block (some vertices keep sliding) -- a margin of a few steps was used up every two or three blocks (measured: 19
-                # cuts in 60 blocks, 10 s for 0.1 s of iterations).  Doubling makes the cuts of a long fit few; never more than `halo`.
-                self.margin = min(self.halo, max(self._wanted_margin(), 2.0 * self._cut_margin))
-        elif self.per_point and self._blocks_since_partition >= 100 and self._blocks_total - self._last_shrink >= 100:
-            # the shares have lasted a hundred blocks with room to spare: a smaller margin holds fewer vertices (never less than half)
-            want = max(self._wanted_margin(), 2.0 * (worst + drift))
-            if want < 0.5 * self._cut_margin:
-                self.margin = max(want, 0.5 * self._cut_margin)
-                self._last_shrink = self._blocks_total
-                self.last_partition = None
+            if margin is not None:
+                if margin < self._cut_margin:
+                    self._last_shrink = self._blocks_total
+                self.margin = margin
         t2 = time.perf_counter()
         self.host_ms['block_tail_collectives_and_copy'] = (t1 - t0) * 1e3
         self.host_ms['block_tail_host_mesh'] = (t2 - t1) * 1e3

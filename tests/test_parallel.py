@@ -565,6 +565,33 @@ def test_a_rank_that_works_out_only_its_own_share_agrees_with_the_full_partition
             assert (q, r) in seg and np.array_equal(g, seg[(q, r)][1]) and np.array_equal(o, seg[(q, r)][0]), (n, r, q)
 
 
+def test_margin_policy_cuts_a_long_fit_rarely():
+    """A long fit on a fixed topology: growth + drift of a converged mesh still rise by ~1.8 nm per block (measured on C3).  The margin
+    doubles when it runs out, so the cuts stay few (a cut costs hundreds of blocks' worth of time) -- the rule "five times the last step"
+    alone cut new shares every two or three blocks."""
+    halo, min_margin = 60.0, 3.0
+    cut_margin, cuts, on_shares, since_shrink = 5.0, 0, 0, 10 ** 9       # shares cut with a small margin (a caller's optimize_layout)
+    worst = drift = 0.0
+    for block in range(400):
+        worst += 0.7
+        drift += 1.05
+        on_shares += 1
+        since_shrink += 1
+        cut, margin = parallel.margin_after_block(worst, drift, 1.05, cut_margin, cut_margin, halo, min_margin, True, on_shares, since_shrink)
+        assert worst + drift <= cut_margin                           # never beyond what the shares guarantee (the rule cuts BEFORE that block)
+        if cut:
+            cuts += 1
+            if margin < cut_margin:
+                since_shrink = 0
+            cut_margin, worst, drift, on_shares = margin, 0.0, 0.0, 0
+    assert cuts <= 20 and cut_margin == halo                         # 5 -> 10 -> 20 -> 40 -> 60, then once per ~30 blocks
+    # one radius for all (no per-localization margin): the rule only says "cut"
+    assert parallel.margin_after_block(50.0, 8.0, 2.0, 60.0, 60.0, 60.0, 3.0, False, 5, 5) == (True, None)
+    # a hundred quiet blocks on shares with a large margin: a smaller one, never less than half
+    assert parallel.margin_after_block(1.0, 2.0, 0.1, 60.0, 60.0, 60.0, 3.0, True, 120, 10 ** 9) == (True, 30.0)
+    assert parallel.margin_after_block(1.0, 2.0, 0.1, 60.0, 60.0, 60.0, 3.0, True, 50, 10 ** 9) == (False, None)
+
+
 @pytest.mark.parametrize('thin', [None, 25.0])
 def test_bisect_tiles_cuts_space_consistently(thin):
     """the tiles partition the localizations in balanced counts, and classify() puts every localization into its own tile -- with cuts across
