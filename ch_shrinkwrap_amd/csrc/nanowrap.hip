@@ -1665,10 +1665,13 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
             NW_HIP(hipStreamSynchronize(ctx->stream));
             const bool last_ran = ctx->search_done > 0 && ctx->search_done == ctx->search_iters && host[ctx->search_done - 1].executed;
             const auto tcp0 = std::chrono::steady_clock::now();
-            if (last_ran) copy_out_staged(ctx, pos_out, ctx->wb_rows, ctx->wb_stride);
-            if (last_ran && getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
-                fprintf(stderr, "[nanowrap] search_end: copy-out of the staged result alone %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tcp0).count());
-            else NW_TRY(write_back_impl(ctx, pos_out, ctx->wb_rows, ctx->wb_stride));
+            if (last_ran) {
+                copy_out_staged(ctx, pos_out, ctx->wb_rows, ctx->wb_stride);
+                if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
+                    fprintf(stderr, "[nanowrap] search_end: copy-out of the staged result alone %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tcp0).count());
+            } else {
+                NW_TRY(write_back_impl(ctx, pos_out, ctx->wb_rows, ctx->wb_stride));
+            }
             if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
                 fprintf(stderr, "[nanowrap] search_end: wait + copy-out of the staged result %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw0).count());
         } else {
