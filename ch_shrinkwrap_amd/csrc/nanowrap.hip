@@ -172,6 +172,7 @@ struct nw_ctx {
     int comm_rank = 0, comm_ranks = 1;
     uint32_t comm_mode = 0;                // NW_FLAG_COMM_* of the current search
     DevBuf<unsigned char> comm_scratch;    // staging of host buffers given to nw_comm_all_reduce
+    int64_t n_staged_copy_outs = 0, n_write_backs = 0;      // nw_debug, what = 2
     std::vector<uint64_t> comm_patterns;   // communication patterns (mode, sizes, peers) that have run one block outside a capture (nw_search)
     bool direct_out = false;         // nw_search: the last update of the block writes its result into the pinned staging buffer itself
     BlockGraph graphs[4];
@@ -2171,6 +2172,7 @@ static int ensure_staging(nw_ctx *ctx)
 static int64_t rows_per_copy_thread() { static const int64_t v = getenv("NW_HOST_ROWS_PER_THREAD") ? std::max<int64_t>(1000, atoll(getenv("NW_HOST_ROWS_PER_THREAD"))) : 25000; return v; }      // developer knob
 static void copy_out_staged(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes)
 {
+    ctx->n_staged_copy_outs += 1;
     const int64_t M = ctx->M;
     const float *stage = (const float *)ctx->pin;
     const bool masked = rows && ctx->have_valid;
@@ -2194,6 +2196,7 @@ static int write_back_impl(nw_ctx *ctx, float *contiguous, void *rows, int64_t r
 {
     if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_write_back: mesh not set");
     if (rows && row_stride_bytes < 12) return fail(ctx, NW_ERR_BADARG, "nw_write_back: bad stride");
+    ctx->n_write_backs += 1;
     const int64_t M = ctx->M;
     NW_TRY(ensure_staging(ctx));
     float *stage = (float *)ctx->pin;
@@ -2416,6 +2419,10 @@ NW_EXPORT int nw_debug(nw_ctx *ctx, int what, void *a, void *b, int cap, int *n)
 {
     if (what == 0) return debug_nn_stats(ctx, (int64_t *)a);
     if (what == 1) return debug_items(ctx, (int32_t *)a, (uint32_t *)b, cap, n);
+    if (what == 2 && ctx && a) {          // how a block's result reached the host so far: {staged copy-outs, sliced write-backs} (int64[2])
+        ((int64_t *)a)[0] = ctx->n_staged_copy_outs; ((int64_t *)a)[1] = ctx->n_write_backs;
+        return NW_OK;
+    }
     return NW_ERR_BADARG;
 }
 

@@ -331,7 +331,10 @@ int nw_accumulator_quantum(nw_ctx *ctx, double *q);
  * what = 1: the work list of the query -- a = int32 {first localization in sorted order, count}[cap], b = uint32 cost[cap] (duration in
  *   s_memtime ticks / 16 the last query measured for each item; zeros once the list has been ordered: heavy first, light last), *n = items in
  *   the list.  With NW_ITEM_TIMES set in the environment the timing stays on, durations are in 10 ns ticks of the clock all XCDs share, and b
- *   must hold 2 * cap entries: the second `cap` receive when each item started -- the launch's time line (tools/nn_costs.py). */
+ *   must hold 2 * cap entries: the second `cap` receive when each item started -- the launch's time line (tools/nn_costs.py).
+ * what = 2: a = int64 out[2]: how often a block's result has reached the host so far as a copy-out of the staging buffer the last update
+ *   kernel wrote (the fast path of results up to 4 MB), and how often as a sliced device-to-host write-back (larger results, or a block
+ *   the device-side stop condition ended early) -- a block must take ONE of the two. */
 int nw_debug(nw_ctx *ctx, int what, void *a, void *b, int cap, int *n);
 
 #ifdef __cplusplus

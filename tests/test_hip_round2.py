@@ -208,6 +208,26 @@ def test_host_edit_between_two_fits_reaches_the_device():
     assert rel_rms(b, m1.vertices) <= 1e-6
 
 
+def test_a_block_brings_its_result_to_the_host_once():
+    """A block's result reaches the host EITHER as a copy-out of the staging buffer its last update kernel wrote (results up to 4 MB) OR as
+    a sliced device-to-host write-back (a block the stop condition ended early, larger results) -- never both (a misplaced `else` once ran
+    the write-back after every copy-out: same values, 25 % slower blocks, and no test noticed)."""
+    import ctypes
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    c = synth.make_config('c3', scale=0.05, seed=9)
+    pts, s = c['points'], 1.0 / c['sigma'].ravel()
+    for level in (0, 4):
+        mesh = TriMesh(c['vertices'].copy(), c['faces'])
+        cg = CG(mesh, pts)
+        cg.set_profiling(level)
+        for block in range(5):
+            cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s)
+        n = (ctypes.c_int64 * 2)()
+        cg._native.check(cg._L.nw_debug(cg._h, 2, n, None, 0, None))
+        assert (n[0], n[1]) == (5, 0), (level, n[0], n[1])
+
+
 def test_profiling_levels_do_not_change_the_result():
     """Identical fits (6 blocks of 5) with profiling off (blocks replayed as hipGraphs), with every query launch bracketed (every
     kernel launched from the host), with every stage bracketed, and at level 4 (the block's first iteration launched directly with its
