@@ -1952,7 +1952,7 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         return fail(ctx, NW_ERR_BADARG, "nw_search on a sharded mesh: the boundary rows must go round between the phases (NW_FLAG_COMM_HALO with a communicator, or nw_search_begin / nw_iter_* / nw_search_end with the caller's collectives)");
     NW_TRY(nw_search_begin(ctx, lams, n_lams, num_iters, flags));
     const auto t1 = std::chrono::steady_clock::now();
-    // A block is a fixed launch sequence (begin ops + num_iters x 11 launches) with block-relative arguments: captured once as a
+    // A block is a fixed launch sequence (begin ops + num_iters x 10 launches) with block-relative arguments: captured once as a
     // hipGraph and replayed for later blocks while nothing it bakes in has changed (sizes, buffers, grid, flags, lambda, quantum,
     // warm/cold start).  Host-side enqueue drops from ~3.5 us per launch to one graph launch: what small meshes are bound by.
     // Not with per-launch profiling (levels 1, 2): events recorded by graph nodes do not give elapsed times on ROCm 7.2 (they read 0).
