@@ -1783,6 +1783,19 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head)
         ctx->capturing = false;
         hipGraph_t graph = nullptr;
         const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+        if (graph && getenv("NW_VERBOSE")) {          // what the recording holds (with a communicator: what RCCL put into it)
+            size_t nn = 0;
+            if (hipGraphGetNodes(graph, nullptr, &nn) == hipSuccess && nn > 0) {
+                std::vector<hipGraphNode_t> nodes(nn);
+                int cnt[16] = {0};
+                if (hipGraphGetNodes(graph, nodes.data(), &nn) == hipSuccess)
+                    for (size_t i = 0; i < nn; ++i) { hipGraphNodeType ty; if (hipGraphNodeGetType(nodes[i], &ty) == hipSuccess && (int)ty >= 0 && (int)ty < 16) cnt[(int)ty] += 1; }
+                fprintf(stderr, "[nanowrap] recorded graph: %zu nodes -- kernel %d, memcpy %d, memset %d, host %d, child graph %d, empty %d, event wait %d, event record %d\n", nn,
+                        cnt[hipGraphNodeTypeKernel], cnt[hipGraphNodeTypeMemcpy], cnt[hipGraphNodeTypeMemset], cnt[hipGraphNodeTypeHost], cnt[hipGraphNodeTypeGraph],
+                        cnt[hipGraphNodeTypeEmpty], cnt[hipGraphNodeTypeWaitEvent], cnt[hipGraphNodeTypeEventRecord]);
+            }
+            (void)hipGetLastError();
+        }
         if (r == NW_OK && ce == hipSuccess && graph && hipGraphInstantiate(&ea, graph, nullptr, nullptr, 0) != hipSuccess) ea = nullptr;
         if (graph) (void)hipGraphDestroy(graph);
     }
