@@ -44,8 +44,84 @@ def build_hip_library(force=False, verbose=False):
     if force or not os.path.exists(OBJ_SORT) or os.path.getmtime(OBJ_SORT) < os.path.getmtime(SRC_SORT):
         run([hipcc, '-O3', '--offload-arch=gfx950', '-fPIC', '-fvisibility=hidden', '-Wno-unused-value', '-c', '-o', OBJ_SORT, SRC_SORT])
     run([hipcc] + [f for f in HIPCC_FLAGS if f != '-shared'] + ['-c', '-o', OBJ_MAIN, SRC])
+    check_kernel_budgets(verbose=verbose)          # before the link: a kernel that spills or outgrows its occupancy never ships
     run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB, OBJ_MAIN, OBJ_SORT])
     return LIB
+
+
+# ---- resource budget of the per-iteration kernels ---------------------------------------------------------------------------------
+# The kernels are tuned to an occupancy (waves per SIMD = 512 // VGPRs, capped at 8) that nothing but the register allocator enforces:
+# a compiler bump or an innocent edit can spill (scratch > 0: round 2's 20-byte spill of k_nn_wave was only noticed through WRITE_SIZE
+# in a profile) or cross a VGPR step and silently halve the waves in flight.  The build reads the gfx950 code object's metadata notes
+# (.vgpr_count, .private_segment_fixed_size, .sgpr_spill_count, .group_segment_fixed_size) out of csrc/nanowrap.o and fails on a
+# violation; tests/test_abi.py asserts the same numbers.  Budget = (max VGPRs, max LDS bytes); scratch and VGPR spills must be 0.
+LLVM_BIN = os.environ.get('NW_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+KERNEL_BUDGETS = {
+    # kernel (demangled prefix)       VGPRs  LDS
+    'k_nn_wave<false>':               (80, 8 * 1024),      # 6 waves per SIMD (amdgpu_waves_per_eu(6,8)); wave-private lists in LDS
+    'k_attract':                      (64, 20 * 1024),     # 8 workgroups per CU: 64 VGPRs and 18 KB of LDS (the per-workgroup scatter table)
+    'k_face_centroids':               (64, 8 * 1024),
+    'k_centroid_scatter':             (64, 0),
+    'k_scan_final':                   (64, 1024),
+    'k_prior_directions':             (168, 1024),         # 3 waves per SIMD (2 048 waves in all: two per SIMD)
+    'k_subspace_point_sums':          (128, 20 * 1024),    # 4 waves per SIMD cover the launch in one round (rows of two localizations in flight)
+    'k_solve_update':                 (128, 1024),
+}
+
+
+def kernel_resources(obj=None):
+    """{demangled kernel name: {'vgpr', 'sgpr', 'scratch', 'lds', 'vgpr_spill', 'sgpr_spill'}} of the gfx950 code object inside `obj`."""
+    import re
+    import tempfile
+    obj = obj or OBJ_MAIN
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, 'fat.bin'), os.path.join(td, 'dev.co')
+        subprocess.check_call(['objcopy', '-O', 'binary', '--only-section=.hip_fatbin', obj, fat])
+        subprocess.check_call([os.path.join(LLVM_BIN, 'clang-offload-bundler'), '--unbundle', '--type=o', '--input=' + fat,
+                               '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
+        notes = subprocess.check_output([os.path.join(LLVM_BIN, 'llvm-readelf'), '--notes', co]).decode()
+    out = {}
+    for entry in re.split(r'\n\s+- \.agpr_count', notes)[1:]:
+        def field(f, default='0'):
+            m = re.search(r'\.%s:\s+(\S+)' % f, entry)
+            return m.group(1) if m else default
+        sym = field('name', '')
+        if not sym:
+            continue
+        # demangled by hand (no c++filt dependency): _Z<len><name>[I L b <0|1> E E]... -> name, name<false>, name<true>
+        m = re.match(r'_Z(\d+)', sym)
+        name = sym
+        if m:
+            n0 = m.end()
+            name = sym[n0:n0 + int(m.group(1))]
+            t = re.match(r'ILb([01])EE', sym[n0 + int(m.group(1)):])
+            if t:
+                name += '<true>' if t.group(1) == '1' else '<false>'
+        out[name] = {'vgpr': int(field('vgpr_count')), 'sgpr': int(field('sgpr_count')), 'scratch': int(field('private_segment_fixed_size')),
+                     'lds': int(field('group_segment_fixed_size')), 'vgpr_spill': int(field('vgpr_spill_count')), 'sgpr_spill': int(field('sgpr_spill_count'))}
+    return out
+
+
+def check_kernel_budgets(obj=None, verbose=False):
+    """Raise RuntimeError if a budgeted kernel is missing, uses scratch, spills VGPRs, or exceeds its VGPR / LDS budget."""
+    res = kernel_resources(obj)
+    bad = []
+    for k, (max_vgpr, max_lds) in KERNEL_BUDGETS.items():
+        r = res.get(k)
+        if r is None:
+            bad.append('%s: not in the code object' % k)
+            continue
+        if verbose:
+            print('  %-28s %3d VGPRs (<= %3d)  %5d B LDS (<= %5d)  scratch %d' % (k, r['vgpr'], max_vgpr, r['lds'], max_lds, r['scratch']))
+        if r['scratch'] or r['vgpr_spill']:
+            bad.append('%s: %d bytes of scratch, %d VGPRs spilled' % (k, r['scratch'], r['vgpr_spill']))
+        if r['vgpr'] > max_vgpr:
+            bad.append('%s: %d VGPRs, budget %d' % (k, r['vgpr'], max_vgpr))
+        if r['lds'] > max_lds:
+            bad.append('%s: %d bytes of LDS, budget %d' % (k, r['lds'], max_lds))
+    if bad:
+        raise RuntimeError('kernel resource budget violated:\n  ' + '\n  '.join(bad))
+    return res
 
 
 HOST_LIB = os.path.join(HERE, 'libnw_remesh.so')

@@ -54,3 +54,23 @@ def test_no_gpu_means_loud_failure():
     v, f = icosphere(1, 10.0)
     with pytest.raises(RuntimeError):
         ShrinkwrapMeshConjGrad(TriMesh(v, f), np.zeros((10, 3), 'f4'))
+
+
+def test_kernels_stay_within_their_resource_budget():
+    """The per-iteration kernels are tuned to an occupancy that only the register allocator enforces: no scratch, no spilled VGPRs,
+    VGPRs and LDS within ch_shrinkwrap_amd/build.py's KERNEL_BUDGETS (read from the gfx950 code object's notes; build() fails likewise)."""
+    from ch_shrinkwrap_amd import build
+    build.build_hip_library()
+    res = build.check_kernel_budgets()                  # raises on a violation
+    nn = res['k_nn_wave<false>']
+    assert nn['vgpr'] <= 80 and nn['scratch'] == 0 and nn['vgpr_spill'] == 0 and nn['sgpr_spill'] == 0
+    for k in build.KERNEL_BUDGETS:
+        assert res[k]['scratch'] == 0, k
+    # a kernel over its budget is caught (budget lowered by one register for the check)
+    worst = dict(build.KERNEL_BUDGETS)
+    try:
+        build.KERNEL_BUDGETS['k_nn_wave<false>'] = (res['k_nn_wave<false>']['vgpr'] - 1, 8 * 1024)
+        with pytest.raises(RuntimeError):
+            build.check_kernel_budgets()
+    finally:
+        build.KERNEL_BUDGETS.clear(); build.KERNEL_BUDGETS.update(worst)
