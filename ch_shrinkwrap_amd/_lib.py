@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libnanowrap_hip.so')
+LIB_PATH = os.environ.get('NW_LIB_PATH') or os.path.join(HERE, 'libnanowrap_hip.so')      # (NW_LIB_PATH: developer knob, A/B of two builds on one box)
 
 NW_OK = 0
 NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM, NW_ERR_INTERNAL, NW_ERR_REMOTE = -1, -2, -3, -4, -5, -6, -7, -8

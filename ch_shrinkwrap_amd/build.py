@@ -63,7 +63,8 @@ KERNEL_BUDGETS = {
     'k_face_centroids':               (64, 8 * 1024),
     'k_centroid_scatter':             (64, 0),
     'k_scan_final':                   (64, 1024),
-    'k_prior_directions':             (168, 1024),         # 3 waves per SIMD (2 048 waves in all: two per SIMD)
+    'k_prior_ring':                   (128, 1024),         # (only launched on its own with NW_RING_IN_NN=0: the ring half rides in the query launch)
+    'k_prior_directions':             (96, 1024),          # streaming since the ring half left it: 5 waves per SIMD
     'k_subspace_point_sums':          (128, 20 * 1024),    # 4 waves per SIMD cover the launch in one round (rows of two localizations in flight)
     'k_solve_update':                 (128, 1024),
 }

@@ -273,10 +273,13 @@ struct nw_ctx {
     DevBuf<float4> cent_tmp, cent;
     DevBuf<int> fcell, frank, face, vidx, ambig_list, ambig_count;
     DevBuf<float> dist, w, res, S, fdef, pi;
+    DevBuf<float4> ring4;             // ring half of the curvature prior, per vertex: {1-ring position sums (f32), number of neighbours} ...
+    DevBuf<double> ring_a;            // ... and the normal-consistency sum: written beside the query (k_nn_wave's appended workgroups), read by k_prior_directions
     DevBuf<long long> vacc;           // (M, 4) fixed-point accumulator {A^T res, sum w}: exact, order-independent sums
     DevBuf<double> scalars;           // [NW_N_SCALARS][NW_SPARTS] sums of the current iteration, NW_SPARTS ordered parts per slot (k_reduce_scalars)
     DevBuf<float> wv;                 // per-vertex weights of the 'wfunc' regulariser (NW_FLAG_WFUNC)
     DevBuf<double> part_a, part_p, part_s;   // per-workgroup partial sums of k_attract / k_prior_directions / k_subspace_point_sums
+    DevBuf<int> tickets;              // 3 x NW_SPARTS arrival counters of the folded reduction (nw_publish_row): zero between launches
     bool vacc_dirty = true;           // something other than the iteration has written the scatter accumulator since it was last zeroed
     int attract_rows = 0;             // rows of part_a the last attraction wrote (its workgroups)
     double w_quantum = 1.0;           // fixed-point quantum of the {w} column
@@ -596,12 +599,37 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->S.ensure(9 * M));
     NW_HIP(ctx->fdef.ensure(3 * M));
     NW_HIP(ctx->pi.ensure(M));
+    NW_HIP(ctx->ring4.ensure(M));
+    NW_HIP(ctx->ring_a.ensure(M));
     NW_HIP(ctx->scalars.ensure(NW_N_SCALARS * NW_SPARTS));
     NW_HIP(ctx->part_a.ensure((size_t)5 * attract_blocks(ctx)));
     NW_HIP(ctx->part_s.ensure((size_t)9 * subspace_blocks(ctx)));
     NW_HIP(ctx->part_p.ensure((size_t)14 * prior_blocks(ctx)));
     NW_HIP(ctx->wv.ensure(ctx->M));
+    if (!ctx->tickets.p) {
+        NW_HIP(ctx->tickets.ensure(3 * NW_SPARTS));
+        NW_HIP(hipMemsetAsync(ctx->tickets.p, 0, 3 * NW_SPARTS * sizeof(int), ctx->stream));
+    }
     return NW_OK;
+}
+
+// NW_FOLD_REDUCE=1 (developer knob): the producers add their partial rows themselves (nw_publish_row) and the k_reduce_scalars launch is
+// dropped.  Measured twice and slower both times (round 3; round 5 with the row published before the scatter table's flush: k_attract
+// 35 -> 68 us -- the publishing wave's returning ticket queues behind the other waves' flush atomics and keeps its workgroup's LDS and
+// wave slots; k_prior_directions +2.5 us, k_subspace_point_sums +5 us: what the launch costs): off by default.
+static bool fold_reduce() { static const bool on = getenv("NW_FOLD_REDUCE") && atoi(getenv("NW_FOLD_REDUCE")) != 0; return on; }
+static NwFold fold_args(const nw_ctx *ctx, int table, int nblk)
+{
+    NwFold f;
+    memset(&f, 0, sizeof(f));
+    f.sc = fold_reduce() ? ctx->scalars.p : nullptr;
+    f.tickets = ctx->tickets.p + table * NW_SPARTS;
+    f.nblk = nblk;
+    f.slot0 = table == 0 ? SC_RES2 : (table == 1 ? SC_HC : SC_SS);
+    f.max_slot = SC_MAXD;
+    f.status_slot = table == 1 ? SC_STATUS : -1;
+    f.status = &ctx->state.p->status;
+    return f;
 }
 
 }  // namespace
@@ -1274,7 +1302,7 @@ static int resort_by_projection(nw_ctx *ctx)
 }
 
 enum { QP_GRID = 1, QP_NN = 2, QP_FIXUP = 4, QP_ATTRACT = 8, QP_ALL = 15 };     // parts of the first half of an iteration
-static int launch_query(nw_ctx *ctx, int it, int parts = QP_GRID | QP_NN | QP_FIXUP);
+static int launch_query(nw_ctx *ctx, int it, int parts = QP_GRID | QP_NN | QP_FIXUP, bool with_ring = false);
 static NwAttractArgs attract_args(const nw_ctx *ctx);
 static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head = false);
 // Cell-size tuner, once per localization cloud.  The query is exact for every cell size, and its cost depends on more than the rule
@@ -1512,7 +1540,17 @@ static int enqueue_begin_ops(nw_ctx *ctx)
 // the query kernel resolves its ambiguous localizations itself (default); NW_FUSE_FIXUP=0 brings back the separate fix-up launch
 static bool fuse_fixup() { static const bool on = !(getenv("NW_FUSE_FIXUP") && atoi(getenv("NW_FUSE_FIXUP")) == 0); return on; }
 
-static int launch_query(nw_ctx *ctx, int it, int parts)
+// the ring half of the curvature prior rides in the query launch (workgroups appended to its grid: they run in its drain); NW_RING_IN_NN=0
+// (developer knob) makes it a launch of its own in front of k_prior_directions
+static bool ring_in_nn() { static const bool on = !(getenv("NW_RING_IN_NN") && atoi(getenv("NW_RING_IN_NN")) == 0); return on; }
+static NwRingArgs ring_args(const nw_ctx *ctx)
+{
+    NwRingArgs r;
+    r.M = (int)ctx->M; r.maxdeg = ctx->maxdeg; r.nbr_t = ctx->nbr_t.p; r.meshpos = ctx->meshpos.p; r.nrm = ctx->nrm.p; r.ring4 = ctx->ring4.p; r.ring_a = ctx->ring_a.p;
+    return r;
+}
+
+static int launch_query(nw_ctx *ctx, int it, int parts, bool with_ring)
 {
     const int64_t F = ctx->F;
     const NwGrid g = ctx->grid;
@@ -1536,14 +1574,19 @@ static int launch_query(nw_ctx *ctx, int it, int parts)
         static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
         const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;   // one wave = one work item
         const int nbp = nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
-if (ctx->nn_stats.p) {
-            hipLaunchKernelGGL(k_nn_wave<true>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+        NwRingArgs R = ring_args(ctx);
+        const bool ring_here = with_ring && ring_in_nn();
+        if (!ring_here) R.M = 0;
+        const int nbq = nbp;                                          // workgroups of the query proper; behind them one thread per vertex for the ring half
+        const int nbt = nbq + (ring_here ? (int)((ctx->M + tb - 1) / tb) : 0);
+        if (ctx->nn_stats.p) {
+            hipLaunchKernelGGL(k_nn_wave<true>, dim3(nbt), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (item_times ? 64 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max);
+                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max, R, nbq);
         } else {
-            hipLaunchKernelGGL(k_nn_wave<false>, dim3(nbp), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
+            hipLaunchKernelGGL(k_nn_wave<false>, dim3(nbt), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (item_times ? 64 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max);
+                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max, R, nbq);
         }
         if (ctx->face_warm && !ctx->items_by_cost) ctx->item_cost_valid = true;      // (a cold query's costs say little about the warm ones)
         ctx->face_warm = true;
@@ -1563,10 +1606,10 @@ static int iter_attract_parts(nw_ctx *ctx, int parts)
     if (ctx->begin_ops_pending) NW_TRY(enqueue_begin_ops(ctx));
     const int it = ctx->search_done;
     const int64_t N = ctx->N;
-    if (parts & (QP_GRID | QP_NN | QP_FIXUP)) NW_TRY(launch_query(ctx, it, parts & (QP_GRID | QP_NN | QP_FIXUP)));
+    if (parts & (QP_GRID | QP_NN | QP_FIXUP)) NW_TRY(launch_query(ctx, it, parts & (QP_GRID | QP_NN | QP_FIXUP), true));
     if (parts & QP_ATTRACT) {
         StageScope s(ctx, ST_ATTRACT);
-        hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts.p, ctx->face.p, attract_args(ctx), ctx->state.p, it);
+        hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts.p, ctx->face.p, attract_args(ctx), ctx->state.p, it, fold_args(ctx, 0, attract_blocks(ctx)));
         ctx->attract_rows = attract_blocks(ctx);
     }
     NW_HIP(hipGetLastError());
@@ -1593,16 +1636,18 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
         const bool wfunc = (ctx->search_flags & NW_FLAG_WFUNC) != 0;
         if (wfunc)
             hipLaunchKernelGGL(k_vertex_area_weights, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->NB, ctx->nbr.p, ctx->pos.p, ctx->wv.p, ctx->state.p, it);
-        hipLaunchKernelGGL(k_prior_directions, dim3(prior_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->maxdeg, ctx->nbr_t.p, ctx->pos.p,
+        if (!ring_in_nn()) hipLaunchKernelGGL(k_prior_ring, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, ring_args(ctx), ctx->state.p, it);
+        hipLaunchKernelGGL(k_prior_directions, dim3(prior_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->ring4.p, ctx->ring_a.p, ctx->pos.p,
                            ctx->meshpos.p, ctx->nrm.p, ctx->vacc.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->part_p.p, ctx->state.p, it, n_search,
-                           ctx->acc_quantum, ctx->w_quantum, wfunc ? ctx->wv.p : nullptr, ctx->have_owned ? ctx->owned.p : nullptr);
+                           ctx->acc_quantum, ctx->w_quantum, wfunc ? ctx->wv.p : nullptr, ctx->have_owned ? ctx->owned.p : nullptr, fold_args(ctx, 2, prior_blocks(ctx)));
     }
     {
         StageScope s(ctx, ST_AS);
-        hipLaunchKernelGGL(k_subspace_point_sums, dim3(subspace_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, ctx->vidx.p, ctx->w.p, ctx->res.p,
-                           ctx->mask.p, ctx->S.p, ctx->part_s.p, ctx->state.p, it, n_search);
-        // the 24 sums of this iteration, added in a fixed order (deterministic); multi-GPU runs all-reduce them after this call
-        hipLaunchKernelGGL(k_reduce_scalars, dim3(3 * NW_SPARTS), dim3(NW_BLOCK), 0, ctx->stream, ctx->part_a.p, ctx->attract_rows, ctx->part_p.p, prior_blocks(ctx),
+        hipLaunchKernelGGL(k_subspace_point_sums, dim3(subspace_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, (int)ctx->M, ctx->vidx.p, ctx->w.p, ctx->res.p,
+                           ctx->mask.p, ctx->S.p, ctx->part_s.p, ctx->state.p, it, n_search, fold_args(ctx, 1, subspace_blocks(ctx)));
+        // the 28 sums of this iteration, added in a fixed order (deterministic) by the producers' last arrivers (nw_publish_row); multi-GPU
+        // runs all-reduce them after this call
+        if (!fold_reduce()) hipLaunchKernelGGL(k_reduce_scalars, dim3(3 * NW_SPARTS), dim3(NW_BLOCK), 0, ctx->stream, ctx->part_a.p, ctx->attract_rows, ctx->part_p.p, prior_blocks(ctx),
                            ctx->part_s.p, subspace_blocks(ctx), ctx->scalars.p, ctx->state.p, it);
     }
     NW_HIP(hipGetLastError());
@@ -1746,7 +1791,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->ctile.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
-                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p,
+                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p, ctx->ring4.p, ctx->ring_a.p, ctx->tickets.p,
                           ctx->hb_local.p, ctx->hb_slot.p, ctx->hb_slot2local.p, ctx->halo_acc.p, ctx->halo_rows.p, ctx->face_sorted ? ctx->face_orig.p : nullptr,
                           ctx->have_peers ? ctx->px_ghost.p : nullptr, ctx->have_peers ? ctx->px_owned.p : nullptr, ctx->have_peers ? ctx->px_send.p : nullptr,
                           ctx->have_peers ? ctx->px_recv.p : nullptr};

@@ -6,6 +6,11 @@
 #define NW_BLOCK 256
 #define NW_WAVE 64
 
+// wide loads / stores at 4-byte alignment (gfx950 global memory instructions take any dword-aligned address; a row of S is 36 bytes)
+typedef float nw_f4u __attribute__((ext_vector_type(4), aligned(4)));        // 16-byte load at 4-byte alignment (a row of S is 36 bytes)
+typedef float nw_f3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef int nw_i3u __attribute__((ext_vector_type(3), aligned(4)));
+
 // ---- uniform grid ------------------------------------------------------------------------------------------
 // Face centroids are binned into the cells of edge h of one dense lattice (x fastest: a (z,y) row of cells is one contiguous
 // candidate range of the cell-sorted centroid array).  The localizations are NOT binned: they are Morton-sorted once (nw_nn.h).
@@ -31,11 +36,42 @@ __device__ __forceinline__ int nw_cell_index(const NwGrid &g, int ix, int iy, in
     return ix + g.gx * (iy + g.gy * iz);
 }
 
-// ---- wave / block reductions (wave64 shuffles; no LDS for the intra-wave part) ------------------------------
+// ---- wave / block reductions ---------------------------------------------------------------------------------------------------------
+// Wave-wide sum of a double on the VECTOR ALU alone: a butterfly of DPP moves inside each row of 16 lanes (quad permutes, row_half_mirror,
+// row_mirror), then v_permlane16_swap / v_permlane32_swap (gfx950) between the rows.  __shfl_xor compiles to ds_bpermute_b32 -- an
+// instruction of the LDS pipe, which a CU's four SIMDs share, twelve per double: the fourteen sums of k_prior_directions were ~170 of them
+// per wave and bounded that kernel once its gathers had gone (round 5: 14.2 -> 7 us).  Every lane ends with the same total; the
+// association is a fixed tree, so the sums stay deterministic.
+__device__ __forceinline__ double nw_dpp_xadd(double v, int ctrl_id)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_id) {
+    case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0xb1, 0xf, 0xf, false); hi = __builtin_amdgcn_mov_dpp(hi, 0xb1, 0xf, 0xf, false); break;       // quad_perm [1,0,3,2]
+    case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x4e, 0xf, 0xf, false); hi = __builtin_amdgcn_mov_dpp(hi, 0x4e, 0xf, 0xf, false); break;       // quad_perm [2,3,0,1]
+    case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xf, 0xf, false); break;     // row_half_mirror
+    default: lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xf, 0xf, false); break;    // row_mirror
+    }
+    return v + __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double nw_wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = nw_dpp_xadd(v, 0);
+    v = nw_dpp_xadd(v, 1);
+    v = nw_dpp_xadd(v, 2);
+    v = nw_dpp_xadd(v, 3);
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
     return v;
 }
 
@@ -87,6 +123,100 @@ __device__ __forceinline__ void nw_block_reduce_store_lds(double (&v)[NV], doubl
     }
 }
 
+// ---- the normal-equation sums without a reduction launch (round 5) --------------------------------------------------------------------
+// Until round 4 a fourth launch (k_reduce_scalars, 5.7 us + a kernel boundary) added the producers' per-workgroup rows.  Now the rows are
+// added by the producers themselves: the workgroups of a launch form NW_SPARTS groups of consecutive rows, every workgroup takes a
+// ticket of its group after publishing its row, and the workgroup whose ticket is the group's last adds the group's rows -- in row
+// order, so the sums do not depend on which workgroup that was -- into sc[slot][group], exactly the table k_solve_update reads.
+// Hand-off (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads", first row): the row is stored write-through (agent-scope relaxed
+// stores = `sc1`) by lanes of ONE wave, that wave waits for its stores (`s_waitcnt vmcnt(0)`), ONE lane takes the ticket (agent-scope
+// atomic add on one unsharded counter); the last arriver reads every row with `sc1` loads after its add has returned.  No fence.
+// Round 3 tried this and lost (k_attract 35 -> 74 us): there the wait also covered the wave's scatter atomics.  Here the caller publishes
+// BEFORE it flushes its scatter table, and only the publishing wave waits.
+struct NwFold {
+    double *sc;            // [NW_N_SCALARS][NW_SPARTS]; NULL: rows only (k_reduce_scalars adds them)
+    int *tickets;          // this launch's NW_SPARTS counters, zero between launches (the last arriver resets its own)
+    int nblk;              // rows (= workgroups) of this launch
+    int slot0;             // first slot of the row's columns
+    int max_slot;          // slot of the MAXCOL column (a maximum, not a sum), if any
+    int status_slot;       // >= 0: this launch also writes the status slot (1.0 in group 0 if the device status is set)
+    const int *status;
+};
+#define NW_FOLD_PARTS 32   // = NW_SPARTS (nw_kernels.h)
+
+// called by ALL lanes of wave 0 with the workgroup's row in lanes 0..NV-1 (`mine`); MAXCOL: column that holds a maximum (values >= 0), -1 none
+template <int NV, int MAXCOL>
+__device__ __forceinline__ void nw_publish_row(double mine, double *__restrict__ part, const NwFold &Fd)
+{
+    const int lane = threadIdx.x & 63;
+    double *row = part + (int64_t)blockIdx.x * NV;
+    if (!Fd.sc) { if (lane < NV) row[lane] = mine; return; }
+    if (lane < NV) __hip_atomic_store(row + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int per = (Fd.nblk + NW_FOLD_PARTS - 1) / NW_FOLD_PARTS;
+    const int g = (int)blockIdx.x / per;
+    const int r0 = g * per, r1 = min(r0 + per, Fd.nblk);
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(Fd.tickets + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != r1 - r0 - 1) return;
+    // last of its group: the group's rows, flat and coalesced, NT lanes (a multiple of NV: a lane stays on its column), four chains
+    constexpr int NT = (64 / NV) * NV;
+    const double *p = part + (int64_t)r0 * NV;
+    const int total = (r1 - r0) * NV;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (lane < NT) {
+        int e = lane;
+        if (MAXCOL >= 0 && lane % NV == MAXCOL) {
+            for (; e < total; e += NT) a0 = fmax(a0, __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        } else {
+            for (; e + 3 * NT < total; e += 4 * NT) {
+                const double x0 = __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(p + e + NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double x2 = __hip_atomic_load(p + e + 2 * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x3 = __hip_atomic_load(p + e + 3 * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+            }
+            for (; e < total; e += NT) a0 += __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a0 = (a0 + a1) + (a2 + a3);
+        }
+    }
+    // the NT / NV lanes of a column, in lane order
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NT / NV; ++k) {
+        const double o = __shfl(a0, (lane % NV) + k * NV, 64);
+        if (MAXCOL >= 0 && lane % NV == MAXCOL) s = fmax(s, o); else s += o;
+    }
+    if (lane < NV) Fd.sc[((MAXCOL >= 0 && lane == MAXCOL) ? Fd.max_slot : Fd.slot0 + lane) * NW_FOLD_PARTS + g] = s;
+    if (g == 0) {
+        // groups without a workgroup (fewer workgroups than groups): their parts are zero
+        const int used = (Fd.nblk + per - 1) / per;
+        for (int gg = used; gg < NW_FOLD_PARTS; ++gg)
+            if (lane < NV) Fd.sc[((MAXCOL >= 0 && lane == MAXCOL) ? Fd.max_slot : Fd.slot0 + lane) * NW_FOLD_PARTS + gg] = 0.0;
+    }
+    if (Fd.status_slot >= 0 && lane == 0) Fd.sc[Fd.status_slot * NW_FOLD_PARTS + g] = (g == 0 && *Fd.status != 0) ? 1.0 : 0.0;
+    if (Fd.status_slot >= 0 && g == 0 && lane == 0) { const int used = (Fd.nblk + per - 1) / per; for (int gg = used; gg < NW_FOLD_PARTS; ++gg) Fd.sc[Fd.status_slot * NW_FOLD_PARTS + gg] = 0.0; }
+    if (lane == 0) __hip_atomic_store(Fd.tickets + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The workgroup's NV sums: wave sums on the vector ALU, 4 NV doubles through LDS, the row published by wave 0 (nw_publish_row).
+// s_w: NV * 4 doubles.  All threads call it; returns after wave 0 has published (the other waves do not wait for the ticket).
+template <int NV>
+__device__ __forceinline__ void nw_block_sums_publish(double (&v)[NV], double *__restrict__ part, double *s_w, const NwFold &Fd)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double s = nw_wave_sum(v[k]);
+        if (lane == 0) s_w[k * 4 + wv] = s;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        double mine = 0.0;
+        if (lane < NV) mine = (s_w[lane * 4 + 0] + s_w[lane * 4 + 1]) + (s_w[lane * 4 + 2] + s_w[lane * 4 + 3]);
+        nw_publish_row<NV, -1>(mine, part, Fd);
+    }
+}
+
 // plain (non-replicated) variant with float64 atomics for the set-up reductions (mesh area, weight sums): not on the iteration path
 template <int NV>
 __device__ __forceinline__ void nw_block_reduce_atomic(double (&v)[NV], double *out, double *s_part /* [NV*4] */)
@@ -112,4 +242,73 @@ __device__ __forceinline__ int nw_xcd_remap(int b, int n)
     const int chunk = (n + 7) >> 3;
     const int i = (b & 7) * chunk + (b >> 3);
     return i < n ? i : -1;
+}
+
+// ---- the ring half of the curvature prior ----------------------------------------------------------------------------------------------
+// _ncc() (mesh_conj_grad.py:770-820) needs, per vertex, the 1-ring centroid (float32 sum in slot order, :782-788) and the normal-consistency
+// sum (:796-800) -- both functions of the MESH positions and the block-stale normals alone, i.e. known before the iteration's query and
+// scatter have run; only the gate min(pi^2, 1) (:807-814) needs this iteration's A^T 1.  The ring half is therefore computed apart
+// (round 5) by workgroups APPENDED to the query launch's grid (k_nn_wave): they are dispatched when the query's own workgroups have all
+// started, i.e. they run in the launch's long drain, on compute units the query no longer fills, and the 1-ring gathers (20 x 4 + ~6 x 24
+// bytes a vertex) leave the iteration's critical path.  k_prior_directions then streams {ring sums, accumulator, estimate, own normal}.
+// Output per vertex: ring4 = {sum x, sum y, sum z (float32), number of neighbours (int bits)}, ring_a = the normal-consistency sum (f64).
+struct NwRingArgs {
+    int M, maxdeg;
+    const int *nbr_t;                 // slot-major 1-ring table [NB][M]
+    const float *meshpos, *nrm;
+    float4 *ring4;
+    double *ring_a;
+};
+
+// one vertex; the arithmetic and its order are exactly the former first half of k_prior_directions.  Written for FEW registers (it shares
+// a kernel with the query, whose 80 VGPRs it must not exceed): the ring is walked four slots at a time, positions are fetched again for
+// the second pass (they are in the CU's cache by then).
+__device__ __forceinline__ void nw_prior_ring_vertex(const NwRingArgs &R, int v)
+{
+    const int M = R.M, maxdeg = R.maxdeg;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int ms = 0;
+    for (int s0 = 0; s0 < maxdeg; s0 += 4) {
+        int nb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nb[s] = (s0 + s < maxdeg) ? R.nbr_t[(int64_t)(s0 + s) * M + v] : -1;
+        float q[4][3];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int n = nb[s] >= 0 ? nb[s] : v;
+            q[s][0] = R.meshpos[3 * n]; q[s][1] = R.meshpos[3 * n + 1]; q[s][2] = R.meshpos[3 * n + 2];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (nb[s] >= 0) { sx += q[s][0]; sy += q[s][1]; sz += q[s][2]; ++ms; }
+    }
+    double asum = 0.0;
+    if (ms > 0) {
+        const double vcx = (double)sx / ms, vcy = (double)sy / ms, vcz = (double)sz / ms;
+        const float Nx = R.nrm[3 * v], Ny = R.nrm[3 * v + 1], Nz = R.nrm[3 * v + 2];
+        for (int s0 = 0; s0 < maxdeg; s0 += 4) {
+            int nb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) nb[s] = (s0 + s < maxdeg) ? R.nbr_t[(int64_t)(s0 + s) * M + v] : -1;
+            float q[4][3], u[4][3];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int n = nb[s] >= 0 ? nb[s] : v;
+                q[s][0] = R.meshpos[3 * n]; q[s][1] = R.meshpos[3 * n + 1]; q[s][2] = R.meshpos[3 * n + 2];
+                u[s][0] = R.nrm[3 * n]; u[s][1] = R.nrm[3 * n + 1]; u[s][2] = R.nrm[3 * n + 2];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (nb[s] >= 0) {
+                    const double cnx = (double)q[s][0] - vcx, cny = (double)q[s][1] - vcy, cnz = (double)q[s][2] - vcz;
+                    const double cdot = (cnx * (double)u[s][0] + cny * (double)u[s][1]) + cnz * (double)u[s][2];
+                    const float ndn = (u[s][0] * Nx + u[s][1] * Ny) + u[s][2] * Nz;
+                    const float den = sqrtf(2.0f * (fmaxf(ndn, 0.0f) + 1.0f));
+                    asum += cdot / (double)den;
+                }
+            }
+        }
+    }
+    R.ring4[v] = make_float4(sx, sy, sz, __int_as_float(ms));
+    R.ring_a[v] = asum;
 }

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
 #define NW_HT_PROBES 48    // a contribution that finds no slot within this many probes goes to HBM directly (unsorted input only)
 
 __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__restrict__ pts, const int *__restrict__ face, const NwAttractArgs A,
-                                                     NwDevState *__restrict__ st, int it)
+                                                     NwDevState *__restrict__ st, int it, const NwFold Fd)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ int s_key[NW_HT];
@@ -440,33 +440,32 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__res
         }
     }
     __syncthreads();
+    // per-workgroup partial sums (row of 5: four sums + the largest NN distance of the workgroup, which a sharded run checks against
+    // its halo radius; a same-address atomicMax from every wave serialised: 40 us at 1M localizations, 0.7 ms at 5M) -- published BEFORE
+    // the table is flushed (round 5): the publishing wave waits for its own memory operations, which must not include the flush's
+    // atomics (nw_publish_row); waves 1-3 start flushing meanwhile.  Wave sums on the vector ALU (nw_wave_sum).
+    {
+        __shared__ double s_w[5 * 4];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double sk = nw_wave_sum(red[k]);
+            if (lane == 0) s_w[k * 4 + wv] = sk;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+        if (lane == 0) s_w[16 + wv] = (double)dmax;
+        __syncthreads();
+        if (wv == 0) {
+            double mine = 0.0;
+            if (lane < 4) mine = (s_w[lane * 4 + 0] + s_w[lane * 4 + 1]) + (s_w[lane * 4 + 2] + s_w[lane * 4 + 3]);
+            else if (lane == 4) mine = fmax(fmax(s_w[16], s_w[17]), fmax(s_w[18], s_w[19]));
+            nw_publish_row<5, 4>(mine, A.part, Fd);
+        }
+    }
     for (int t = threadIdx.x; t < NW_HT * 4; t += NW_BLOCK) {
         const int key = s_key[t >> 2];                     // four adjacent lanes flush the four components of one vertex
         if (key >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(A.vacc) + 4 * (int64_t)key + (t & 3), s_val[(t & 3) * NW_HT + (t >> 2)]);
-    }
-    // per-workgroup partial sums (row of 5: four sums + the largest NN distance of the workgroup, which a sharded run checks against
-    // its halo radius; a same-address atomicMax from every wave serialised: 40 us at 1M localizations, 0.7 ms at 5M).  The four sums
-    // go through LDS memory (the flushed table's) so that only one wave does wave reductions: see nw_block_reduce_store_lds.
-    {
-        __shared__ float s_dmax[4];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
-        if ((threadIdx.x & 63) == 0) s_dmax[threadIdx.x >> 6] = dmax;
-        __syncthreads();                                      // the table has been flushed: its memory is free
-        double *s_red = reinterpret_cast<double *>(s_val);    // 4 * 256 doubles of the 4 * NW_HT the table holds
-        const int tid = threadIdx.x;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s_red[k * NW_BLOCK + tid] = red[k];
-        __syncthreads();
-        if (tid < 64) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double *c = s_red + k * NW_BLOCK + tid;
-                const double sk = nw_wave_sum((c[0] + c[64]) + (c[128] + c[192]));
-                if (tid == 0) A.part[(int64_t)blockIdx.x * 5 + k] = sk;
-            }
-            if (tid == 0) A.part[(int64_t)blockIdx.x * 5 + 4] = (double)fmaxf(fmaxf(s_dmax[0], s_dmax[1]), fmaxf(s_dmax[2], s_dmax[3]));
-        }
     }
 }
 
@@ -477,11 +476,19 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__res
 //   fdef = _ncc(): 1-ring centroid (f32 slot-ordered sum -> /ms in f64), alpha from neighbour normals (block-stale)
 //          and current mesh positions; isolated vertices keep their position           :770-820
 //   prefs = f - fdef (f64), stored f32; S1 = -prefs                                    :257-258
-__global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg, const int *__restrict__ nbr_t, const float *__restrict__ pos,
+__global__ __launch_bounds__(NW_BLOCK) void k_prior_ring(const NwRingArgs R, const NwDevState *__restrict__ st, int it)
+{
+    // the ring half as a launch of its own (NW_RING_IN_NN=0, and a query launched without its ring workgroups): see nw_device.h
+    if (st->iter_base + it >= st->stop_at) return;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < R.M) nw_prior_ring_vertex(R, v);
+}
+
+__global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, const float4 *__restrict__ ring4, const double *__restrict__ ring_a, const float *__restrict__ pos,
                                                               const float *__restrict__ meshpos, const float *__restrict__ nrm,
                                                               const long long *__restrict__ vacc, float *__restrict__ S, float *__restrict__ fdef_out,
                                                               float *__restrict__ pi_out, double *__restrict__ part, NwDevState *__restrict__ st, int it, int n_search,
-                                                              double q, double qw, const float *__restrict__ wv, const unsigned char *__restrict__ owned)
+                                                              double q, double qw, const float *__restrict__ wv, const unsigned char *__restrict__ owned, const NwFold Fd)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ double s_part[14 * 4];
@@ -489,90 +496,48 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
 #pragma unroll
     for (int k = 0; k < 14; ++k) red[k] = 0.0;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < M; v += gridDim.x * blockDim.x) {
+        // everything this vertex needs, requested at once (the ring half -- the 1-ring gathers -- has run beside the query: nw_device.h)
         const longlong2 a01 = *reinterpret_cast<const longlong2 *>(vacc + 4 * (int64_t)v), a23 = *reinterpret_cast<const longlong2 *>(vacc + 4 * (int64_t)v + 2);
+        const float4 rg = ring4[v];
+        const double asum = ring_a[v];
+        const nw_f3u Nn = *reinterpret_cast<const nw_f3u *>(nrm + 3 * (int64_t)v);
+        const nw_f3u Pm = *reinterpret_cast<const nw_f3u *>(meshpos + 3 * (int64_t)v);
+        const nw_f3u Pf = *reinterpret_cast<const nw_f3u *>(pos + 3 * (int64_t)v);
+        float *Srow = S + (int64_t)v * 9;
+        const float s2c[3] = {n_search > 2 ? Srow[2] : 0.0f, n_search > 2 ? Srow[5] : 0.0f, n_search > 2 ? Srow[8] : 0.0f};
+        const float lw = wv ? wv[v] : 1.0f;
+        const bool mine = owned ? owned[v] != 0 : true;
         const float4 acc = make_float4((float)((double)a01.x * q), (float)((double)a01.y * q), (float)((double)a23.x * q), (float)((double)a23.y * qw));
         const float sw = acc.w;
         const float pi = sqrtf((sw * sw + sw * sw) + sw * sw);
         const float gate = fminf(pi * pi, 1.0f);
         pi_out[v] = pi;
-        // the first 8 ring slots are fetched with independent (unrolled, predicated) loads so that their latencies
-        // overlap; valence > 8 falls through to the generic tail loops
-        int nb[8];
-        float qx[8], qy[8], qz[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) nb[s] = (s < maxdeg) ? nbr_t[(int64_t)s * M + v] : -1;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int n = nb[s] >= 0 ? nb[s] : v;
-            qx[s] = meshpos[3 * n]; qy[s] = meshpos[3 * n + 1]; qz[s] = meshpos[3 * n + 2];
-        }
-        // pass 1: centroid (float32 sum in slot order)
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        int ms = 0;
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-            if (nb[s] >= 0) { sx += qx[s]; sy += qy[s]; sz += qz[s]; ++ms; }
-        for (int s = 8; s < maxdeg; ++s) {
-            const int n = nbr_t[(int64_t)s * M + v];
-            if (n >= 0) {
-                sx += meshpos[3 * n]; sy += meshpos[3 * n + 1]; sz += meshpos[3 * n + 2];
-                ++ms;
-            }
-        }
+        const int ms = __float_as_int(rg.w);
         double fd[3];
         if (ms > 0) {
-            const double vcx = (double)sx / ms, vcy = (double)sy / ms, vcz = (double)sz / ms;
-            const float Nx = nrm[3 * v], Ny = nrm[3 * v + 1], Nz = nrm[3 * v + 2];
-            double asum = 0.0;
-            float ux[8], uy[8], uz[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int n = nb[s] >= 0 ? nb[s] : v;
-                ux[s] = nrm[3 * n]; uy[s] = nrm[3 * n + 1]; uz[s] = nrm[3 * n + 2];
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (nb[s] >= 0) {
-                    const double cnx = (double)qx[s] - vcx, cny = (double)qy[s] - vcy, cnz = (double)qz[s] - vcz;
-                    const double cdot = (cnx * (double)ux[s] + cny * (double)uy[s]) + cnz * (double)uz[s];
-                    const float ndn = (ux[s] * Nx + uy[s] * Ny) + uz[s] * Nz;
-                    const float den = sqrtf(2.0f * (fmaxf(ndn, 0.0f) + 1.0f));
-                    asum += cdot / (double)den;
-                }
-            }
-            for (int s = 8; s < maxdeg; ++s) {
-                const int n = nbr_t[(int64_t)s * M + v];
-                if (n >= 0) {
-                    const double cnx = (double)meshpos[3 * n] - vcx, cny = (double)meshpos[3 * n + 1] - vcy, cnz = (double)meshpos[3 * n + 2] - vcz;
-                    const float nx = nrm[3 * n], ny = nrm[3 * n + 1], nz = nrm[3 * n + 2];
-                    const double cdot = (cnx * (double)nx + cny * (double)ny) + cnz * (double)nz;
-                    const float ndn = (nx * Nx + ny * Ny) + nz * Nz;
-                    const float den = sqrtf(2.0f * (fmaxf(ndn, 0.0f) + 1.0f));
-                    asum += cdot / (double)den;
-                }
-            }
+            const double vcx = (double)rg.x / ms, vcy = (double)rg.y / ms, vcz = (double)rg.z / ms;
             const double alpha = (asum / ms) * (double)gate;
-            fd[0] = vcx + alpha * (double)Nx; fd[1] = vcy + alpha * (double)Ny; fd[2] = vcz + alpha * (double)Nz;
+            fd[0] = vcx + alpha * (double)Nn.x; fd[1] = vcy + alpha * (double)Nn.y; fd[2] = vcz + alpha * (double)Nn.z;
         } else {
-            fd[0] = meshpos[3 * v]; fd[1] = meshpos[3 * v + 1]; fd[2] = meshpos[3 * v + 2];
+            fd[0] = Pm.x; fd[1] = Pm.y; fd[2] = Pm.z;
         }
+        const float pf[3] = {Pf.x, Pf.y, Pf.z};
         const float s0[3] = {acc.x, acc.y, acc.z};
         // regulariser: identity (Lfuncs = ["I"], mesh_conj_grad.py:38) or the diagonal 'wfunc' (:724-735), L x = x * wv
-        const float lw = wv ? wv[v] : 1.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            double p64 = (double)pos[3 * v + c] - fd[c];
+            double p64 = (double)pf[c] - fd[c];
             if (wv) p64 = p64 * (double)lw;                       // wfunc(f - fdef): float64 * float32 -> float64 (:257, conj_grad.py:191)
             const float p32 = (float)p64;                         // prefs[:, 0] is a float32 array
             const float s1 = wv ? -1.0f * (p32 * lw) : -1.0f * p32;      // S[:, 1] = -Lh(prefs) (:258)
-            float *row = S + (int64_t)(3 * v + c) * 3;
-            const float s2 = (n_search > 2) ? row[2] : 0.0f;
+            float *row = Srow + 3 * c;
+            const float s2 = s2c[c];
             row[0] = s0[c];
             row[1] = s1;
             fdef_out[3 * v + c] = (float)fd[c];
             // LS_k = L(S_k) in float32 (conj_grad.py:199); Hw = LS^T LS, Gw = -LS^T prefs64 (:211-212).  A sharded mesh counts every
             // vertex once: on the rank that owns it
-            if (owned && !owned[v]) continue;
+            if (!mine) continue;
             const float l0 = wv ? s0[c] * lw : s0[c], l1 = wv ? s1 * lw : s1, l2 = wv ? s2 * lw : s2;
             red[0] += (double)l0 * l0;
             red[1] += (double)l0 * l1;
@@ -590,7 +555,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, int maxdeg
             red[13] += (double)s1 * s1;
         }
     }
-    nw_block_reduce_store<14>(red, part, s_part);
+    nw_block_sums_publish<14>(red, part, s_part, Fd);
 }
 
 // weights of the 'wfunc' regulariser from the CURRENT estimate f (mesh_conj_grad.py:733 -> vertex_area_weights,
@@ -618,54 +583,81 @@ __global__ __launch_bounds__(NW_BLOCK) void k_vertex_area_weights(int M, int NB,
 //   AS_k[i] = sum_j w_ij S_k[v_ij] (f32, corner order, mesh_conj_grad.py:544-545 via conj_grad.py:198)
 //   Hc = AS^T AS, Gc = AS^T res over the masked entries (conj_grad.py:198-203)
 // S is stored (3M,3) row-major exactly as the reference's `cg.S`, so the 9 floats of one vertex are contiguous.
-__global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, const int *__restrict__ vidx, const float *__restrict__ w, const float *__restrict__ res,
+// Memory-level parallelism (round 5): a thread's NW_SUBSPACE_PPT localizations are independent, but written as a loop with the index
+// load, the row gather and the masked residual load of each corner inside conditionals the compiler issued them one after the other --
+// ~28 dependent round trips per thread, SQ_WAIT_ANY 78 % of the wave cycles, 20 us for 37 MB.  Now: (1) the vertex ids, weights,
+// residuals and masks of ALL the thread's localizations are loaded unconditionally (a thread beyond N reads localization 0 and
+// contributes through an empty mask), (2) the twelve 36-byte rows of S are gathered two localizations at a time (3 wide loads a row).
+// Three round trips in all; the arithmetic and its order are unchanged (bit-identical sums).
+__global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, int M, const int *__restrict__ vidx, const float *__restrict__ w, const float *__restrict__ res,
                                                                  const unsigned char *__restrict__ mask, const float *__restrict__ S, double *__restrict__ part,
-                                                                 const NwDevState *__restrict__ st, int it, int n_search)
+                                                                 const NwDevState *__restrict__ st, int it, int n_search, const NwFold Fd)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
-    __shared__ double s_red[9 * NW_BLOCK];
+    __shared__ double s_w[9 * 4];
     // NW_SUBSPACE_PPT localizations per thread (consecutive tiles of 256): the nine sums are reduced over the workgroup once per
     // 1024 localizations -- the shuffles of that reduction go through the CU's LDS pipe, which bounded the kernel at one per thread
     const int blk = nw_xcd_remap(blockIdx.x, (N + NW_BLOCK * NW_SUBSPACE_PPT - 1) / (NW_BLOCK * NW_SUBSPACE_PPT));      // see k_attract
     double red[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) red[k] = 0.0;
+    nw_i3u vi[NW_SUBSPACE_PPT];
+    nw_f3u wj[NW_SUBSPACE_PPT], rr[NW_SUBSPACE_PPT];
+    unsigned msk[NW_SUBSPACE_PPT];
 #pragma unroll
     for (int p = 0; p < NW_SUBSPACE_PPT; ++p) {
-      const int64_t i = blk < 0 ? (int64_t)N : ((int64_t)blk * NW_SUBSPACE_PPT + p) * NW_BLOCK + threadIdx.x;
-      if (i < N) {
-        const unsigned m = mask[i];
-        float as[3][3];   // [direction][component]
+        const int64_t i = blk < 0 ? (int64_t)N : ((int64_t)blk * NW_SUBSPACE_PPT + p) * NW_BLOCK + threadIdx.x;
+        const int64_t ic = i < N ? i : 0;
+        vi[p] = *reinterpret_cast<const nw_i3u *>(vidx + 3 * ic);
+        wj[p] = *reinterpret_cast<const nw_f3u *>(w + 3 * ic);
+        rr[p] = *reinterpret_cast<const nw_f3u *>(res + 3 * ic);
+        const unsigned m = mask[ic];
+        msk[p] = i < N ? m : 0u;
+    }
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+    for (int h = 0; h < NW_SUBSPACE_PPT; h += 2) {
+        float row[2][3][9];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) as[k][c] = 0.0f;
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int v = vidx[3 * i + j];
-            const float wj = w[3 * i + j];
-            // the vertex's 9 floats in three wide loads (4 + 4 + 1) instead of nine scattered dword gathers
-            float row[9];
-            __builtin_memcpy(row, S + (int64_t)v * 9, sizeof(row));
+            for (int j = 0; j < 3; ++j) {
+                // (an id outside the mesh can only be the leftover of an attraction step that raised the internal-error status: never dereferenced)
+                const unsigned v = min((unsigned)vi[h + q][j], (unsigned)(M - 1));
+                const float *src = S + (int64_t)v * 9;
+                const nw_f4u a = *reinterpret_cast<const nw_f4u *>(src), b = *reinterpret_cast<const nw_f4u *>(src + 4);
+                row[q][j][0] = a.x; row[q][j][1] = a.y; row[q][j][2] = a.z; row[q][j][3] = a.w;
+                row[q][j][4] = b.x; row[q][j][5] = b.y; row[q][j][6] = b.z; row[q][j][7] = b.w;
+                row[q][j][8] = src[8];
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float as[3][3];   // [direction][component]
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) as[k][c] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float wq = wj[h + q][j];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    as[0][c] = as[0][c] + row[q][j][3 * c + 0] * wq;
+                    as[1][c] = as[1][c] + row[q][j][3 * c + 1] * wq;
+                    if (n_search > 2) as[2][c] = as[2][c] + row[q][j][3 * c + 2] * wq;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                as[0][c] = as[0][c] + row[3 * c + 0] * wj;
-                as[1][c] = as[1][c] + row[3 * c + 1] * wj;
-                if (n_search > 2) as[2][c] = as[2][c] + row[3 * c + 2] * wj;
+                if (msk[h + q] & (1u << c)) {
+                    const double a0 = as[0][c], a1 = as[1][c], a2 = as[2][c], r = rr[h + q][c];
+                    red[0] += a0 * a0; red[1] += a0 * a1; red[2] += a0 * a2;
+                    red[3] += a1 * a1; red[4] += a1 * a2; red[5] += a2 * a2;
+                    red[6] += a0 * r;  red[7] += a1 * r;  red[8] += a2 * r;
+                }
             }
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (m & (1u << c)) {
-                const double a0 = as[0][c], a1 = as[1][c], a2 = as[2][c], r = res[3 * i + c];
-                red[0] += a0 * a0; red[1] += a0 * a1; red[2] += a0 * a2;
-                red[3] += a1 * a1; red[4] += a1 * a2; red[5] += a2 * a2;
-                red[6] += a0 * r;  red[7] += a1 * r;  red[8] += a2 * r;
-            }
-        }
-      }
     }
-    nw_block_reduce_store_lds<9>(red, part, s_red);
+    nw_block_sums_publish<9>(red, part, s_w, Fd);
 }
 
 // Start of a block (search() call) in ONE launch: the estimate restarts from the mesh positions (fs = vertices.copy(),
@@ -693,12 +685,33 @@ __global__ __launch_bounds__(NW_BLOCK) void k_block_begin(int M, int64_t n_res, 
     if (zero_vacc) for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < 4 * (int64_t)M; t += stride) vacc[t] = 0ll;
 }
 
+// End of a block whose result goes straight to the host (round 5): the block's logs and the device state are copied into pinned host
+// memory by this one-workgroup launch behind the block's last kernel, then a FLAG word in pinned memory takes the next value of a device
+// counter.  The host thread that waits for the block spins on that word (a load from its own cache until the PCIe write invalidates the
+// line) instead of sleeping in hipStreamSynchronize, whose wake-up comes 40-50 us after the last kernel (completion interrupt); the
+// library's copy threads are woken shortly before the block's expected end and spin on the same word.  Stream order makes the flag
+// the last thing the block writes: the result (written by k_solve_update) is complete when it shows.
+__global__ __launch_bounds__(NW_BLOCK) void k_block_done(const unsigned *__restrict__ logs_words, int n_words, const NwDevState *__restrict__ st,
+                                                        unsigned *__restrict__ pin_words, unsigned *__restrict__ pin_state, int *__restrict__ counter, int *host_flag)
+{
+    for (int t = threadIdx.x; t < n_words; t += NW_BLOCK) pin_words[t] = logs_words[t];
+    if (threadIdx.x < (int)(sizeof(NwDevState) / 4)) pin_state[threadIdx.x] = reinterpret_cast<const unsigned *>(st)[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int v = *counter + 1;
+        *counter = v;
+        __hip_atomic_store(host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // K7: <=3x3 regularised normal equations (every workgroup solves them redundantly from the reduced sums),
 // f += S c, last step -> S2, write-back, per-iteration log, stop condition.
 //   H = Hc + lam^2 Hw accumulated in place in float32, G likewise (conj_grad.py:208-215); float32 LU with
 //   partial pivoting (LAPACK sgesv through numpy.linalg.solve, :219); fnew = f0 + S.c in float32 (:227);
 //   S[:,2] = fnew - f; f = fnew; mesh positions updated at valid vertices only (mesh_conj_grad.py:281-289).
 struct NwSolve { float c[3]; float H[9]; float G[3]; int singular; };
+__device__ const unsigned char nw_byte_one = 1;
 
 // index of (r,c) in the packed upper triangle {00,01,02,11,12,22}
 __device__ __forceinline__ constexpr int nw_tri(int r, int c) { return r <= c ? (r == 0 ? c : (r == 1 ? 2 + c : 5)) : (c == 0 ? r : (c == 1 ? 2 + r : 5)); }
@@ -773,12 +786,39 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ NwSolve s_sol;
     __shared__ double s_sc[SC_COUNT];
+    // Round 5: the vertex data of the thread's first two vertices (S rows, estimate, valid flag) are requested BEFORE the sums and the
+    // solve, so that their latency runs beside that serial prologue; all 32 ordered parts of a sum are requested at once (one round
+    // trip instead of four).  Per vertex: three wide loads of the 36-byte S row + one of the position instead of a load-wait-store
+    // chain per component.  Arithmetic unchanged.
+    const int stride = (int)(gridDim.x * blockDim.x);
+    const int v0 = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int NPRE = 2;
+    float pre_row[NPRE][9], pre_pos[NPRE][3];
+    unsigned char pre_ok[NPRE];
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+        const int v = v0 + u * stride;
+        const int vc = v < M ? v : 0;
+        const float *src = S + (int64_t)vc * 9;
+        const nw_f4u a = *reinterpret_cast<const nw_f4u *>(src), b = *reinterpret_cast<const nw_f4u *>(src + 4);
+        pre_row[u][0] = a.x; pre_row[u][1] = a.y; pre_row[u][2] = a.z; pre_row[u][3] = a.w;
+        pre_row[u][4] = b.x; pre_row[u][5] = b.y; pre_row[u][6] = b.z; pre_row[u][7] = b.w;
+        pre_row[u][8] = src[8];
+        const nw_f3u p3 = *reinterpret_cast<const nw_f3u *>(pos + 3 * (int64_t)vc);
+        pre_pos[u][0] = p3.x; pre_pos[u][1] = p3.y; pre_pos[u][2] = p3.z;
+        pre_ok[u] = *(valid ? valid + vc : &nw_byte_one);          // (one unconditional load: a load inside a branch would end in a full wait)
+    }
     if (threadIdx.x < SC_COUNT) {
+        double pp[NW_SPARTS];
+#pragma unroll
+        for (int b = 0; b < NW_SPARTS; ++b) pp[b] = sc_parts[threadIdx.x * NW_SPARTS + b];
         double t = 0.0;
-        if (threadIdx.x == SC_MAXD) { for (int b = 0; b < NW_SPARTS; ++b) t = fmax(t, sc_parts[threadIdx.x * NW_SPARTS + b]); }
-        else {
-#pragma unroll 8
-            for (int b = 0; b < NW_SPARTS; ++b) t += sc_parts[threadIdx.x * NW_SPARTS + b];
+        if (threadIdx.x == SC_MAXD) {
+#pragma unroll
+            for (int b = 0; b < NW_SPARTS; ++b) t = fmax(t, pp[b]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < NW_SPARTS; ++b) t += pp[b];
         }
         s_sc[threadIdx.x] = t;
     }
@@ -790,29 +830,46 @@ __global__ __launch_bounds__(NW_BLOCK) void k_solve_update(int M, float lam, int
     // a status raised earlier in this iteration (NaN in the weight matrix / A f / A^T r: the reference asserts BEFORE `self.f[:] = fnew`,
     // mesh_conj_grad.py:514,548,580 vs :288) leaves the estimate, the mesh positions and the staged result at the last good iterate
     const bool failed = st->status != 0 || sc[SC_STATUS] > 0.0;     // (the second: another rank's, summed in with the normal-equation sums)
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < M; v += gridDim.x * blockDim.x) {
-      if (!sol.singular && !failed) {
-        const bool ok = valid ? valid[v] != 0 : true;
+    const bool go = !sol.singular && !failed;
+    auto update_vertex = [&](int v, const float (&row)[9], const float (&f0)[3], bool ok) {
+        float fn[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float *row = S + (int64_t)(3 * v + c) * 3;
-            float step = row[0] * sol.c[0];
-            step = step + row[1] * sol.c[1];
-            if (n_search > 2) step = step + row[2] * sol.c[2];
-            const float f0 = pos[3 * v + c];
-            float fn = f0 + step;
-            if ((flags & 1u) && !(fn > 0.0f)) fn = fn * 0.0f;       // fnew*(fnew > 0), mesh_conj_grad.py:277-278
-            if (!(flags & 2u)) row[2] = fn - f0;
-            pos[3 * v + c] = fn;
-            if (ok) meshpos[3 * v + c] = fn;
-            if (host_out) host_out[3 * v + c] = fn;
+            float step = row[3 * c + 0] * sol.c[0];
+            step = step + row[3 * c + 1] * sol.c[1];
+            if (n_search > 2) step = step + row[3 * c + 2] * sol.c[2];
+            fn[c] = f0[c] + step;
+            if ((flags & 1u) && !(fn[c] > 0.0f)) fn[c] = fn[c] * 0.0f;       // fnew*(fnew > 0), mesh_conj_grad.py:277-278
         }
-      } else if (host_out) {
+        if (go) {
+            if (!(flags & 2u)) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) host_out[3 * v + c] = pos[3 * v + c];
-      }
-      *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)v) = make_longlong2(0, 0);          // ready for the next scatter
-      *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)v + 2) = make_longlong2(0, 0);
+                for (int c = 0; c < 3; ++c) S[(int64_t)v * 9 + 3 * c + 2] = fn[c] - f0[c];
+            }
+            nw_f3u o; o.x = fn[0]; o.y = fn[1]; o.z = fn[2];
+            *reinterpret_cast<nw_f3u *>(pos + 3 * (int64_t)v) = o;
+            if (ok) *reinterpret_cast<nw_f3u *>(meshpos + 3 * (int64_t)v) = o;
+            if (host_out) *reinterpret_cast<nw_f3u *>(host_out + 3 * (int64_t)v) = o;
+        } else if (host_out) {
+            nw_f3u o; o.x = f0[0]; o.y = f0[1]; o.z = f0[2];
+            *reinterpret_cast<nw_f3u *>(host_out + 3 * (int64_t)v) = o;
+        }
+        *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)v) = make_longlong2(0, 0);          // ready for the next scatter
+        *reinterpret_cast<longlong2 *>(vacc + 4 * (int64_t)v + 2) = make_longlong2(0, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+        const int v = v0 + u * stride;
+        if (v < M) update_vertex(v, pre_row[u], pre_pos[u], pre_ok[u] != 0);
+    }
+    for (int v = v0 + NPRE * stride; v < M; v += stride) {
+        float row[9], f0[3];
+        const float *src = S + (int64_t)v * 9;
+        const nw_f4u a = *reinterpret_cast<const nw_f4u *>(src), b = *reinterpret_cast<const nw_f4u *>(src + 4);
+        row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w; row[4] = b.x; row[5] = b.y; row[6] = b.z; row[7] = b.w; row[8] = src[8];
+        const nw_f3u p3 = *reinterpret_cast<const nw_f3u *>(pos + 3 * (int64_t)v);
+        f0[0] = p3.x; f0[1] = p3.y; f0[2] = p3.z;
+        update_vertex(v, row, f0, valid ? valid[v] != 0 : true);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // logs (mesh_conj_grad.py:262-274)

@@ -500,9 +500,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                  const int *__restrict__ cstart, const float4 *__restrict__ cent, const float4 *__restrict__ cent_by_face, int F,
                                                  int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
                                                  NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats,
-                                                 unsigned *__restrict__ item_cost, const int *__restrict__ face_orig, float outl_f, int outl_max)
+                                                 unsigned *__restrict__ item_cost, const int *__restrict__ face_orig, float outl_f, int outl_max,
+                                                 const NwRingArgs R, int nb_query)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
+    // Workgroups behind the query's own (blockIdx >= nb_query): the ring half of the curvature prior, one thread per vertex (nw_device.h).
+    // They are dispatched last, so they run while the query's last waves drain.
+    if ((int)blockIdx.x >= nb_query) {
+        const int v = ((int)blockIdx.x - nb_query) * (int)blockDim.x + (int)threadIdx.x;
+        if (v < R.M) nw_prior_ring_vertex(R, v);
+        return;
+    }
     __shared__ NwWaveLds s_wave[4];
     NwStats S;
 #pragma unroll
