@@ -49,15 +49,16 @@ def algorithmic_bytes(N, M, F):
     """Compulsory traffic per ITERATION and per kernel, from the itemised list in SURVEY.md section 8(d)
     (4-byte elements, each named array read/written once per stage)."""
     per_kernel = {
-        # NN query 12 r + 8 w per point; candidate reads >= 12 per face
-        'k_nn_wave': 20 * N + 12 * F,
+        # NN query 12 r + 8 w per point; candidate reads >= 12 per face; + the ring half of _ncc, which rides in this launch since
+        # round 5 (workgroups appended to its grid): adjacency 24 + 4, neighbour positions 12, neighbour normals 12 per vertex
+        'k_nn_wave': 20 * N + 12 * F + 52 * M,
         # weights 28 r + 24 w, A f + residual 64 r + 12 w, A^T res 36 r, A^T 1 24 r per point;
         # weight gather 12 + A f 12 + A^T outputs 12 + 4 per vertex
         'k_attract': 188 * N + 40 * M,
         # 3 x (A S_k) 3*24 r + 3*12 w, reductions over AS/res 84 r per point; A S_k inputs 36 per vertex
         'k_subspace_point_sums': 192 * N + 36 * M,
-        # _ncc 68, S1 36, reductions over S/prefs 84 per vertex
-        'k_prior_directions': 188 * M,
+        # _ncc 68 (of which 52 -- the 1-ring gathers -- are charged to the query launch, see above), S1 36, reductions over S/prefs 84 per vertex
+        'k_prior_directions': 136 * M,
         'k_solve_update': 72 * M,
         # centroid input 12 per vertex; index read 12 + centroid write 12 + grid build 12 + 8 per face
         'grid_build': 12 * M + 44 * F,
@@ -296,6 +297,7 @@ def run_rank(args):
             cg.set_profiling(level)
 
     def fence():
+        cg_of().synchronize()                    # the library's stream AND its host copy threads (vertex records written behind a block)
         torch.cuda.synchronize()                 # (device-wide: the library's own stream included)
         if multi:
             dist.barrier()

@@ -59,13 +59,13 @@ LLVM_BIN = os.environ.get('NW_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
 KERNEL_BUDGETS = {
     # kernel (demangled prefix)       VGPRs  LDS
     'k_nn_wave<false>':               (80, 8 * 1024),      # 6 waves per SIMD (amdgpu_waves_per_eu(6,8)); wave-private lists in LDS
-    'k_attract':                      (64, 20 * 1024),     # 8 workgroups per CU: 64 VGPRs and 18 KB of LDS (the per-workgroup scatter table)
+    'k_attract':                      (72, 20 * 1024),     # 7 workgroups per CU (the run sums keep 24 more registers alive; LDS-pipe-bound: 7 or 8 is the same), 18 KB of LDS each
     'k_face_centroids':               (64, 8 * 1024),
     'k_centroid_scatter':             (64, 0),
     'k_scan_final':                   (64, 1024),
     'k_prior_ring':                   (128, 1024),         # (only launched on its own with NW_RING_IN_NN=0: the ring half rides in the query launch)
     'k_prior_directions':             (96, 1024),          # streaming since the ring half left it: 5 waves per SIMD
-    'k_subspace_point_sums':          (128, 20 * 1024),    # 4 waves per SIMD cover the launch in one round (rows of two localizations in flight)
+    'k_subspace_point_sums':          (128, 1024),         # 4 waves per SIMD cover the launch in one round (rows of two localizations in flight)
     'k_solve_update':                 (128, 1024),
 }
 

@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <functional>
 #include <atomic>
+#include <memory>
 
 #include "../../include/nanowrap.h"
 #include "nw_kernels.h"
@@ -92,54 +93,125 @@ enum { ST_TOTAL = 0, ST_GRID = 1, ST_NN = 2, ST_ATTRACT = 3, ST_PRIOR = 4, ST_AS
 
 }  // namespace
 
-// Small persistent host thread pool for the write-back (the strided copy into the caller's vertex records is host-memory
-// bound: one thread moves ~0.4 GB/s of 12-byte rows).  run(f) executes f(0..n-1), slice 0 on the calling thread.
+// Small persistent host thread pool for the write-back (the strided copy into the caller's vertex records is host-memory bound: one
+// thread moves ~0.4 GB/s of 12-byte rows).  A job is a number of CHUNKS taken from a shared counter by whoever is awake -- the calling
+// thread included -- and it ends when every chunk has been done, not when every thread has shown up: a thread the scheduler wakes late
+// (the GPU boxes' hosts are shared; a woken thread can arrive 15 ms later) finds the counter exhausted and goes back to sleep, instead
+// of holding the block up (round 5).  arm(): work is about to come -- the threads wake now and spin for it for a bounded time.
 struct NwHostPool {
+    struct Job { std::function<void(int)> fn; int n = 0; std::atomic<int> next{0}, done{0}; };
     std::vector<std::thread> th;
     std::mutex m;
-    std::condition_variable cv_work, cv_done;
-    std::function<void(int)> fn;
-    unsigned long generation = 0;
-    int pending = 0;
+    std::condition_variable cv_work;
+    std::shared_ptr<Job> job;
+    std::atomic<unsigned long> generation{0};
+    unsigned long arm_generation = 0;
     bool stop = false;
     int n = 1;
+    static void work(Job &j)
+    {
+        for (;;) {
+            const int c = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= j.n) break;
+            j.fn(c);
+            j.done.fetch_add(1, std::memory_order_release);
+        }
+    }
     void start(int threads, int device)
     {
         n = threads < 1 ? 1 : threads;
         for (int t = 1; t < n; ++t)
-            th.emplace_back([this, t, device] {
+            th.emplace_back([this, device] {
                 (void)hipSetDevice(device);
-                unsigned long seen = 0;
+                unsigned long seen = 0, seen_arm = 0;
                 for (;;) {
-                    std::function<void(int)> f;
+                    std::shared_ptr<Job> j;
                     {
                         std::unique_lock<std::mutex> lk(m);
-                        cv_work.wait(lk, [&] { return stop || generation != seen; });
+                        cv_work.wait(lk, [&] { return stop || generation.load() != seen || arm_generation != seen_arm; });
                         if (stop) return;
-                        seen = generation;
-                        f = fn;
+                        if (generation.load() == seen) {
+                            // armed: spin for the job (bounded), then take it like a woken thread
+                            seen_arm = arm_generation;
+                            lk.unlock();
+                            const auto t0 = std::chrono::steady_clock::now();
+                            while (generation.load(std::memory_order_acquire) == seen) {
+                                for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
+                                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1500)) break;
+                            }
+                            lk.lock();
+                            if (stop) return;
+                            if (generation.load() == seen) continue;          // nothing came: back to sleep
+                        }
+                        seen_arm = arm_generation;
+                        seen = generation.load();
+                        j = job;
                     }
-                    f(t);
-                    {
-                        std::lock_guard<std::mutex> lk(m);
-                        if (--pending == 0) cv_done.notify_one();
-                    }
+                    if (j) work(*j);
                 }
             });
     }
-    void run(const std::function<void(int)> &f)
+    void arm()
     {
-        if (n > 1) {
+        if (n <= 1) return;
+        {
             std::lock_guard<std::mutex> lk(m);
-            fn = f; pending = n - 1; ++generation;
+            ++arm_generation;
         }
-        if (n > 1) cv_work.notify_all();
-        f(0);
-        if (n > 1) {
-            std::unique_lock<std::mutex> lk(m);
-            cv_done.wait(lk, [&] { return pending == 0; });
+        cv_work.notify_all();
+    }
+    // a job in the BACKGROUND: the pool's threads work through it while the caller goes on (a block's strided mesh records, written
+    // while the next block runs on the GPU); wait_posted() lends a hand with what is left and returns when it is done
+    std::shared_ptr<Job> posted;
+    void post_chunks(int nchunks, const std::function<void(int)> &f)
+    {
+        wait_posted();
+        if (nchunks <= 0) return;
+        if (n <= 1) { for (int c = 0; c < nchunks; ++c) f(c); return; }
+        auto j = std::make_shared<Job>();
+        j->fn = f; j->n = nchunks;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = j;
+            generation.fetch_add(1, std::memory_order_release);
+        }
+        cv_work.notify_all();
+        posted = j;
+    }
+    void wait_posted()
+    {
+        if (!posted) return;
+        std::shared_ptr<Job> j = posted;
+        posted.reset();
+        work(*j);
+        while (j->done.load(std::memory_order_acquire) < j->n)
+            for (int k = 0; k < 8; ++k) __builtin_ia32_pause();
+        std::lock_guard<std::mutex> lk(m);
+        if (job == j) job.reset();
+    }
+    // f(c) for c in [0, nchunks), each exactly once, on whichever threads are awake; returns when all have been done
+    void run_chunks(int nchunks, const std::function<void(int)> &f)
+    {
+        wait_posted();
+        if (nchunks <= 0) return;
+        if (n <= 1 || nchunks == 1) { for (int c = 0; c < nchunks; ++c) f(c); return; }
+        auto j = std::make_shared<Job>();
+        j->fn = f; j->n = nchunks;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = j;
+            generation.fetch_add(1, std::memory_order_release);
+        }
+        cv_work.notify_all();
+        work(*j);
+        while (j->done.load(std::memory_order_acquire) < nchunks)
+            for (int k = 0; k < 8; ++k) __builtin_ia32_pause();
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (job == j) job.reset();
         }
     }
+    void run(const std::function<void(int)> &f) { run_chunks(n, f); }
     void shutdown()
     {
         {
@@ -175,7 +247,7 @@ struct nw_ctx {
     int64_t n_staged_copy_outs = 0, n_write_backs = 0;      // nw_debug, what = 2
     std::vector<uint64_t> comm_patterns;   // communication patterns (mode, sizes, peers) that have run one block outside a capture (nw_search)
     bool direct_out = false;         // nw_search: the last update of the block writes its result into the pinned staging buffer itself
-    BlockGraph graphs[4];
+    BlockGraph graphs[8];
     int graph_next = 0;
     uint64_t grid_generation = 0;
     int item_points = 64;
@@ -303,9 +375,21 @@ struct nw_ctx {
     void *wb_rows = nullptr;          // strided write-back target registered with nw_set_write_back
     int64_t wb_stride = 0;
     void *pin_log = nullptr;          // pinned staging for the per-iteration logs + device state
+    int *pin_flag = nullptr;          // pinned: the word k_block_done writes last (its device counter's value); the waiting host thread spins on it
+    DevBuf<int> done_count;           // that counter
+    int done_expected = 0;            // value the flag takes when the block in flight has ended
+    bool done_launched = false;       // a k_block_done is queued behind the block in flight (nw_search with a staged result)
+    double block_us_ema = 0.0;        // how long blocks like the last one take from launch to flag (the copy threads are woken shortly before)
+    uint64_t block_us_key = 0;
+    std::chrono::steady_clock::time_point block_t0;
+    int sliced_S = 0, sliced_base = 0;      // a large result on its way to the staging buffer in slices (k_copy_slice): how many, flag value before them
+    int64_t sliced_rows = 0;
     size_t pin_log_bytes = 0;
-    void *pin = nullptr;              // pinned staging for the write-back
-    size_t pin_bytes = 0;
+    void *pin = nullptr;              // pinned staging for the write-back: the half of pin_base in use (two halves: with NW_FLAG_ROWS_ASYNC the copy
+    size_t pin_bytes = 0;             // threads still read the last block's half while the next block's last kernel fills the other)
+    void *pin_base = nullptr;
+    int pin_sel = 0;
+    bool rows_async = false;          // this block: the strided vertex records are filled in the background (NW_FLAG_ROWS_ASYNC)
     NwHostPool *pool = nullptr;       // host threads of the write-back (created on first use)
     std::vector<hipEvent_t> wb_events;
     std::vector<unsigned char> valid_host;
@@ -683,9 +767,10 @@ NW_EXPORT void nw_destroy(nw_ctx *ctx)
     ctx->dist.release(); ctx->w.release(); ctx->res.release(); ctx->vacc.release(); ctx->S.release(); ctx->fdef.release(); ctx->pi.release();
     ctx->scalars.release(); ctx->part_a.release(); ctx->part_p.release(); ctx->part_s.release(); ctx->wv.release(); ctx->state.release(); ctx->logs.release(); ctx->mm.release(); ctx->tmp_f.release(); ctx->tmp_f2.release();
     for (auto &gph : ctx->graphs) { if (gph.exec) (void)hipGraphExecDestroy(gph.exec); }
-    if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
-    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->pool) { ctx->pool->wait_posted(); ctx->pool->shutdown(); delete ctx->pool; }
+    if (ctx->pin_base) (void)hipHostFree(ctx->pin_base);
     if (ctx->pin_log) (void)hipHostFree(ctx->pin_log);
+    if (ctx->pin_flag) (void)hipHostFree(ctx->pin_flag);
     for (hipEvent_t e : ctx->wb_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -708,6 +793,7 @@ NW_EXPORT int nw_synchronize(nw_ctx *ctx)
 {
     if (!ctx) return NW_ERR_BADARG;
     NW_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->pool) ctx->pool->wait_posted();            // (NW_FLAG_ROWS_ASYNC: the vertex records of the last block)
     return NW_OK;
 }
 
@@ -927,6 +1013,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     NW_HIP(hipSetDevice(ctx->device));
     const int64_t M = n_vertices, F = n_faces;
     const bool topo_change = (M != ctx->M) || (F != ctx->F);
+    ctx->full_staged = false;                             // (a staged whole-mesh result belonged to the previous mesh)
     ctx->M = M; ctx->F = F; ctx->NB = n_nbr;
     NW_HIP(ctx->pos.ensure(3 * M));
     NW_HIP(ctx->meshpos.ensure(3 * M));
@@ -940,6 +1027,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     NW_HIP(hipMemcpyAsync(ctx->faces.p, faces, 3 * F * sizeof(int), hipMemcpyDefault, ctx->stream));       // (caller's order; re-ordered below)
     ctx->face_sorted = false;
     ctx->have_valid = valid != nullptr;
+    if (ctx->pool) ctx->pool->wait_posted();              // (a block's vertex records still being written read the valid flags)
     if (valid) {
         NW_HIP(ctx->valid.ensure(M));
         NW_HIP(hipMemcpyAsync(ctx->valid.p, valid, M, hipMemcpyDefault, ctx->stream));
@@ -1022,6 +1110,7 @@ NW_EXPORT int nw_set_boundary(nw_ctx *ctx, const int32_t *b_local, const int32_t
 {
     if (!ctx || !ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary: mesh not set");
     if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_set_boundary inside a search");
+    ctx->full_staged = false;
     NW_HIP(hipSetDevice(ctx->device));
     if (n_slots < 0) { ctx->have_boundary = false; ctx->have_peers = false; ctx->pos_unpack_pending = false; return nw_set_owned(ctx, nullptr); }
     if (n_local < 0 || n_local > ctx->M || n_local > n_slots || (n_local > 0 && (!b_local || !b_slot)) || !owned || !gv || n_global <= 0 || n_global > 0x7fffffff / 4)
@@ -1183,6 +1272,7 @@ NW_EXPORT int nw_halo_rows(nw_ctx *ctx, int what, int unpack)
 NW_EXPORT int nw_halo_set_reference(nw_ctx *ctx, const float *full, const float *d0, int64_t n_d0)
 {
     if (!ctx || !ctx->have_boundary || !full) return fail(ctx, NW_ERR_BADARG, "nw_halo_set_reference: no boundary set (nw_set_boundary)");
+    ctx->full_staged = false;
     NW_HIP(hipMemcpyAsync(ctx->halo_ref.p, full, (size_t)3 * ctx->M_global * sizeof(float), hipMemcpyDefault, ctx->stream));
     ctx->have_halo_d0 = false; ctx->halo_d0_n = 0;
     if (d0) {
@@ -1202,6 +1292,7 @@ NW_EXPORT int nw_halo_block_stats(nw_ctx *ctx, double max_dist)
 {
     if (!ctx || !ctx->have_boundary || !ctx->have_halo_ref) return fail(ctx, NW_ERR_BADARG, "nw_halo_block_stats: boundary and reference first (nw_set_boundary, nw_halo_set_reference)");
     if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_halo_block_stats inside a search");
+    ctx->full_staged = false;                             // (the statistics asked for by hand replace the staged ones of the last block)
     NW_HIP(hipMemsetAsync(ctx->halo_stats.p, 0, 4 * sizeof(float), ctx->stream));
     const int blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (ctx->M_global + NW_BLOCK - 1) / NW_BLOCK));
     hipLaunchKernelGGL(k_halo_block_stats, dim3(blocks), dim3(NW_BLOCK), 0, ctx->stream, ctx->M_global, ctx->halo_full.p, ctx->halo_ref.p, (float)max_dist,
@@ -1487,7 +1578,8 @@ NW_EXPORT int nw_search_begin(nw_ctx *ctx, const float *lams, int n_lams, int nu
     ctx->lam0 = lams[0];
     ctx->full_staged = false;
     ctx->comm_mode = flags & (NW_FLAG_COMM_TILES | NW_FLAG_COMM_REPLICATED | NW_FLAG_COMM_HALO);
-    ctx->search_flags = flags & ~(NW_FLAG_RESULT_TO_HOST | NW_FLAG_COMM_TILES | NW_FLAG_COMM_REPLICATED | NW_FLAG_COMM_HALO);
+    ctx->search_flags = flags & ~(NW_FLAG_RESULT_TO_HOST | NW_FLAG_COMM_TILES | NW_FLAG_COMM_REPLICATED | NW_FLAG_COMM_HALO | NW_FLAG_ROWS_ASYNC);
+    ctx->rows_async = (flags & NW_FLAG_ROWS_ASYNC) != 0 && ctx->wb_rows != nullptr;
     ctx->direct_out = false;
     if ((flags & NW_FLAG_RESULT_TO_HOST) && num_iters > 0 && 3 * ctx->M * sizeof(float) <= (4u << 20) && !(getenv("NW_DIRECT_OUT") && atoi(getenv("NW_DIRECT_OUT")) == 0)) {
         NW_TRY(ensure_staging(ctx));                // (larger results: the sliced copy of nw_search_end is the faster one)
@@ -1676,6 +1768,97 @@ NW_EXPORT int nw_iter_update(nw_ctx *ctx)
 static int write_back_impl(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes);
 static int ensure_staging(nw_ctx *ctx);
 static void copy_out_staged(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes);
+static bool copy_out_chunks(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes, int64_t slice_rows, int flag_base);
+
+// pinned landing zone of a block's logs (n records) + the device state behind them
+static int ensure_pin_log(nw_ctx *ctx, int n_records)
+{
+    const size_t log_bytes = (size_t)std::max(n_records, 1) * sizeof(nw_iter_log);
+    if (ctx->pin_log_bytes < log_bytes + sizeof(NwDevState)) {
+        if (ctx->pin_log) (void)hipHostFree(ctx->pin_log);
+        ctx->pin_log = nullptr; ctx->pin_log_bytes = 0;
+        NW_HIP(hipHostMalloc(&ctx->pin_log, 2 * log_bytes + sizeof(NwDevState), hipHostMallocDefault));
+        ctx->pin_log_bytes = 2 * log_bytes + sizeof(NwDevState);
+    }
+    return NW_OK;
+}
+
+// The end of a block as a word in pinned memory (k_block_done): queued behind the block's last kernel by nw_search when the result is
+// staged by that kernel.  NW_SPIN_WAIT=0 (developer knob): the blocking hipStreamSynchronize of round 4.
+static bool spin_wait_on() { static const bool on = !(getenv("NW_SPIN_WAIT") && atoi(getenv("NW_SPIN_WAIT")) == 0); return on; }
+static int enqueue_block_done(nw_ctx *ctx)
+{
+    ctx->done_launched = false;
+    if (!spin_wait_on() || ctx->search_done <= 0) return NW_OK;
+    NW_TRY(ensure_pin_log(ctx, ctx->search_iters));
+    if (!ctx->pin_flag) {
+        NW_HIP(hipHostMalloc((void **)&ctx->pin_flag, 64, hipHostMallocDefault));
+        ctx->pin_flag[0] = 0;
+        NW_HIP(ctx->done_count.ensure(1));
+        NW_HIP(hipMemsetAsync(ctx->done_count.p, 0, sizeof(int), ctx->stream));
+        ctx->done_expected = 0;
+    }
+    NwDevState *stp = (NwDevState *)((char *)ctx->pin_log + ctx->pin_log_bytes - sizeof(NwDevState));
+    hipLaunchKernelGGL(k_block_done, dim3(1), dim3(NW_BLOCK), 0, ctx->stream, (const unsigned *)ctx->logs.p, (int)((size_t)ctx->search_done * sizeof(nw_iter_log) / 4),
+                       ctx->state.p, (unsigned *)ctx->pin_log, (unsigned *)stp, ctx->done_count.p, ctx->pin_flag);
+    NW_HIP(hipGetLastError());
+    ctx->done_expected += 1;
+    ctx->done_launched = true;
+    return NW_OK;
+}
+
+// a result above the direct-output limit: slices of the estimate into the staging buffer behind the block's last kernel, each launch
+// announcing the one before it (k_copy_slice), k_block_done behind the last
+static int enqueue_sliced_result(nw_ctx *ctx)
+{
+    ctx->sliced_S = 0;
+    if (!spin_wait_on() || ctx->search_done <= 0) return NW_OK;
+    static const int64_t rows_per_slice = getenv("NW_SLICE_ROWS") ? std::max<int64_t>(4096, atoll(getenv("NW_SLICE_ROWS")) & ~(int64_t)3) : 65536;
+    NW_TRY(ensure_staging(ctx));
+    NW_TRY(enqueue_block_done(ctx));            // (allocates flag and counter; its launch is re-issued behind the slices below)
+    if (!ctx->done_launched) return NW_OK;
+    // that launch went first: it only copied logs that are complete anyway and took one flag value; the slices follow, then the real end
+    const int base = ctx->done_expected;
+    const int S = (int)((ctx->M + rows_per_slice - 1) / rows_per_slice);
+    for (int sI = 0; sI < S; ++sI) {
+        const int64_t v0 = (int64_t)sI * rows_per_slice, v1 = std::min<int64_t>(ctx->M, v0 + rows_per_slice);
+        const int64_t nf = 3 * (v1 - v0);
+        const int blocks = (int)std::min<int64_t>(512, std::max<int64_t>(1, (nf / 4 + NW_BLOCK - 1) / NW_BLOCK));
+        hipLaunchKernelGGL(k_copy_slice, dim3(blocks), dim3(NW_BLOCK), 0, ctx->stream, ctx->pos.p + 3 * v0, (float *)ctx->pin + 3 * v0, nf, ctx->done_count.p, ctx->pin_flag);
+    }
+    NW_HIP(hipGetLastError());
+    ctx->done_expected += S;
+    NW_TRY(enqueue_block_done(ctx));
+    ctx->sliced_S = S; ctx->sliced_base = base; ctx->sliced_rows = rows_per_slice;
+    return NW_OK;
+}
+
+// wait for the flag (true), or give up (false: the caller synchronises the stream the ordinary way).  The calling thread spins on the
+// pinned word; once the block is within 250 us of its expected end the copy threads are woken so that they spin too (NwHostPool::arm).
+static bool wait_block_done(nw_ctx *ctx, int want)
+{
+    if (!ctx->done_launched) return false;
+    volatile int *flag = ctx->pin_flag;
+    const auto t0 = ctx->block_t0;
+    const double expect_us = ctx->block_us_ema;
+    bool armed = false;
+    long spins = 0;
+    for (;;) {
+        if (*flag - want >= 0) break;
+        for (int k = 0; k < 8; ++k) __builtin_ia32_pause();
+        if ((++spins & 63) == 0) {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (!armed && ctx->pool && expect_us > 0 && us > expect_us - 250.0) { ctx->pool->arm(); armed = true; }
+            if (us > 2000.0 + 20.0 * expect_us) {                      // far beyond anything a healthy block takes: let the runtime say what happened
+                if (hipStreamQuery(ctx->stream) != hipErrorNotReady) { (void)hipGetLastError(); return *flag - want >= 0; }
+                if (us > 30e6) return false;
+            }
+        }
+    }
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    ctx->block_us_ema = ctx->block_us_ema > 0 ? 0.7 * ctx->block_us_ema + 0.3 * us : us;
+    return true;
+}
 
 NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *loopcount)
 {
@@ -1685,18 +1868,15 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
     ctx->in_search = false;
     // logs + device state land in PINNED memory: a device-to-host copy into pageable memory blocks the host until everything queued
     // before it has run, which would serialise "wait for the kernels", the two small copies and the position slices below
-    const size_t log_bytes = (size_t)std::max(ctx->search_done, 1) * sizeof(nw_iter_log);
-    if (ctx->pin_log_bytes < log_bytes + sizeof(NwDevState)) {
-        if (ctx->pin_log) (void)hipHostFree(ctx->pin_log);
-        ctx->pin_log = nullptr; ctx->pin_log_bytes = 0;
-        NW_HIP(hipHostMalloc(&ctx->pin_log, 2 * log_bytes + sizeof(NwDevState), hipHostMallocDefault));
-        ctx->pin_log_bytes = 2 * log_bytes + sizeof(NwDevState);
-    }
+    NW_TRY(ensure_pin_log(ctx, std::max(ctx->search_done, ctx->search_iters)));
     nw_iter_log *host = (nw_iter_log *)ctx->pin_log;
     NwDevState *stp = (NwDevState *)((char *)ctx->pin_log + ctx->pin_log_bytes - sizeof(NwDevState));
-    if (ctx->search_done > 0)
-        NW_HIP(hipMemcpyAsync(host, ctx->logs.p, (size_t)ctx->search_done * sizeof(nw_iter_log), hipMemcpyDeviceToHost, ctx->stream));
-    NW_HIP(hipMemcpyAsync(stp, ctx->state.p, sizeof(NwDevState), hipMemcpyDeviceToHost, ctx->stream));
+    const bool by_flag = ctx->done_launched;                 // k_block_done brings logs and state along, and says when
+    if (!by_flag) {
+        if (ctx->search_done > 0)
+            NW_HIP(hipMemcpyAsync(host, ctx->logs.p, (size_t)ctx->search_done * sizeof(nw_iter_log), hipMemcpyDeviceToHost, ctx->stream));
+        NW_HIP(hipMemcpyAsync(stp, ctx->state.p, sizeof(NwDevState), hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (pos_out) {
         // the positions come back in slices that host threads copy out (contiguous result + the registered strided vertex records)
         // while the later slices are still in flight; a device pointer gets a plain copy
@@ -1708,7 +1888,13 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
             // the block's last update wrote the result into the pinned staging buffer itself: wait for the stream, copy out.  (If the
             // device-side stop condition ended the block early that kernel did not run: the ordinary copy below takes over.)
             const auto tw0 = std::chrono::steady_clock::now();
-            NW_HIP(hipStreamSynchronize(ctx->stream));
+            if (!(by_flag && wait_block_done(ctx, ctx->done_expected))) {
+                if (by_flag) {          // (the flag did not come: the copies it would have made, the ordinary way)
+                    if (ctx->search_done > 0) NW_HIP(hipMemcpyAsync(host, ctx->logs.p, (size_t)ctx->search_done * sizeof(nw_iter_log), hipMemcpyDeviceToHost, ctx->stream));
+                    NW_HIP(hipMemcpyAsync(stp, ctx->state.p, sizeof(NwDevState), hipMemcpyDeviceToHost, ctx->stream));
+                }
+                NW_HIP(hipStreamSynchronize(ctx->stream));
+            }
             const bool last_ran = ctx->search_done > 0 && ctx->search_done == ctx->search_iters && host[ctx->search_done - 1].executed;
             const auto tcp0 = std::chrono::steady_clock::now();
             if (last_ran) {
@@ -1720,8 +1906,22 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
             }
             if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
                 fprintf(stderr, "[nanowrap] search_end: wait + copy-out of the staged result %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw0).count());
+        } else if (by_flag && ctx->sliced_S > 0 && wait_block_done(ctx, ctx->sliced_base + 1)) {
+            // the block's kernels have run and the slices are landing in the staging buffer: the copy threads take them as they come
+            const auto tw0 = std::chrono::steady_clock::now();
+            ctx->n_write_backs += 1;
+            if (!copy_out_chunks(ctx, pos_out, ctx->wb_rows, ctx->wb_stride, ctx->sliced_rows, ctx->sliced_base)) {
+                NW_HIP(hipStreamSynchronize(ctx->stream));           // (says what happened to the device, if anything)
+                return fail(ctx, NW_ERR_HIP, "the block's result did not arrive in the staging buffer");
+            }
+            if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
+                fprintf(stderr, "[nanowrap] search_end: %d slices through the flag word, copy-out %ld us after the last kernel\n", ctx->sliced_S, (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw0).count());
         } else {
             const auto tw0 = std::chrono::steady_clock::now();
+            if (by_flag) {          // (the flag did not come: the copies it would have made, the ordinary way)
+                if (ctx->search_done > 0) NW_HIP(hipMemcpyAsync(host, ctx->logs.p, (size_t)ctx->search_done * sizeof(nw_iter_log), hipMemcpyDeviceToHost, ctx->stream));
+                NW_HIP(hipMemcpyAsync(stp, ctx->state.p, sizeof(NwDevState), hipMemcpyDeviceToHost, ctx->stream));
+            }
             NW_TRY(write_back_impl(ctx, pos_out, ctx->wb_rows, ctx->wb_stride));
             if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
                 fprintf(stderr, "[nanowrap] search_end: wait + sliced write-back %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw0).count());
@@ -1729,6 +1929,7 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
     }
     const auto ts0 = std::chrono::steady_clock::now();
     ctx->direct_out = false;
+    ctx->done_launched = false; ctx->sliced_S = 0;
     NW_HIP(hipStreamSynchronize(ctx->stream));
     if (getenv("NW_VERBOSE") && atoi(getenv("NW_VERBOSE")) >= 3)
         fprintf(stderr, "[nanowrap] search_end: final synchronize %ld us\n", (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - ts0).count());
@@ -1851,7 +2052,7 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head)
     ctx->begin_ops_pending = true;          // recorded, not run
     if (!ea) return nullptr;
     nw_ctx::BlockGraph &dst = ctx->graphs[ctx->graph_next];
-    ctx->graph_next = (ctx->graph_next + 1) % 4;
+    ctx->graph_next = (ctx->graph_next + 1) % 8;
     if (dst.exec) (void)hipGraphExecDestroy(dst.exec);
     dst.exec = ea; dst.key = key;
     return &dst;
@@ -2017,12 +2218,20 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     // a host result comes back straight from the block's last update kernel (pinned staging buffer, then host threads copy it out)
     static const bool direct_on = !(getenv("NW_DIRECT_OUT") && atoi(getenv("NW_DIRECT_OUT")) == 0);
     ctx->direct_out = false;
-    if (direct_on && pos_out && num_iters > 0) {
+    bool pos_on_device = false;
+    if (pos_out && num_iters > 0) {
         hipPointerAttribute_t attr;
-        const bool on_device = hipPointerGetAttributes(&attr, pos_out) == hipSuccess && attr.type == hipMemoryTypeDevice;
+        pos_on_device = hipPointerGetAttributes(&attr, pos_out) == hipSuccess && attr.type == hipMemoryTypeDevice;
         (void)hipGetLastError();
         // (above ~4 MB the sliced copy, which overlaps the transfer with the host-side copy-out, is the faster one: measured at 810k vertices)
-        if (!on_device && 3 * ctx->M * sizeof(float) <= (4u << 20)) { NW_TRY(ensure_staging(ctx)); ctx->direct_out = true; }
+        if (!pos_on_device) {
+            NW_TRY(ensure_staging(ctx));
+            if (ctx->rows_async) {          // the copy threads may still be reading the half the last block was staged in: this block takes the other
+                ctx->pin_sel ^= 1;
+                ctx->pin = (char *)ctx->pin_base + (ctx->pin_sel ? ctx->pin_bytes : 0);
+            }
+        }
+        if (direct_on && !pos_on_device && 3 * ctx->M * sizeof(float) <= (4u << 20)) ctx->direct_out = true;
     }
     ctx->last_direct_out = ctx->direct_out;
     bool replayed = false;
@@ -2049,6 +2258,12 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         }
     }
     nw_ctx::BlockGraph *slot = eager_first ? nullptr : block_graph(ctx, num_iters, head);
+    {
+        // (how long blocks like this one take, launch to end: the copy threads are woken shortly before -- wait_block_done)
+        const uint64_t bk = ((uint64_t)num_iters << 48) ^ ((uint64_t)ctx->N << 20) ^ (uint64_t)ctx->M ^ ((uint64_t)ctx->profiling << 60);
+        if (bk != ctx->block_us_key) { ctx->block_us_key = bk; ctx->block_us_ema = 0.0; }
+        ctx->block_t0 = std::chrono::steady_clock::now();
+    }
     if (slot) {
         if (hipGraphLaunch(slot->exec, ctx->stream) == hipSuccess) {
             const int n_done = head ? num_iters - 1 : num_iters;
@@ -2064,6 +2279,8 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         if (r != NW_OK) { ctx->in_search = false; return r; }
     }
     if ((cmode & NW_FLAG_COMM_HALO) && ctx->have_boundary && ctx->have_halo_ref && num_iters > 0) {
+        // (a failure in here must leave the ctx usable -- the caller's recovery, HaloExceeded / new shares, reuses it: the search is over either way)
+        auto tail = [&]() -> int {
         // The tail of a sharded block, enqueued behind its last iteration (no host round trip in between): the owners' rows of the whole
         // mesh go round, then the three numbers the ranks agree on per block (exactness of the sharded query, drift, next quantum), and
         // both land in pinned host memory -- nw_search_end's one synchronisation covers them (nw_host_copy_rows with src = NULL and
@@ -2089,6 +2306,18 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
         if (!tail_direct) NW_HIP(hipMemcpyAsync(ctx->pin_full, ctx->halo_full.p, fb, hipMemcpyDeviceToHost, ctx->stream));
         NW_HIP(hipMemcpyAsync((char *)ctx->pin_full + fb, ctx->halo_stats.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         ctx->full_staged = true;
+        return NW_OK;
+        };
+        const int rt = tail();
+        if (rt != NW_OK) { ctx->in_search = false; ctx->full_staged = false; ctx->begin_ops_pending = false; return rt; }
+    }
+    ctx->sliced_S = 0;
+    if (ctx->direct_out) {
+        const int r = enqueue_block_done(ctx);                  // the block's end as a word in pinned memory (the host spins on it)
+        if (r != NW_OK) { ctx->in_search = false; return r; }
+    } else if (pos_out && num_iters > 0 && !pos_on_device) {
+        const int r = enqueue_sliced_result(ctx);               // a large result: slices into the staging buffer, each announced by the next launch
+        if (r != NW_OK) { ctx->in_search = false; return r; }
     }
     const auto t2 = std::chrono::steady_clock::now();
     if (trace_blocks) (void)hipEventRecord(tb1, ctx->stream);
@@ -2206,12 +2435,15 @@ NW_EXPORT int nw_get(nw_ctx *ctx, int what, void *dst, int64_t nbytes)
 // pinned staging buffer for a block's result (3 M floats) and the host threads that copy it out
 static int ensure_staging(nw_ctx *ctx)
 {
-    const size_t bytes = (size_t)3 * ctx->M * sizeof(float);
+    const size_t bytes = (((size_t)3 * ctx->M * sizeof(float)) + 4095) & ~(size_t)4095;
     if (ctx->pin_bytes < bytes) {
-        if (ctx->pin) (void)hipHostFree(ctx->pin);
-        ctx->pin = nullptr; ctx->pin_bytes = 0;
-        NW_HIP(hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault));
+        if (ctx->pool) ctx->pool->wait_posted();
+        if (ctx->pin_base) (void)hipHostFree(ctx->pin_base);
+        ctx->pin = nullptr; ctx->pin_base = nullptr; ctx->pin_bytes = 0;
+        NW_HIP(hipHostMalloc(&ctx->pin_base, 2 * bytes, hipHostMallocDefault));
         ctx->pin_bytes = bytes;
+        ctx->pin_sel = 0;
+        ctx->pin = ctx->pin_base;
     }
     if (!ctx->pool) {
         int T = 8;
@@ -2231,23 +2463,58 @@ static int64_t rows_per_copy_thread() { static const int64_t v = getenv("NW_HOST
 static void copy_out_staged(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes)
 {
     ctx->n_staged_copy_outs += 1;
+    (void)copy_out_chunks(ctx, contiguous, rows, row_stride_bytes, 0, 0);
+}
+
+// The staged result -> the caller's arrays, in chunks of 8192 rows taken from a counter by the copy threads and the calling thread
+// (NwHostPool::run_chunks).  slice_rows > 0: the staging buffer is being filled slice by slice (k_copy_slice launches behind the block's
+// last kernel); the flag word reads flag_base + 1 + (slices complete), and a chunk waits for its slice.
+static bool copy_out_chunks(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes, int64_t slice_rows, int flag_base)
+{
     const int64_t M = ctx->M;
     const float *stage = (const float *)ctx->pin;
     const bool masked = rows && ctx->have_valid;
     const unsigned char *vstage = masked ? ctx->valid_host.data() : nullptr;
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->pool->n, M / rows_per_copy_thread()));
-    auto work = [&](int t) {
-        if (t >= T) return;
-        const int64_t v0 = M * t / T, v1 = M * (t + 1) / T;
+    const int64_t chunk = slice_rows > 0 ? std::max<int64_t>(4096, slice_rows / 2) : 8192;
+    const int nchunks = (int)((M + chunk - 1) / chunk);
+    volatile int *flag = ctx->pin_flag;
+    // NW_FLAG_ROWS_ASYNC: the contiguous result now, the strided records behind the caller's back (the pool's threads; nw_synchronize, the
+    // next block's copy-out and everything that touches the staging buffer or the records' description wait for them)
+    const bool defer_rows = ctx->rows_async && rows && ctx->pool && ctx->pool->n > 1;
+    std::atomic<bool> failed(false);
+    auto work = [&](int c) {
+        const int64_t v0 = (int64_t)c * chunk, v1 = std::min<int64_t>(M, v0 + chunk);
+        if (slice_rows > 0) {
+            const int need = flag_base + 1 + (int)((v1 - 1) / slice_rows) + 1;      // the chunk's last slice complete
+            long spins = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (*flag - need < 0 && !failed.load(std::memory_order_relaxed)) {
+                for (int k = 0; k < 8; ++k) __builtin_ia32_pause();
+                // (a slice is tens of microseconds of PCIe: seconds of silence mean the device is not going to answer)
+                if ((++spins & 4095) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) failed = true;
+            }
+            if (failed.load()) return;
+        }
         if (contiguous) memcpy(contiguous + 3 * v0, stage + 3 * v0, (size_t)(v1 - v0) * 12);
-        if (rows) {
+        if (rows && !defer_rows) {
             char *dst = (char *)rows;
             for (int64_t v = v0; v < v1; ++v)
                 if (!masked || vstage[v]) memcpy(dst + v * row_stride_bytes, stage + 3 * v, 12);
         }
     };
-    if (T == 1) work(0);
-    else ctx->pool->run(work);
+    if (!ctx->pool) { for (int c = 0; c < nchunks; ++c) work(c); return !failed.load(); }
+    if (contiguous || !defer_rows || slice_rows > 0) ctx->pool->run_chunks(nchunks, work);
+    if (failed.load()) return false;
+    if (defer_rows) {
+        char *dst = (char *)rows;
+        const int64_t rchunk = 8192;
+        ctx->pool->post_chunks((int)((M + rchunk - 1) / rchunk), [=](int c) {           // (by value: the job outlives this frame)
+            const int64_t v0 = (int64_t)c * rchunk, v1 = std::min<int64_t>(M, v0 + rchunk);
+            for (int64_t v = v0; v < v1; ++v)
+                if (!masked || vstage[v]) memcpy(dst + v * row_stride_bytes, stage + 3 * v, 12);
+        });
+    }
+    return true;
 }
 
 static int write_back_impl(nw_ctx *ctx, float *contiguous, void *rows, int64_t row_stride_bytes)
@@ -2300,7 +2567,7 @@ NW_EXPORT int nw_host_copy_rows(nw_ctx *ctx, const float *src, int64_t n_rows, f
 {
     if (!ctx || n_rows < 0) return NW_ERR_BADARG;
     if (!src) {          // the whole mesh a sharded nw_search block left in pinned memory (its tail; nw_search_end has synchronised)
-        if (!ctx->full_staged || n_rows != ctx->M_global) return fail(ctx, NW_ERR_BADARG, "nw_host_copy_rows: no staged result of a sharded block (nw_search with NW_FLAG_COMM_HALO)");
+        if (!ctx->full_staged || n_rows != ctx->M_global || ctx->pin_full_bytes < (size_t)12 * (size_t)n_rows + 16) return fail(ctx, NW_ERR_BADARG, "nw_host_copy_rows: no staged result of a sharded block (nw_search with NW_FLAG_COMM_HALO)");
         src = (const float *)ctx->pin_full;
     }
     if (rows && row_stride_bytes < 12) return fail(ctx, NW_ERR_BADARG, "nw_host_copy_rows: bad stride");

@@ -55,8 +55,7 @@ struct NwAttractArgs {
 // contribution that finds no slot within PROBES probes goes to HBM directly -- integer sums: the path taken does not change the result)
 // and its share to the caller's partial sums.  `rot` in {0,1,2} rotates the corner order (neighbouring lanes mostly share their
 // face: three different accumulators at a time instead of one three times over).
-template <int SLOTS, int BITS, int PROBES>
-__device__ __forceinline__ void nw_attract_point(const NwAttractArgs &A, int i, const float4 P, int f, int rot, int *s_key, unsigned long long *s_val,
+__device__ __forceinline__ void nw_attract_point(const NwAttractArgs &A, int i, const float4 P, int f, int (&vout)[3], unsigned long long (&q)[3][4],
                                                  double (&red)[4], float &dmax, bool &bad)
 {
     const float p[3] = {P.x, P.y, P.z};
@@ -111,10 +110,69 @@ __device__ __forceinline__ void nw_attract_point(const NwAttractArgs &A, int i, 
     __builtin_memcpy(A.vidx + 3 * (int64_t)i, v, 12);
     __builtin_memcpy(A.wout + 3 * (int64_t)i, w, 12);
 #pragma unroll
-    for (int j0 = 0; j0 < 3; ++j0) {
-        const int jr = j0 + rot, j = jr >= 3 ? jr - 3 : jr;
-        const int vj = j == 0 ? v[0] : (j == 1 ? v[1] : v[2]);
-        const float wj = j == 0 ? w[0] : (j == 1 ? w[1] : w[2]);
+    for (int j = 0; j < 3; ++j) {
+        vout[j] = v[j];
+        const float c[4] = {w[j] * r[0], w[j] * r[1], w[j] * r[2], w[j]};     // float32 products, as the reference forms them
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double x = (double)c[k] * (k < 3 ? A.inv_q : A.inv_qw);           // exact scaling (powers of two)
+            bad |= !(fabs(x) < 7.0e13);                                             // far beyond the bound behind the quantum / inf / NaN: raise the NaN status
+            q[j][k] = (unsigned long long)nw_round_to_i64(x);
+        }
+    }
+}
+
+// Runs of lanes with the same nearest face (the localizations are sorted by their foot point: 2.6 consecutive lanes share a face on
+// average at 2.5 localizations per face, a wave's 64 localizations touch ~25 distinct vertices) are added up on the vector ALU before
+// anything goes to the LDS table (round 5): a segmented inclusive scan over the rows of 16 lanes (DPP row_shr 1, 2, 4, 8), after which
+// the LAST lane of every run holds the run's twelve sums and is the only one that probes the table and issues ds_add_u64.  The sums are
+// integers, so the regrouping does not change a bit of the result.  Call from uniform control flow (every lane of the wave): `run` is the
+// lane's face, or any value unique in its row for a lane without a localization (whose q must be zero).  Returns whether the lane is
+// the last of its run.
+__device__ __forceinline__ bool nw_run_sums(unsigned long long (&q)[3][4], int run)
+{
+    const int lane = threadIdx.x & 63;
+    // head: first lane of its row of 16, or a different run than the lane before
+    const int prev = __builtin_amdgcn_update_dpp(~run, run, 0x111, 0xf, 0xf, false);        // row_shr:1 (lanes without a source keep ~run: a head)
+    int flag = (prev != run) ? 1 : 0;
+    const int next_head = __builtin_amdgcn_update_dpp(1, flag, 0x101, 0xf, 0xf, false);    // row_shl:1 (the row's last lane: 1)
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+        const int ctrl = step == 0 ? 0x111 : (step == 1 ? 0x112 : (step == 2 ? 0x114 : 0x118));     // row_shr:1/2/4/8
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int lo = (int)(unsigned)(q[j][k] & 0xffffffffull), hi = (int)(unsigned)(q[j][k] >> 32);
+                int tlo, thi;
+                if (step == 0) { tlo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); thi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); }
+                else if (step == 1) { tlo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); thi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); }
+                else if (step == 2) { tlo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); thi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); }
+                else { tlo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); thi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); }
+                const unsigned long long t = ((unsigned long long)(unsigned)thi << 32) | (unsigned long long)(unsigned)tlo;
+                q[j][k] += flag ? 0ull : t;
+            }
+        int tf;
+        if (step == 0) tf = __builtin_amdgcn_update_dpp(1, flag, 0x111, 0xf, 0xf, false);
+        else if (step == 1) tf = __builtin_amdgcn_update_dpp(1, flag, 0x112, 0xf, 0xf, false);
+        else if (step == 2) tf = __builtin_amdgcn_update_dpp(1, flag, 0x114, 0xf, 0xf, false);
+        else tf = __builtin_amdgcn_update_dpp(1, flag, 0x118, 0xf, 0xf, false);
+        flag |= tf;
+        (void)ctrl;
+    }
+    (void)lane;
+    return next_head != 0;
+}
+
+// the run's sums into the workgroup's table (the last lane of a run only)
+// (The corner order was rotated per lane while every lane scattered -- neighbouring lanes shared their face; the last lanes of different
+// runs do not, and a run-time corner index would put q[][] into scratch memory: the build's resource guard refuses that.)
+template <int SLOTS, int BITS, int PROBES>
+__device__ __forceinline__ void nw_attract_scatter(const NwAttractArgs &A, const int (&v)[3], const unsigned long long (&q)[3][4], int *s_key, unsigned long long *s_val)
+{
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int vj = v[j];
         unsigned hsh = ((unsigned)vj * 2654435761u) >> (32 - BITS);
         bool slot = false;
         for (int probe = 0; probe < PROBES; ++probe) {
@@ -123,14 +181,11 @@ __device__ __forceinline__ void nw_attract_point(const NwAttractArgs &A, int i, 
             hsh = (hsh + 1) & (SLOTS - 1);
         }
         unsigned long long *a = s_val + hsh;
-        const float c[4] = {wj * r[0], wj * r[1], wj * r[2], wj};     // float32 products, as the reference forms them
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const double x = (double)c[k] * (k < 3 ? A.inv_q : A.inv_qw);           // exact scaling (powers of two)
-            bad |= !(fabs(x) < 7.0e13);                                             // far beyond the bound behind the quantum / inf / NaN: raise the NaN status
-            const unsigned long long q = (unsigned long long)nw_round_to_i64(x);
-            if (slot) atomicAdd(a + k * SLOTS, q);
-            else atomicAdd(reinterpret_cast<unsigned long long *>(A.vacc) + 4 * (int64_t)vj + k, q);
+            const unsigned long long x = q[j][k];
+            if (slot) atomicAdd(a + k * SLOTS, x);
+            else atomicAdd(reinterpret_cast<unsigned long long *>(A.vacc) + 4 * (int64_t)vj + k, x);
         }
     }
 }

@@ -433,11 +433,21 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__res
         // a face id outside [0, F) can only come from a bug in the NN query: never dereference it (a faulting kernel can
         // take the whole node down), raise the internal-error status instead
         if (i < N && (unsigned)f_raw >= (unsigned)A.F) atomicCAS(&st->status, 0, -7 /* NW_ERR_INTERNAL */);
-        if (i < N && (unsigned)f_raw < (unsigned)A.F) {
+        const bool ok = i < N && (unsigned)f_raw < (unsigned)A.F;
+        unsigned long long q[3][4];
+        int v[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[j][k] = 0ull;
+        if (ok) {
             bool bad = false;
-            nw_attract_point<NW_HT, NW_HT_BITS, NW_HT_PROBES>(A, i, pts[i], f_raw, (int)(threadIdx.x % 3u), s_key, s_val, red, dmax, bad);
+            nw_attract_point(A, i, pts[i], f_raw, v, q, red, dmax, bad);
             if (bad) atomicCAS(&st->status, 0, -3 /* NW_ERR_NAN */);
         }
+        // (uniform control flow from here: the run sums move data between lanes)
+        const bool last_of_run = nw_run_sums(q, ok ? f_raw : -2 - (int)(threadIdx.x & 15));
+        if (ok && last_of_run) nw_attract_scatter<NW_HT, NW_HT_BITS, NW_HT_PROBES>(A, v, q, s_key, s_val);
     }
     __syncthreads();
     // per-workgroup partial sums (row of 5: four sums + the largest NN distance of the workgroup, which a sharded run checks against
@@ -589,6 +599,9 @@ __global__ __launch_bounds__(NW_BLOCK) void k_vertex_area_weights(int M, int NB,
 // residuals and masks of ALL the thread's localizations are loaded unconditionally (a thread beyond N reads localization 0 and
 // contributes through an empty mask), (2) the twelve 36-byte rows of S are gathered two localizations at a time (3 wide loads a row).
 // Three round trips in all; the arithmetic and its order are unchanged (bit-identical sums).
+// (Round 5 also tried ONE gather per run of lanes that share their face -- 2.6 lanes on average; the first lane of a run gathers the three
+// rows, parks them in the wave's LDS buffer, every lane of the run reads them back: bit-identical, 22.8 us against 22.0 for gather +
+// reduce -- the kernel is bound by neither the gathers' address rate nor their latency any more; not kept.)
 __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, int M, const int *__restrict__ vidx, const float *__restrict__ w, const float *__restrict__ res,
                                                                  const unsigned char *__restrict__ mask, const float *__restrict__ S, double *__restrict__ part,
                                                                  const NwDevState *__restrict__ st, int it, int n_search, const NwFold Fd)
@@ -703,6 +716,23 @@ __global__ __launch_bounds__(NW_BLOCK) void k_block_done(const unsigned *__restr
         *counter = v;
         __hip_atomic_store(host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// A slice of a large result into the pinned staging buffer (results above 4 MB: the last update kernel writing 10-20 MB over PCIe itself
+// would hold the host's copy threads back until its end).  The launch first tells the host that everything queued before it has run --
+// the flag word takes the counter's next value, see k_block_done -- so the copy threads take slice s while slice s + 1 is in flight.
+__global__ __launch_bounds__(NW_BLOCK) void k_copy_slice(const float *__restrict__ src, float *__restrict__ dst, int64_t n_floats, int *__restrict__ counter, int *host_flag)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int v = *counter + 1;
+        *counter = v;
+        __hip_atomic_store(host_flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const int64_t n4 = n_floats >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) d4[i] = s4[i];
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n_floats & 3)) dst[4 * n4 + threadIdx.x] = src[4 * n4 + threadIdx.x];
 }
 
 // K7: <=3x3 regularised normal equations (every workgroup solves them redundantly from the reduced sums),

@@ -23,6 +23,7 @@ Differences that are deliberate and documented:
 There is no CPU fallback: without libnanowrap_hip.so and a GPU the constructor raises.
 """
 import ctypes
+import os
 import numpy as np
 
 from . import _lib as nw
@@ -59,6 +60,10 @@ class NativeContext(object):
             pass
 
 
+# NW_ROWS_ASYNC=0 (developer knob): the vertex records are complete when search() returns, as until round 4
+_ROWS_ASYNC = os.environ.get('NW_ROWS_ASYNC', '1') != '0'
+
+
 def _as_f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -86,10 +91,10 @@ class ShrinkwrapMeshConjGrad(object):
 
         self._mesh_vertex_mask = mesh._vertices['halfedge'] != -1                      # :44
         self._all_valid = bool(self._mesh_vertex_mask.all())
-        self._vertices = mesh._vertices['position']                                    # :46 (view)
-        self.M = self._vertices.shape[0]
-        self.dims = self._vertices.shape[1]
-        self.shape = self._vertices.shape
+        self._vertices_view = mesh._vertices['position']                               # :46 (view)
+        self.M = self._vertices_view.shape[0]
+        self.dims = self._vertices_view.shape[1]
+        self.shape = self._vertices_view.shape
         self.faces = mesh.faces                                                        # :47
         if hasattr(mesh, 'neighbor_vertex_table'):                                     # :50-54 (native table builder of the substrate)
             self.vertex_neighbors = mesh.neighbor_vertex_table()
@@ -233,10 +238,16 @@ class ShrinkwrapMeshConjGrad(object):
         # write-back (mesh_conj_grad.py:288-290) inside the call: the library copies the positions out in slices (the (M,3) result and
         # the strided mesh._vertices['position'] rows of the valid vertices) while the rest of the transfer is still in flight
         out = self._result_buffer()
-        posv = self.mesh._vertices['position']
+        # a mesh that knows about deferred rows (trimesh.TriMesh): its records are reached WITHOUT waiting for the previous block's rows --
+        # the library orders the two copies itself -- and this block's rows may be written while the caller goes on (NW_FLAG_ROWS_ASYNC)
+        records = self.mesh.__dict__.get('_vertex_records') if getattr(self.mesh, '_accepts_deferred_rows', False) else None
+        posv = (records if records is not None else self.mesh._vertices)['position']
         direct = posv.dtype == np.float32 and posv.strides[1] == 4 and posv.strides[0] >= 12
+        deferred = records is not None and direct and _ROWS_ASYNC and num_iters > 0
         self._native.check(self._L.nw_set_write_back(self._h, ctypes.c_void_p(posv.ctypes.data) if direct else None, posv.strides[0] if direct else 0))
-        code = self._L.nw_search(self._h, nw.ptr(lams_a), lams_a.size, num_iters, flags, nw.ptr(out), logs, ctypes.byref(lc))
+        code = self._L.nw_search(self._h, nw.ptr(lams_a), lams_a.size, num_iters, flags | (nw.NW_FLAG_ROWS_ASYNC if deferred else 0), nw.ptr(out), logs, ctypes.byref(lc))
+        if deferred:
+            self.mesh.__dict__['_rows_pending'] = self._flush_rows      # (before anything can raise: the rows may be in flight)
         self._native.check(self._L.nw_set_write_back(self._h, None, 0))
         self._native.check(code)
         self._consume_logs(logs, lc.value)
@@ -247,6 +258,23 @@ class ShrinkwrapMeshConjGrad(object):
         self.f = self.fs.ravel()
         self.mesh._initialize_curvature_vectors()
         return np.real(self.fs)
+
+    @property
+    def _vertices(self):
+        """the view of the mesh's position rows the reference keeps (mesh_conj_grad.py:46) -- complete (see _flush_rows)"""
+        if self.mesh.__dict__.get('_rows_pending') is not None:
+            self._flush_rows()
+        return self._vertices_view
+
+    def _flush_rows(self):
+        """Wait for the host threads that fill the mesh's vertex records behind a block (NW_FLAG_ROWS_ASYNC); trimesh.TriMesh calls
+        this before anybody reads `_vertices`."""
+        self.mesh.__dict__['_rows_pending'] = None
+        self._native.check(self._L.nw_synchronize(self._h))
+
+    def synchronize(self):
+        """Device stream drained and host-side copies finished (nw_synchronize)."""
+        self._flush_rows()
 
     def _consume_logs(self, logs, executed):
         self.loopcount = executed

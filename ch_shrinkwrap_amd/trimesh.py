@@ -161,6 +161,26 @@ def _build_halfedges(faces, n_vertices):
 class TriMesh(object):
     """Duck-typed stand-in for the PYME mesh object the optimiser reads (see module docstring)."""
 
+    # The vertex records may be behind the optimiser by one block: with NW_FLAG_ROWS_ASYNC (include/nanowrap.h) `search()` returns when
+    # its (M,3) result is complete and the library's host threads fill the 'position' rows of the 120-byte records while the caller goes
+    # on -- typically while the next block runs on the GPU.  Every access to `_vertices` first waits for them (`_rows_pending`, set by
+    # the optimiser), so nobody sees a half-written array; a mesh class without this property (PYME's) gets the synchronous write-back.
+    _accepts_deferred_rows = True
+
+    @property
+    def _vertices(self):
+        pending = self.__dict__.get('_rows_pending')
+        if pending is not None:
+            pending()
+        return self.__dict__['_vertex_records']
+
+    @_vertices.setter
+    def _vertices(self, records):
+        pending = self.__dict__.get('_rows_pending')
+        if pending is not None:
+            pending()
+        self.__dict__['_vertex_records'] = records
+
     def __init__(self, vertices, faces, max_vertices=None):
         vertices = np.ascontiguousarray(vertices, dtype='f4')
         faces = np.ascontiguousarray(faces, dtype='i4')

@@ -60,6 +60,12 @@ typedef enum nw_weights_mode {
 #define NW_FLAG_COMM_HALO       64u
 #define NW_FLAG_RESULT_TO_HOST 8u    /* nw_search_begin only: nw_search_end will be given a HOST pos_out -- the block's last nw_iter_update then writes the
                                         result into the pinned staging buffer itself, as nw_search arranges on its own (the write-back, mesh_conj_grad.py:288-289) */
+#define NW_FLAG_ROWS_ASYNC 128u    /* nw_search with a strided target registered (nw_set_write_back): the call returns when `pos_out` is complete; the vertex
+                                      records are filled by the library's host threads while the caller goes on (typically: while the next block runs on
+                                      the GPU -- the 12-byte writes into 120-byte records are memory-bound host work, 95 us per block at 200 000 vertices).
+                                      nw_synchronize waits for them; so do the next block's copy-out, nw_set_mesh and nw_destroy.  The records must stay
+                                      allocated until then, and nobody may read them before.  (The reference updates the mesh inside every iteration,
+                                      mesh_conj_grad.py:288-290; without this flag the records are complete when nw_search returns.) */
 
 /* per-iteration record; the reference keeps these as Python lists / attributes:
  * tests, ress, prefs (mesh_conj_grad.py:269-271), cpred, wpreds (:274, conj_grad.py:223-225) */
@@ -118,7 +124,7 @@ void nw_destroy(nw_ctx *ctx);
 const char *nw_last_error(nw_ctx *ctx);
 /* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int nw_set_stream(nw_ctx *ctx, void *hip_stream);
-int nw_synchronize(nw_ctx *ctx);
+int nw_synchronize(nw_ctx *ctx);                  /* the ctx's stream has drained AND the host threads have finished (NW_FLAG_ROWS_ASYNC) */
 
 /* ---- inputs -------------------------------------------------------------------------------------------- */
 /* localizations + residual weighting; replaces the `points` setter (mesh_conj_grad.py:127-130, without the
