@@ -119,6 +119,10 @@ def parse_args(argv=None):
                     help='N > 1: tiles = one vesicle per rank (BASELINE configs[4], weak scaling); halo = ONE mesh sharded over the ranks (strong scaling)')
     ap.add_argument('--halo', type=float, default=60.0, help='--mode halo: margin (nm) of the first shares -- every rank holds the faces within (nearest distance + margin) of each of its localizations; budget for the growth of a nearest distance + the drift of the mesh until new shares are cut (bench.py cuts them again, with three times the last block\'s movement, after its warm-up)')
     ap.add_argument('--exchange', choices=['peers', 'dense'], default='peers', help="--mode halo: how the boundary rows go round -- 'peers': between the ranks that share them (the copies' partial sums to the vertex's owner, its sum and new position back); 'dense': two all-reduces over the global list of boundary vertices")
+    ap.add_argument('--collectives', choices=['library', 'group'], default=os.environ.get('NW_BENCH_COLLECTIVES', 'library'),
+                    help="--gpus N over RCCL: 'library' = the library's own communicator issues a block's collectives on its stream, recorded in the block's hipGraph (nw_comm_init; default); "
+                         "'group' = the fall-back that needs none of that: the split-phase C-ABI with torch.distributed's all-reduces between the phases (what the gloo tests drive). "
+                         "NW_GRAPH_COMM=0 keeps 'library' but launches multi-rank blocks one by one instead of replaying a recording")
     ap.add_argument('--scale', type=float, default=1.0, help='shrink the workload (debug only; the reported config says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph-pass', action='store_true', help='skip the extra un-instrumented (graph-replay) pass (profiling runs)')
@@ -261,7 +265,7 @@ def run_rank(args):
     # NW_BENCH_BACKEND=gloo (ranks sharing one GPU, which RCCL refuses): the same protocol through the split-phase C-ABI with the process
     # group's all-reduces between the phases, kernels and collectives on one dedicated torch stream.
     from ch_shrinkwrap_amd.mesh_conj_grad import NativeContext
-    native_comm = multi and backend == 'nccl'
+    native_comm = multi and backend == 'nccl' and args.collectives == 'library'
     tstream = torch.cuda.Stream() if (multi and not native_comm) else None
     native = NativeContext(local_rank, None) if native_comm else None
     comm = parallel.NativeComm(native, dist) if native_comm else None

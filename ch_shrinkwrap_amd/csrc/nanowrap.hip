@@ -2257,6 +2257,10 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
             ctx->comm_patterns.push_back(pat);
         }
     }
+    // NW_GRAPH_COMM=0: blocks with collectives are never recorded (every launch and every RCCL call issued directly, as in the first block of a
+    // pattern) -- the fall-back if RCCL's kernels as graph nodes misbehave on some node; single-GPU blocks are not affected
+    static const bool graph_comm = !(getenv("NW_GRAPH_COMM") && atoi(getenv("NW_GRAPH_COMM")) == 0);
+    if (!graph_comm && ctx->comm && ctx->comm_ranks > 1 && cmode) eager_first = true;
     nw_ctx::BlockGraph *slot = eager_first ? nullptr : block_graph(ctx, num_iters, head);
     {
         // (how long blocks like this one take, launch to end: the copy threads are woken shortly before -- wait_block_done)

@@ -15,6 +15,9 @@
 #include <cstdio>
 #include <thread>
 #include <atomic>
+#include <mutex>
+#include <exception>
+#include <system_error>
 #include <utility>
 #include <climits>
 
@@ -48,11 +51,28 @@ void parallel_for(int64_t n, int64_t min_chunk, Fn fn)
 {
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads(), n / std::max<int64_t>(min_chunk, 1)));
     if (T <= 1) { fn((int64_t)0, n); return; }
+    // An exception in a worker (std::bad_alloc of its scratch) must not escape its thread (std::terminate), and one on the calling thread --
+    // or from the std::thread constructor -- must not destroy joinable threads: every body runs under a catch-all that keeps the first
+    // exception, the threads are joined whatever happens, and the exception is re-thrown on the calling thread (the C boundary maps it).
+    std::exception_ptr err;
+    std::mutex err_m;
+    auto guarded = [&](int64_t lo, int64_t hi) {
+        try { fn(lo, hi); }
+        catch (...) { std::lock_guard<std::mutex> lk(err_m); if (!err) err = std::current_exception(); }
+    };
     std::vector<std::thread> th;
     th.reserve(T - 1);
-    for (int t = 1; t < T; ++t) th.emplace_back([=] { fn(n * t / T, n * (t + 1) / T); });
-    fn((int64_t)0, n / T);
+    int started = 1;
+    try {
+        for (int t = 1; t < T; ++t) { th.emplace_back([&guarded, n, t, T] { guarded(n * t / T, n * (t + 1) / T); }); started = t + 1; }
+    } catch (...) {
+        std::lock_guard<std::mutex> lk(err_m);
+        if (!err) err = std::current_exception();
+    }
+    guarded((int64_t)0, n / T);
+    for (int t = started; t < T; ++t) guarded(n * t / T, n * (t + 1) / T);        // (threads that could not be started: their chunks here)
     for (auto &x : th) x.join();
+    if (err) std::rethrow_exception(err);
 }
 
 // twin[3f+k] = the half-edge running the other way along edge (faces[f][k], faces[f][k+1]), -1 on a boundary.  Linear time:
@@ -450,6 +470,8 @@ NWR_EXPORT int nwr_halfedge_twins(const int32_t *faces, int64_t n_faces, int64_t
         return match_twins(faces, n_faces, n_vertices, twin);
     } catch (const std::bad_alloc &) {
         return NWR_ERR_NOMEM;
+    } catch (const std::exception &) {          // (std::system_error of a thread that could not be started, ...: no exception crosses the C boundary)
+        return NWR_ERR_NOMEM;
     }
 }
 
@@ -526,6 +548,8 @@ NWR_EXPORT int nwr_mesh_geometry(const void *positions, int64_t pos_stride_bytes
         return NWR_OK;
     } catch (const std::bad_alloc &) {
         return NWR_ERR_NOMEM;
+    } catch (const std::exception &) {          // (std::system_error of a thread that could not be started, ...: no exception crosses the C boundary)
+        return NWR_ERR_NOMEM;
     }
 }
 
@@ -583,6 +607,8 @@ NWR_EXPORT int nwr_build_topology(const int32_t *faces, int64_t n_faces, int64_t
         });
         return NWR_OK;
     } catch (const std::bad_alloc &) {
+        return NWR_ERR_NOMEM;
+    } catch (const std::exception &) {          // (std::system_error of a thread that could not be started, ...: no exception crosses the C boundary)
         return NWR_ERR_NOMEM;
     }
 }
@@ -899,10 +925,15 @@ static int seam_pass(std::vector<float> &V, std::vector<int32_t> &F, const std::
         std::atomic<int> next{0};
         std::vector<std::thread> th;
         auto work = [&] {
-            std::vector<int> g2l(nv, -1);
-            for (int i = next.fetch_add(1); i < npieces; i = next.fetch_add(1)) piece_run(pieces[i], V, F, g2l, n_iterations, L, max_valence, seeds.data());
+            int i = -1;
+            try {
+                std::vector<int> g2l(nv, -1);
+                for (i = next.fetch_add(1); i < npieces; i = next.fetch_add(1)) piece_run(pieces[i], V, F, g2l, n_iterations, L, max_valence, seeds.data());
+            } catch (...) {                                   // (out of memory in a worker: its piece, and with it the pass, reports it)
+                if (i >= 0 && i < npieces) pieces[i].rc = NWR_ERR_NOMEM; else pieces[0].rc = NWR_ERR_NOMEM;
+            }
         };
-        for (int t = 1; t < T; ++t) th.emplace_back(work);
+        try { for (int t = 1; t < T; ++t) th.emplace_back(work); } catch (...) {}       // (fewer threads than wanted: the others take the pieces)
         work();
         for (auto &x : th) x.join();
     }
@@ -977,11 +1008,18 @@ static int remesh_partitioned(const float *vertices, int64_t n_vertices, const i
     const int T = std::min(n_threads(), NWR_REGIONS);
     {
         std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t] {
+        std::atomic<int> next_run{0};
+        auto work = [&] {
+            int r = -1;
+            try {
                 std::vector<int> g2l((size_t)n_vertices, -1);
-                for (int r = t; r < NWR_REGIONS; r += T) piece_run(pieces[r], V, F, g2l, n_iterations, L, max_valence, nullptr);
-            });
+                for (r = next_run.fetch_add(1); r < NWR_REGIONS; r = next_run.fetch_add(1)) piece_run(pieces[r], V, F, g2l, n_iterations, L, max_valence, nullptr);
+            } catch (...) {
+                if (r >= 0 && r < NWR_REGIONS) pieces[r].rc = NWR_ERR_NOMEM; else pieces[0].rc = NWR_ERR_NOMEM;
+            }
+        };
+        try { for (int t = 1; t < T; ++t) th.emplace_back(work); } catch (...) {}
+        work();
         for (auto &x : th) x.join();
     }
     nwr_stats tot{};
@@ -1093,8 +1131,9 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
             rc = remesh_partitioned(vertices, n_vertices, faces, n_faces, n_iterations, L, max_valence, ov, of, stats, &min_edge2);
             // safety net: an edge of (nearly) no length in the result -- never seen since the rims wait for their pass -- and the
             // serial algorithm takes over
-            if (rc == NWR_OK && !(min_edge2 > 1e-12 * (double)L * (double)L)) {
-                if (std::getenv("NWR_VERBOSE")) std::fprintf(stderr, "[nw_remesh] an edge of no length in the partitioned result: the serial algorithm takes over\n");
+            if (rc != NWR_OK || !(min_edge2 > 1e-12 * (double)L * (double)L)) {
+                // (also when a piece failed -- out of memory in a worker, a runaway guard: the serial algorithm on the whole mesh decides)
+                if (std::getenv("NWR_VERBOSE")) std::fprintf(stderr, "[nw_remesh] the partitioned pass %s: the serial algorithm takes over\n", rc != NWR_OK ? "failed" : "left an edge of no length");
                 rc = remesh_core(vertices, n_vertices, faces, n_faces, n_iterations, target_edge_length, relax_lambda, n_relax, max_valence, nullptr, ov, of, nullptr, stats, nullptr);
             }
         } else {
@@ -1109,6 +1148,8 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
         *out_vertices = pv; *out_n_vertices = (int64_t)(ov.size() / 3); *out_faces = pf; *out_n_faces = (int64_t)(of.size() / 3);
         return NWR_OK;
     } catch (const std::bad_alloc &) {
+        return NWR_ERR_NOMEM;
+    } catch (const std::exception &) {          // (std::system_error of a thread that could not be started, ...: no exception crosses the C boundary)
         return NWR_ERR_NOMEM;
     }
 }

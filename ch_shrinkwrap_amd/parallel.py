@@ -831,8 +831,9 @@ class HaloScene(object):
     an oracle-backed one)."""
 
     def __init__(self, mesh, points, dist, halo, make_executor=None, native=None, torch_stream=None, comm=None, per_point=None, min_margin=None,
-                 exchange='peers'):
+                 exchange='peers', allow_recut_every_block=False):
         self.mesh, self.points, self.dist, self.halo = mesh, np.ascontiguousarray(points, np.float32), dist, float(halo)
+        self.allow_recut_every_block = bool(allow_recut_every_block)
         # per_point: shares cut with PER-LOCALIZATION halos -- a rank holds every face within (nearest distance now + margin) of each of
         # its localizations instead of everything within `halo` of its tile's bounding box: the halo then pays for the mesh's movement
         # (the margin: at most `halo`, a few times the last block's movement where a caller asks for the set-up, doubled whenever it runs out),
@@ -870,7 +871,19 @@ class HaloScene(object):
 
     # -- set-up (once per topology) ---------------------------------------------------------------------------------------------
     def mesh_changed(self):
-        """the host mesh was edited (remesh, surgery, positions set by hand): partition and upload again before the next block"""
+        """the host mesh was edited (remesh, surgery, positions set by hand): partition and upload again before the next block.
+
+        Cutting shares is HOST work of 0.2-0.5 s per rank at a million localizations (nearest distances + the reach classes' k-d trees)
+        against ~1.5 ms for the block it serves: a caller that edits the mesh after EVERY block -- the recipe's pattern, 39 iterations
+        with remesh_frequency 5, recipe_modules/surface_fitting.py:17,30 -- would spend 99 % of its time cutting.  The third edit in a row
+        with at most one block in between is refused (RuntimeError) unless the scene was built with `allow_recut_every_block=True`: such
+        fits run on ONE GPU (ShrinkwrapMembrane does), or as independent tiles."""
+        since = self._blocks_total - getattr(self, '_last_edit_block', -10 ** 9)
+        self._edits_in_a_row = (getattr(self, '_edits_in_a_row', 0) + 1) if since <= 1 else 1
+        self._last_edit_block = self._blocks_total
+        if self._edits_in_a_row >= 3 and not getattr(self, 'allow_recut_every_block', False):
+            raise RuntimeError("HaloScene: the mesh was edited after each of the last three blocks -- re-cutting a sharded mesh's shares costs hundreds of blocks' worth of "
+                               "host time (0.2-0.5 s per rank against ~1.5 ms per block); fit a mesh that is remeshed every block on one GPU, or pass allow_recut_every_block=True")
         self.last_partition = None
 
     def _hip_executor(self, local_mesh, local_points):

@@ -82,6 +82,43 @@ def test_rccl_path_replays_blocks_with_their_collectives(mode):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize('mode,extra,env', [('tiles', [], {}), ('halo', [], {}), ('halo', ['--exchange', 'dense'], {}),
+                                            ('tiles', ['--collectives', 'group'], {}), ('halo', [], {'NW_GRAPH_COMM': '0'})])
+def test_two_ranks_over_rccl_when_two_gpus_are_visible(mode, extra, env):
+    """The first thing a multi-GPU box should run (skipped on the one-GPU boxes this was built on): TWO ranks on TWO devices over RCCL --
+    the library's communicator with its grouped ncclSend / ncclRecv of the owner-wise exchange and the all-reduces recorded into the
+    block's hipGraph ('tiles', 'halo', 'halo' with the dense exchange), and the two fall-backs: the split-phase C-ABI over torch's process
+    group (--collectives group) and multi-rank blocks launched one by one (NW_GRAPH_COMM=0)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL refuses two ranks on one device)')
+    p = _run(['--gpus', '2', '--steps', '10', '--warmup', '5', '--scale', '0.1', '--mode', mode, '--no-cpu-baseline'] + extra, timeout=800, extra_env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['rccl']['backend'] == 'nccl' and j['rccl']['world_size_seen'] == 2
+    assert len({d['device'] for d in j['rccl']['devices']}) == 2
+    assert j['value'] > 0 and j['config']['mode'] == mode
+    assert j['rccl']['collectives_issued_by'].startswith('the process group' if '--collectives' in extra else 'the library')
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_fall_backs_of_the_multi_rank_path_run_with_one_rank():
+    """What a one-GPU box can check of the two fall-backs: ONE nccl rank through torch's process group with the split-phase
+    C-ABI (--collectives group) and through the library's communicator with NW_GRAPH_COMM=0 (blocks launched one by one, never recorded)."""
+    for extra, env in ((['--collectives', 'group'], {}), ([], {'NW_GRAPH_COMM': '0'})):
+        e = dict(env, NW_BENCH_FORCE_DIST='1')
+        p = _run(['--gpus', '1', '--steps', '10', '--warmup', '5', '--scale', '0.05', '--mode', 'tiles', '--no-cpu-baseline'] + extra, timeout=800, extra_env=e)
+        assert p.returncode == 0, p.stderr[-3000:]
+        j = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+        assert j['rccl']['backend'] == 'nccl' and j['steps'] == 10 and j['value'] > 0
+        assert j['rccl']['collectives_issued_by'].startswith('the process group' if extra else 'the library')
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_two_ranks_started_by_the_drivers_launcher_print_one_json_line():
     """The driver's own command for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N --steps K --warmup W` (RANK / LOCAL_RANK / WORLD_SIZE come from the launcher; bench.py must not start

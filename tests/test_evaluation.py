@@ -139,8 +139,8 @@ def test_recipe_fit_left_to_converge(name, scale, floor):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('name,scale', [('c2', 1.0), ('c4', 0.02)])
-def test_recipe_fit_with_the_builtin_remesher(name, scale):
+@pytest.mark.parametrize('name,scale,limit', [('c2', 1.0, 9.0), ('c4', 0.02, 13.0)])
+def test_recipe_fit_with_the_builtin_remesher(name, scale, limit):
     """The recipe module's default fit -- 39 iterations, remeshed every 5 by this package's own remesher -- from the +20 nm start surface:
     39 iterations do not converge a fit that starts 20 nm off (C2: 8.1 nm, C4 x 0.02: 11.2 nm observed: reported, not thresholds -- see
     test_recipe_fit_left_to_converge for the statement about quality); what IS asserted: the metric falls well below the start's and the
@@ -154,6 +154,9 @@ def test_recipe_fit_with_the_builtin_remesher(name, scale):
     print(name, 'start', q0, 'fitted', q, 'vertices', mesh.vertices.shape[0])
     assert q0['mse_rms'] >= 20.0
     assert q['mse_rms'] <= 0.6 * q0['mse_rms']
+    # the absolute limits of round 3 stay beside the relative statement (without them a drift of the remesher would go unnoticed --
+    # C2 moved from 6.8 to 8.1 nm when the partitioned remesher and its rim rules came in; 8.1 / 11.2 nm observed since)
+    assert q['mse_rms'] <= limit, (name, q['mse_rms'], limit)
     assert len(mesh.block_log) == 7 and np.isfinite(mesh.vertices).all()
     # closed 2-manifold after seven remeshing passes: every edge shared by exactly two faces
     f = mesh.faces

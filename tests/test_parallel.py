@@ -849,3 +849,29 @@ def test_hip_executor_two_ranks_share_one_gpu(mode):
     rms = rel_rms(got, ref)
     print('HIP executor, 2 ranks on one GPU, mode %s: vertex RMS vs single-process nw_search %.3e' % (mode, rms))
     assert rms <= 1e-5
+
+
+def test_a_sharded_mesh_refuses_to_be_recut_after_every_block():
+    """cutting shares costs hundreds of blocks' worth of host time, and the recipe remeshes after every block -- a caller
+    that edits the mesh after each of three blocks in a row is told so (unless it insists)."""
+    from ch_shrinkwrap_amd.parallel import HaloScene
+    sc = object.__new__(HaloScene)
+    sc._blocks_total, sc.last_partition, sc.allow_recut_every_block = 0, 'p', False
+    sc.mesh_changed()                       # a new mesh before the first block: fine
+    sc._blocks_total += 1
+    sc.mesh_changed()
+    sc._blocks_total += 1
+    with pytest.raises(RuntimeError):
+        sc.mesh_changed()
+    # an edit now and then is what the mode is for
+    sc2 = object.__new__(HaloScene)
+    sc2._blocks_total, sc2.last_partition, sc2.allow_recut_every_block = 0, 'p', False
+    for _ in range(5):
+        sc2.mesh_changed()
+        sc2._blocks_total += 4
+    assert sc2.last_partition is None
+    sc3 = object.__new__(HaloScene)
+    sc3._blocks_total, sc3.last_partition, sc3.allow_recut_every_block = 0, 'p', True
+    for _ in range(5):
+        sc3.mesh_changed()
+        sc3._blocks_total += 1
