@@ -1043,10 +1043,10 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
         NW_HIP(ctx->valid.ensure(M));
         NW_HIP(hipMemsetAsync(cnt.p, 0, M * sizeof(int), ctx->stream));
         NW_HIP(hipMemsetAsync(ctx->d_small.p, 0, 8 * sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(k_ring_collect, dim3(nblk(3 * F)), dim3(NW_BLOCK), 0, ctx->stream, ctx->faces.p, (int)F, (int)M, n_nbr, cnt.p, pairs.p, ctx->d_small.p);
+        hipLaunchKernelGGL(k_ring_collect, dim3(nblk(3 * F)), dim3(NW_BLOCK), 0, ctx->stream, ctx->faces.p, (int)F, (int)M, n_nbr, cnt.p, pairs.p, ctx->d_small.p, (const int *)nullptr);
         DevBuf<unsigned char> vtmp;
         NW_HIP(vtmp.ensure(M));
-        hipLaunchKernelGGL(k_ring_order, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, (int)M, n_nbr, cnt.p, pairs.p, ctx->nbr.p, valid ? vtmp.p : ctx->valid.p);
+        hipLaunchKernelGGL(k_ring_order, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, (int)M, n_nbr, cnt.p, pairs.p, ctx->nbr.p, valid ? vtmp.p : ctx->valid.p, (int *)nullptr, (int *)nullptr);
         NW_HIP(hipGetLastError());
         int err[2] = {0, 0};
         NW_HIP(hipMemcpyAsync(err, ctx->d_small.p, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
@@ -2656,7 +2656,7 @@ NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nb
                            float *k0, float *k1, float *e0, float *e1, float *H, float *K, float *dH, float *dK, float *E, float *pE,
                            float *dE_neighbors, float *dEdN)
 {
-    if (!ctx || !nbr_next || !nbr_area) return NW_ERR_BADARG;
+    if (!ctx || ((nbr_next == nullptr) != (nbr_area == nullptr))) return NW_ERR_BADARG;
     if (!ctx->have_mesh) return fail(ctx, NW_ERR_BADARG, "nw_curvature: mesh not set");
     NW_HIP(hipSetDevice(ctx->device));
     const int64_t M = ctx->M;
@@ -2668,8 +2668,29 @@ NW_EXPORT int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nb
     std::string msg;
     do {
         if (d_next.ensure((size_t)M * NB) != hipSuccess || d_area.ensure((size_t)M * NB) != hipSuccess || d_out.ensure((size_t)18 * M) != hipSuccess) { rc = NW_ERR_NOMEM; break; }
-        if (hipMemcpyAsync(d_next.p, nbr_next, (size_t)M * NB * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
-        if (hipMemcpyAsync(d_area.p, nbr_area, (size_t)M * NB * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        if (nbr_next) {
+            if (hipMemcpyAsync(d_next.p, nbr_next, (size_t)M * NB * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+            if (hipMemcpyAsync(d_area.p, nbr_area, (size_t)M * NB * 4, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+        } else {
+            // Both tables from the faces and positions on the device (round 5; SURVEY 8 f1: the block boundary without host table builders): the
+            // ring walk of nw_set_mesh once more, this time keeping per slot the face's third corner and the face; then the faces' areas.  The
+            // ring order found here is the one of NW_ARR_NBR (same pairs, same start rule with the caller's half-edge ids), so the slots line up.
+            DevBuf<int> cnt, slot_face, ring_chk;
+            DevBuf<int4> pairs;
+            if (cnt.ensure(M) != hipSuccess || pairs.ensure((size_t)M * NB) != hipSuccess || slot_face.ensure((size_t)M * NB) != hipSuccess || ring_chk.ensure((size_t)M * NB) != hipSuccess ||
+                ctx->d_small.ensure(8) != hipSuccess) { rc = NW_ERR_NOMEM; break; }
+            if (hipMemsetAsync(cnt.p, 0, M * sizeof(int), ctx->stream) != hipSuccess || hipMemsetAsync(ctx->d_small.p, 0, 8 * sizeof(int), ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }
+            hipLaunchKernelGGL(k_ring_collect, dim3(nblk(3 * ctx->F)), dim3(NW_BLOCK), 0, ctx->stream, ctx->faces.p, (int)ctx->F, (int)M, NB, cnt.p, pairs.p, ctx->d_small.p,
+                               ctx->face_sorted ? ctx->face_orig.p : (const int *)nullptr);
+            hipLaunchKernelGGL(k_ring_order, dim3(nblk(M)), dim3(NW_BLOCK), 0, ctx->stream, (int)M, NB, cnt.p, pairs.p, ring_chk.p, (unsigned char *)nullptr, d_next.p, slot_face.p);
+            hipLaunchKernelGGL(k_slot_area, dim3(nblk((int64_t)M * NB)), dim3(NW_BLOCK), 0, ctx->stream, (int64_t)M * NB, slot_face.p, ctx->faces.p, ctx->meshpos.p, d_area.p);
+            // the slots must be those of the table the kernel walks (NW_ARR_NBR): a table the caller gave nw_set_mesh in another order cannot be paired
+            hipLaunchKernelGGL(k_count_mismatch, dim3(nblk((int64_t)M * NB)), dim3(NW_BLOCK), 0, ctx->stream, (int64_t)M * NB, ring_chk.p, ctx->nbr.p, ctx->d_small.p + 2);
+            int bad_slots = 0;
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&bad_slots, ctx->d_small.p + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }      // (the scratch buffers die with this scope)
+            if (bad_slots != 0) return fail(ctx, NW_ERR_BADARG, "nw_curvature: the 1-ring table given to nw_set_mesh does not follow the library's ring order -- pass nbr_next and nbr_area in that table's order");
+        }
         if (jitter) {
             if (d_jit.ensure((size_t)3 * M) != hipSuccess) { rc = NW_ERR_NOMEM; break; }
             if (hipMemcpyAsync(d_jit.p, jitter, (size_t)3 * M * 8, hipMemcpyDefault, ctx->stream) != hipSuccess) { rc = NW_ERR_HIP; break; }

@@ -243,7 +243,10 @@ __global__ __launch_bounds__(NW_BLOCK) void k_sample_nn(const float *__restrict_
 
 // 1-ring table from the faces array alone, pass 1: every face corner (a -> b, then c, counter-clockwise)
 // deposits {b, c, half-edge id 3f+k} in a slot of its vertex a.  err[0] counts vertices whose degree exceeds the table width.
-__global__ void k_ring_collect(const int *__restrict__ faces, int F, int M, int NB, int *__restrict__ cnt, int4 *__restrict__ pairs, int *__restrict__ err)
+// face_orig (may be NULL): the faces array is in the library's internal order (nw_set_mesh sorts it); the half-edge id that decides where a
+// fan starts is the CALLER's, 3 * face_orig[f] + k.  The fourth component keeps the internal face (its area: k_ring_order's face_out).
+__global__ void k_ring_collect(const int *__restrict__ faces, int F, int M, int NB, int *__restrict__ cnt, int4 *__restrict__ pairs, int *__restrict__ err,
+                               const int *__restrict__ face_orig)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * F) return;
@@ -251,7 +254,7 @@ __global__ void k_ring_collect(const int *__restrict__ faces, int F, int M, int 
     const int a = faces[3 * f + k], b = faces[3 * f + (k + 1) % 3], c = faces[3 * f + (k + 2) % 3];
     if ((unsigned)a >= (unsigned)M || (unsigned)b >= (unsigned)M || (unsigned)c >= (unsigned)M) { atomicAdd(err + 1, 1); return; }
     const int slot = atomicAdd(&cnt[a], 1);
-    if (slot < NB) pairs[(int64_t)a * NB + slot] = make_int4(b, c, i, 0);
+    if (slot < NB) pairs[(int64_t)a * NB + slot] = make_int4(b, c, face_orig ? 3 * face_orig[f] + k : i, f);
     else atomicAdd(err, 1);
 }
 
@@ -259,14 +262,17 @@ __global__ void k_ring_collect(const int *__restrict__ faces, int F, int M, int 
 // lowest-numbered outgoing half-edge -- for a boundary vertex at the outgoing half-edge that has no twin -- and walk
 // counter-clockwise (the neighbour after b is the third corner c of the face that holds a -> b) until the fan closes or ends.
 // Open fans list their outgoing half-edges only.  valid[a] = the vertex has at least one face.
-__global__ void k_ring_order(int M, int NB, const int *__restrict__ cnt, const int4 *__restrict__ pairs, int *__restrict__ nbr, unsigned char *__restrict__ valid)
+// next_out / face_out (may be NULL): per slot, the vertex the NEXT half-edge of the slot's half-edge a -> b points to (the face's third
+// corner) and the face itself -- what c_curvature_grad reads through the half-edge records (membrane_mesh_utils.c:1099-1104).
+__global__ void k_ring_order(int M, int NB, const int *__restrict__ cnt, const int4 *__restrict__ pairs, int *__restrict__ nbr, unsigned char *__restrict__ valid,
+                             int *__restrict__ next_out, int *__restrict__ face_out)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= M) return;
     const int n = min(cnt[a], NB);
     const int4 *P = pairs + (int64_t)a * NB;
     int *out = nbr + (int64_t)a * NB;
-    valid[a] = n > 0;
+    if (valid) valid[a] = n > 0;
     int start = -1, start_he = 0x7fffffff, bstart = -1, bstart_he = -1;
     for (int i = 0; i < n; ++i) {
         const int4 p = P[i];
@@ -279,13 +285,41 @@ __global__ void k_ring_order(int M, int NB, const int *__restrict__ cnt, const i
     int cur = start, s = 0;
     while (cur >= 0 && s < NB) {
         const int4 p = P[cur];
+        if (next_out) next_out[(int64_t)a * NB + s] = p.y;
+        if (face_out) face_out[(int64_t)a * NB + s] = p.w;
         out[s++] = p.x;
         int nxt = -1;
         for (int j = 0; j < n; ++j) if (P[j].x == p.y) { nxt = j; break; }
         if (nxt == start) break;
         cur = nxt;
     }
-    for (; s < NB; ++s) out[s] = -1;
+    for (; s < NB; ++s) {
+        out[s] = -1;
+        if (next_out) next_out[(int64_t)a * NB + s] = -1;
+        if (face_out) face_out[(int64_t)a * NB + s] = -1;
+    }
+}
+
+// area of the face behind every ring slot: 0.5 |(p1 - p0) x (p2 - p0)| with the corners in the face's own order, every float32 operation
+// rounded on its own -- trimesh.TriMesh.update_geometry / nwr_mesh_geometry step for step, so the table equals the host substrate's bit for bit
+__global__ void k_slot_area(int64_t n_slots, const int *__restrict__ slot_face, const int *__restrict__ faces, const float *__restrict__ pos, float *__restrict__ area)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const int f = slot_face[i];
+    if (f < 0) { area[i] = 0.0f; return; }
+    const int v0 = faces[3 * f], v1 = faces[3 * f + 1], v2 = faces[3 * f + 2];
+    const float a0 = pos[3 * v1] - pos[3 * v0], a1 = pos[3 * v1 + 1] - pos[3 * v0 + 1], a2 = pos[3 * v1 + 2] - pos[3 * v0 + 2];
+    const float b0 = pos[3 * v2] - pos[3 * v0], b1 = pos[3 * v2 + 1] - pos[3 * v0 + 1], b2 = pos[3 * v2 + 2] - pos[3 * v0 + 2];
+    const float c0 = a1 * b2 - a2 * b1, c1 = a2 * b0 - a0 * b2, c2 = a0 * b1 - a1 * b0;      // (-ffp-contract=off: products rounded before the difference)
+    const float n = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
+    area[i] = 0.5f * n;
+}
+
+__global__ void k_count_mismatch(int64_t n, const int *__restrict__ a, const int *__restrict__ b, int *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != b[i]) atomicAdd(out, 1);
 }
 
 // neighbour table (M, NB) row-major -> slot-major ELL nbr_t[s*M + v] (coalesced over vertices) + max degree

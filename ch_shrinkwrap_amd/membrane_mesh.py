@@ -15,6 +15,7 @@ For `remesh` this package ships its own implementation of the published algorith
 csrc/remesh.cpp); when no hook is installed the topology is held fixed and that is logged once.  The numerical path of every block is the HIP library; there is no CPU fallback.
 """
 import math
+import os
 import numpy as np
 
 from .trimesh import TriMesh
@@ -72,7 +73,8 @@ class MembraneMesh(TriMesh):
     def _topology_changed(self, vertices, faces):
         """Rebuild the half-edge tables for a new (vertices, faces) pair; the optimiser of the old topology is dropped."""
         props, vprops = self.vertex_properties, self.vertex_vector_properties
-        TriMesh.__init__(self, vertices, faces)
+        # (inside a fit the vertex normals of a new topology are the device's to compute: nw_set_mesh with nrm = NULL)
+        TriMesh.__init__(self, vertices, faces, vertex_normals=not getattr(self, '_in_fit', False))
         self.vertex_properties, self.vertex_vector_properties = props, vprops
         self._initialize_curvature_vectors()
 
@@ -140,17 +142,25 @@ class MembraneMesh(TriMesh):
             self._native = NativeContext(self._device)
         nat = self._native
         M = self._vertices.shape[0]
-        pos = np.ascontiguousarray(self._vertices['position'], 'f4')
-        nrm = np.ascontiguousarray(self.vertex_normals, 'f4')
-        nbr = self.neighbor_vertex_table()
-        valid = np.ascontiguousarray(self._vertices['halfedge'] != -1, 'u1')
-        if skip_prob > 0:                                   # `(halfedge == -1) || (r2() < skip_prob)`: float32 draw against the float32 argument
-            u = np.random.default_rng(0).random(M) if skip_u is None else np.asarray(skip_u)
-            valid = np.ascontiguousarray(valid & ~(u.astype(np.float32) < np.float32(skip_prob)), 'u1')
-        faces = np.ascontiguousarray(self.faces, 'i4')
-        nat.check(nat.L.nw_set_mesh(nat.h, nw.ptr(pos), nw.ptr(nrm), nw.ptr(nbr), nw.ptr(valid), nw.ptr(faces), M, faces.shape[0], nbr.shape[1]))
-        nat.mesh_key = None                                 # uploaded outside an optimiser: do not assume it is reusable
-        nxt, area = self._neighbor_tables()
+        host_tables = os.environ.get('NW_HOST_TABLES', '0') == '1'
+        key = getattr(nat, 'mesh_key', None)
+        if skip_prob == 0 and not host_tables and key is not None and key[0] == id(self) and key[1] == M and key[2] == int(self.faces.shape[0]):
+            # the block that has just ended left THIS mesh on the device -- positions of its last iteration, normals refreshed there
+            # (_block_boundary): nothing is uploaded, and the kernel's two tables are built on the device as well (nw_curvature with NULL
+            # tables, round 5) -- the block boundary's neck selection runs without a host table builder
+            nxt, area = None, None
+        else:
+            pos = np.ascontiguousarray(self._vertices['position'], 'f4')
+            nrm = np.ascontiguousarray(self.vertex_normals, 'f4')
+            nbr = self.neighbor_vertex_table()
+            valid = np.ascontiguousarray(self._vertices['halfedge'] != -1, 'u1')
+            if skip_prob > 0:                               # `(halfedge == -1) || (r2() < skip_prob)`: float32 draw against the float32 argument
+                u = np.random.default_rng(0).random(M) if skip_u is None else np.asarray(skip_u)
+                valid = np.ascontiguousarray(valid & ~(u.astype(np.float32) < np.float32(skip_prob)), 'u1')
+            faces = np.ascontiguousarray(self.faces, 'i4')
+            nat.check(nat.L.nw_set_mesh(nat.h, nw.ptr(pos), nw.ptr(nrm), nw.ptr(nbr), nw.ptr(valid), nw.ptr(faces), M, faces.shape[0], nbr.shape[1]))
+            nat.mesh_key = None                             # uploaded outside an optimiser: do not assume it is reusable
+            nxt, area = self._neighbor_tables() if host_tables else (None, None)      # (the substrate's ring order is the library's: the tables can be built there)
         jit = None if jitter is None else np.ascontiguousarray(jitter, 'f8')
         self._initialize_curvature_vectors()
         dEdN = np.zeros((M, 3), 'f4')
@@ -275,12 +285,20 @@ class MembraneMesh(TriMesh):
         self._host_mesh_changed()
         self.cg = None
         done = 0
+        self._in_fit = True
+        try:
+            return self._run_blocks(points, lams, s, weights, plan)
+        finally:
+            self._in_fit = False
+
+    def _run_blocks(self, points, lams, s, weights, plan):
+        done = 0
         while done < plan.n_iter:
             # a new optimiser per block (:1510-1512).  The localizations stay resident in HBM; while nothing touched the host mesh
             # the device copy is current (positions written by the last block, normals refreshed on the device) and only the
             # optimiser's history restarts
             self.cg = ShrinkwrapMeshConjGrad(self, points, search_k=self.search_k, search_rad=self.search_rad,
-                                             shield_sigma=self._mean_edge_length / 2.0, native=self._native, reuse_device_mesh=True)
+                                             shield_sigma=self._mean_edge_length / 2.0, native=self._native, reuse_device_mesh=True, device_tables=True)
             n = min(plan.n_iter - done, plan.block)
             self.cg.search(points, lams=lams, num_iters=n, sigma_inv=s, weights=weights)                  # :1516-1517
             done += n

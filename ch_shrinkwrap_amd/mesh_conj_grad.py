@@ -72,7 +72,7 @@ class ShrinkwrapMeshConjGrad(object):
     """MI355X-native counterpart of ch_shrinkwrap.mesh_conj_grad.ShrinkwrapMeshConjGrad (mesh_conj_grad.py:20)."""
 
     def __init__(self, mesh, points, sigma=None, search_k=200, search_rad=100, shield_sigma=None, use_octree=False,
-                 device=0, native=None, stream=None, reuse_device_mesh=False):
+                 device=0, native=None, stream=None, reuse_device_mesh=False, device_tables=False):
         # TikhonovConjugateGradient.__init__ (conj_grad.py:35-43)
         self.tests, self.ress, self.prefs = [], [], []
         self.Lfuncs, self.Lhfuncs = ["I"], ["I"]            # mesh_conj_grad.py:38
@@ -96,19 +96,20 @@ class ShrinkwrapMeshConjGrad(object):
         self.dims = self._vertices_view.shape[1]
         self.shape = self._vertices_view.shape
         self.faces = mesh.faces                                                        # :47
-        if hasattr(mesh, 'neighbor_vertex_table'):                                     # :50-54 (native table builder of the substrate)
-            self.vertex_neighbors = mesh.neighbor_vertex_table()
-        else:
-            n = mesh._halfedges['vertex'][mesh._vertices['neighbors']]
-            n[mesh._vertices['neighbors'] == -1] = -1
-            self.vertex_neighbors = np.ascontiguousarray(n, dtype=np.int32)
-        self.N = self.vertex_neighbors.shape[1]
+        # device_tables (the driver's block loop, membrane_mesh.MembraneMesh): the library builds the 1-ring table and the vertex normals
+        # itself from faces and positions (nw_set_mesh with nbr = nrm = NULL; the same ring order as the host substrate's) -- no table is
+        # built or uploaded here; `vertex_neighbors` is then made on first use
+        self._device_tables = bool(device_tables) and getattr(mesh, '_accepts_deferred_rows', False) and os.environ.get('NW_HOST_TABLES', '0') != '1'
+        self._vertex_neighbors = None
+        if not self._device_tables:
+            self._vertex_neighbors = self._host_ring_table()                           # :50-54
+        self.N = int(mesh._vertices['neighbors'].shape[1])
 
         self._native = native if native is not None else NativeContext(device, stream)
         self._L = self._native.L
         self._h = self._native.h
         self.points = points
-        topo = (id(mesh), self.M, int(np.asarray(self.faces).shape[0]), self.vertex_neighbors.shape[1])
+        topo = (id(mesh), self.M, int(np.asarray(self.faces).shape[0]), self.N)
         if reuse_device_mesh and getattr(self._native, 'mesh_key', None) == topo:
             # same mesh object, same topology, positions/normals already current on the device (refresh_normals()):
             # a new optimiser only restarts the logs and the stop-condition history
@@ -123,11 +124,32 @@ class ShrinkwrapMeshConjGrad(object):
         self.mask = None
 
     # -- uploads ------------------------------------------------------------------------------
+    def _host_ring_table(self):
+        mesh = self.mesh
+        if hasattr(mesh, 'neighbor_vertex_table'):                                     # (native table builder of the substrate)
+            return mesh.neighbor_vertex_table()
+        n = mesh._halfedges['vertex'][mesh._vertices['neighbors']]
+        n[mesh._vertices['neighbors'] == -1] = -1
+        return np.ascontiguousarray(n, dtype=np.int32)
+
+    @property
+    def vertex_neighbors(self):
+        if self._vertex_neighbors is None:
+            self._vertex_neighbors = self._host_ring_table()
+        return self._vertex_neighbors
+
+    @vertex_neighbors.setter
+    def vertex_neighbors(self, table):
+        self._vertex_neighbors = table
+
     def _upload_mesh(self):
         pos = _as_f32(self.mesh._vertices['position'])
-        nrm = _as_f32(self.mesh.vertex_normals)
         faces = np.ascontiguousarray(self.faces, dtype=np.int32)
         valid = np.ascontiguousarray(self._mesh_vertex_mask, dtype=np.uint8)
+        if self._device_tables:
+            self._native.check(self._L.nw_set_mesh(self._h, nw.ptr(pos), None, None, nw.ptr(valid), nw.ptr(faces), pos.shape[0], faces.shape[0], self.N))
+            return
+        nrm = _as_f32(self.mesh.vertex_normals)
         self._native.check(self._L.nw_set_mesh(self._h, nw.ptr(pos), nw.ptr(nrm), nw.ptr(self.vertex_neighbors), nw.ptr(valid),
                                                nw.ptr(faces), pos.shape[0], faces.shape[0], self.vertex_neighbors.shape[1]))
 
@@ -436,6 +458,8 @@ class ShrinkwrapMeshConjGrad(object):
         nrm = np.empty((self.M, 3), np.float32)
         self._native.check(self._L.nw_refresh_normals(self._h, nw.ptr(nrm), 0.0))
         self.mesh._vertices['normal'][:] = nrm
+        if hasattr(self.mesh, '_normals_stale'):
+            self.mesh._normals_stale = False
         return nrm
 
     # -- timing hooks for bench.py ------------------------------------------------------------------

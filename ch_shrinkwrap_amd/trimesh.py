@@ -181,7 +181,7 @@ class TriMesh(object):
             pending()
         self.__dict__['_vertex_records'] = records
 
-    def __init__(self, vertices, faces, max_vertices=None):
+    def __init__(self, vertices, faces, max_vertices=None, vertex_normals=True):
         vertices = np.ascontiguousarray(vertices, dtype='f4')
         faces = np.ascontiguousarray(faces, dtype='i4')
         M = vertices.shape[0] if max_vertices is None else int(max_vertices)
@@ -197,7 +197,10 @@ class TriMesh(object):
         if not self._build_topology_native(faces):
             self._halfedges, self._origin = _build_halfedges(faces, M)
             self._build_rings()
-        self.update_geometry()
+        # vertex_normals=False (the driver's block loop): the device computes them with the next upload and hands them back after the block;
+        # whoever asks before that gets them computed here, on first use (`vertex_normals`)
+        self._normals_stale = not vertex_normals
+        self.update_geometry(vertex_normals=vertex_normals)
         self.cg = None
         self.vertex_properties = []
         self.vertex_vector_properties = []
@@ -306,6 +309,9 @@ class TriMesh(object):
 
     @property
     def vertex_normals(self):
+        if self.__dict__.get('_normals_stale', False):
+            self._normals_stale = False
+            self.update_geometry(vertex_normals=True)
         return self._vertices['normal']
 
     @property

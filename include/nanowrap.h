@@ -294,7 +294,10 @@ int nw_lfunc(nw_ctx *ctx, int kind, const float *x, const float *f0, float *out)
  * what the caller's arrays held.  Works on the ctx's CURRENT device-resident mesh positions, the
  * normals of nw_set_mesh / nw_refresh_normals and the neighbour table of nw_set_mesh (walk stops at the first -1, as the
  * reference's does).  nbr_next (M,NB) i32 = halfedges[halfedges[neighbors[j]].next].vertex, nbr_area (M,NB) f32 =
- * faces[halfedges[neighbors[j]].face].area.  jitter: (M,3) float64 in [0,1) standing for the reference's rand() stream
+ * faces[halfedges[neighbors[j]].face].area; BOTH NULL (round 5): the library builds the two tables itself from its faces and current
+ * positions (the ring walk of nw_set_mesh keeping the face's third corner and the face; areas 0.5 |(p1 - p0) x (p2 - p0)| in float32, every
+ * operation rounded on its own: bit for bit what trimesh.TriMesh / nwr_mesh_geometry hold) -- valid when the 1-ring table follows the
+ * library's ring order (built by nw_set_mesh(nbr = NULL), or by the host substrate, whose order is the same); any other order is refused.  jitter: (M,3) float64 in [0,1) standing for the reference's rand() stream
  * (:1017), or NULL for a deterministic hash of (vertex, axis).  Outputs (host or device): k0,k1,H,K,dH,dK,E,pE,
  * dE_neighbors (M) f32; e0,e1,dEdN (M,3) f32; any output pointer may be NULL. */
 int nw_curvature(nw_ctx *ctx, const int32_t *nbr_next, const float *nbr_area, const double *jitter,

@@ -125,3 +125,59 @@ print('CRC', zlib.crc32(np.ascontiguousarray(out).tobytes()), float(np.abs(out).
         assert r.returncode == 0, r.stderr[-2000:]
         crcs.append([l for l in r.stdout.splitlines() if l.startswith('CRC')][-1])
     assert crcs[0] == crcs[1], crcs
+
+
+def test_curvature_tables_built_on_the_device_equal_the_host_substrates(monkeypatch):
+    """nw_curvature with NULL tables builds nbr_next / nbr_area from the faces and positions on the device: every one of the twelve outputs
+    must equal, bit for bit, the call with the tables the host substrate builds (remesh.ring_tables) -- on a closed mesh, on a mesh with a
+    boundary (open fans) and with unused vertex slots; and the fast path of the block boundary (nothing uploaded: the block left the mesh
+    on the device) must give what a fresh upload of the same mesh gives."""
+    from ch_shrinkwrap_amd import membrane_mesh as mm
+    from ch_shrinkwrap_amd.trimesh import icosphere
+    from ch_shrinkwrap_amd.synth import sphere_cloud
+    names = ('_k_0', '_k_1', '_e_0', '_e_1', '_H', '_K', '_dH', '_dK', '_E', '_pE', '_dE_neighbors')
+    v, f = icosphere(4, 100.0)
+    v = (v * (1.0 + 0.05 * np.sin(v[:, :1] * 0.07))).astype('f4')
+    open_f = f[: f.shape[0] // 2]                                     # half a sphere: a boundary loop
+    for faces in (f, open_f):
+        out = {}
+        for host in ('1', '0'):
+            monkeypatch.setenv('NW_HOST_TABLES', host)
+            m = mm.MembraneMesh(v.copy(), faces, kc=1.0)
+            d = m.curvature_grad_c(dN=0.1)
+            out[host] = [d.copy()] + [getattr(m, n).copy() for n in names]
+        for a, b in zip(out['1'], out['0']):
+            assert np.array_equal(a, b, equal_nan=True)
+    # the block boundary's fast path
+    monkeypatch.setenv('NW_HOST_TABLES', '0')
+    pts = sphere_cloud(20000, 100.0, 5.0, seed=2)
+    m = mm.MembraneMesh(v.copy(), f, kc=1.0, step_size=20.0, max_iter=5, remesh_frequency=0, delaunay_remesh_frequency=0)
+    m.shrink_wrap(pts, np.full(pts.shape, 5.0, 'f4'))
+    assert m._native.mesh_key is not None and m._native.mesh_key[0] == id(m)
+    d_fast = m.curvature_grad_c(dN=0.1)
+    fast = [d_fast.copy()] + [getattr(m, n).copy() for n in names]
+    m._native.mesh_key = None                                         # forget that the device holds it: a fresh upload of positions and normals
+    d_up = m.curvature_grad_c(dN=0.1)
+    up = [d_up.copy()] + [getattr(m, n).copy() for n in names]
+    for a, b in zip(fast, up):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_driver_with_device_built_tables_follows_the_host_tables_fit(monkeypatch):
+    """The driver's block loop lets the library build the 1-ring table and the vertex normals (nw_set_mesh with nbr = nrm = NULL).  The ring
+    table is the host substrate's bit for bit (test_hip_parity); the normals are the device's fixed-point sums instead of the host's
+    float64 ones -- the same vectors to ~1e-7 --, so two 3-block fits stay within 1e-5 of the bounding box of each other."""
+    from conftest import rel_rms
+    from ch_shrinkwrap_amd import membrane_mesh as mm, synth
+    c = synth.make_config('c2', scale=0.1, seed=5)
+    res = {}
+    for host in ('1', '0'):
+        monkeypatch.setenv('NW_HOST_TABLES', host)
+        m = mm.MembraneMesh(c['vertices'].copy(), c['faces'], kc=1.0, step_size=20.0, max_iter=15, remesh_frequency=5, delaunay_remesh_frequency=0)
+        m.remesher = None
+        m._warned_fixed_topology = True
+        m.shrink_wrap(c['points'], c['sigma'])
+        res[host] = m.vertices.copy()
+        if host == '0':
+            assert m.cg._device_tables and m.cg._vertex_neighbors is None            # no host table was built for the optimiser
+    assert rel_rms(res['0'], res['1']) <= 1e-5
