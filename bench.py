@@ -42,12 +42,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 BLOCK = 5               # remesh_frequency of the headline config
-PMC_FILE = 'r04_pmc_traffic.json'     # PMC passes of the headline workload (tools/profile_round.sh), committed under profiles/
+PMC_FILE = 'r05_pmc_traffic.json'     # PMC passes of the headline workload (tools/profile_round.sh), committed under profiles/
 
 
-def algorithmic_bytes(N, M, F):
+def algorithmic_bytes(N, M, F, attract_in_query=False):
     """Compulsory traffic per ITERATION and per kernel, from the itemised list in SURVEY.md section 8(d)
-    (4-byte elements, each named array read/written once per stage)."""
+    (4-byte elements, each named array read/written once per stage).  attract_in_query: the launch of k_nn_wave as the timed region runs it
+    since round 5 -- the query's workgroups, then the ring half of the prior, then the attraction step of the same work items (workgroups
+    appended to the grid): its bytes are the three stages' together."""
     per_kernel = {
         # NN query 12 r + 8 w per point; candidate reads >= 12 per face; + the ring half of _ncc, which rides in this launch since
         # round 5 (workgroups appended to its grid): adjacency 24 + 4, neighbour positions 12, neighbour normals 12 per vertex
@@ -63,6 +65,8 @@ def algorithmic_bytes(N, M, F):
         # centroid input 12 per vertex; index read 12 + centroid write 12 + grid build 12 + 8 per face
         'grid_build': 12 * M + 44 * F,
     }
+    if attract_in_query:
+        per_kernel['k_nn_wave'] += per_kernel['k_attract']
     return per_kernel, 436 * N + 348 * M + 68 * F      # SURVEY.md section 8(d) total used by builder and judge
 
 
@@ -357,6 +361,10 @@ def run_rank(args):
         fence()
         dt_graph = time.perf_counter() - tg
     set_profiling(2)
+    # per-stage timings: every stage a launch of its own (in the timed region the attraction step rides in the query launch: nw_debug what = 3)
+    fused_query = not multi or native_comm
+    if hasattr(cg_of(), 'separate_attraction'):
+        cg_of().separate_attraction(True)
     ctimer = None
     if multi and not native_comm:
         ctimer = parallel.CollectiveTimer()          # device time inside the collectives of the extra iterations
@@ -396,6 +404,7 @@ def run_rank(args):
         else:
             Nl, Ml, Fl = N, M, F
         per_kernel, per_iter = algorithmic_bytes(Nl, Ml, Fl)
+        per_kernel_timed, _ = algorithmic_bytes(Nl, Ml, Fl, attract_in_query=os.environ.get('NW_ATTRACT_IN_NN', '1') != '0')
         # dominant kernel by device time, from HIP events recorded around each launch on the library's stream
         kern = {'nn': 'k_nn_wave', 'attract': 'k_attract', 'as': 'k_subspace_point_sums', 'prior': 'k_prior_directions',
                 'update': 'k_solve_update'}          # single-kernel stages (grid build and the NN fix-up are reported in stage_ms_per_iter)
@@ -405,7 +414,8 @@ def run_rank(args):
         else:
             ms_tot, launches = stage[dom]                    # (extra pass: the NN query is no longer the dominant kernel)
         avg_ms = ms_tot / max(launches, 1)
-        achieved = per_kernel[kern[dom]] / (avg_ms * 1e-3) / 1e9
+        dom_bytes = per_kernel_timed[kern[dom]] if (dom == 'nn' and nn_launches > 0) else per_kernel[kern[dom]]
+        achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', PMC_FILE)     # NOT measured by this run
         if os.path.exists(tfile) and args.config == 'c3' and args.scale == 1.0 and world == 1:
@@ -448,13 +458,15 @@ def run_rank(args):
             'roofline': {'bound': 'hbm', 'kernel': kern[dom], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': ('profiles/%s (rocprofv3 --pmc passes of this workload, committed; not re-measured by this run)' % PMC_FILE if traffic is not None else None),
-                         'algorithmic_bytes_per_launch': per_kernel[kern[dom]], 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'launch_holds': ('the nearest-face query, the ring half of the curvature prior (1-ring gathers) and -- behind a warm query -- the attraction step of the same work items: workgroups appended to k_nn_wave\'s grid run in the query\'s drain (round 5); algorithmic bytes = the three stages\' (SURVEY 8d items)' if dom == 'nn' else None),
                          'launches_note': 'HIP events on the library stream around the k_nn_wave launch of the last iteration of every block of %d of the timed region (that iteration is launched from the host while the replayed hipGraph of the block\'s other iterations is still running)' % BLOCK,
                          'measured_copy_peak': measured_copy_ceiling(torch)},
             'roofline_iteration': {'algorithmic_bytes': per_iter, 'device_ms': stage['total'][0] / n_extra,
                                    'achieved': per_iter / (stage['total'][0] / n_extra * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
                                    'unit': 'GB/s', 'note': 'sum of per-stage HIP-event spans of %d extra iterations run after the timed region%s' % (n_extra, ' (rank 0, its share)' if world > 1 else '')},
             'stage_ms_per_iter': {k: stage[k][0] / n_extra for k in stage},
+            'stage_ms_note': 'HIP-event spans of %d extra iterations behind the timed region with EVERY stage a launch of its own (nw_debug what = 3); in the timed region the attraction step rides in the query launch, whose live average is roofline.avg_launch_ms' % n_extra,
             'nn_max_ring': cg_of().nn_max_ring, 'mean_dist_nm': cg_of().mean_dist,
         }
         out['roofline_iteration']['frac'] = out['roofline_iteration']['achieved'] / HBM_PEAK_GBS
@@ -484,7 +496,25 @@ def run_rank(args):
         ca_ms = sum(stage[k][0] for k in ca) / n_extra
         out['roofline_attraction_curvature'] = {'kernels': [kern[k] for k in ca], 'algorithmic_bytes': ca_bytes, 'device_ms': ca_ms,
                                                 'achieved': ca_bytes / (ca_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                                'frac': ca_bytes / (ca_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                                'frac': ca_bytes / (ca_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                'note': 'SURVEY 8d algorithmic bytes (the unfused itemisation both builder and judge use) over the four kernels\' HIP-event spans as launches of their own; frac_physical = the same spans against the bytes the PMC counters saw (file-sourced)'}
+        # what the counters say these four kernels really move (committed PMC passes; lower bound = FETCH_SIZE + WRITE_SIZE, see the file's _bounds)
+        if os.path.exists(tfile) and args.config == 'c3' and args.scale == 1.0 and world == 1:
+            try:
+                pj = json.load(open(tfile))
+                phys = sum(pj[kern[k]] for k in ca)
+                out['roofline_attraction_curvature'].update({'traffic': phys, 'traffic_upper': sum(pj['_bounds'][kern[k]][1] for k in ca),
+                                                             'frac_physical': phys / (ca_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                             'traffic_source': 'profiles/%s (not re-measured by this run)' % PMC_FILE,
+                                                             'wait_share': {kern[k]: pj.get('_wait_share', {}).get(kern[k]) for k in ca}})
+            except Exception:
+                pass
+        # the iteration as the timed region runs it: the query launch holds the attraction step (live average) -- the per-stage sum minus the
+        # two stages it replaces
+        if nn_launches > 0 and stage['attract'][1] > 0:
+            fused = stage['total'][0] / n_extra - stage['nn'][0] / max(stage['nn'][1], 1) - stage['attract'][0] / max(stage['attract'][1], 1) + nn_ms / nn_launches
+            out['roofline_iteration']['device_ms_fused_query'] = fused
+            out['roofline_iteration']['frac_fused_query'] = per_iter / (fused * 1e-3) / 1e9 / HBM_PEAK_GBS
         # The dominant kernel is not an HBM kernel (25 MB algorithmic per launch): it is bound by VALU instruction issue.  VALU
         # wave-instructions per launch from the committed SQ_INSTS_VALU pass (tools/profile_round.sh; file-sourced like `traffic`),
         # against two peaks: the guide's 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction, and the ~4.1 cycles per

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NW_LIB_PATH') or os.path.join(HERE, 'libnanowrap_hip.so')      # (NW_LIB_PATH: developer knob, A/B of two builds on one box)
 
 NW_OK = 0
-NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM, NW_ERR_INTERNAL, NW_ERR_REMOTE = -1, -2, -3, -4, -5, -6, -7, -8
+NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM, NW_ERR_INTERNAL, NW_ERR_REMOTE, NW_ERR_HANDOFF = -1, -2, -3, -4, -5, -6, -7, -8, -9
 NW_WEIGHTS_FROM_SIGMA_INV, NW_WEIGHTS_SCALAR, NW_WEIGHTS_ARRAY, NW_WEIGHTS_PRENORMALIZED = 0, 1, 2, 3
 NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP, NW_FLAG_WFUNC, NW_FLAG_RESULT_TO_HOST = 1, 2, 4, 8
 NW_FLAG_COMM_TILES, NW_FLAG_COMM_REPLICATED, NW_FLAG_COMM_HALO = 16, 32, 64

@@ -58,7 +58,7 @@ def build_hip_library(force=False, verbose=False):
 LLVM_BIN = os.environ.get('NW_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
 KERNEL_BUDGETS = {
     # kernel (demangled prefix)       VGPRs  LDS
-    'k_nn_wave<false>':               (80, 8 * 1024),      # 6 waves per SIMD (amdgpu_waves_per_eu(6,8)); wave-private lists in LDS
+    'k_nn_wave<false>':               (80, 10 * 1024),     # 6 waves per SIMD (amdgpu_waves_per_eu(6,8)): 12 workgroups of 128 per CU; LDS = the larger of the query's wave-private lists and the appended attraction workgroups' table (9.4 KB)
     'k_attract':                      (72, 20 * 1024),     # 7 workgroups per CU (the run sums keep 24 more registers alive; LDS-pipe-bound: 7 or 8 is the same), 18 KB of LDS each
     'k_face_centroids':               (64, 8 * 1024),
     'k_centroid_scatter':             (64, 0),

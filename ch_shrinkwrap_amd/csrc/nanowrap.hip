@@ -291,6 +291,9 @@ struct nw_ctx {
     bool have_data = false;
     DevBuf<NwItem> items;             // work list of the NN query: runs of <= 64 Morton-consecutive localizations
     DevBuf<unsigned> item_cost;       // measured duration of every item in the last query (until the list has been ordered by it)
+    bool handoff_off = false;         // NW_ERR_HANDOFF was raised once: the attraction step stays a launch of its own
+    DevBuf<int> query_serial;         // number of grid builds so far (k_face_centroids): the value a finished item's word takes
+    DevBuf<int> item_done;            // per work item: the number of the last iteration whose query has left it (the attraction workgroups of the same launch poll it)
     bool items_by_cost = false;       // the list has been ordered longest-first (once per work list)
     bool item_cost_valid = false;     // a warm query has filled item_cost for the current list
     int nitems = 0;
@@ -500,6 +503,24 @@ double desired_cell(const nw_ctx *ctx, double mean_dist, double spacing)
 // ---- work list of the NN query ---------------------------------------------------------------------------
 // Items = runs of <= 64 consecutive localizations of the Morton-sorted list that stay inside one aligned Morton block of edge
 // morton_unit * 2^level (about four cells): a dense block is cut into equal runs, a sparse one is a single under-filled wave.
+// per-item words of the in-launch hand-off query -> attraction step (zero = no iteration yet), and rows of partial sums for as many
+// attraction workgroups as the query has workgroups
+int ensure_item_done(nw_ctx *ctx)
+{
+    const size_t want = (size_t)std::max(ctx->nitems, 1) + 256;
+    if (!ctx->query_serial.p) {
+        NW_HIP(ctx->query_serial.ensure(1));
+        NW_HIP(hipMemsetAsync(ctx->query_serial.p, 0, sizeof(int), ctx->stream));
+    }
+    if (ctx->item_done.n < want) {
+        NW_HIP(ctx->item_done.ensure(2 * want));
+        NW_HIP(hipMemsetAsync(ctx->item_done.p, 0, 2 * want * sizeof(int), ctx->stream));
+    }
+    const size_t rows = (size_t)(ctx->nitems / 2 + 8 * 16 + 8);         // >= the query's workgroups for 128-thread workgroups (nn_workgroups)
+    if (ctx->part_a.n < 5 * rows) NW_HIP(ctx->part_a.ensure(5 * rows));
+    return NW_OK;
+}
+
 int build_items(nw_ctx *ctx, int level)
 {
     const int64_t N = ctx->N;
@@ -531,6 +552,7 @@ int build_items(nw_ctx *ctx, int level)
     ctx->item_level = level;
     NW_HIP(ctx->item_cost.ensure((size_t)2 * nitems));        // (second half: start times, developer aid NW_ITEM_TIMES)
     NW_HIP(hipMemsetAsync(ctx->item_cost.p, 0, (size_t)2 * nitems * sizeof(unsigned), ctx->stream));
+    NW_TRY(ensure_item_done(ctx));
     ctx->items_by_cost = false; ctx->item_cost_valid = false;
     if (getenv("NW_VERBOSE"))
         fprintf(stderr, "[nanowrap] work list: Morton level %d (block %.2f), %d blocks, %d items (%.1f localizations per wave)\n", level,
@@ -1393,7 +1415,7 @@ static int resort_by_projection(nw_ctx *ctx)
 }
 
 enum { QP_GRID = 1, QP_NN = 2, QP_FIXUP = 4, QP_ATTRACT = 8, QP_ALL = 15 };     // parts of the first half of an iteration
-static int launch_query(nw_ctx *ctx, int it, int parts = QP_GRID | QP_NN | QP_FIXUP, bool with_ring = false);
+static int launch_query(nw_ctx *ctx, int it, int parts = QP_GRID | QP_NN | QP_FIXUP, bool with_ring = false, bool with_attract = false, bool *attract_rode = nullptr);
 static NwAttractArgs attract_args(const nw_ctx *ctx);
 static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head = false);
 // Cell-size tuner, once per localization cloud.  The query is exact for every cell size, and its cost depends on more than the rule
@@ -1512,6 +1534,7 @@ static int order_items_by_cost(nw_ctx *ctx)
     NW_HIP(ctx->item_cost.ensure((size_t)2 * m));
     NW_HIP(hipStreamSynchronize(ctx->stream));
     ctx->nitems = m;
+    NW_TRY(ensure_item_done(ctx));
     ctx->items_by_cost = true;
     if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] work list: heavy items first%s: %d -> %d items\n", split ? ", heavy items cut" : "", n, m);
     return NW_OK;
@@ -1642,8 +1665,21 @@ static NwRingArgs ring_args(const nw_ctx *ctx)
     return r;
 }
 
-static int launch_query(nw_ctx *ctx, int it, int parts, bool with_ring)
+// the attraction step rides in the query launch too (one workgroup per workgroup of the query, appended behind the ring workgroups: they fill
+// the launch's drain); NW_ATTRACT_IN_NN=0 (developer knob): k_attract as a launch of its own behind the query
+static bool attract_in_nn() { static const bool on = !(getenv("NW_ATTRACT_IN_NN") && atoi(getenv("NW_ATTRACT_IN_NN")) == 0); return on; }
+static int nn_workgroups(const nw_ctx *ctx, int *tb_out = nullptr)
 {
+    static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;
+    static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
+    const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;
+    if (tb_out) *tb_out = tb;
+    return nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
+}
+
+static int launch_query(nw_ctx *ctx, int it, int parts, bool with_ring, bool with_attract, bool *attract_rode)
+{
+    if (attract_rode) *attract_rode = false;
     const int64_t F = ctx->F;
     const NwGrid g = ctx->grid;
     if (parts & QP_GRID) {
@@ -1651,7 +1687,7 @@ static int launch_query(nw_ctx *ctx, int it, int parts, bool with_ring)
         static const bool tile_fuse = !(getenv("NW_TILE_FUSE") && atoi(getenv("NW_TILE_FUSE")) == 0);      // developer knob: 0 = the scan's own first pass
         int *tiles = tile_fuse ? ctx->ctile.p : nullptr;
         hipLaunchKernelGGL(k_face_centroids, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, g, ctx->pos.p, ctx->faces.p, (int)F,
-                           ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->ccount.p, tiles, ctx->ambig_count.p, ctx->state.p, it);
+                           ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->ccount.p, tiles, ctx->ambig_count.p, ctx->state.p, it, ctx->query_serial.p);
         NW_TRY(scan_exclusive(ctx, ctx->ccount.p, g.ncell, ctx->cstart.p, true, tiles));      // also re-zeroes the histogram
         hipLaunchKernelGGL(k_centroid_scatter, dim3(nblk(F)), dim3(NW_BLOCK), 0, ctx->stream, (int)F, ctx->cent_tmp.p, ctx->fcell.p, ctx->frank.p, ctx->cstart.p,
                            ctx->cent.p, ctx->state.p, it, ctx->ctile.p, (g.ncell + NW_SCAN_TILE - 1) / NW_SCAN_TILE);
@@ -1670,15 +1706,20 @@ static int launch_query(nw_ctx *ctx, int it, int parts, bool with_ring)
         const bool ring_here = with_ring && ring_in_nn();
         if (!ring_here) R.M = 0;
         const int nbq = nbp;                                          // workgroups of the query proper; behind them one thread per vertex for the ring half
-        const int nbt = nbq + (ring_here ? (int)((ctx->M + tb - 1) / tb) : 0);
+        const int nbr = ring_here ? 8 * (int)(((ctx->M + tb - 1) / tb + 7) / 8) : 0;      // (a multiple of 8: the attraction workgroups behind them keep the query's XCD mapping)
+        const bool attract_here = with_attract && attract_in_nn() && fuse_fixup() && ctx->item_done.p != nullptr && tb <= 128 && !ctx->handoff_off;
+        const int nbt = nbq + nbr + (attract_here ? nbq : 0);
+        const NwAttractArgs AA = attract_args(ctx);
+        int *done_p = attract_here ? ctx->item_done.p : nullptr;
+        if (attract_here) { ctx->attract_rows = nbq; if (attract_rode) *attract_rode = true; }
         if (ctx->nn_stats.p) {
             hipLaunchKernelGGL(k_nn_wave<true>, dim3(nbt), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (item_times ? 64 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max, R, nbq);
+                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max, R, nbq, nbr, AA, done_p, ctx->query_serial.p);
         } else {
             hipLaunchKernelGGL(k_nn_wave<false>, dim3(nbt), dim3(tb), 0, ctx->stream, g, ctx->items.p, ctx->nitems, ctx->pts.p, ctx->cstart.p, ctx->cent.p,
                            ctx->cent_tmp.p, (int)F, ctx->face.p, (ctx->face_warm ? 1 : 0) | nn_map | (fuse_fixup() ? 8 : 0) | (no_outliers ? 16 : 0) | (item_times ? 64 : 0), ctx->ambig_list.p, ctx->ambig_count.p,
-                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max, R, nbq);
+                           ctx->state.p, it, ctx->nn_stats.p, (ctx->items_by_cost && !item_times) ? nullptr : ctx->item_cost.p, ctx->face_sorted ? ctx->face_orig.p : nullptr, outl_f, outl_max, R, nbq, nbr, AA, done_p, ctx->query_serial.p);
         }
         if (ctx->face_warm && !ctx->items_by_cost) ctx->item_cost_valid = true;      // (a cold query's costs say little about the warm ones)
         ctx->face_warm = true;
@@ -1698,8 +1739,12 @@ static int iter_attract_parts(nw_ctx *ctx, int parts)
     if (ctx->begin_ops_pending) NW_TRY(enqueue_begin_ops(ctx));
     const int it = ctx->search_done;
     const int64_t N = ctx->N;
-    if (parts & (QP_GRID | QP_NN | QP_FIXUP)) NW_TRY(launch_query(ctx, it, parts & (QP_GRID | QP_NN | QP_FIXUP), true));
-    if (parts & QP_ATTRACT) {
+    // (only behind a WARM query: a cold one -- the first of a topology -- has waves that walk the whole grid for a far localization and
+    // take milliseconds; its attraction step stays a launch of its own)
+    const bool attract_rides = (parts & QP_NN) && (parts & QP_ATTRACT) && attract_in_nn() && fuse_fixup() && ctx->item_done.p != nullptr && ctx->face_warm && !ctx->handoff_off;
+    bool rode = false;
+    if (parts & (QP_GRID | QP_NN | QP_FIXUP)) NW_TRY(launch_query(ctx, it, parts & (QP_GRID | QP_NN | QP_FIXUP), true, attract_rides, &rode));
+    if ((parts & QP_ATTRACT) && !rode) {
         StageScope s(ctx, ST_ATTRACT);
         hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts.p, ctx->face.p, attract_args(ctx), ctx->state.p, it, fold_args(ctx, 0, attract_blocks(ctx)));
         ctx->attract_rows = attract_blocks(ctx);
@@ -1970,6 +2015,11 @@ NW_EXPORT int nw_search_end(nw_ctx *ctx, float *pos_out, nw_iter_log *log, int *
         if (code == NW_ERR_NAN) return fail(ctx, NW_ERR_NAN, "NaN detected in weight matrix / A f / A^T r (reference asserts at mesh_conj_grad.py:514,548,580)");
         if (code == NW_ERR_SINGULAR) return fail(ctx, NW_ERR_SINGULAR, "singular subspace normal equations (numpy.linalg.solve would raise LinAlgError)");
         if (code == NW_ERR_INTERNAL) return fail(ctx, NW_ERR_INTERNAL, "internal error: the nearest-face query produced an invalid face id");
+        if (code == NW_ERR_HANDOFF) {
+            ctx->handoff_off = true;                          // (from now on k_attract is a launch of its own behind the query)
+            for (auto &gph : ctx->graphs) if (gph.exec) { (void)hipGraphExecDestroy(gph.exec); gph.exec = nullptr; }
+            return fail(ctx, NW_ERR_HANDOFF, "the attraction step inside the query launch gave up waiting for its work item (200 ms); the ctx now runs the two as separate launches: run the block again");
+        }
         return fail(ctx, code, "device-side error");
     }
     return NW_OK;
@@ -1986,13 +2036,13 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     uint32_t lb; memcpy(&lb, &ctx->lam0, 4); mix(lb);
     uint64_t qb; memcpy(&qb, &ctx->acc_quantum, 8); mix(qb);
     uint32_t sb; memcpy(&sb, &ctx->sinv_scalar, 4); mix(sb); memcpy(&sb, &ctx->w_scalar, 4); mix(sb);
-    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 4 ? 256 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0) | (ctx->have_boundary ? 512 : 0) | (ctx->vacc_dirty ? 1024 : 0));
+    mix((ctx->sinv_array ? 1 : 0) | (ctx->w_array ? 2 : 0) | (ctx->have_valid ? 4 : 0) | (ctx->have_owned ? 8 : 0) | (ctx->nn_stats.p ? 16 : 0) | (ctx->profiling == 4 ? 256 : 0) | (ctx->direct_out ? 64 : 0) | (ctx->have_data ? 128 : 0) | (ctx->have_boundary ? 512 : 0) | (ctx->vacc_dirty ? 1024 : 0) | (ctx->handoff_off ? 2048 : 0));
     mixp(ctx->direct_out ? ctx->pin : nullptr);
     mixp(ctx->have_data ? ctx->dat.p : nullptr);
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->ctile.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
-                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p, ctx->ring4.p, ctx->ring_a.p, ctx->tickets.p,
+                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p, ctx->ring4.p, ctx->ring_a.p, ctx->tickets.p, ctx->item_done.p, ctx->query_serial.p,
                           ctx->hb_local.p, ctx->hb_slot.p, ctx->hb_slot2local.p, ctx->halo_acc.p, ctx->halo_rows.p, ctx->face_sorted ? ctx->face_orig.p : nullptr,
                           ctx->have_peers ? ctx->px_ghost.p : nullptr, ctx->have_peers ? ctx->px_owned.p : nullptr, ctx->have_peers ? ctx->px_send.p : nullptr,
                           ctx->have_peers ? ctx->px_recv.p : nullptr};
@@ -2771,6 +2821,11 @@ NW_EXPORT int nw_debug(nw_ctx *ctx, int what, void *a, void *b, int cap, int *n)
     if (what == 1) return debug_items(ctx, (int32_t *)a, (uint32_t *)b, cap, n);
     if (what == 2 && ctx && a) {          // how a block's result reached the host so far: {staged copy-outs, sliced write-backs} (int64[2])
         ((int64_t *)a)[0] = ctx->n_staged_copy_outs; ((int64_t *)a)[1] = ctx->n_write_backs;
+        return NW_OK;
+    }
+    if (what == 3 && ctx) {               // cap != 0: the attraction step as a launch of its own from now on (per-stage timings); 0: back inside the query launch
+        if (ctx->in_search) return fail(ctx, NW_ERR_BADARG, "nw_debug(3) inside a search");
+        ctx->handoff_off = cap != 0;
         return NW_OK;
     }
     return NW_ERR_BADARG;

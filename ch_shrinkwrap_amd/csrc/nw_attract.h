@@ -189,3 +189,46 @@ __device__ __forceinline__ void nw_attract_scatter(const NwAttractArgs &A, const
         }
     }
 }
+
+// The attraction step of one workgroup's localizations when the caller is NOT k_attract: the workgroups k_nn_wave appends to its grid
+// (round 5) -- one wave per work item of the query, the item's localizations one per lane.  The caller has initialised the table
+// (s_key = -1, s_val = 0) and passed a barrier.  `ok`: the lane has a localization i with a face f_raw inside [0, F).  The workgroup's
+// row of partial sums goes to A.part[row] (k_reduce_scalars adds the rows).  blockDim.x = 64 * (waves), at most 4 waves.
+template <int HT, int HT_BITS, int PROBES>
+__device__ __forceinline__ void nw_attract_workgroup(const NwAttractArgs &A, const float4 *__restrict__ pts, int i, bool ok, int f_raw, NwDevState *__restrict__ st,
+                                                     int *s_key, unsigned long long *s_val, double *s_w /* [20] */, int row)
+{
+    double red[4] = {0.0, 0.0, 0.0, 0.0};
+    float dmax = 0.0f;
+    unsigned long long q[3][4];
+    int v[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[j][k] = 0ull;
+    if (ok) {
+        bool bad = false;
+        nw_attract_point(A, i, pts[i], f_raw, v, q, red, dmax, bad);
+        if (bad) atomicCAS(&st->status, 0, -3 /* NW_ERR_NAN */);
+    }
+    const bool last_of_run = nw_run_sums(q, ok ? f_raw : -2 - (int)(threadIdx.x & 15));
+    if (ok && last_of_run) nw_attract_scatter<HT, HT_BITS, PROBES>(A, v, q, s_key, s_val);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 20) s_w[threadIdx.x] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double sk = nw_wave_sum(red[k]);
+        if (lane == 0) s_w[k * 4 + wv] = sk;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+    if (lane == 0) s_w[16 + wv] = (double)dmax;
+    __syncthreads();
+    if (threadIdx.x < 4) A.part[(int64_t)row * 5 + threadIdx.x] = (s_w[threadIdx.x * 4 + 0] + s_w[threadIdx.x * 4 + 1]) + (s_w[threadIdx.x * 4 + 2] + s_w[threadIdx.x * 4 + 3]);
+    else if (threadIdx.x == 4) A.part[(int64_t)row * 5 + 4] = fmax(fmax(s_w[16], s_w[17]), fmax(s_w[18], s_w[19]));
+    for (int t = threadIdx.x; t < HT * 4; t += (int)blockDim.x) {
+        const int key = s_key[t >> 2];                     // four adjacent lanes flush the four components of one vertex
+        if (key >= 0) atomicAdd(reinterpret_cast<unsigned long long *>(A.vacc) + 4 * (int64_t)key + (t & 3), s_val[(t & 3) * HT + (t >> 2)]);
+    }
+}

@@ -351,7 +351,8 @@ __global__ void k_nbr_transpose(const int *__restrict__ nbr, int M, int NB, int 
 #define NW_FC_TT 64        // scan tiles a workgroup's cells may lie in before its tile counts go to memory one by one
 __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const float *__restrict__ pos, const int *__restrict__ faces, int F,
                                                             float4 *__restrict__ cent_tmp, int *__restrict__ fcell, int *__restrict__ frank, int *__restrict__ count,
-                                                            int *__restrict__ tile_sums, int *__restrict__ ambig_count, NwDevState *__restrict__ st, int it)
+                                                            int *__restrict__ tile_sums, int *__restrict__ ambig_count, NwDevState *__restrict__ st, int it,
+                                                            int *__restrict__ query_serial)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ int s_key[NW_FC_HT], s_cnt[NW_FC_HT];
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_face_centroids(NwGrid g, const flo
     if (threadIdx.x < NW_FC_TT) { s_tkey[threadIdx.x] = -1; s_tcnt[threadIdx.x] = 0; }
     __syncthreads();
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f == 0) *ambig_count = 0;
+    if (f == 0) { *ambig_count = 0; *query_serial += 1; }      // (the serial number of the query this grid is built for: k_nn_wave's in-launch hand-off)
     int slot = 0, local = 0;
     if (f < F) {
         const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];

@@ -51,6 +51,8 @@
 #define NW_NN_CULL 4e-6f          // relative slack of the cell-culling test (rounding of the box distance)
 #define NW_ITEM_POINTS 64
 #define NW_OUTLIERS 8               // lanes per wave that may be resolved on their own (k_nn_wave)
+#define NW_NNA_HT 256                // slots of the scatter table of an attraction workgroup inside the query launch (two items: <= 128 localizations)
+#define NW_NNA_HT_BITS 8
 
 struct NwItem { int p0, n; };
 
@@ -501,17 +503,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                  int *__restrict__ face_io, int warm, int *__restrict__ ambig_list, int *__restrict__ ambig_count,
                                                  NwDevState *__restrict__ st, int it, unsigned long long *__restrict__ stats,
                                                  unsigned *__restrict__ item_cost, const int *__restrict__ face_orig, float outl_f, int outl_max,
-                                                 const NwRingArgs R, int nb_query)
+                                                 const NwRingArgs R, int nb_query, int nb_ring, const NwAttractArgs A, int *__restrict__ item_done, const int *__restrict__ query_serial)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
-    // Workgroups behind the query's own (blockIdx >= nb_query): the ring half of the curvature prior, one thread per vertex (nw_device.h).
-    // They are dispatched last, so they run while the query's last waves drain.
-    if ((int)blockIdx.x >= nb_query) {
+    // One LDS block for the three kinds of workgroup of this launch: the query's wave-private lists, or the attraction step's table.
+    constexpr int LDS_QUERY = 4 * (int)sizeof(NwWaveLds), LDS_ATTRACT = NW_NNA_HT * 4 + NW_NNA_HT * 4 * 8 + 20 * 8;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS_QUERY > LDS_ATTRACT ? LDS_QUERY : LDS_ATTRACT];
+    // what item_done[] reads once THIS query has left an item: the number of grid builds so far (k_face_centroids counts them; never reset,
+    // so a word left by an earlier block, mesh or optimiser cannot be mistaken for this query's)
+    const int epoch = item_done ? *query_serial : 0;
+    // Workgroups behind the query's own: they are dispatched last, so they run while the query's last waves drain (the launch's last third:
+    // 6 100 waves in flight at 10 % of it, 2 000 at 80 %, 200 at 90 %).
+    //   [nb_query, nb_query + nb_ring): the ring half of the curvature prior, one thread per vertex (nw_device.h);
+    //   behind them, one workgroup per workgroup of the query: the ATTRACTION STEP of the same work items (nw_attract.h), a wave per item.
+    if ((int)blockIdx.x >= nb_query && (int)blockIdx.x < nb_query + nb_ring) {
         const int v = ((int)blockIdx.x - nb_query) * (int)blockDim.x + (int)threadIdx.x;
         if (v < R.M) nw_prior_ring_vertex(R, v);
         return;
     }
-    __shared__ NwWaveLds s_wave[4];
+    if ((int)blockIdx.x >= nb_query + nb_ring) {
+        // The attraction step of an item needs the item's nearest faces: the query's wave stores them write-through (agent-scope stores),
+        // waits for the stores, and one lane then stores the iteration's number into item_done[item]; the wave here polls that word and reads
+        // the faces with agent-scope loads (MI355X_MICROARCH.md, hand-offs with sc1 loads).  Nothing in the query waits for anything, and a
+        // workgroup of this kind is dispatched only after every workgroup of the query on its XCD has been (in-order dispatch; observed, not
+        // promised) -- so the wait ends.  Should dispatch ever be out of order and the wait not end within 200 ms, the wave gives up and
+        // raises NW_ERR_HANDOFF: the block fails loudly instead of hanging or using an old face, and the host runs the two steps as separate
+        // launches from then on.
+        int *s_key = reinterpret_cast<int *>(s_raw);
+        unsigned long long *s_val = reinterpret_cast<unsigned long long *>(s_raw + NW_NNA_HT * 4);
+        double *s_w = reinterpret_cast<double *>(s_raw + NW_NNA_HT * 4 + NW_NNA_HT * 4 * 8);
+        for (int t = threadIdx.x; t < NW_NNA_HT; t += (int)blockDim.x) s_key[t] = -1;
+        for (int t = threadIdx.x; t < NW_NNA_HT * 4; t += (int)blockDim.x) s_val[t] = 0ull;
+        __syncthreads();
+        const int ab = (int)blockIdx.x - nb_query - nb_ring;
+        const int wpb_a = (int)blockDim.x >> 6, nwb_a = (nitems + wpb_a - 1) / wpb_a;
+        int wb_a;
+        if (warm & 4) {                                   // (the query's own mapping: the item's faces and vertices are in this XCD's L2)
+            const int x = ab & 7, l = ab >> 3;
+            wb_a = ((l / NW_XCD_RUN) * 8 + x) * NW_XCD_RUN + (l % NW_XCD_RUN);
+            if (wb_a >= nwb_a) wb_a = -1;
+        } else if (warm & 2) wb_a = ab < nwb_a ? ab : -1;
+        else wb_a = nw_xcd_remap(ab, nwb_a);
+        const int wi_a = __builtin_amdgcn_readfirstlane(wb_a * wpb_a + (int)(threadIdx.x >> 6));
+        const int lane_a = threadIdx.x & 63;
+        bool have = wb_a >= 0 && wi_a < nitems;
+        NwItem item_a; item_a.p0 = 0; item_a.n = 0;
+        if (have) {
+            item_a = items[wi_a];
+            int seen = 0;
+            if (lane_a == 0) {
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    seen = __hip_atomic_load(item_done + wi_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen == epoch) break;
+                    __builtin_amdgcn_s_sleep(16);
+                    if (wall_clock64() - t0 > 20000000ull) break;        // 200 ms of the 100 MHz clock: no warm item takes a hundredth of that
+                }
+            }
+            seen = __builtin_amdgcn_readfirstlane(seen);
+            if (seen != epoch) { if (lane_a == 0) atomicCAS(&st->status, 0, -9 /* NW_ERR_HANDOFF */); have = false; }
+        }
+        const bool act = have && lane_a < item_a.n;
+        const int gi_a = item_a.p0 + (act ? lane_a : 0);
+        int f_raw = 0;
+        if (act) {
+            f_raw = __hip_atomic_load(face_io + gi_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)f_raw >= (unsigned)A.F) atomicCAS(&st->status, 0, -7 /* NW_ERR_INTERNAL */);
+        }
+        nw_attract_workgroup<NW_NNA_HT, NW_NNA_HT_BITS, 48>(A, pts, gi_a, act && (unsigned)f_raw < (unsigned)A.F, f_raw, st, s_key, s_val, s_w, ab);
+        return;
+    }
+    NwWaveLds *s_wave = reinterpret_cast<NwWaveLds *>(s_raw);
     NwStats S;
 #pragma unroll
     for (int k = 0; k < NWS_COUNT; ++k) S.v[k] = 0;
@@ -748,10 +810,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 const int res = nw_fixup_point(g, nw_readlane_f(Pw.x, j), nw_readlane_f(Pw.y, j), nw_readlane_f(Pw.z, j), C0, cstart, cent, lane, face_orig);
                 if (lane == j) fid = res;
             }
-            if (active) face_io[gi] = fid;
+            if (active) {
+                if (item_done) __hip_atomic_store(face_io + gi, fid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through: read by another CU in this launch
+                else face_io[gi] = fid;
+            }
         } else if (active) {
             face_io[gi] = fid;
             if (amb) { const int k = atomicAdd(ambig_count, 1); ambig_list[k] = gi; }
+        }
+        if (item_done) {
+            // the item's faces are out: wait for the stores, then say so (one lane; the attraction workgroups of this launch poll the word)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(item_done + wi, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (STATS) S.v[NWS_T_TAIL] += (int)((__builtin_amdgcn_s_memtime() - t_tail) >> 4);

@@ -483,6 +483,11 @@ class ShrinkwrapMeshConjGrad(object):
             a, b = self.stage_ms_total[k]
             self.stage_ms_total[k] = (a + ms, b + n)
 
+    def separate_attraction(self, on=True):
+        """Per-stage timings want the attraction step as a launch of its own (k_attract behind the query) instead of in workgroups appended to
+        the query launch (the default; bit-identical results): nw_debug(what = 3)."""
+        self._native.check(self._L.nw_debug(self._h, 3, None, None, 1 if on else 0, None))
+
     def optimize_layout(self):
         """do the library's pending one-off set-up now (the projection re-sort after the first block) instead of at the next search()"""
         self._native.check(self._L.nw_optimize_layout(self._h))

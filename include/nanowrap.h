@@ -36,7 +36,9 @@ typedef enum nw_status {
     NW_ERR_NONFINITE = -5,   /* non-finite localization or vertex coordinate (cKDTree cannot index it) */
     NW_ERR_NOMEM = -6,
     NW_ERR_INTERNAL = -7,    /* invariant violated inside the library (reported instead of risking a GPU fault) */
-    NW_ERR_REMOTE = -8       /* multi-GPU: another rank raised a status in this iteration (its own code is in that rank's log); this rank stopped with it */
+    NW_ERR_REMOTE = -8,      /* multi-GPU: another rank raised a status in this iteration (its own code is in that rank's log); this rank stopped with it */
+    NW_ERR_HANDOFF = -9      /* the attraction step that rides in the query launch gave up waiting for its work item's nearest faces (200 ms; it never
+                                uses an old face): the block is cancelled and the ctx runs the two as separate launches from then on -- run the block again */
 } nw_status;
 
 /* how the residual weights are given -- mirrors `search(..., weights=None, sigma_inv=1.0)`,
@@ -343,7 +345,10 @@ int nw_accumulator_quantum(nw_ctx *ctx, double *q);
  *   must hold 2 * cap entries: the second `cap` receive when each item started -- the launch's time line (tools/nn_costs.py).
  * what = 2: a = int64 out[2]: how often a block's result has reached the host so far as a copy-out of the staging buffer the last update
  *   kernel wrote (the fast path of results up to 4 MB), and how often as a sliced device-to-host write-back (larger results, or a block
- *   the device-side stop condition ended early) -- a block must take ONE of the two. */
+ *   the device-side stop condition ended early) -- a block must take ONE of the two.
+ * what = 3: cap != 0 makes the attraction step a launch of its own from now on (k_attract behind the query), cap = 0 puts it back into the
+ *   query launch (workgroups appended to k_nn_wave's grid: the default).  Results are bit-identical either way; bench.py takes its per-stage
+ *   timings with the steps apart. */
 int nw_debug(nw_ctx *ctx, int what, void *a, void *b, int cap, int *n);
 
 #ifdef __cplusplus

@@ -102,9 +102,10 @@ def test_large_result_comes_back_in_announced_slices_and_its_host_tail_is_bounde
     assert t_with - t_without < 1.5e-3, (t_with, t_without)
 
 
-def test_ring_half_inside_the_query_launch_equals_its_own_launch():
-    """NW_RING_IN_NN=0 computes the ring half of the curvature prior as a launch of its own instead of in workgroups appended to the
-    query's grid: bit-identical fits (the knob is read once per process: two child processes)."""
+def test_stages_inside_the_query_launch_equal_their_own_launches():
+    """The ring half of the curvature prior and the attraction step ride in the query launch (workgroups appended to k_nn_wave's grid; the
+    attraction step of a work item waits for the item's nearest faces through a word in memory).  NW_RING_IN_NN=0 / NW_ATTRACT_IN_NN=0 make
+    each a launch of its own: bit-identical fits (the knobs are read once per process: child processes)."""
     code = r'''
 import sys, numpy as np, zlib
 sys.path.insert(0, %r)
@@ -119,12 +120,34 @@ for b in range(3):
 print('CRC', zlib.crc32(np.ascontiguousarray(out).tobytes()), float(np.abs(out).sum()))
 ''' % ROOT
     crcs = []
-    for knob in ('1', '0'):
-        env = dict(os.environ, NW_RING_IN_NN=knob)
+    for knobs in ({}, {'NW_RING_IN_NN': '0'}, {'NW_ATTRACT_IN_NN': '0'}, {'NW_RING_IN_NN': '0', 'NW_ATTRACT_IN_NN': '0'}):
+        env = dict(os.environ, **knobs)
         r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         crcs.append([l for l in r.stdout.splitlines() if l.startswith('CRC')][-1])
-    assert crcs[0] == crcs[1], crcs
+    assert len(set(crcs)) == 1, crcs
+
+
+def test_attraction_step_toggled_at_run_time_gives_the_same_bits():
+    """nw_debug(what = 3) moves the attraction step out of the query launch and back (bench.py times its stages apart): the same fit either
+    way, block by block, also across the switch."""
+    TriMesh, CG = _imports()
+    from ch_shrinkwrap_amd import synth
+    c = synth.make_config('c3', scale=0.1, seed=6)
+    pts, s = c['points'], 1.0 / c['sigma'].ravel()
+    outs = {}
+    for plan in ('inside', 'apart', 'mixed'):
+        cg = CG(TriMesh(c['vertices'].copy(), c['faces']), pts)
+        res = []
+        for block in range(6):
+            if plan == 'apart' or (plan == 'mixed' and block % 2 == 1):
+                cg.separate_attraction(True)
+            else:
+                cg.separate_attraction(False)
+            res.append(cg.search(pts, lams=c['lams'], num_iters=5, sigma_inv=s).copy())
+        outs[plan] = res
+    for a, b, m in zip(outs['inside'], outs['apart'], outs['mixed']):
+        assert np.array_equal(a, b) and np.array_equal(a, m)
 
 
 def test_curvature_tables_built_on_the_device_equal_the_host_substrates(monkeypatch):

@@ -3,7 +3,8 @@
   <tag>_bench.json                       the bench line of the same round (no profiler attached)
   <tag>_pmc_and_trace_summary.json       per-kernel HBM traffic from the FETCH_SIZE / WRITE_SIZE passes + average durations
   <tag>_sq_counters.json                 per-kernel SQ counters (mean per dispatch)
-  r04_pmc_traffic.json                   what bench.py reports as roofline.traffic (tagged there as file-sourced)
+  r05_pmc_traffic.json                   what bench.py reports as roofline.traffic / roofline_attraction_curvature.traffic (tagged there as file-sourced),
+                                         with SQ_WAIT_ANY / SQ_WAVE_CYCLES per kernel (_wait_share)
 HBM bytes per launch: both counters are in KiB; gfx950's FETCH_SIZE counts exactly half of a WIDE coalesced read (16 B per lane) and other
 access widths are uncalibrated (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).  So the doubling is applied only to
 the kernel whose loads are 16 B per lane -- k_nn_wave: float4 localizations, float4 centroids -- and every kernel gets both bounds:
@@ -62,7 +63,10 @@ bench = json.loads(open(os.path.join(src, 'bench.log')).read().strip().splitline
 json.dump(bench, open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
 
 WIDE_LOADS = ('k_nn_wave', 'k_nn_fixup')                # kernels whose global loads are 16 B per lane (float4 localizations / centroids)
-fetch, write = counters('fetch'), counters('write')
+# every stage a launch of its own (NW_ATTRACT_IN_NN=0) for the per-kernel numbers; the dominant launch -- k_nn_wave as the timed region runs
+# it, with the ring half of the prior and the attraction step inside -- from the passes without the knob
+fetch, write = counters('fetch_apart'), counters('write_apart')
+fetch_f, write_f = counters('fetch_fused'), counters('write_fused')
 iters = 10                                             # bench.py --steps 10 in the PMC passes
 traffic = {}
 for k in sorted(set(fetch) | set(write)):
@@ -83,21 +87,35 @@ summary = dict(traffic_raw=traffic,
                     '--kernel-trace --stats pass (' + tag + '_kernel_stats.csv)')
 json.dump(summary, open(os.path.join(dst, tag + '_pmc_and_trace_summary.json'), 'w'), indent=1)
 
-sq = counters('sq')
+sq = counters('sq_apart')
+sq_f = counters('sq_fused')
 json.dump({k: dict({c: sum(v) / len(v) for c, v in d.items()}, dispatches=max(len(v) for v in d.values())) for k, d in sorted(sq.items())},
           open(os.path.join(dst, tag + '_sq_counters.json'), 'w'), indent=1)
 
 out = {k: traffic[k]['hbm_bytes_per_launch'] for k in ('k_nn_wave', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_prior_directions', 'k_solve_update', 'k_reduce_scalars')
        if k in traffic}
+if 'k_nn_wave' in traffic:
+    out['k_nn_wave_query_and_ring_only'] = traffic['k_nn_wave']['hbm_bytes_per_launch']
+    f = fetch_f.get('k_nn_wave', {}).get('FETCH_SIZE', [0.0]); w = write_f.get('k_nn_wave', {}).get('WRITE_SIZE', [0.0])
+    # (the fused launch mixes 16-byte-per-lane loads -- the query -- with dword gathers -- the attraction step: x2 for the query's share of the
+    # fetches, measured apart, x1 for the rest)
+    fq = traffic['k_nn_wave']['FETCH_SIZE_KB']
+    ff, wf = mean_tail(f, iters), mean_tail(w, iters)
+    out['k_nn_wave'] = (ff + min(fq, ff) + wf) * 1024
+    out['_bounds_fused_k_nn_wave'] = [(ff + wf) * 1024, (2 * ff + wf) * 1024]
 out['grid_build'] = sum(traffic[k]['hbm_bytes_per_launch'] * (3 if k.startswith('k_scan') and False else 1) for k in grid if k in traffic)
+if 'k_nn_wave' in sq_f and 'SQ_INSTS_VALU' in sq_f['k_nn_wave']:
+    out['k_nn_wave_valu_wave_instructions'] = mean_tail(sq_f['k_nn_wave']['SQ_INSTS_VALU'], iters)
 if 'k_nn_wave' in sq and 'SQ_INSTS_VALU' in sq['k_nn_wave']:
-    out['k_nn_wave_valu_wave_instructions'] = mean_tail(sq['k_nn_wave']['SQ_INSTS_VALU'], iters)
+    out['k_nn_wave_valu_wave_instructions_query_and_ring_only'] = mean_tail(sq['k_nn_wave']['SQ_INSTS_VALU'], iters)
 out['_note'] = ('HBM bytes per launch from separate rocprofv3 --pmc passes: (2*FETCH_SIZE + WRITE_SIZE)*1024 for k_nn_wave (16-byte-per-lane loads: gfx950 FETCH_SIZE '
                 'counts half of those, MI355X_MICROARCH.md section HBM), (FETCH_SIZE + WRITE_SIZE)*1024 for the gather kernels (other widths are uncalibrated: their x2 upper '
                 'bound is in _bounds); mean of the timed iterations of bench.py --steps 10 --warmup 10; profiles/' + tag + '_*')
 out['_bounds'] = {k: [traffic[k]['hbm_bytes_lower'], traffic[k]['hbm_bytes_upper']] for k in traffic}
 out['_source_tag'] = tag
-json.dump(out, open(os.path.join(dst, 'r04_pmc_traffic.json'), 'w'), indent=1)
+out['_wait_share'] = {k: (sum(d['SQ_WAIT_ANY']) / max(sum(d['SQ_WAVE_CYCLES']), 1.0)) for k, d in sq.items() if 'SQ_WAIT_ANY' in d and 'SQ_WAVE_CYCLES' in d}
+out['_wait_share_note'] = 'SQ_WAIT_ANY / SQ_WAVE_CYCLES per kernel (share of its waves\' cycles spent waiting for anything), same --pmc pass as the SQ counters'
+json.dump(out, open(os.path.join(dst, 'r05_pmc_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
 for k in ('k_nn_wave', 'k_nn_fixup', 'k_attract', 'k_subspace_point_sums', 'k_reduce_scalars', 'k_prior_directions', 'k_solve_update', 'k_face_centroids', 'k_scan_tile_sums', 'k_scan_final', 'k_centroid_scatter'):
     if k in dur:
