@@ -516,7 +516,7 @@ int ensure_item_done(nw_ctx *ctx)
         NW_HIP(ctx->item_done.ensure(2 * want));
         NW_HIP(hipMemsetAsync(ctx->item_done.p, 0, 2 * want * sizeof(int), ctx->stream));
     }
-    const size_t rows = (size_t)(ctx->nitems / 2 + 8 * 16 + 8);         // >= the query's workgroups for 128-thread workgroups (nn_workgroups)
+    const size_t rows = (size_t)(ctx->nitems + 8 * 16 + 8);             // >= the query's workgroups whatever their size (64-thread workgroups: one per item; launch_query pads to 128)
     if (ctx->part_a.n < 5 * rows) NW_HIP(ctx->part_a.ensure(5 * rows));
     return NW_OK;
 }
@@ -1668,15 +1668,6 @@ static NwRingArgs ring_args(const nw_ctx *ctx)
 // the attraction step rides in the query launch too (one workgroup per workgroup of the query, appended behind the ring workgroups: they fill
 // the launch's drain); NW_ATTRACT_IN_NN=0 (developer knob): k_attract as a launch of its own behind the query
 static bool attract_in_nn() { static const bool on = !(getenv("NW_ATTRACT_IN_NN") && atoi(getenv("NW_ATTRACT_IN_NN")) == 0); return on; }
-static int nn_workgroups(const nw_ctx *ctx, int *tb_out = nullptr)
-{
-    static const int nn_map = getenv("NW_NN_MAP") ? (atoi(getenv("NW_NN_MAP")) == 0 ? 0 : (atoi(getenv("NW_NN_MAP")) == 1 ? 2 : 4)) : 4;
-    static const int tb = getenv("NW_NN_BLOCK") ? std::max(64, std::min(256, atoi(getenv("NW_NN_BLOCK")) & ~63)) : 128;
-    const int wpb = tb / 64, nb = (ctx->nitems + wpb - 1) / wpb;
-    if (tb_out) *tb_out = tb;
-    return nn_map == 4 ? (8 * NW_XCD_RUN) * ((nb + 8 * NW_XCD_RUN - 1) / (8 * NW_XCD_RUN)) : 8 * ((nb + 7) / 8);
-}
-
 static int launch_query(nw_ctx *ctx, int it, int parts, bool with_ring, bool with_attract, bool *attract_rode)
 {
     if (attract_rode) *attract_rode = false;
