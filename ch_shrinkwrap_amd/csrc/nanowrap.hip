@@ -354,7 +354,6 @@ struct nw_ctx {
     DevBuf<double> scalars;           // [NW_N_SCALARS][NW_SPARTS] sums of the current iteration, NW_SPARTS ordered parts per slot (k_reduce_scalars)
     DevBuf<float> wv;                 // per-vertex weights of the 'wfunc' regulariser (NW_FLAG_WFUNC)
     DevBuf<double> part_a, part_p, part_s;   // per-workgroup partial sums of k_attract / k_prior_directions / k_subspace_point_sums
-    DevBuf<int> tickets;              // 3 x NW_SPARTS arrival counters of the folded reduction (nw_publish_row): zero between launches
     bool vacc_dirty = true;           // something other than the iteration has written the scatter accumulator since it was last zeroed
     int attract_rows = 0;             // rows of part_a the last attraction wrote (its workgroups)
     double w_quantum = 1.0;           // fixed-point quantum of the {w} column
@@ -712,31 +711,10 @@ int alloc_work(nw_ctx *ctx)
     NW_HIP(ctx->part_s.ensure((size_t)9 * subspace_blocks(ctx)));
     NW_HIP(ctx->part_p.ensure((size_t)14 * prior_blocks(ctx)));
     NW_HIP(ctx->wv.ensure(ctx->M));
-    if (!ctx->tickets.p) {
-        NW_HIP(ctx->tickets.ensure(3 * NW_SPARTS));
-        NW_HIP(hipMemsetAsync(ctx->tickets.p, 0, 3 * NW_SPARTS * sizeof(int), ctx->stream));
-    }
     return NW_OK;
 }
 
-// NW_FOLD_REDUCE=1 (developer knob): the producers add their partial rows themselves (nw_publish_row) and the k_reduce_scalars launch is
-// dropped.  Measured twice and slower both times (round 3; round 5 with the row published before the scatter table's flush: k_attract
-// 35 -> 68 us -- the publishing wave's returning ticket queues behind the other waves' flush atomics and keeps its workgroup's LDS and
-// wave slots; k_prior_directions +2.5 us, k_subspace_point_sums +5 us: what the launch costs): off by default.
-static bool fold_reduce() { static const bool on = getenv("NW_FOLD_REDUCE") && atoi(getenv("NW_FOLD_REDUCE")) != 0; return on; }
-static NwFold fold_args(const nw_ctx *ctx, int table, int nblk)
-{
-    NwFold f;
-    memset(&f, 0, sizeof(f));
-    f.sc = fold_reduce() ? ctx->scalars.p : nullptr;
-    f.tickets = ctx->tickets.p + table * NW_SPARTS;
-    f.nblk = nblk;
-    f.slot0 = table == 0 ? SC_RES2 : (table == 1 ? SC_HC : SC_SS);
-    f.max_slot = SC_MAXD;
-    f.status_slot = table == 1 ? SC_STATUS : -1;
-    f.status = &ctx->state.p->status;
-    return f;
-}
+// (Folding k_reduce_scalars into its producers with tickets was built twice -- rounds 3 and 5 -- and is slower both times: tools/experiments/r05_notes.md)
 
 }  // namespace
 
@@ -1737,7 +1715,7 @@ static int iter_attract_parts(nw_ctx *ctx, int parts)
     if (parts & (QP_GRID | QP_NN | QP_FIXUP)) NW_TRY(launch_query(ctx, it, parts & (QP_GRID | QP_NN | QP_FIXUP), true, attract_rides, &rode));
     if ((parts & QP_ATTRACT) && !rode) {
         StageScope s(ctx, ST_ATTRACT);
-        hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts.p, ctx->face.p, attract_args(ctx), ctx->state.p, it, fold_args(ctx, 0, attract_blocks(ctx)));
+        hipLaunchKernelGGL(k_attract, dim3(attract_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)N, ctx->pts.p, ctx->face.p, attract_args(ctx), ctx->state.p, it);
         ctx->attract_rows = attract_blocks(ctx);
     }
     NW_HIP(hipGetLastError());
@@ -1767,15 +1745,14 @@ NW_EXPORT int nw_iter_directions(nw_ctx *ctx)
         if (!ring_in_nn()) hipLaunchKernelGGL(k_prior_ring, dim3(nblk(ctx->M)), dim3(NW_BLOCK), 0, ctx->stream, ring_args(ctx), ctx->state.p, it);
         hipLaunchKernelGGL(k_prior_directions, dim3(prior_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->M, ctx->ring4.p, ctx->ring_a.p, ctx->pos.p,
                            ctx->meshpos.p, ctx->nrm.p, ctx->vacc.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->part_p.p, ctx->state.p, it, n_search,
-                           ctx->acc_quantum, ctx->w_quantum, wfunc ? ctx->wv.p : nullptr, ctx->have_owned ? ctx->owned.p : nullptr, fold_args(ctx, 2, prior_blocks(ctx)));
+                           ctx->acc_quantum, ctx->w_quantum, wfunc ? ctx->wv.p : nullptr, ctx->have_owned ? ctx->owned.p : nullptr);
     }
     {
         StageScope s(ctx, ST_AS);
         hipLaunchKernelGGL(k_subspace_point_sums, dim3(subspace_blocks(ctx)), dim3(NW_BLOCK), 0, ctx->stream, (int)ctx->N, (int)ctx->M, ctx->vidx.p, ctx->w.p, ctx->res.p,
-                           ctx->mask.p, ctx->S.p, ctx->part_s.p, ctx->state.p, it, n_search, fold_args(ctx, 1, subspace_blocks(ctx)));
-        // the 28 sums of this iteration, added in a fixed order (deterministic) by the producers' last arrivers (nw_publish_row); multi-GPU
-        // runs all-reduce them after this call
-        if (!fold_reduce()) hipLaunchKernelGGL(k_reduce_scalars, dim3(3 * NW_SPARTS), dim3(NW_BLOCK), 0, ctx->stream, ctx->part_a.p, ctx->attract_rows, ctx->part_p.p, prior_blocks(ctx),
+                           ctx->mask.p, ctx->S.p, ctx->part_s.p, ctx->state.p, it, n_search);
+        // the 28 sums of this iteration, added in a fixed order (deterministic); multi-GPU runs all-reduce them after this call
+        hipLaunchKernelGGL(k_reduce_scalars, dim3(3 * NW_SPARTS), dim3(NW_BLOCK), 0, ctx->stream, ctx->part_a.p, ctx->attract_rows, ctx->part_p.p, prior_blocks(ctx),
                            ctx->part_s.p, subspace_blocks(ctx), ctx->scalars.p, ctx->state.p, it);
     }
     NW_HIP(hipGetLastError());
@@ -2033,7 +2010,7 @@ static uint64_t block_graph_key(const nw_ctx *ctx)
     const void *ptrs[] = {ctx->pts.p, ctx->sinv.p, ctx->wnorm.p, ctx->mask.p, ctx->items.p, ctx->ccount.p, ctx->cstart.p, ctx->scan_tmp.p, ctx->ctile.p, ctx->pos.p, ctx->meshpos.p, ctx->nrm.p,
                           ctx->nbr.p, ctx->nbr_t.p, ctx->faces.p, ctx->valid.p, ctx->owned.p, ctx->cent_tmp.p, ctx->cent.p, ctx->fcell.p, ctx->frank.p, ctx->face.p, ctx->vidx.p,
                           ctx->ambig_list.p, ctx->ambig_count.p, ctx->dist.p, ctx->w.p, ctx->res.p, ctx->S.p, ctx->fdef.p, ctx->pi.p, ctx->vacc.p, ctx->scalars.p, ctx->part_a.p,
-                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p, ctx->ring4.p, ctx->ring_a.p, ctx->tickets.p, ctx->item_done.p, ctx->query_serial.p,
+                          ctx->part_p.p, ctx->part_s.p, ctx->wv.p, ctx->state.p, ctx->logs.p, ctx->nn_stats.p, ctx->ring4.p, ctx->ring_a.p, ctx->item_done.p, ctx->query_serial.p,
                           ctx->hb_local.p, ctx->hb_slot.p, ctx->hb_slot2local.p, ctx->halo_acc.p, ctx->halo_rows.p, ctx->face_sorted ? ctx->face_orig.p : nullptr,
                           ctx->have_peers ? ctx->px_ghost.p : nullptr, ctx->have_peers ? ctx->px_owned.p : nullptr, ctx->have_peers ? ctx->px_send.p : nullptr,
                           ctx->have_peers ? ctx->px_recv.p : nullptr};

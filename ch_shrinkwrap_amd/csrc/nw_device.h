@@ -123,85 +123,10 @@ __device__ __forceinline__ void nw_block_reduce_store_lds(double (&v)[NV], doubl
     }
 }
 
-// ---- the normal-equation sums without a reduction launch (round 5) --------------------------------------------------------------------
-// Until round 4 a fourth launch (k_reduce_scalars, 5.7 us + a kernel boundary) added the producers' per-workgroup rows.  Now the rows are
-// added by the producers themselves: the workgroups of a launch form NW_SPARTS groups of consecutive rows, every workgroup takes a
-// ticket of its group after publishing its row, and the workgroup whose ticket is the group's last adds the group's rows -- in row
-// order, so the sums do not depend on which workgroup that was -- into sc[slot][group], exactly the table k_solve_update reads.
-// Hand-off (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads", first row): the row is stored write-through (agent-scope relaxed
-// stores = `sc1`) by lanes of ONE wave, that wave waits for its stores (`s_waitcnt vmcnt(0)`), ONE lane takes the ticket (agent-scope
-// atomic add on one unsharded counter); the last arriver reads every row with `sc1` loads after its add has returned.  No fence.
-// Round 3 tried this and lost (k_attract 35 -> 74 us): there the wait also covered the wave's scatter atomics.  Here the caller publishes
-// BEFORE it flushes its scatter table, and only the publishing wave waits.
-struct NwFold {
-    double *sc;            // [NW_N_SCALARS][NW_SPARTS]; NULL: rows only (k_reduce_scalars adds them)
-    int *tickets;          // this launch's NW_SPARTS counters, zero between launches (the last arriver resets its own)
-    int nblk;              // rows (= workgroups) of this launch
-    int slot0;             // first slot of the row's columns
-    int max_slot;          // slot of the MAXCOL column (a maximum, not a sum), if any
-    int status_slot;       // >= 0: this launch also writes the status slot (1.0 in group 0 if the device status is set)
-    const int *status;
-};
-#define NW_FOLD_PARTS 32   // = NW_SPARTS (nw_kernels.h)
-
-// called by ALL lanes of wave 0 with the workgroup's row in lanes 0..NV-1 (`mine`); MAXCOL: column that holds a maximum (values >= 0), -1 none
-template <int NV, int MAXCOL>
-__device__ __forceinline__ void nw_publish_row(double mine, double *__restrict__ part, const NwFold &Fd)
-{
-    const int lane = threadIdx.x & 63;
-    double *row = part + (int64_t)blockIdx.x * NV;
-    if (!Fd.sc) { if (lane < NV) row[lane] = mine; return; }
-    if (lane < NV) __hip_atomic_store(row + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int per = (Fd.nblk + NW_FOLD_PARTS - 1) / NW_FOLD_PARTS;
-    const int g = (int)blockIdx.x / per;
-    const int r0 = g * per, r1 = min(r0 + per, Fd.nblk);
-    int old = 0;
-    if (lane == 0) old = __hip_atomic_fetch_add(Fd.tickets + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old != r1 - r0 - 1) return;
-    // last of its group: the group's rows, flat and coalesced, NT lanes (a multiple of NV: a lane stays on its column), four chains
-    constexpr int NT = (64 / NV) * NV;
-    const double *p = part + (int64_t)r0 * NV;
-    const int total = (r1 - r0) * NV;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (lane < NT) {
-        int e = lane;
-        if (MAXCOL >= 0 && lane % NV == MAXCOL) {
-            for (; e < total; e += NT) a0 = fmax(a0, __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        } else {
-            for (; e + 3 * NT < total; e += 4 * NT) {
-                const double x0 = __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x1 = __hip_atomic_load(p + e + NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double x2 = __hip_atomic_load(p + e + 2 * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x3 = __hip_atomic_load(p + e + 3 * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a0 += x0; a1 += x1; a2 += x2; a3 += x3;
-            }
-            for (; e < total; e += NT) a0 += __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a0 = (a0 + a1) + (a2 + a3);
-        }
-    }
-    // the NT / NV lanes of a column, in lane order
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < NT / NV; ++k) {
-        const double o = __shfl(a0, (lane % NV) + k * NV, 64);
-        if (MAXCOL >= 0 && lane % NV == MAXCOL) s = fmax(s, o); else s += o;
-    }
-    if (lane < NV) Fd.sc[((MAXCOL >= 0 && lane == MAXCOL) ? Fd.max_slot : Fd.slot0 + lane) * NW_FOLD_PARTS + g] = s;
-    if (g == 0) {
-        // groups without a workgroup (fewer workgroups than groups): their parts are zero
-        const int used = (Fd.nblk + per - 1) / per;
-        for (int gg = used; gg < NW_FOLD_PARTS; ++gg)
-            if (lane < NV) Fd.sc[((MAXCOL >= 0 && lane == MAXCOL) ? Fd.max_slot : Fd.slot0 + lane) * NW_FOLD_PARTS + gg] = 0.0;
-    }
-    if (Fd.status_slot >= 0 && lane == 0) Fd.sc[Fd.status_slot * NW_FOLD_PARTS + g] = (g == 0 && *Fd.status != 0) ? 1.0 : 0.0;
-    if (Fd.status_slot >= 0 && g == 0 && lane == 0) { const int used = (Fd.nblk + per - 1) / per; for (int gg = used; gg < NW_FOLD_PARTS; ++gg) Fd.sc[Fd.status_slot * NW_FOLD_PARTS + gg] = 0.0; }
-    if (lane == 0) __hip_atomic_store(Fd.tickets + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The workgroup's NV sums: wave sums on the vector ALU, 4 NV doubles through LDS, the row published by wave 0 (nw_publish_row).
-// s_w: NV * 4 doubles.  All threads call it; returns after wave 0 has published (the other waves do not wait for the ticket).
+// The workgroup's NV sums: wave sums on the vector ALU, 4 NV doubles through LDS, the row stored by wave 0 (k_reduce_scalars adds the rows of
+// all workgroups in a fixed order).  s_w: NV * 4 doubles.  All threads call it.
 template <int NV>
-__device__ __forceinline__ void nw_block_sums_publish(double (&v)[NV], double *__restrict__ part, double *s_w, const NwFold &Fd)
+__device__ __forceinline__ void nw_block_sums_store(double (&v)[NV], double *__restrict__ part, double *s_w)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -210,11 +135,8 @@ __device__ __forceinline__ void nw_block_sums_publish(double (&v)[NV], double *_
         if (lane == 0) s_w[k * 4 + wv] = s;
     }
     __syncthreads();
-    if (wv == 0) {
-        double mine = 0.0;
-        if (lane < NV) mine = (s_w[lane * 4 + 0] + s_w[lane * 4 + 1]) + (s_w[lane * 4 + 2] + s_w[lane * 4 + 3]);
-        nw_publish_row<NV, -1>(mine, part, Fd);
-    }
+    if (threadIdx.x < NV)
+        part[(int64_t)blockIdx.x * NV + threadIdx.x] = (s_w[threadIdx.x * 4 + 0] + s_w[threadIdx.x * 4 + 1]) + (s_w[threadIdx.x * 4 + 2] + s_w[threadIdx.x * 4 + 3]);
 }
 
 // plain (non-replicated) variant with float64 atomics for the set-up reductions (mesh area, weight sums): not on the iteration path

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_nn_fixup(NwGrid g, const int *__re
 #define NW_HT_PROBES 48    // a contribution that finds no slot within this many probes goes to HBM directly (unsorted input only)
 
 __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__restrict__ pts, const int *__restrict__ face, const NwAttractArgs A,
-                                                     NwDevState *__restrict__ st, int it, const NwFold Fd)
+                                                     NwDevState *__restrict__ st, int it)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ int s_key[NW_HT];
@@ -486,9 +486,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__res
     }
     __syncthreads();
     // per-workgroup partial sums (row of 5: four sums + the largest NN distance of the workgroup, which a sharded run checks against
-    // its halo radius; a same-address atomicMax from every wave serialised: 40 us at 1M localizations, 0.7 ms at 5M) -- published BEFORE
-    // the table is flushed (round 5): the publishing wave waits for its own memory operations, which must not include the flush's
-    // atomics (nw_publish_row); waves 1-3 start flushing meanwhile.  Wave sums on the vector ALU (nw_wave_sum).
+    // its halo radius; a same-address atomicMax from every wave serialised: 40 us at 1M localizations, 0.7 ms at 5M).  Wave sums on the
+    // vector ALU (nw_wave_sum).
     {
         __shared__ double s_w[5 * 4];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -501,12 +500,8 @@ __global__ __launch_bounds__(NW_BLOCK) void k_attract(int N, const float4 *__res
         for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
         if (lane == 0) s_w[16 + wv] = (double)dmax;
         __syncthreads();
-        if (wv == 0) {
-            double mine = 0.0;
-            if (lane < 4) mine = (s_w[lane * 4 + 0] + s_w[lane * 4 + 1]) + (s_w[lane * 4 + 2] + s_w[lane * 4 + 3]);
-            else if (lane == 4) mine = fmax(fmax(s_w[16], s_w[17]), fmax(s_w[18], s_w[19]));
-            nw_publish_row<5, 4>(mine, A.part, Fd);
-        }
+        if (threadIdx.x < 4) A.part[(int64_t)blockIdx.x * 5 + threadIdx.x] = (s_w[threadIdx.x * 4 + 0] + s_w[threadIdx.x * 4 + 1]) + (s_w[threadIdx.x * 4 + 2] + s_w[threadIdx.x * 4 + 3]);
+        else if (threadIdx.x == 4) A.part[(int64_t)blockIdx.x * 5 + 4] = fmax(fmax(s_w[16], s_w[17]), fmax(s_w[18], s_w[19]));
     }
     for (int t = threadIdx.x; t < NW_HT * 4; t += NW_BLOCK) {
         const int key = s_key[t >> 2];                     // four adjacent lanes flush the four components of one vertex
@@ -533,7 +528,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, const floa
                                                               const float *__restrict__ meshpos, const float *__restrict__ nrm,
                                                               const long long *__restrict__ vacc, float *__restrict__ S, float *__restrict__ fdef_out,
                                                               float *__restrict__ pi_out, double *__restrict__ part, NwDevState *__restrict__ st, int it, int n_search,
-                                                              double q, double qw, const float *__restrict__ wv, const unsigned char *__restrict__ owned, const NwFold Fd)
+                                                              double q, double qw, const float *__restrict__ wv, const unsigned char *__restrict__ owned)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ double s_part[14 * 4];
@@ -600,7 +595,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_prior_directions(int M, const floa
             red[13] += (double)s1 * s1;
         }
     }
-    nw_block_sums_publish<14>(red, part, s_part, Fd);
+    nw_block_sums_store<14>(red, part, s_part);
 }
 
 // weights of the 'wfunc' regulariser from the CURRENT estimate f (mesh_conj_grad.py:733 -> vertex_area_weights,
@@ -639,7 +634,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_vertex_area_weights(int M, int NB,
 // reduce -- the kernel is bound by neither the gathers' address rate nor their latency any more; not kept.)
 __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, int M, const int *__restrict__ vidx, const float *__restrict__ w, const float *__restrict__ res,
                                                                  const unsigned char *__restrict__ mask, const float *__restrict__ S, double *__restrict__ part,
-                                                                 const NwDevState *__restrict__ st, int it, int n_search, const NwFold Fd)
+                                                                 const NwDevState *__restrict__ st, int it, int n_search)
 {
     if (st->iter_base + it >= st->stop_at) return;       // `it` = iteration of this search() block, iter_base = iterations before it
     __shared__ double s_w[9 * 4];
@@ -705,7 +700,7 @@ __global__ __launch_bounds__(NW_BLOCK) void k_subspace_point_sums(int N, int M, 
             }
         }
     }
-    nw_block_sums_publish<9>(red, part, s_w, Fd);
+    nw_block_sums_store<9>(red, part, s_w);
 }
 
 // Start of a block (search() call) in ONE launch: the estimate restarts from the mesh positions (fs = vertices.copy(),
