@@ -255,7 +255,9 @@ class MembraneMesh(TriMesh):
     def _block_boundary(self, points, done, plan):
         # :1524-1527 -- geometry refreshed from the new positions: vertex normals on the device (they feed the next block's
         # curvature prior; positions and normals stay resident), face areas / edge lengths on the host
-        self.cg.refresh_normals()
+        # (with this package's optimiser they stay on the device until somebody reads mesh.vertex_normals; any other optimiser object
+        # offering refresh_normals() is called the plain way)
+        (getattr(self.cg, 'refresh_normals_lazy', None) or self.cg.refresh_normals)()
         self.update_geometry(vertex_normals=False)
         if plan.punch and done % self.delaunay_remesh_frequency == 0 and self.hole_puncher is not None:   # :1530-1532
             self.hole_puncher(self, points, self.delaunay_eps)

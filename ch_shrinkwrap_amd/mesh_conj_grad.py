@@ -452,15 +452,29 @@ class ShrinkwrapMeshConjGrad(object):
         a, b, c = self.tests[-3:]
         return (c < b) and (b < a) and (a < 1e-6)
 
-    def refresh_normals(self):
+    def refresh_normals(self, fetch=True):
         """Block-boundary refresh for an unchanged topology (_membrane_mesh.pyx:1524-1527) on the device: vertex normals are
-        recomputed from the device-resident positions, kept in HBM for the next block and written to mesh.vertex_normals."""
-        nrm = np.empty((self.M, 3), np.float32)
+        recomputed from the device-resident positions and kept in HBM for the next block.  fetch=True writes them to mesh.vertex_normals at
+        once; fetch=False (the driver's block loop, with a mesh whose `vertex_normals` property can fetch on first use) leaves them on the
+        device until somebody asks."""
+        lazy = not fetch and hasattr(self.mesh, '_normals_stale')
+        nrm = None if lazy else np.empty((self.M, 3), np.float32)
         self._native.check(self._L.nw_refresh_normals(self._h, nw.ptr(nrm), 0.0))
+        if lazy:
+            self.mesh._normals_stale = self._fetch_normals
+            return None
         self.mesh._vertices['normal'][:] = nrm
         if hasattr(self.mesh, '_normals_stale'):
             self.mesh._normals_stale = False
         return nrm
+
+    def refresh_normals_lazy(self):
+        return self.refresh_normals(fetch=False)
+
+    def _fetch_normals(self):
+        nrm = np.empty((self.M, 3), np.float32)
+        self._native.check(self._L.nw_get(self._h, nw.NW_ARR_NRM, nw.ptr(nrm), nrm.nbytes))
+        self.mesh._vertices['normal'][:] = nrm
 
     # -- timing hooks for bench.py ------------------------------------------------------------------
     def set_profiling(self, level=2):
