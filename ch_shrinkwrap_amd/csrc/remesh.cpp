@@ -134,6 +134,7 @@ struct HalfEdgeMesh {
     // refused tests every iteration.  (With relaxation every vertex moves in every iteration: `all_dirty`.)
     std::vector<int> estamp;
     int cur_it = 1;
+    int it_base = 0;                            // (a session's mesh lives through many calls: stamps of an earlier call must not look fresh)
     bool all_dirty = false;
     bool fresh_edge(int h) const { return all_dirty || estamp[h] >= cur_it - 1; }
     void mark(int v)
@@ -644,6 +645,105 @@ NWR_EXPORT int nwr_ring_tables(const void *halfedges, int64_t he_stride, int64_t
     return NWR_OK;
 }
 
+// The iterations of the algorithm on a built mesh (split / collapse / flip, optional relaxation), then flips while a vertex is above the
+// degree limit.  L > 0.
+static int run_passes(HalfEdgeMesh &m, int n_iterations, double L, float relax_lambda, int n_relax, bool verbose, bool first_all)
+{
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const double high = 4.0 / 3.0 * L, low = 4.0 / 5.0 * L;
+    // How many splits the target length can explain: a face with longest edges l1 >= l2 ends up as about (l1 / high + 1)(l2 / high + 1)
+    // pieces -- quadratic for a large isotropic face, linear in its length for a sliver (a star-projected tube has 39 x 1 nm faces and
+    // needs half a million splits at L = 3 nm, which a bound from the MEDIAN edge took for a runaway).  Four times the sum over the
+    // faces per iteration and something feeds on itself; more than 2^26 in all (a vertex flung far away: edges of 10^5 targets)
+    // and the input is refused before any work is done.
+    double pieces = 0.0;
+    for (size_t f = 0; f < m.fhe.size(); ++f) {
+        const int h = m.fhe[f];
+        if (h < 0) continue;
+        double e[3] = {std::sqrt(m.l2[h]), std::sqrt(m.l2[m.next[h]]), std::sqrt(m.l2[m.prev[h]])};
+        std::sort(e, e + 3);
+        pieces += (e[2] / high + 1.0) * (e[1] / high + 1.0);
+    }
+    if (!(pieces < 67108864.0)) return NWR_ERR_RUNAWAY;
+    const int64_t split0 = m.n_split;
+    m.split_cap = split0 + (int64_t)(4.0 * pieces * std::max(n_iterations, 1)) + 100000;
+    const bool relaxing = n_relax > 0;
+    for (int it = 0; it < n_iterations; ++it) {
+        m.cur_it = m.it_base + it + 1;
+        // (first_all: the first iteration of a call looks at every edge -- the mesh is new, or, a session, every vertex has moved since the
+        // last call; not for a seeded run, whose caller has stamped the edges that are to be looked at)
+        m.all_dirty = relaxing || (first_all && it == 0);
+        const int64_t ops_before = m.n_split + m.n_collapse + m.n_flip;
+        const auto t0 = now();
+        m.split_long_edges(high * high);
+        const auto t1 = now();
+        m.collapse_short_edges(low * low, high * high);
+        const auto t2 = now();
+        m.equalize_valences();
+        if (verbose) std::fprintf(stderr, "[nw_remesh] iteration %d: split %.1f ms, collapse %.1f ms, flip %.1f ms (%lld / %lld / %lld operations so far)\n", it, ms(t0, t1), ms(t1, t2),
+                                  ms(t2, now()), (long long)m.n_split, (long long)m.n_collapse, (long long)m.n_flip);
+        if (relaxing) m.relax(relax_lambda, n_relax);
+        if (m.corrupt) return NWR_ERR_NONMANIFOLD;
+        if (m.n_split > m.split_cap) return NWR_ERR_RUNAWAY;
+        // a pass that changed nothing would be repeated unchanged by every later iteration (no relaxation to move vertices)
+        if (!relaxing && m.n_split + m.n_collapse + m.n_flip == ops_before) break;
+    }
+    // splits can pile degree onto a vertex faster than one flip pass removes it: keep flipping while it helps
+    m.all_dirty = true;
+    for (int extra = 0; extra < 6 && n_iterations > 0; ++extra) {
+        int mv = 0;
+        for (size_t v = 0; v < m.pos.size(); ++v) if (m.vhe[v] >= 0) mv = std::max(mv, m.val[v]);
+        if (mv <= m.max_valence) break;
+        const int64_t before = m.n_flip;
+        m.equalize_valences();
+        if (m.corrupt) return NWR_ERR_NONMANIFOLD;
+        if (m.n_flip == before) break;
+    }
+    m.it_base += n_iterations + 2;
+    return NWR_OK;
+}
+
+// compact: faces that are alive, vertices they reference (ids compacted, relative order kept).  out_orig[v'] = the input vertex (< n_vertices_in)
+// an output vertex was, or -1; slot_of_out[v'] = its slot in the mesh (a session scatters the next call's positions through it).
+static void extract_mesh(HalfEdgeMesh &m, int64_t n_vertices_in, std::vector<float> &ov, std::vector<int32_t> &of, std::vector<int> *out_orig, nwr_stats *stats,
+                         std::vector<int> *slot_of_out)
+{
+    std::vector<int> remap(m.pos.size(), -1);
+    int64_t nf = 0;
+    for (size_t f = 0; f < m.fhe.size(); ++f) nf += m.fhe[f] >= 0;
+    of.assign(3 * (size_t)nf, 0);
+    std::vector<unsigned char> used(m.pos.size(), 0);
+    int64_t k = 0;
+    for (size_t f = 0; f < m.fhe.size(); ++f) {
+        const int h = m.fhe[f];
+        if (h < 0) continue;
+        const int a = m.vert[m.prev[h]], b = m.vert[h], c = m.vert[m.next[h]];
+        of[3 * k] = a; of[3 * k + 1] = b; of[3 * k + 2] = c;
+        used[a] = used[b] = used[c] = 1;
+        ++k;
+    }
+    int64_t nv = 0;
+    for (size_t v = 0; v < m.pos.size(); ++v) if (used[v]) remap[v] = (int)nv++;
+    ov.assign(3 * (size_t)nv, 0.0f);
+    if (out_orig) out_orig->assign((size_t)nv, -1);
+    if (slot_of_out) slot_of_out->assign((size_t)nv, -1);
+    for (size_t v = 0; v < m.pos.size(); ++v) {
+        if (remap[v] < 0) continue;
+        ov[3 * remap[v]] = (float)m.pos[v].x; ov[3 * remap[v] + 1] = (float)m.pos[v].y; ov[3 * remap[v] + 2] = (float)m.pos[v].z;
+        if (out_orig && (int64_t)v < n_vertices_in) (*out_orig)[remap[v]] = (int)v;
+        if (slot_of_out) (*slot_of_out)[remap[v]] = (int)v;
+    }
+    for (int64_t i = 0; i < 3 * nf; ++i) of[i] = remap[of[i]];
+    if (stats) {
+        stats->n_split = m.n_split; stats->n_collapse = m.n_collapse; stats->n_flip = m.n_flip;
+        double sl = 0; int64_t n = 0; int mv = 0;
+        for (size_t h = 0; h < m.vert.size(); ++h) if (m.alive((int)h)) { sl += std::sqrt(m.len2((int)h)); ++n; }
+        for (size_t v = 0; v < m.pos.size(); ++v) if (used[v]) mv = std::max(mv, m.val[v]);
+        stats->mean_edge_length = n ? sl / n : 0.0; stats->max_valence = mv; stats->reserved = 0;
+    }
+}
+
 // The serial remesher on one (sub-)mesh.  seed: per-vertex flags -- only edges around flagged vertices are looked at by the collapse and
 // flip passes until an operation freshens more (NULL: every edge, the plain algorithm).  out_orig[v'] = the input vertex an output vertex
 // was, or -1 for a vertex a split created.  target_edge_length must be > 0 when the caller remeshes pieces of one mesh (the default,
@@ -669,92 +769,17 @@ static int remesh_core(const float *vertices, int64_t n_vertices, const int32_t 
             for (int64_t v = 0; v < n_vertices; ++v) if (seed[v]) m.mark((int)v);
         }
         if (verbose) std::fprintf(stderr, "[nw_remesh] build %.1f ms\n", ms(t_start, now()));
-        double L = target_edge_length, L_in = 1.0, L_med = 1.0;
+        double L = target_edge_length, L_in = 1.0;
         {
-            double s = 0; int64_t n = 0;
-            std::vector<double> len(m.vert.size());
-            for (size_t h = 0; h < m.vert.size(); ++h) { len[h] = std::sqrt(m.len2((int)h)); s += len[h]; ++n; }
-            L_in = n ? s / n : 1.0;                 // mean edge length of the input (PYME's default target)
-            if (n) { std::nth_element(len.begin(), len.begin() + n / 2, len.end()); L_med = len[n / 2]; }      // (robust against a few wild edges)
+            double sl = 0; int64_t n = 0;
+            for (size_t h = 0; h < m.vert.size(); ++h) { sl += std::sqrt(m.len2((int)h)); ++n; }
+            L_in = n ? sl / n : 1.0;                 // mean edge length of the input (PYME's default target)
         }
         if (mean_edge_in) *mean_edge_in = L_in;
         if (!(L > 0)) L = L_in;
-        const double high = 4.0 / 3.0 * L, low = 4.0 / 5.0 * L;
-        m.all_dirty = n_relax > 0;
-        // How many splits the target length can explain: a face with longest edges l1 >= l2 ends up as about (l1 / high + 1)(l2 / high + 1)
-        // pieces -- quadratic for a large isotropic face, linear in its length for a sliver (a star-projected tube has 39 x 1 nm faces and
-        // needs half a million splits at L = 3 nm, which a bound from the MEDIAN edge took for a runaway).  Four times the sum over the
-        // faces per iteration and something feeds on itself; more than 2^26 in all (a vertex flung far away: edges of 10^5 targets)
-        // and the input is refused before any work is done.
-        double pieces = 0.0;
-        for (size_t h = 0; h + 2 < m.vert.size(); h += 3) {
-            double e[3] = {std::sqrt(m.len2((int)h)), std::sqrt(m.len2((int)h + 1)), std::sqrt(m.len2((int)h + 2))};
-            std::sort(e, e + 3);
-            pieces += (e[2] / high + 1.0) * (e[1] / high + 1.0);
-        }
-        if (!(pieces < 67108864.0)) return NWR_ERR_RUNAWAY;
-        m.split_cap = (int64_t)(4.0 * pieces * std::max(n_iterations, 1)) + 100000;
-        (void)L_med;
-        for (int it = 0; it < n_iterations; ++it) {
-            m.cur_it = it + 1;
-            const int64_t ops_before = m.n_split + m.n_collapse + m.n_flip;
-            const auto t0 = now();
-            m.split_long_edges(high * high);
-            const auto t1 = now();
-            m.collapse_short_edges(low * low, high * high);
-            const auto t2 = now();
-            m.equalize_valences();
-            if (verbose) std::fprintf(stderr, "[nw_remesh] iteration %d: split %.1f ms, collapse %.1f ms, flip %.1f ms (%lld / %lld / %lld operations so far)\n", it, ms(t0, t1), ms(t1, t2),
-                                      ms(t2, now()), (long long)m.n_split, (long long)m.n_collapse, (long long)m.n_flip);
-            if (n_relax > 0) m.relax(relax_lambda, n_relax);
-            if (m.corrupt) return NWR_ERR_NONMANIFOLD;
-            if (m.n_split > m.split_cap) return NWR_ERR_RUNAWAY;
-            // a pass that changed nothing would be repeated unchanged by every later iteration (no relaxation to move vertices)
-            if (n_relax == 0 && m.n_split + m.n_collapse + m.n_flip == ops_before) break;
-        }
-        // splits can pile degree onto a vertex faster than one flip pass removes it: keep flipping while it helps
-        m.all_dirty = true;
-        for (int extra = 0; extra < 6 && n_iterations > 0; ++extra) {
-            int mv = 0;
-            for (size_t v = 0; v < m.pos.size(); ++v) if (m.vhe[v] >= 0) mv = std::max(mv, m.val[v]);
-            if (mv <= m.max_valence) break;
-            const int64_t before = m.n_flip;
-            m.equalize_valences();
-            if (m.corrupt) return NWR_ERR_NONMANIFOLD;
-            if (m.n_flip == before) break;
-        }
-        // compact: faces that are alive, vertices they reference
-        std::vector<int> remap(m.pos.size(), -1);
-        int64_t nf = 0;
-        for (size_t f = 0; f < m.fhe.size(); ++f) nf += m.fhe[f] >= 0;
-        of.assign(3 * (size_t)nf, 0);
-        std::vector<unsigned char> used(m.pos.size(), 0);
-        int64_t k = 0;
-        for (size_t f = 0; f < m.fhe.size(); ++f) {
-            const int h = m.fhe[f];
-            if (h < 0) continue;
-            const int a = m.vert[m.prev[h]], b = m.vert[h], c = m.vert[m.next[h]];
-            of[3 * k] = a; of[3 * k + 1] = b; of[3 * k + 2] = c;
-            used[a] = used[b] = used[c] = 1;
-            ++k;
-        }
-        int64_t nv = 0;
-        for (size_t v = 0; v < m.pos.size(); ++v) if (used[v]) remap[v] = (int)nv++;
-        ov.assign(3 * (size_t)nv, 0.0f);
-        if (out_orig) out_orig->assign((size_t)nv, -1);
-        for (size_t v = 0; v < m.pos.size(); ++v) {
-            if (remap[v] < 0) continue;
-            ov[3 * remap[v]] = (float)m.pos[v].x; ov[3 * remap[v] + 1] = (float)m.pos[v].y; ov[3 * remap[v] + 2] = (float)m.pos[v].z;
-            if (out_orig && (int64_t)v < n_vertices) (*out_orig)[remap[v]] = (int)v;
-        }
-        for (int64_t i = 0; i < 3 * nf; ++i) of[i] = remap[of[i]];
-        if (stats) {
-            stats->n_split = m.n_split; stats->n_collapse = m.n_collapse; stats->n_flip = m.n_flip;
-            double s = 0; int64_t n = 0; int mv = 0;
-            for (size_t h = 0; h < m.vert.size(); ++h) if (m.alive((int)h)) { s += std::sqrt(m.len2((int)h)); ++n; }
-            for (size_t v = 0; v < m.pos.size(); ++v) if (used[v]) mv = std::max(mv, m.val[v]);
-            stats->mean_edge_length = n ? s / n : 0.0; stats->max_valence = mv; stats->reserved = 0;
-        }
+        rc = run_passes(m, n_iterations, L, relax_lambda, n_relax, verbose, seed == nullptr);
+        if (rc != NWR_OK) return rc;
+        extract_mesh(m, n_vertices, ov, of, out_orig, stats, nullptr);
         if (verbose) std::fprintf(stderr, "[nw_remesh] total %.1f ms\n", ms(t_start, now()));
         return NWR_OK;
     }

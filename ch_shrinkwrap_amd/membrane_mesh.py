@@ -74,7 +74,10 @@ class MembraneMesh(TriMesh):
         """Rebuild the half-edge tables for a new (vertices, faces) pair; the optimiser of the old topology is dropped."""
         props, vprops = self.vertex_properties, self.vertex_vector_properties
         # (inside a fit the vertex normals of a new topology are the device's to compute: nw_set_mesh with nrm = NULL)
-        TriMesh.__init__(self, vertices, faces, vertex_normals=not getattr(self, '_in_fit', False))
+        # ... and the host's half-edge records and 1-rings are built when somebody asks for them (lazy_topology): the device builds its own
+        # tables and the remesher works from the face array
+        in_fit = getattr(self, '_in_fit', False)
+        TriMesh.__init__(self, vertices, faces, vertex_normals=not in_fit, lazy_topology=in_fit)
         self.vertex_properties, self.vertex_vector_properties = props, vprops
         self._initialize_curvature_vectors()
 
@@ -141,7 +144,7 @@ class MembraneMesh(TriMesh):
         if self._native is None:
             self._native = NativeContext(self._device)
         nat = self._native
-        M = self._vertices.shape[0]
+        M = self._position_records().shape[0]
         host_tables = os.environ.get('NW_HOST_TABLES', '0') == '1'
         key = getattr(nat, 'mesh_key', None)
         if skip_prob == 0 and not host_tables and key is not None and key[0] == id(self) and key[1] == M and key[2] == int(self.faces.shape[0]):
@@ -170,7 +173,7 @@ class MembraneMesh(TriMesh):
         return dEdN
 
     def _initialize_curvature_vectors(self):
-        sz = self._vertices.shape[0]                                   # _membrane_mesh.pyx:188-200
+        sz = self._position_records().shape[0]                         # _membrane_mesh.pyx:188-200
         for name in ('_H', '_K', '_E', '_k_0', '_k_1', '_pE', '_dH', '_dK', '_dE_neighbors'):
             setattr(self, name, np.zeros(sz, np.float32))
         self._e_0 = np.zeros((sz, 3), np.float32)

@@ -89,9 +89,11 @@ class ShrinkwrapMeshConjGrad(object):
         self._iter_logs = []
         self._fs_pool = []
 
-        self._mesh_vertex_mask = mesh._vertices['halfedge'] != -1                      # :44
+        # (a mesh that builds its topology records on demand -- trimesh.TriMesh -- is asked in a way that does not trigger the build)
+        records = mesh._position_records() if hasattr(mesh, '_position_records') else mesh._vertices
+        self._mesh_vertex_mask = mesh.valid_vertex_mask() if hasattr(mesh, 'valid_vertex_mask') else records['halfedge'] != -1    # :44
         self._all_valid = bool(self._mesh_vertex_mask.all())
-        self._vertices_view = mesh._vertices['position']                               # :46 (view)
+        self._vertices_view = records['position']                                      # :46 (view)
         self.M = self._vertices_view.shape[0]
         self.dims = self._vertices_view.shape[1]
         self.shape = self._vertices_view.shape
@@ -103,8 +105,9 @@ class ShrinkwrapMeshConjGrad(object):
         self._vertex_neighbors = None
         if not self._device_tables:
             self._vertex_neighbors = self._host_ring_table()                           # :50-54
-        self.N = int(mesh._vertices['neighbors'].shape[1])
+        self.N = int(records.dtype['neighbors'].shape[0])
 
+        self._records = (lambda: mesh._position_records()) if hasattr(mesh, '_position_records') else (lambda: mesh._vertices)
         self._native = native if native is not None else NativeContext(device, stream)
         self._L = self._native.L
         self._h = self._native.h
@@ -143,7 +146,7 @@ class ShrinkwrapMeshConjGrad(object):
         self._vertex_neighbors = table
 
     def _upload_mesh(self):
-        pos = _as_f32(self.mesh._vertices['position'])
+        pos = _as_f32(self._vertices_view)
         faces = np.ascontiguousarray(self.faces, dtype=np.int32)
         valid = np.ascontiguousarray(self._mesh_vertex_mask, dtype=np.uint8)
         if self._device_tables:
@@ -263,7 +266,7 @@ class ShrinkwrapMeshConjGrad(object):
         # a mesh that knows about deferred rows (trimesh.TriMesh): its records are reached WITHOUT waiting for the previous block's rows --
         # the library orders the two copies itself -- and this block's rows may be written while the caller goes on (NW_FLAG_ROWS_ASYNC)
         records = self.mesh.__dict__.get('_vertex_records') if getattr(self.mesh, '_accepts_deferred_rows', False) else None
-        posv = (records if records is not None else self.mesh._vertices)['position']
+        posv = (records if records is not None else self._records())['position']
         direct = posv.dtype == np.float32 and posv.strides[1] == 4 and posv.strides[0] >= 12
         deferred = records is not None and direct and _ROWS_ASYNC and num_iters > 0
         self._native.check(self._L.nw_set_write_back(self._h, ctypes.c_void_p(posv.ctypes.data) if direct else None, posv.strides[0] if direct else 0))
@@ -345,7 +348,7 @@ class ShrinkwrapMeshConjGrad(object):
         """write-back (mesh_conj_grad.py:288-290): one D2H into pinned memory, then the (M,3) result array and the strided
         mesh._vertices['position'] rows (valid vertices only) are filled by the library."""
         out = self._result_buffer()
-        posv = self.mesh._vertices['position']
+        posv = self._records()['position']
         stride = posv.strides[0]
         if posv.dtype == np.float32 and posv.strides[1] == 4 and stride >= 12:
             self._native.check(self._L.nw_write_back(self._h, nw.ptr(out), ctypes.c_void_p(posv.ctypes.data), stride))
@@ -463,7 +466,7 @@ class ShrinkwrapMeshConjGrad(object):
         if lazy:
             self.mesh._normals_stale = self._fetch_normals
             return None
-        self.mesh._vertices['normal'][:] = nrm
+        self._records()['normal'][:] = nrm
         if hasattr(self.mesh, '_normals_stale'):
             self.mesh._normals_stale = False
         return nrm
@@ -474,7 +477,7 @@ class ShrinkwrapMeshConjGrad(object):
     def _fetch_normals(self):
         nrm = np.empty((self.M, 3), np.float32)
         self._native.check(self._L.nw_get(self._h, nw.NW_ARR_NRM, nw.ptr(nrm), nrm.nbytes))
-        self.mesh._vertices['normal'][:] = nrm
+        self._records()['normal'][:] = nrm
 
     # -- timing hooks for bench.py ------------------------------------------------------------------
     def set_profiling(self, level=2):

@@ -171,12 +171,14 @@ def mesh_geometry(positions, faces, vertex_normals=True, out=None):
 
 def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):
     """`MembraneMesh.remesher` hook: remesh the valid part of `mesh` and rebuild its half-edge tables in place."""
-    valid = mesh._vertices['halfedge'] != -1
+    # (asked in a way that does not make a TriMesh with lazy topology build its half-edge records: the remesher works from the faces)
+    valid = mesh.valid_vertex_mask() if hasattr(mesh, 'valid_vertex_mask') else mesh._vertices['halfedge'] != -1
+    pos = mesh.vertices if hasattr(mesh, 'valid_vertex_mask') else mesh._vertices['position']
     if valid.all():                                   # (the usual case: no spare or deleted vertex slots -- nothing to renumber)
-        v, f = mesh._vertices['position'], mesh.faces
+        v, f = pos, mesh.faces
     else:
         remap = np.cumsum(valid) - 1
-        v = mesh._vertices['position'][valid]
+        v = pos[valid]
         f = remap[mesh.faces]
     nv, nf = remesh(v, f, n, target_edge_length, l, n_relax)
     mesh._topology_changed(nv, nf)

@@ -167,12 +167,55 @@ class TriMesh(object):
     # the optimiser), so nobody sees a half-written array; a mesh class without this property (PYME's) gets the synchronous write-back.
     _accepts_deferred_rows = True
 
+    # The half-edge records and the vertex records' topology fields ('halfedge', 'valence', 'neighbors') may not have been built yet
+    # (`lazy_topology`: the driver's block loop, where the device builds its own tables from the faces and the remesher works from the face
+    # array -- nobody on the host reads them between two blocks, and building them was a fifth of a block boundary).  `_vertices`,
+    # `_halfedges` and `_origin` build them on first access; code that only wants positions / normals asks `_position_records()`.
     @property
     def _vertices(self):
         pending = self.__dict__.get('_rows_pending')
         if pending is not None:
             pending()
+        if self.__dict__.get('_topology_pending'):
+            self._build_topology()
         return self.__dict__['_vertex_records']
+
+    def _position_records(self):
+        """The vertex records for somebody who reads or writes 'position' / 'normal' only: waits for rows a block is still writing, not for
+        the topology fields."""
+        pending = self.__dict__.get('_rows_pending')
+        if pending is not None:
+            pending()
+        return self.__dict__['_vertex_records']
+
+    @property
+    def _halfedges(self):
+        if self.__dict__.get('_topology_pending'):
+            self._build_topology()
+        return self.__dict__['_halfedge_records']
+
+    @_halfedges.setter
+    def _halfedges(self, records):
+        self.__dict__['_halfedge_records'] = records
+
+    @property
+    def _origin(self):
+        if self.__dict__.get('_topology_pending'):
+            self._build_topology()
+        return self.__dict__['_halfedge_origin']
+
+    @_origin.setter
+    def _origin(self, origin):
+        self.__dict__['_halfedge_origin'] = origin
+
+    def valid_vertex_mask(self):
+        """`_vertices['halfedge'] != -1` (the reference's test for a vertex slot in use, mesh_conj_grad.py:44) without building the topology:
+        a slot is in use exactly when a face refers to it."""
+        if not self.__dict__.get('_topology_pending'):
+            return self._vertices['halfedge'] != -1
+        mask = np.zeros(self.__dict__['_vertex_records'].shape[0], bool)
+        mask[self._faces_arr.ravel()] = True
+        return mask
 
     @_vertices.setter
     def _vertices(self, records):
@@ -181,22 +224,26 @@ class TriMesh(object):
             pending()
         self.__dict__['_vertex_records'] = records
 
-    def __init__(self, vertices, faces, max_vertices=None, vertex_normals=True):
+    def __init__(self, vertices, faces, max_vertices=None, vertex_normals=True, lazy_topology=False):
         vertices = np.ascontiguousarray(vertices, dtype='f4')
         faces = np.ascontiguousarray(faces, dtype='i4')
         M = vertices.shape[0] if max_vertices is None else int(max_vertices)
+        self.__dict__['_topology_pending'] = False
         self._vertices = np.zeros(M, VERTEX_DTYPE)
-        self._vertices['halfedge'] = -1
-        self._vertices['neighbors'] = -1
-        self._vertices['position'][:vertices.shape[0]] = vertices
+        rec = self.__dict__['_vertex_records']
+        rec['position'][:vertices.shape[0]] = vertices
         self._nv = vertices.shape[0]
         self._faces_arr = faces
         self._ring_vertex_table = None
         self._faces = np.zeros(faces.shape[0], FACE_DTYPE)
         self._faces['halfedge'] = 3 * np.arange(faces.shape[0], dtype='i4')
-        if not self._build_topology_native(faces):
-            self._halfedges, self._origin = _build_halfedges(faces, M)
-            self._build_rings()
+        # (the half-edge records exist from the start: update_geometry writes their 'length' field, which needs the faces only)
+        self._halfedges = np.zeros(3 * faces.shape[0], HALFEDGE_DTYPE)
+        self._origin = None
+        if lazy_topology and faces.shape[0] > 0 and int(faces.min()) >= 0 and int(faces.max()) < M:
+            self.__dict__['_topology_pending'] = True
+        else:
+            self._build_topology()
         # vertex_normals=False (the driver's block loop): the device computes them with the next upload and hands them back after the block;
         # whoever asks before that gets them computed here, on first use (`vertex_normals`)
         self._normals_stale = not vertex_normals
@@ -206,28 +253,41 @@ class TriMesh(object):
         self.vertex_vector_properties = []
 
     # -- topology ---------------------------------------------------------------------------
+    def _build_topology(self):
+        """Half-edge records and 1-rings of the face array (at construction, or -- `lazy_topology` -- when somebody first asks)."""
+        self.__dict__['_topology_pending'] = False
+        rec = self.__dict__['_vertex_records']
+        rec['halfedge'] = -1
+        rec['neighbors'] = -1
+        if not self._build_topology_native(self._faces_arr):
+            lengths = self.__dict__['_halfedge_records']['length'].copy()
+            self._halfedges, self._origin = _build_halfedges(self._faces_arr, rec.shape[0])
+            self.__dict__['_halfedge_records']['length'] = lengths
+            self._build_rings()
+
     def _build_topology_native(self, faces):
         """Half-edge records and 1-rings in one native pass (include/nw_remesh.h: nwr_build_topology, the same conventions as the
         NumPy definitions below, which stay the fallback for inputs the library rejects -- non-manifold edges)."""
         if getattr(TriMesh, '_numpy_topology', False) or faces.shape[0] < 1:
             return False
         from .remesh import build_topology
-        he = np.zeros(3 * faces.shape[0], HALFEDGE_DTYPE)
+        he = self.__dict__['_halfedge_records']           # (the native pass fills vertex / face / twin / next / prev; 'length' is update_geometry's)
+        rec = self.__dict__['_vertex_records']
         try:
-            origin = build_topology(faces, he, self._vertices)
+            origin = build_topology(faces, he, rec)
         except (RuntimeError, ValueError):                # (a missing library raises ImportError and is NOT hidden)
-            self._vertices['halfedge'] = -1
-            self._vertices['neighbors'] = -1
-            self._vertices['valence'] = 0
+            rec['halfedge'] = -1
+            rec['neighbors'] = -1
+            rec['valence'] = 0
             return False
-        self._halfedges, self._origin = he, origin
-        self._vertices['locally_manifold'] = 1
-        self._vertices['component'] = 0
+        self._origin = origin
+        rec['locally_manifold'] = 1
+        rec['component'] = 0
         return True
 
     def _build_rings(self):
         he = self._halfedges
-        M = self._vertices.shape[0]
+        M = self.__dict__['_vertex_records'].shape[0]
         nhe = he.shape[0]
         origin = self._origin
         twin, prev = he['twin'], he['prev']
@@ -264,7 +324,8 @@ class TriMesh(object):
     def update_geometry(self, vertex_normals=True):
         """Face normals/areas, half-edge lengths and (unless they were refreshed on the device) vertex normals from the
         current positions.  This is the block-boundary refresh the reference triggers at _membrane_mesh.pyx:1524-1527."""
-        pos = self._vertices['position']
+        rec = self._position_records()
+        pos = rec['position']
         f = self._faces_arr
         self.__dict__['_mean_edge_cache'] = None
         if vertex_normals:
@@ -273,8 +334,8 @@ class TriMesh(object):
             try:                                              # native, bit-identical to the NumPy definition below
                 from .remesh import mesh_geometry
                 # (written straight into the records' fields: no staging arrays)
-                mesh_geometry(pos, f, vertex_normals, out=(self._faces['normal'], self._faces['area'], self._halfedges['length'],
-                                                           self._vertices['normal'] if vertex_normals else None))
+                mesh_geometry(pos, f, vertex_normals, out=(self._faces['normal'], self._faces['area'], self.__dict__['_halfedge_records']['length'],
+                                                           rec['normal'] if vertex_normals else None))
                 return
             except (RuntimeError, ValueError):                # an input the library rejects: NumPy definition below
                 pass
@@ -299,7 +360,7 @@ class TriMesh(object):
         with np.errstate(invalid='ignore', divide='ignore'):
             vn = vn / l[:, None]
         vn[~np.isfinite(vn)] = 0
-        self._vertices['normal'] = vn.astype('f4')
+        rec['normal'] = vn.astype('f4')
 
     # -- PYME-like attribute surface --------------------------------------------------------
     @property
@@ -308,7 +369,7 @@ class TriMesh(object):
 
     @property
     def vertices(self):
-        return self._vertices['position']
+        return self._position_records()['position']
 
     @property
     def vertex_normals(self):
@@ -319,7 +380,7 @@ class TriMesh(object):
                 stale()                                   # the device holds them (the optimiser refreshed them there): fetched on first use
             else:
                 self.update_geometry(vertex_normals=True)
-        return self._vertices['normal']
+        return self._position_records()['normal']
 
     @property
     def face_normals(self):
@@ -334,7 +395,7 @@ class TriMesh(object):
         # (cached per geometry refresh: the driver asks twice per block, 2.3 ms a time at 1.2 million half-edges)
         cached = self.__dict__.get('_mean_edge_cache')
         if cached is None:
-            l = self._halfedges['length']
+            l = self.__dict__['_halfedge_records']['length']          # (of every face's three edges: no topology needed)
             cached = np.mean(l[l != -1])
             self.__dict__['_mean_edge_cache'] = cached
         return cached

@@ -339,3 +339,37 @@ def test_hook_that_edits_the_records_in_place_reaches_the_next_optimiser(recorde
     assert len(tables) == 2
     assert tables[0][victim, deg - 1] >= 0 and tables[1][victim, deg - 1] == -1
     assert np.array_equal(np.delete(tables[0], victim, 0), np.delete(tables[1], victim, 0))
+
+
+def test_topology_records_built_on_first_use_equal_the_eager_ones(recorder):
+    """`lazy_topology` (what the driver asks for between two blocks): positions, geometry refreshes, the mean edge length and the test for a
+    vertex slot in use work from the face array alone; the first access to the half-edge records, the vertex records or a ring table builds
+    the topology, and everything then equals a mesh built the eager way -- with unused vertex slots as well."""
+    v, f = geodesic_sphere(6, 30.0)
+    for spare in (0, 5):
+        eager = TriMesh(v, f, max_vertices=v.shape[0] + spare)
+        lazy = TriMesh(v, f, max_vertices=v.shape[0] + spare, lazy_topology=True)
+        assert lazy.__dict__['_topology_pending']
+        assert np.array_equal(lazy.vertices, eager.vertices)
+        assert lazy._mean_edge_length == eager._mean_edge_length
+        assert np.array_equal(lazy.valid_vertex_mask(), eager._vertices['halfedge'] != -1)
+        assert np.array_equal(lazy.vertex_normals, eager.vertex_normals)
+        lazy.vertices[:] *= 1.01
+        eager.vertices[:] *= 1.01
+        lazy.update_geometry()
+        eager.update_geometry()
+        assert lazy.area() == eager.area()
+        assert lazy.__dict__['_topology_pending'], 'none of the above needs the half-edge records'
+        first = (lambda: lazy._halfedges, lambda: lazy._vertices, lambda: lazy.neighbor_vertex_table(), lambda: lazy.vertex_neighbors)[spare % 4]
+        first()
+        assert not lazy.__dict__['_topology_pending']
+        assert np.array_equal(lazy._halfedges, eager._halfedges) and np.array_equal(lazy._origin, eager._origin)
+        assert np.array_equal(lazy._vertices, eager._vertices)
+        assert np.array_equal(lazy.neighbor_vertex_table(), eager.neighbor_vertex_table())
+    # the driver: after a fit with the built-in remesher the records are there for whoever asks
+    m = _mesh(kc=1.0, step_size=20.0, max_iter=10, remesh_frequency=5, delaunay_remesh_frequency=0, remesher='builtin')
+    m.shrink_wrap(np.zeros((5, 3), 'f4'), 10.0, minimum_edge_length=m._mean_edge_length / 2)
+    assert m.__dict__['_topology_pending'], 'nothing in the block loop asked for the host topology'
+    ref = TriMesh(m.vertices.copy(), m.faces)
+    assert np.array_equal(m._vertices['neighbors'], ref._vertices['neighbors']) and np.array_equal(m._halfedges['twin'], ref._halfedges['twin'])
+    assert np.array_equal(m._halfedges['length'], ref._halfedges['length'])
