@@ -16,6 +16,9 @@
 #include <thread>
 #include <atomic>
 #include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <pthread.h>
 #include <exception>
 #include <system_error>
 #include <utility>
@@ -44,35 +47,120 @@ int n_threads()
     return (int)std::max(1u, std::min(hc ? hc : 1u, 16u));
 }
 
-// fn(lo, hi) over [0, n) cut into contiguous chunks, one per thread (the calling thread takes the first).  Only for loops whose iterations
-// write disjoint outputs: the result does not depend on the number of threads.
+// NWR_VERBOSE=2: wall time of the stages between two marks (a call's serial stretches are what is left to shorten)
+struct StageClock {
+    const bool on = std::getenv("NWR_VERBOSE") && std::atoi(std::getenv("NWR_VERBOSE")) >= 2;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[nw_remesh]     %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
+// Worker threads that live as long as the process (started on first use): a remesh of 4 10^5 faces is a dozen short parallel loops plus two
+// rounds of pieces, and starting 15 threads for each of them cost more than some of the loops.  One job at a time; the caller works too.
+// A caller that finds the pool taken (two Python threads in the library at once) or that is itself a worker (a loop inside a piece) runs
+// its job on its own thread -- every job is written so that its result does not depend on who runs which part.
+class Pool {
+public:
+    // task(i) for every i in [0, n), handed out one at a time, on at most max_threads threads (the caller included).  An exception in a
+    // task (std::bad_alloc of a scratch vector) never leaves its thread: the first one is kept and re-thrown on the calling thread.
+    template <class Fn>
+    void run(int n, int max_threads, Fn task)
+    {
+        if (n <= 0) return;
+        std::exception_ptr err;
+        std::mutex err_m;
+        auto guarded = [&](int i) {
+            try { task(i); }
+            catch (...) { std::lock_guard<std::mutex> lk(err_m); if (!err) err = std::current_exception(); }
+        };
+        const int want = std::min(std::min(max_threads, n), n_threads());
+        if (want <= 1 || tl_worker || !busy_.try_lock()) {
+            for (int i = 0; i < n; ++i) guarded(i);
+        } else {
+            std::lock_guard<std::mutex> hold(busy_, std::adopt_lock);
+            ensure_threads(want - 1);
+            std::atomic<int> next{0};
+            auto drain = [&] { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) guarded(i); };
+            std::function<void()> job = drain;
+            const int helpers = std::min(want - 1, (int)th_.size());
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                job_ = &job; wanted_ = helpers; running_ = 0; ++gen_;
+            }
+            if (helpers > 0) cv_work_.notify_all();
+            drain();
+            {
+                // no helper may still be inside `job` (or about to enter it) when it goes out of scope
+                std::unique_lock<std::mutex> lk(m_);
+                wanted_ = 0;                                  // (helpers that have not started yet stay out)
+                cv_done_.wait(lk, [&] { return running_ == 0; });
+                job_ = nullptr;
+            }
+        }
+        if (err) std::rethrow_exception(err);
+    }
+
+    static Pool &get()
+    {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            g_pool = new Pool();                              // (never destroyed: its threads wait on a condition variable until the process ends)
+            pthread_atfork(nullptr, nullptr, [] { g_pool = new Pool(); });     // a forked child has none of the threads: a new pool, started on first use
+        });
+        return *g_pool;
+    }
+
+private:
+    static Pool *g_pool;
+    static thread_local bool tl_worker;
+    std::mutex busy_, m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> th_;
+    std::function<void()> *job_ = nullptr;
+    int wanted_ = 0, running_ = 0;
+    uint64_t gen_ = 0;
+
+    void ensure_threads(int n)
+    {
+        while ((int)th_.size() < n) {
+            try { th_.emplace_back([this] { worker(); }); th_.back().detach(); }
+            catch (...) { break; }                            // (fewer threads than wanted: the others take the work)
+        }
+    }
+    void worker()
+    {
+        tl_worker = true;
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (wanted_ <= 0 || !job_) continue;
+            --wanted_; ++running_;
+            std::function<void()> *job = job_;
+            lk.unlock();
+            (*job)();
+            lk.lock();
+            if (--running_ == 0) cv_done_.notify_all();
+        }
+    }
+};
+Pool *Pool::g_pool = nullptr;
+thread_local bool Pool::tl_worker = false;
+
+// fn(lo, hi) over [0, n) cut into contiguous chunks, one per thread.  Only for loops whose iterations write disjoint outputs: the result
+// does not depend on the number of threads.
 template <class Fn>
 void parallel_for(int64_t n, int64_t min_chunk, Fn fn)
 {
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads(), n / std::max<int64_t>(min_chunk, 1)));
     if (T <= 1) { fn((int64_t)0, n); return; }
-    // An exception in a worker (std::bad_alloc of its scratch) must not escape its thread (std::terminate), and one on the calling thread --
-    // or from the std::thread constructor -- must not destroy joinable threads: every body runs under a catch-all that keeps the first
-    // exception, the threads are joined whatever happens, and the exception is re-thrown on the calling thread (the C boundary maps it).
-    std::exception_ptr err;
-    std::mutex err_m;
-    auto guarded = [&](int64_t lo, int64_t hi) {
-        try { fn(lo, hi); }
-        catch (...) { std::lock_guard<std::mutex> lk(err_m); if (!err) err = std::current_exception(); }
-    };
-    std::vector<std::thread> th;
-    th.reserve(T - 1);
-    int started = 1;
-    try {
-        for (int t = 1; t < T; ++t) { th.emplace_back([&guarded, n, t, T] { guarded(n * t / T, n * (t + 1) / T); }); started = t + 1; }
-    } catch (...) {
-        std::lock_guard<std::mutex> lk(err_m);
-        if (!err) err = std::current_exception();
-    }
-    guarded((int64_t)0, n / T);
-    for (int t = started; t < T; ++t) guarded(n * t / T, n * (t + 1) / T);        // (threads that could not be started: their chunks here)
-    for (auto &x : th) x.join();
-    if (err) std::rethrow_exception(err);
+    Pool::get().run(T, T, [&](int t) { fn(n * t / T, n * (t + 1) / T); });
 }
 
 // twin[3f+k] = the half-edge running the other way along edge (faces[f][k], faces[f][k+1]), -1 on a boundary.  Linear time:
@@ -80,13 +168,16 @@ void parallel_for(int64_t n, int64_t min_chunk, Fn fn)
 int match_twins(const int32_t *faces, int64_t nf, int64_t nv, int *twin)
 {
     const int64_t nh = 3 * nf;
+    StageClock clk;
     std::vector<int> first(nv + 1, 0), out(nh);
     for (int64_t h = 0; h < nh; ++h) first[faces[h] + 1] += 1;
     for (int64_t v = 0; v < nv; ++v) first[v + 1] += first[v];
+    if (nf > 100000) clk.mark("twins: count");
     {
         std::vector<int> fill(first.begin(), first.end() - 1);
         for (int64_t h = 0; h < nh; ++h) out[fill[faces[h]]++] = (int)h;
     }
+    if (nf > 100000) clk.mark("twins: fill");
     // target vertex of every half-edge, laid out next to the bucket entries (one sequential read per candidate)
     std::vector<int> tgt(nh), out_tgt(nh);
     parallel_for(nf, 1 << 15, [&](int64_t lo, int64_t hi) {
@@ -102,6 +193,7 @@ int match_twins(const int32_t *faces, int64_t nf, int64_t nv, int *twin)
             twin[h] = t;
         }
     });
+    if (nf > 100000) clk.mark("twins: match");
     if (bad.load()) return NWR_ERR_NONMANIFOLD;
     // the same directed edge twice: both copies found the same twin, which can point back at only one of them; an unmatched
     // duplicate pair shows up among the half-edges leaving their origin
@@ -114,6 +206,7 @@ int match_twins(const int32_t *faces, int64_t nf, int64_t nv, int *twin)
             if (same != 1) bad.store(1, std::memory_order_relaxed);
         }
     });
+    if (nf > 100000) clk.mark("twins: check");
     return bad.load() ? NWR_ERR_NONMANIFOLD : NWR_OK;
 }
 
@@ -838,27 +931,99 @@ static void piece_run(Piece &p, const std::vector<float> &V, const std::vector<i
                        seed_global ? lseed.data() : nullptr, p.ov, p.of, &p.orig, &p.st, nullptr);
 }
 
+// every piece on a thread of the pool.  The global -> local vertex map is a scratch array per thread that lives across calls (all -1 between
+// pieces: piece_run leaves it clean); a piece that throws (out of memory) reports it through its rc, and with it the pass.
+static void run_pieces(std::vector<Piece> &pieces, const std::vector<float> &V, const std::vector<int32_t> &F, int n_iterations, float L, int max_valence,
+                       const unsigned char *seed_global)
+{
+    const size_t nv = V.size() / 3;
+    Pool::get().run((int)pieces.size(), n_threads(), [&](int i) {
+        static thread_local std::vector<int> g2l;
+        try {
+            if (g2l.size() < nv) g2l.assign(nv, -1);
+            piece_run(pieces[i], V, F, g2l, n_iterations, L, max_valence, seed_global);
+        } catch (...) {
+            pieces[i].rc = NWR_ERR_NOMEM;
+            std::vector<int>().swap(g2l);                     // (may have been left half-written)
+        }
+    });
+}
+
+// the ids in [0, n) for which keep(i) holds, ascending: chunks on all threads, their lists joined in chunk order
+template <class Pred>
+static std::vector<int> collect_ids(int64_t n, Pred keep)
+{
+    // (keep() is called once per id: it may mark what it keeps.  Every chunk writes its ids at the start of its own stretch of one array;
+    // the stretches are then moved together)
+    const int64_t CH = 1 << 15;
+    const int64_t nch = (n + CH - 1) / CH;
+    std::vector<int> out((size_t)n);
+    std::vector<int64_t> cnt((size_t)nch, 0);
+    parallel_for(nch, 1, [&](int64_t c_lo, int64_t c_hi) {
+        for (int64_t c = c_lo; c < c_hi; ++c) {
+            int *dst = out.data() + c * CH;
+            int64_t k = 0;
+            for (int64_t i = c * CH; i < std::min(n, (c + 1) * CH); ++i) if (keep(i)) dst[k++] = (int)i;
+            cnt[c] = k;
+        }
+    });
+    int64_t tot = 0;
+    for (int64_t c = 0; c < nch; ++c) {
+        if (tot != c * CH && cnt[c] > 0) std::memmove(out.data() + tot, out.data() + c * CH, sizeof(int) * (size_t)cnt[c]);
+        tot += cnt[c];
+    }
+    out.resize((size_t)tot);
+    return out;
+}
+
 // replace the faces of the pieces (disjoint sets) by their remeshed versions: original vertices keep their ids, new ones are appended in
-// piece order; faces: the untouched ones in their order, then the pieces' in piece order
+// piece order; faces: the untouched ones in their order, then the pieces' in piece order.  (Where everything goes follows from the pieces'
+// sizes, so the pieces are written at once.)
 static void splice(std::vector<float> &V, std::vector<int32_t> &F, std::vector<Piece> &pieces)
 {
     const size_t nf = F.size() / 3;
+    StageClock clk;
     std::vector<unsigned char> gone(nf, 0);
-    for (auto &p : pieces) for (int f : p.faces_in) gone[f] = 1;
-    std::vector<int32_t> F2;
-    F2.reserve(F.size() + F.size() / 4);
-    for (size_t f = 0; f < nf; ++f) if (!gone[f]) { F2.push_back(F[3 * f]); F2.push_back(F[3 * f + 1]); F2.push_back(F[3 * f + 2]); }
-    for (auto &p : pieces) {
+    const int np = (int)pieces.size();
+    Pool::get().run(np, n_threads(), [&](int i) { for (int f : pieces[i].faces_in) gone[f] = 1; });
+    size_t n_in_pieces = 0;
+    for (auto &p : pieces) n_in_pieces += p.faces_in.size();
+    std::vector<int> kept;
+    if (n_in_pieces < nf) kept = collect_ids((int64_t)nf, [&](int64_t f) { return !gone[f]; });
+    clk.mark("splice: kept faces");
+    std::vector<size_t> face_at(np + 1), vert_at(np + 1);
+    face_at[0] = kept.size();
+    vert_at[0] = V.size() / 3;
+    for (int i = 0; i < np; ++i) {
+        size_t fresh = 0;
+        for (int o : pieces[i].orig) fresh += o < 0;
+        face_at[i + 1] = face_at[i] + pieces[i].of.size() / 3;
+        vert_at[i + 1] = vert_at[i] + fresh;
+    }
+    clk.mark("splice: offsets");
+    std::vector<int32_t> F2(3 * face_at[np]);
+    V.resize(3 * vert_at[np]);
+    clk.mark("splice: alloc");
+    parallel_for((int64_t)kept.size(), 1 << 15, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) { const size_t f = (size_t)kept[i]; F2[3 * i] = F[3 * f]; F2[3 * i + 1] = F[3 * f + 1]; F2[3 * i + 2] = F[3 * f + 2]; }
+    });
+    clk.mark("splice: copy kept");
+    Pool::get().run(np, n_threads(), [&](int i) {
+        Piece &p = pieces[i];
         std::vector<int> o2g(p.orig.size());
+        size_t at = vert_at[i];
         for (size_t v = 0; v < p.orig.size(); ++v) {
             if (p.orig[v] >= 0) o2g[v] = p.l2g[p.orig[v]];
             else {
-                o2g[v] = (int)(V.size() / 3);
-                V.push_back(p.ov[3 * v]); V.push_back(p.ov[3 * v + 1]); V.push_back(p.ov[3 * v + 2]);
+                o2g[v] = (int)at;
+                V[3 * at] = p.ov[3 * v]; V[3 * at + 1] = p.ov[3 * v + 1]; V[3 * at + 2] = p.ov[3 * v + 2];
+                ++at;
             }
         }
-        for (size_t i = 0; i < p.of.size(); ++i) F2.push_back(o2g[p.of[i]]);
-    }
+        int32_t *dst = F2.data() + 3 * face_at[i];
+        for (size_t k = 0; k < p.of.size(); ++k) dst[k] = o2g[p.of[k]];
+    });
+    clk.mark("splice: pieces");
     F.swap(F2);
 }
 
@@ -883,14 +1048,20 @@ static int seam_pass(std::vector<float> &V, std::vector<int32_t> &F, const std::
                      int n_iterations, float L, int max_valence, nwr_stats &tot)
 {
     const bool verbose = std::getenv("NWR_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_in = now();
     const size_t nv = V.size() / 3, nf = F.size() / 3;
+    StageClock clk;
     // label of a seed = the two lowest runs among its faces (the strip it belongs to); without face_run everything is strip 0
     std::vector<int> vlab(nv, -1);
     if (face_run) {
         std::vector<int> p1(nv, INT32_MAX), p2(nv, INT32_MAX);
-        for (size_t f = 0; f < nf; ++f)
+        // (only the faces at a seed matter: found on all threads, looked at in face order)
+        const std::vector<int> at_seed = collect_ids((int64_t)nf, [&](int64_t f) { return seeds[F[3 * f]] || seeds[F[3 * f + 1]] || seeds[F[3 * f + 2]]; });
+        for (int f : at_seed)
             for (int k = 0; k < 3; ++k) {
-                const int v = F[3 * f + k];
+                const int v = F[3 * (size_t)f + k];
                 if (!seeds[v]) continue;
                 const int r = (*face_run)[f];
                 if (r == p1[v] || r == p2[v]) continue;
@@ -901,20 +1072,24 @@ static int seam_pass(std::vector<float> &V, std::vector<int32_t> &F, const std::
     } else {
         for (size_t v = 0; v < nv; ++v) if (seeds[v]) vlab[v] = 0;
     }
+    clk.mark("seam: seed labels");
     // the zone grows ring by ring; a face takes the lowest label among its labelled vertices, its other vertices take the face's
+    // (the scan for a ring's faces reads the vertex labels of the ring before and writes face labels only: on all threads; the vertices
+    // then take their labels in face order)
     std::vector<int> flab(nf, -1);
-    std::vector<int> fresh;
     for (int ring = 0; ring < NWR_SEAM_RINGS; ++ring) {
-        fresh.clear();
-        for (size_t f = 0; f < nf; ++f) {
-            if (flab[f] >= 0) continue;
+        const std::vector<int> fresh = collect_ids((int64_t)nf, [&](int64_t f) {
+            if (flab[f] >= 0) return false;
             int lab = INT32_MAX;
             for (int k = 0; k < 3; ++k) { const int l = vlab[F[3 * f + k]]; if (l >= 0 && l < lab) lab = l; }
-            if (lab != INT32_MAX) { flab[f] = lab; fresh.push_back((int)f); }
-        }
+            if (lab == INT32_MAX) return false;
+            flab[f] = lab;
+            return true;
+        });
         for (int f : fresh)
             for (int k = 0; k < 3; ++k) { int &l = vlab[F[3 * (size_t)f + k]]; if (l < 0) l = flab[f]; }
     }
+    clk.mark("seam: rings");
     const int nlab = face_run ? NWR_REGIONS * NWR_REGIONS : 1;
     std::vector<int> cnt(nlab, 0);
     size_t nz = 0;
@@ -926,6 +1101,7 @@ static int seam_pass(std::vector<float> &V, std::vector<int32_t> &F, const std::
     std::vector<Piece> pieces(npieces);
     for (int l = 0; l < nlab; ++l) if (cnt[l] > 0) pieces[slot[l]].faces_in.reserve(cnt[l]);
     for (size_t f = 0; f < nf; ++f) if (flab[f] >= 0) pieces[slot[flab[f]]].faces_in.push_back((int)f);
+    clk.mark("seam: strips' faces");
     // the strips' frozen ends: vertices that faces of two strips share
     std::vector<unsigned char> ends(nv, 0);
     size_t nends = 0;
@@ -945,47 +1121,37 @@ static int seam_pass(std::vector<float> &V, std::vector<int32_t> &F, const std::
         for (unsigned char c : seeds) ns += c;
         std::fprintf(stderr, "[nw_remesh] seam pass: %zu seeds, zone of %zu faces (of %zu) in %d strips, %zu vertices at their ends\n", ns, nz, nf, npieces, nends);
     }
-    {
-        const int T = std::min(n_threads(), npieces);
-        std::atomic<int> next{0};
-        std::vector<std::thread> th;
-        auto work = [&] {
-            int i = -1;
-            try {
-                std::vector<int> g2l(nv, -1);
-                for (i = next.fetch_add(1); i < npieces; i = next.fetch_add(1)) piece_run(pieces[i], V, F, g2l, n_iterations, L, max_valence, seeds.data());
-            } catch (...) {                                   // (out of memory in a worker: its piece, and with it the pass, reports it)
-                if (i >= 0 && i < npieces) pieces[i].rc = NWR_ERR_NOMEM; else pieces[0].rc = NWR_ERR_NOMEM;
-            }
-        };
-        try { for (int t = 1; t < T; ++t) th.emplace_back(work); } catch (...) {}       // (fewer threads than wanted: the others take the pieces)
-        work();
-        for (auto &x : th) x.join();
-    }
+    clk.mark("seam: ends");
+    const auto t_zone = now();
+    run_pieces(pieces, V, F, n_iterations, L, max_valence, seeds.data());
     for (auto &p : pieces) {
         if (p.rc != NWR_OK) return p.rc;
         tot.n_split += p.st.n_split; tot.n_collapse += p.st.n_collapse; tot.n_flip += p.st.n_flip;
     }
+    const auto t_run = now();
     splice(V, F, pieces);
+    if (verbose) std::fprintf(stderr, "[nw_remesh] seam pass: zone %.1f ms, strips %.1f ms, splice %.1f ms\n", ms(t_in, t_zone), ms(t_zone, t_run), ms(t_run, now()));
     if (nends == 0) return NWR_OK;
     ends.resize(V.size() / 3, 0);                             // (frozen: they kept their ids; what the strips created is no seed)
     return seam_pass(V, F, ends, nullptr, n_iterations, L, max_valence, tot);
 }
 
 static int remesh_partitioned(const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces, int n_iterations, float L, int max_valence,
-                              std::vector<float> &ov, std::vector<int32_t> &of, nwr_stats *stats, double *min_edge2)
+                              std::vector<float> &ov, std::vector<int32_t> &of, nwr_stats *stats, double *min_edge2, bool *input_bad)
 {
     const bool verbose = std::getenv("NWR_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = now();
+    StageClock clk;
     std::vector<float> V(vertices, vertices + 3 * n_vertices);
     std::vector<int32_t> F(faces, faces + 3 * n_faces);
+    clk.mark("order: copies");
     // Morton order of the faces' centroids over the mesh's bounding cube
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t v = 0; v < n_vertices; ++v) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], V[3 * v + k]); hi[k] = std::max(hi[k], V[3 * v + k]); }
     const double ext = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-30});
-    std::vector<std::pair<unsigned, int>> key((size_t)n_faces);
+    std::vector<unsigned> key((size_t)n_faces);
     parallel_for(n_faces, 1 << 14, [&](int64_t f_lo, int64_t f_hi) {
         for (int64_t f = f_lo; f < f_hi; ++f) {
             unsigned q[3];
@@ -993,66 +1159,87 @@ static int remesh_partitioned(const float *vertices, int64_t n_vertices, const i
                 const double c = ((double)V[3 * (size_t)F[3 * f] + k] + V[3 * (size_t)F[3 * f + 1] + k] + V[3 * (size_t)F[3 * f + 2] + k]) / 3.0;
                 q[k] = (unsigned)std::min(1023.0, std::max(0.0, (c - lo[k]) / ext * 1024.0));
             }
-            key[f] = {spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2), (int)f};
+            key[f] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
         }
     });
-    {
-        // stable LSD radix sort of the 30-bit keys, three passes of 10 bits (faces of equal key keep their order: as std::sort of the
-        // (key, face) pairs would leave them -- a third of its time)
-        std::vector<std::pair<unsigned, int>> tmp(key.size());
-        for (int pass = 0; pass < 3; ++pass) {
-            const int sh = 10 * pass;
-            size_t cnt[1025] = {0};
-            for (const auto &e : key) cnt[((e.first >> sh) & 1023u) + 1] += 1;
-            for (int b = 0; b < 1024; ++b) cnt[b + 1] += cnt[b];
-            for (const auto &e : key) tmp[cnt[(e.first >> sh) & 1023u]++] = e;
-            key.swap(tmp);
-        }
-    }
+    clk.mark("order: keys");
+    // Run r = the faces of rank [n r / R, n (r + 1) / R) in the order of (key, face id) -- what a stable sort by key would give -- with the
+    // faces of a run in the mesh's own order.  No sort is needed for that: a histogram over the keys' upper 16 bits places every bin in the
+    // ranking; a bin that no run boundary cuts belongs to one run as a whole, and only the few bins a boundary cuts are ranked face by face.
     std::vector<Piece> pieces(NWR_REGIONS);
-    parallel_for(NWR_REGIONS, 1, [&](int64_t r_lo, int64_t r_hi) {
-        for (int64_t r = r_lo; r < r_hi; ++r) {
-            const int64_t a = n_faces * r / NWR_REGIONS, b = n_faces * (r + 1) / NWR_REGIONS;
-            pieces[r].faces_in.reserve((size_t)(b - a));
-            for (int64_t i = a; i < b; ++i) pieces[r].faces_in.push_back(key[i].second);
-            std::sort(pieces[r].faces_in.begin(), pieces[r].faces_in.end());          // (the mesh's own face order inside a run)
+    {
+        const int SH = 14, NB = 1 << 16;
+        std::vector<int64_t> start(NB + 1, 0);
+        for (int64_t f = 0; f < n_faces; ++f) start[(key[f] >> SH) + 1] += 1;
+        for (int b = 0; b < NB; ++b) start[b + 1] += start[b];
+        int64_t bound[NWR_REGIONS + 1];
+        for (int r = 0; r <= NWR_REGIONS; ++r) bound[r] = n_faces * r / NWR_REGIONS;
+        auto run_of_rank = [&](int64_t rank) { int r = 0; while (r + 1 < NWR_REGIONS && bound[r + 1] <= rank) ++r; return r; };
+        std::vector<int> bin_run(NB, 0);                       // run of a whole bin, or -1 - (index of the cut bin)
+        std::vector<int> cut_bins;
+        for (int b = 0; b < NB; ++b) {
+            if (start[b + 1] == start[b]) continue;
+            const int r0 = run_of_rank(start[b]), r1 = run_of_rank(start[b + 1] - 1);
+            if (r0 == r1) bin_run[b] = r0;
+            else { bin_run[b] = -1 - (int)cut_bins.size(); cut_bins.push_back(b); }
         }
-    });
-    // vertices on a rim: used by faces of more than one run
+        std::vector<std::vector<std::pair<unsigned, int>>> cut(cut_bins.size());
+        std::vector<int> face_run((size_t)n_faces);
+        for (int64_t f = 0; f < n_faces; ++f) {
+            const int br = bin_run[key[f] >> SH];
+            face_run[f] = br;
+            if (br < 0) cut[-1 - br].push_back({key[f], (int)f});
+        }
+        for (size_t c = 0; c < cut.size(); ++c) {
+            std::sort(cut[c].begin(), cut[c].end());
+            for (size_t i = 0; i < cut[c].size(); ++i) face_run[cut[c][i].second] = run_of_rank(start[cut_bins[c]] + (int64_t)i);
+        }
+        clk.mark("order: ranks");
+        for (int r = 0; r < NWR_REGIONS; ++r) pieces[r].faces_in.reserve((size_t)(bound[r + 1] - bound[r]));
+        for (int64_t f = 0; f < n_faces; ++f) pieces[face_run[f]].faces_in.push_back((int)f);
+    }
+    clk.mark("order: runs");
+    // vertices on a rim: used by faces of more than one run (every run marks its vertices: the first to come claims a vertex, whoever finds
+    // it claimed by another run flags it -- which run claimed it does not matter)
     std::vector<int> vrun((size_t)n_vertices, -1);
     std::vector<unsigned char> rim((size_t)n_vertices, 0);
-    for (int r = 0; r < NWR_REGIONS; ++r)
+    Pool::get().run(NWR_REGIONS, n_threads(), [&](int r) {
         for (int f : pieces[r].faces_in)
             for (int k = 0; k < 3; ++k) {
                 const int v = F[3 * (size_t)f + k];
-                if (vrun[v] < 0) vrun[v] = r;
-                else if (vrun[v] != r) rim[v] = 1;
+                int seen = __atomic_load_n(&vrun[v], __ATOMIC_RELAXED);
+                if (seen < 0) {
+                    int expect = -1;
+                    seen = __atomic_compare_exchange_n(&vrun[v], &expect, r, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED) ? r : expect;
+                }
+                if (seen != r) __atomic_store_n(&rim[v], (unsigned char)1, __ATOMIC_RELAXED);
             }
+    });
+    clk.mark("order: rims");
+    // An input that is no oriented 2-manifold is refused, as the serial path refuses it when it matches the twins of the whole mesh: a mesh
+    // is one exactly when no directed edge a -> b occurs twice (three faces on an edge, or two with the same sense, repeat a direction).
+    // Inside a run its own twin matching finds a repeat (pass 1); a repeat ACROSS runs joins two vertices that both lie on a rim -- a few per
+    // cent of the edges, which are collected, sorted and compared here instead of matching 10^6 half-edges a second time.
+    {
+        const std::vector<int> rr = collect_ids(3 * n_faces, [&](int64_t h) { return rim[F[h]] && rim[F[h - h % 3 + (h + 1) % 3]]; });
+        std::vector<uint64_t> ek(rr.size());
+        for (size_t i = 0; i < rr.size(); ++i) { const int64_t h = rr[i]; ek[i] = ((uint64_t)(uint32_t)F[h] << 32) | (uint32_t)F[h - h % 3 + (h + 1) % 3]; }
+        std::sort(ek.begin(), ek.end());
+        if (std::adjacent_find(ek.begin(), ek.end()) != ek.end()) { if (input_bad) *input_bad = true; return NWR_ERR_NONMANIFOLD; }
+    }
+    clk.mark("order: rim edges");
     const auto t1 = now();
     // pass 1: the runs, independently
     const int T = std::min(n_threads(), NWR_REGIONS);
-    {
-        std::vector<std::thread> th;
-        std::atomic<int> next_run{0};
-        auto work = [&] {
-            int r = -1;
-            try {
-                std::vector<int> g2l((size_t)n_vertices, -1);
-                for (r = next_run.fetch_add(1); r < NWR_REGIONS; r = next_run.fetch_add(1)) piece_run(pieces[r], V, F, g2l, n_iterations, L, max_valence, nullptr);
-            } catch (...) {
-                if (r >= 0 && r < NWR_REGIONS) pieces[r].rc = NWR_ERR_NOMEM; else pieces[0].rc = NWR_ERR_NOMEM;
-            }
-        };
-        try { for (int t = 1; t < T; ++t) th.emplace_back(work); } catch (...) {}
-        work();
-        for (auto &x : th) x.join();
-    }
+    run_pieces(pieces, V, F, n_iterations, L, max_valence, nullptr);
     nwr_stats tot{};
     for (auto &p : pieces) {
         if (p.rc != NWR_OK) return p.rc;
         tot.n_split += p.st.n_split; tot.n_collapse += p.st.n_collapse; tot.n_flip += p.st.n_flip;
     }
+    clk.mark("pass 1: pieces");
     splice(V, F, pieces);
+    clk.mark("pass 1: splice");
     const auto t2 = now();
     // pass 2: the seam zone = faces within NWR_SEAM_RINGS rings of a rim vertex (rim vertices kept their ids: they were frozen)
     if (!std::getenv("NWR_NO_SEAM")) {
@@ -1070,7 +1257,7 @@ static int remesh_partitioned(const float *vertices, int64_t n_vertices, const i
         const size_t nv = V.size() / 3;
         std::vector<int> remap(nv, -1);
         std::vector<unsigned char> used(nv, 0);
-        for (int32_t v : F) used[v] = 1;
+        parallel_for((int64_t)F.size(), 1 << 16, [&](int64_t lo_, int64_t hi_) { for (int64_t i = lo_; i < hi_; ++i) __atomic_store_n(&used[F[i]], (unsigned char)1, __ATOMIC_RELAXED); });
         int64_t n = 0;
         for (size_t v = 0; v < nv; ++v) if (used[v]) remap[v] = (int)n++;
         ov.resize(3 * (size_t)n);
@@ -1126,6 +1313,7 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
     if (n_vertices < 3 || n_faces < 1 || n_vertices > (1ll << 30) || n_faces > (1ll << 29) || n_iterations < 0 || n_relax < 0)
         return NWR_ERR_BADARG;
     *out_vertices = nullptr; *out_faces = nullptr; *out_n_vertices = 0; *out_n_faces = 0;
+    const auto t_call = std::chrono::steady_clock::now();
     try {
         std::vector<float> ov;
         std::vector<int32_t> of;
@@ -1133,8 +1321,17 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
         static const bool part_env = !(std::getenv("NW_REMESH_PARTITION") && std::atoi(std::getenv("NW_REMESH_PARTITION")) == 0);
         const bool part_on = part_env && g_partition.load() != 0;
         if (part_on && n_relax == 0 && n_iterations > 0 && n_faces >= NWR_PARALLEL_MIN_FACES) {
-            for (int64_t i = 0; i < 3 * n_vertices; ++i) if (!std::isfinite(vertices[i])) return NWR_ERR_BADARG;
-            for (int64_t i = 0; i < 3 * n_faces; ++i) if (faces[i] < 0 || faces[i] >= n_vertices) return NWR_ERR_BADARG;
+            {
+                std::atomic<int> bad{0};
+                parallel_for(3 * n_vertices, 1 << 16, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) if (!std::isfinite(vertices[i])) bad.store(1, std::memory_order_relaxed); });
+                parallel_for(n_faces, 1 << 15, [&](int64_t lo, int64_t hi) {
+                    for (int64_t f = lo; f < hi; ++f) {
+                        const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+                        if (a < 0 || a >= n_vertices || b < 0 || b >= n_vertices || c < 0 || c >= n_vertices || a == b || b == c || c == a) bad.store(1, std::memory_order_relaxed);
+                    }
+                });
+                if (bad.load()) return NWR_ERR_BADARG;
+            }
             float L = target_edge_length;
             if (!(L > 0)) {                          // PYME's default: the mean edge length of the input -- of the WHOLE input
                 double s = 0;
@@ -1146,14 +1343,12 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
                     }
                 L = (float)(s / (3.0 * (double)n_faces));
             }
-            // (a non-manifold input is refused like the serial path does: the twin table of the whole mesh)
-            {
-                std::vector<int> twin(3 * (size_t)n_faces);
-                rc = match_twins(faces, n_faces, n_vertices, twin.data());
-                if (rc != NWR_OK) return rc;
-            }
+            // (a non-manifold input is refused like the serial path does: remesh_partitioned looks for a directed edge that occurs twice)
+            if (std::getenv("NWR_VERBOSE")) std::fprintf(stderr, "[nw_remesh] input checks %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
             double min_edge2 = INFINITY;
-            rc = remesh_partitioned(vertices, n_vertices, faces, n_faces, n_iterations, L, max_valence, ov, of, stats, &min_edge2);
+            bool input_bad = false;
+            rc = remesh_partitioned(vertices, n_vertices, faces, n_faces, n_iterations, L, max_valence, ov, of, stats, &min_edge2, &input_bad);
+            if (input_bad) return rc;
             // safety net: an edge of (nearly) no length in the result -- never seen since the rims wait for their pass -- and the
             // serial algorithm takes over
             if (rc != NWR_OK || !(min_edge2 > 1e-12 * (double)L * (double)L)) {

@@ -244,3 +244,36 @@ def test_partitioned_remesher_is_independent_of_the_thread_count_and_as_good_as_
     assert abs(a['nv'] - s['nv']) <= 0.02 * s['nv']
     assert abs(a['mean'] - s['mean']) <= 0.02 * s['mean']
     assert a['mx'] <= 1.15 * s['mx'] and a['mn'] >= 0.5 * s['mn'] and a['deg'] <= 16
+
+
+def test_partitioned_remesher_refuses_what_the_serial_one_refuses():
+    """Above 40 000 faces the input is no longer checked by matching the twins of the whole mesh: a directed edge that occurs twice is found
+    inside a run by the run's own twin matching, across runs among the edges between two rim vertices.  Faces with the wrong sense, an
+    extra face on an edge (three faces on it) and a doubled face must be refused with the serial path's error wherever they lie -- 40
+    random places each, so that both kinds of place are hit --, a face that names a vertex twice or a vertex that does not exist with
+    'bad argument', and the mesh as it was goes through."""
+    v, f = icosphere(6, 100.0)
+    assert f.shape[0] >= 40000
+    rng = np.random.default_rng(5)
+    R.remesh(v, f, 1, 3.0, 0.5, 0)
+    for kind in ('flipped', 'fin', 'doubled'):
+        for i in rng.choice(f.shape[0], 40, replace=False):
+            g = f.copy()
+            if kind == 'flipped':
+                g[i] = g[i, ::-1]
+            elif kind == 'fin':
+                far = int((g[i, 0] + v.shape[0] // 2) % v.shape[0])
+                g = np.vstack([g, [[g[i, 0], g[i, 1], far]]]).astype('i4')
+            else:
+                g = np.vstack([g, g[i:i + 1]]).astype('i4')
+            for serial in (False, True):
+                with pytest.raises(RuntimeError, match='2-manifold'):
+                    R.remesh(v, g, 1, 3.0, 0.5, 0, serial=serial)
+    g = f.copy()
+    g[123, 1] = g[123, 0]
+    with pytest.raises(RuntimeError, match='bad argument'):
+        R.remesh(v, g, 1, 3.0, 0.5, 0)
+    g = f.copy()
+    g[77, 2] = v.shape[0]
+    with pytest.raises(RuntimeError, match='bad argument'):
+        R.remesh(v, g, 1, 3.0, 0.5, 0)
