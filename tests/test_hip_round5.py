@@ -94,10 +94,18 @@ def test_large_result_comes_back_in_announced_slices_and_its_host_tail_is_bounde
     cg._native.check(cg._L.nw_get(cg._h, nw.NW_ARR_POS, nw.ptr(dev), dev.nbytes))
     assert np.array_equal(out, dev)
     assert np.array_equal(mesh._vertices['position'], dev)
-    t0 = time.perf_counter()
-    cg.search(pts, lams=[10.0], num_iters=5, sigma_inv=s, to_host=False)
-    cg.synchronize()
-    t_without = time.perf_counter() - t0
+    # (the bound is on what the path costs, not on one block's luck with the host's scheduler: the best of three of each)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        cg.search(pts, lams=[10.0], num_iters=5, sigma_inv=s)
+        cg.synchronize()
+        t_with = min(t_with, time.perf_counter() - t0)
+    t_without = np.inf
+    for rep in range(3):
+        t0 = time.perf_counter()
+        cg.search(pts, lams=[10.0], num_iters=5, sigma_inv=s, to_host=False)
+        cg.synchronize()
+        t_without = min(t_without, time.perf_counter() - t0)
     print('block of 5 at 361k vertices: %.3f ms with its result on the host, %.3f ms without' % (t_with * 1e3, t_without * 1e3))
     assert t_with - t_without < 1.5e-3, (t_with, t_without)
 
