@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NW_LIB_PATH') or os.path.join(HERE, 'libnanowrap_hip.so')      # (NW_LIB_PATH: developer knob, A/B of two builds on one box)
 
 NW_OK = 0
-NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM, NW_ERR_INTERNAL, NW_ERR_REMOTE, NW_ERR_HANDOFF = -1, -2, -3, -4, -5, -6, -7, -8, -9
+NW_ERR_BADARG, NW_ERR_HIP, NW_ERR_NAN, NW_ERR_SINGULAR, NW_ERR_NONFINITE, NW_ERR_NOMEM, NW_ERR_INTERNAL, NW_ERR_REMOTE, NW_ERR_HANDOFF, NW_ERR_NONMANIFOLD = -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
 NW_WEIGHTS_FROM_SIGMA_INV, NW_WEIGHTS_SCALAR, NW_WEIGHTS_ARRAY, NW_WEIGHTS_PRENORMALIZED = 0, 1, 2, 3
 NW_FLAG_POSITIVITY, NW_FLAG_NO_LAST_STEP, NW_FLAG_WFUNC, NW_FLAG_RESULT_TO_HOST = 1, 2, 4, 8
 NW_FLAG_COMM_TILES, NW_FLAG_COMM_REPLICATED, NW_FLAG_COMM_HALO = 16, 32, 64
@@ -27,7 +27,8 @@ SYMBOLS = ['nw_abi_version', 'nw_create', 'nw_destroy', 'nw_last_error', 'nw_set
            'nw_iter_attract', 'nw_iter_directions', 'nw_iter_update', 'nw_search_end', 'nw_info',
            'nw_apply_A', 'nw_apply_At', 'nw_get', 'nw_write_back', 'nw_device_ptr', 'nw_lfunc', 'nw_curvature', 'nw_set_profiling', 'nw_stage_ms', 'nw_debug', 'nw_set_data', 'nw_accumulator_quantum', 'nw_optimize_layout', 'nw_set_write_back',
            'nw_set_boundary', 'nw_halo_rows', 'nw_halo_gather_owned', 'nw_host_copy_rows',
-           'nw_comm_unique_id', 'nw_comm_init', 'nw_comm_all_reduce', 'nw_halo_set_reference', 'nw_halo_block_stats']
+           'nw_comm_unique_id', 'nw_comm_init', 'nw_comm_all_reduce', 'nw_halo_set_reference', 'nw_halo_block_stats',
+           'nw_remesh_device', 'nw_host_free']
 
 
 class IterLog(ctypes.Structure):
@@ -93,9 +94,9 @@ def load():
     L.nw_optimize_layout.argtypes = [vp]
     L.nw_accumulator_quantum.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     for s in SYMBOLS:
-        if s not in ('nw_destroy', 'nw_last_error'):
+        if s not in ('nw_destroy', 'nw_last_error', 'nw_host_free'):
             getattr(L, s).restype = i32
-    if L.nw_abi_version() != 5:
+    if L.nw_abi_version() != 6:
         raise RuntimeError('libnanowrap_hip.so ABI version mismatch')
     _lib = L
     return L

@@ -1,6 +1,6 @@
 """
 Builds the native pieces in-tree (no pip, no JIT cache):
-  * ch_shrinkwrap_amd/libnanowrap_hip.so  -- the HIP kernels + C-ABI (hipcc, --offload-arch=gfx950)
+  * ch_shrinkwrap_amd/libnanowrap_hip.so  -- the HIP kernels + C-ABI (hipcc, --offload-arch=gfx950): csrc/nanowrap.hip, nw_sort.hip, nw_remesh_dev.hip
   * ch_shrinkwrap_amd/libnw_remesh.so     -- the block-boundary remesher (host C++, g++; include/nw_remesh.h)
 The oracle (test infrastructure) is built by oracle/Makefile, see __graft_entry__.build().
 """
@@ -13,9 +13,11 @@ SRC = os.path.join(HERE, 'csrc', 'nanowrap.hip')
 SRC_SORT = os.path.join(HERE, 'csrc', 'nw_sort.hip')      # set-up radix sort (hipCUB), its own translation unit
 OBJ_SORT = os.path.join(HERE, 'csrc', 'nw_sort.o')
 OBJ_MAIN = os.path.join(HERE, 'csrc', 'nanowrap.o')
+SRC_REMESH = os.path.join(HERE, 'csrc', 'nw_remesh_dev.hip')   # the block-boundary remesher as kernels (hipCUB scans), its own translation unit
+OBJ_REMESH = os.path.join(HERE, 'csrc', 'nw_remesh_dev.o')
 import glob
 # every header of csrc/ is included by nanowrap.hip (directly or through nw_kernels.h): editing any of them must rebuild the library
-DEPS = [SRC, SRC_SORT] + sorted(glob.glob(os.path.join(HERE, 'csrc', '*.h'))) + [os.path.join(os.path.dirname(HERE), 'include', 'nanowrap.h')]
+DEPS = [SRC, SRC_SORT, SRC_REMESH] + sorted(glob.glob(os.path.join(HERE, 'csrc', '*.h'))) + [os.path.join(os.path.dirname(HERE), 'include', 'nanowrap.h')]
 
 # -ffp-contract=off : the parity-critical float32 arithmetic must round products before adding, exactly like
 #                     the NumPy reference (explicit fma() is used where contraction is wanted);
@@ -43,9 +45,12 @@ def build_hip_library(force=False, verbose=False):
 
     if force or not os.path.exists(OBJ_SORT) or os.path.getmtime(OBJ_SORT) < os.path.getmtime(SRC_SORT):
         run([hipcc, '-O3', '--offload-arch=gfx950', '-fPIC', '-fvisibility=hidden', '-Wno-unused-value', '-c', '-o', OBJ_SORT, SRC_SORT])
+    if force or not os.path.exists(OBJ_REMESH) or os.path.getmtime(OBJ_REMESH) < max(os.path.getmtime(SRC_REMESH), os.path.getmtime(DEPS[-1])):
+        run([hipcc, '-O3', '--offload-arch=gfx950', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off', '-Wall', '-Wno-unused-value', '-Wno-unused-function',
+             '-c', '-o', OBJ_REMESH, SRC_REMESH])
     run([hipcc] + [f for f in HIPCC_FLAGS if f != '-shared'] + ['-c', '-o', OBJ_MAIN, SRC])
     check_kernel_budgets(verbose=verbose)          # before the link: a kernel that spills or outgrows its occupancy never ships
-    run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB, OBJ_MAIN, OBJ_SORT])
+    run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB, OBJ_MAIN, OBJ_SORT, OBJ_REMESH])
     return LIB
 
 

@@ -91,10 +91,10 @@ class MembraneMesh(TriMesh):
                 self._warned_fixed_topology = True
             return False
         if isinstance(self.remesher, str):
-            if self.remesher != 'builtin':
-                raise ValueError("remesher must be None, 'builtin' or a callable")
-            from .remesh import builtin_remesher
-            builtin_remesher(self, n, target_edge_length, l, n_relax)
+            if self.remesher not in ('builtin', 'device'):
+                raise ValueError("remesher must be None, 'builtin', 'device' or a callable")
+            from .remesh import builtin_remesher, device_remesher
+            (device_remesher if self.remesher == 'device' else builtin_remesher)(self, n, target_edge_length, l, n_relax)
         else:
             self.remesher(self, n, target_edge_length, l, n_relax)
         return True

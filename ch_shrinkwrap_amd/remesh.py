@@ -169,7 +169,58 @@ def mesh_geometry(positions, faces, vertex_normals=True, out=None):
     return fn, fa, hl, vn
 
 
-def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):
+class DeviceStats(ctypes.Structure):
+    _fields_ = [('n_split', ctypes.c_int64), ('n_collapse', ctypes.c_int64), ('n_flip', ctypes.c_int64), ('mean_edge_length', ctypes.c_double),
+                ('max_valence', ctypes.c_int32), ('rounds_split', ctypes.c_int32), ('rounds_collapse', ctypes.c_int32), ('rounds_flip', ctypes.c_int32)]
+
+
+def remesh_device(vertices, faces, n=5, target_edge_length=-1, max_valence=16, return_stats=False, device=0):
+    """The same remeshing step on the GPU (include/nanowrap.h: nw_remesh_device; csrc/nw_remesh_dev.hip): split / collapse / flip as rounds of
+    independent operations, no relaxation.  A valid result of the algorithm and the same arrays on every run, but not the host remesher's
+    arrays.  Needs libnanowrap_hip.so and a GPU: there is no fallback."""
+    from . import _lib as nw
+    L = nw.load()
+    v = np.ascontiguousarray(vertices, np.float32)
+    f = np.ascontiguousarray(faces, np.int32)
+    if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3:
+        raise ValueError('vertices must be (V,3) and faces (F,3)')
+    target = float(target_edge_length)
+    if not target > 0:                                   # PYME's default: the mean edge length of the input
+        e = v[f] - v[np.roll(f, -1, 1)]
+        target = float(np.sqrt((e.astype('f8') ** 2).sum(2)).mean())
+    ov, of = ctypes.c_void_p(), ctypes.c_void_p()
+    nv, nf = ctypes.c_int64(), ctypes.c_int64()
+    st = DeviceStats()
+    L.nw_remesh_device.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.nw_host_free.argtypes = [ctypes.c_void_p]
+    L.nw_host_free.restype = None
+    rc = L.nw_remesh_device(int(device), v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], int(n), target, int(max_valence),
+                            ctypes.byref(ov), ctypes.byref(nv), ctypes.byref(of), ctypes.byref(nf), ctypes.byref(st))
+    if rc != 0:
+        names = {nw.NW_ERR_BADARG: ERRORS[-1], nw.NW_ERR_NONMANIFOLD: ERRORS[-2], nw.NW_ERR_NOMEM: ERRORS[-3], nw.NW_ERR_HIP: 'a HIP call failed (no GPU?)',
+                 nw.NW_ERR_INTERNAL: 'the half-edge structure broke (a fan that does not close)'}
+        raise RuntimeError('nw_remesh_device: %s' % names.get(rc, 'error %d' % rc))
+    try:
+        out_v = np.ctypeslib.as_array(ctypes.cast(ov, ctypes.POINTER(ctypes.c_float)), shape=(nv.value, 3)).copy()
+        out_f = np.ctypeslib.as_array(ctypes.cast(of, ctypes.POINTER(ctypes.c_int32)), shape=(nf.value, 3)).copy()
+    finally:
+        L.nw_host_free(ov)
+        L.nw_host_free(of)
+    if return_stats:
+        return out_v, out_f, dict(n_split=st.n_split, n_collapse=st.n_collapse, n_flip=st.n_flip, mean_edge_length=st.mean_edge_length, max_valence=st.max_valence,
+                                  rounds=(st.rounds_split, st.rounds_collapse, st.rounds_flip))
+    return out_v, out_f
+
+
+def device_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):
+    """`MembraneMesh.remesher = 'device'`: the block boundary's remesh on the GPU (the reference's call has n_relax = 0: _membrane_mesh.pyx:1546)."""
+    if n_relax:
+        raise ValueError("the device remesher has no tangential relaxation (n_relax must be 0, as at the block boundary); use remesher='builtin'")
+    builtin_remesher(mesh, n, target_edge_length, l, n_relax, _remesh=lambda v, f, n, t, l, r: remesh_device(v, f, n, t, device=getattr(mesh, '_device', 0) or 0))
+
+
+def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10, _remesh=None):
     """`MembraneMesh.remesher` hook: remesh the valid part of `mesh` and rebuild its half-edge tables in place."""
     # (asked in a way that does not make a TriMesh with lazy topology build its half-edge records: the remesher works from the faces)
     valid = mesh.valid_vertex_mask() if hasattr(mesh, 'valid_vertex_mask') else mesh._vertices['halfedge'] != -1
@@ -180,5 +231,5 @@ def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):
         remap = np.cumsum(valid) - 1
         v = pos[valid]
         f = remap[mesh.faces]
-    nv, nf = remesh(v, f, n, target_edge_length, l, n_relax)
+    nv, nf = (_remesh or remesh)(v, f, n, target_edge_length, l, n_relax)
     mesh._topology_changed(nv, nf)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NW_ABI_VERSION 5
+#define NW_ABI_VERSION 6
 
 typedef struct nw_ctx nw_ctx;
 
@@ -37,8 +37,9 @@ typedef enum nw_status {
     NW_ERR_NOMEM = -6,
     NW_ERR_INTERNAL = -7,    /* invariant violated inside the library (reported instead of risking a GPU fault) */
     NW_ERR_REMOTE = -8,      /* multi-GPU: another rank raised a status in this iteration (its own code is in that rank's log); this rank stopped with it */
-    NW_ERR_HANDOFF = -9      /* the attraction step that rides in the query launch gave up waiting for its work item's nearest faces (200 ms; it never
+    NW_ERR_HANDOFF = -9,     /* the attraction step that rides in the query launch gave up waiting for its work item's nearest faces (200 ms; it never
                                 uses an old face): the block is cancelled and the ctx runs the two as separate launches from then on -- run the block again */
+    NW_ERR_NONMANIFOLD = -10 /* nw_remesh_device: the mesh is not an oriented 2-manifold (a directed edge occurs twice: three faces on an edge, or two of one sense) */
 } nw_status;
 
 /* how the residual weights are given -- mirrors `search(..., weights=None, sigma_inv=1.0)`,
@@ -350,6 +351,29 @@ int nw_accumulator_quantum(nw_ctx *ctx, double *q);
  *   query launch (workgroups appended to k_nn_wave's grid: the default).  Results are bit-identical either way; bench.py takes its per-stage
  *   timings with the steps apart. */
 int nw_debug(nw_ctx *ctx, int what, void *a, void *b, int cap, int *n);
+
+/* ---- the block-boundary remesher on the device (ABI 6) ---------------------------------------------------------------------------
+ * Replaces the call `self.remesh(5, target_length, 0.5, n_relax=0)` of the reference's outer loop (_membrane_mesh.pyx:1546; schedule of
+ * target_length :1443-1455, :1544), i.e. PYME's TriangleMesh.remesh -- not in the reference tree: parity unpinned, SURVEY.md 8c.  The same
+ * published algorithm and the same admission tests as the host remesher (include/nw_remesh.h: nwr_remesh), operation by operation, but
+ * as rounds of independent operations (csrc/nw_remesh_dev.hip): per iteration split every edge longer than 4/3 L, collapse every edge
+ * shorter than 4/5 L that may be collapsed, flip where that brings the degrees closer to six, each until nothing is left to do.  No
+ * relaxation.  A valid result of the algorithm (closed stays closed, genus kept, boundary and bow-tie vertices never touched), the same
+ * arrays on every run -- not the host remesher's arrays: the order of the operations differs.
+ * vertices float[3 n_vertices], faces int32[3 n_faces] in HOST memory; target_edge_length > 0; max_valence <= 0 -> 16.  Outputs are
+ * allocated by the library (release with nw_host_free): vertices no face refers to are dropped, ids compacted, relative order kept.
+ * NW_ERR_BADARG: sizes, an index out of range, a face that names a vertex twice, a non-finite vertex, or lengths that call for more than
+ * 2^26 faces; NW_ERR_NONMANIFOLD: a directed edge occurs twice. */
+typedef struct nw_remesh_stats {
+    int64_t n_split, n_collapse, n_flip; /* operations performed */
+    double mean_edge_length;             /* of the result */
+    int32_t max_valence;                 /* of the result */
+    int32_t rounds_split, rounds_collapse, rounds_flip; /* rounds of independent operations over all iterations */
+} nw_remesh_stats;
+int nw_remesh_device(int device, const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces, int n_iterations,
+                     float target_edge_length, int max_valence, float **out_vertices, int64_t *out_n_vertices, int32_t **out_faces,
+                     int64_t *out_n_faces, nw_remesh_stats *stats /* may be NULL */);
+void nw_host_free(void *p);
 
 #ifdef __cplusplus
 }
