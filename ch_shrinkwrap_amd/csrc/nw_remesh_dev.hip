@@ -860,7 +860,10 @@ NW_EXPORT int nw_remesh_device(int device, const float *vertices, int64_t n_vert
         std::vector<int32_t> of;
         int rc = RM_RETRY;
         double room = 1.5;
-        for (int tries = 0; tries < 4 && rc == RM_RETRY; ++tries, room *= 2.0) {
+        if (const char *e = std::getenv("NW_REMESH_ROOM")) room = std::max(0.05, std::atof(e));      // (tests: start too small, so that the retry runs)
+        // (slots of faces and vertices that die are not used again within a call: a target far below the input's lengths, where the split pass
+        // overshoots and the collapses take a third back, needs several times the final size -- the attempt that runs out stops at once)
+        for (int tries = 0; tries < 8 && rc == RM_RETRY; ++tries, room *= 2.0) {
             rc = attempt(vertices, n_vertices, faces, n_faces, n_iterations, (double)target_edge_length, mv, room, ov, of, stats, verbose);
             if (rc == RM_RETRY && verbose) std::fprintf(stderr, "[nw_remesh_device] out of room at %.1f x the expected faces: again with twice that\n", room);
         }

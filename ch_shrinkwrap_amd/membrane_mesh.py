@@ -56,7 +56,7 @@ class MembraneMesh(TriMesh):
         self._sigma = None
         self.cg = None
         # block-boundary topology hooks (PYME's job in the reference; see module docstring)
-        self.remesher = None          # None | 'builtin' | callable(mesh, n, target_edge_length, l, n_relax)
+        self.remesher = None          # None | 'builtin' (host C++) | 'device' (GPU, n_relax = 0 only) | callable(mesh, n, target_edge_length, l, n_relax)
         self.neck_remover = None      # callable(mesh, vertex_ids): delete + repair + remesh (PYME's part of remove_necks)
         self.hole_puncher = None      # callable(mesh, points, eps)
         self.edge_cleaner = None      # callable(mesh)  (remove_extra_short_edges)
@@ -83,11 +83,12 @@ class MembraneMesh(TriMesh):
 
     def remesh(self, n=5, target_edge_length=-1, l=0.5, n_relax=10):
         """TriangleMesh.remesh(n, target_edge_length, l, n_relax) as the reference calls it (_membrane_mesh.pyx:1546, :1219).
-        `self.remesher`: None = topology held fixed; 'builtin' = this package's isotropic remesher (remesh.py, host C++);
+        `self.remesher`: None = topology held fixed; 'builtin' = this package's isotropic remesher (remesh.py, host C++); 'device' = the same
+        algorithm as kernels (include/nanowrap.h: nw_remesh_device; what the block boundary's n_relax = 0 call needs);
         or any callable(mesh, n, target_edge_length, l, n_relax), e.g. one that drives PYME.  Returns True if it ran."""
         if self.remesher is None:
             if not self._warned_fixed_topology:
-                print("MembraneMesh: no remesher installed (mesh.remesher = 'builtin' or a callable) -- topology held fixed")
+                print("MembraneMesh: no remesher installed (mesh.remesher = 'device', 'builtin' or a callable) -- topology held fixed")
                 self._warned_fixed_topology = True
             return False
         if isinstance(self.remesher, str):
@@ -393,7 +394,7 @@ class ShrinkwrapMembrane(object):
         self.minimum_edge_length = 5.0
         self.smooth_curvature = True
         self.device = 0
-        self.remesher = 'builtin'                  # not a trait upstream (PYME always remeshes): None holds the topology fixed
+        self.remesher = 'device'                   # not a trait upstream (PYME always remeshes): 'device' = this package's remesher on the GPU (nw_remesh_device), 'builtin' = the same algorithm on the host (nwr_remesh), None holds the topology fixed
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError('unknown parameter %s' % k)

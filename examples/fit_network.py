@@ -1,7 +1,8 @@
 """
 End-to-end example: fit a membrane to a synthetic single-molecule localization cloud on one MI355X.
 
-    python examples/fit_network.py [scale]        (scale 0.02 = 100 000 localizations, default; 1.0 = 5 000 000)
+    python examples/fit_network.py [scale] [device|builtin]       (scale 0.02 = 100 000 localizations, default; 1.0 = 5 000 000;
+                                                                   the block boundary's remesher on the GPU, default, or on the host)
 
 Mirrors what the PYME recipe module `ShrinkwrapMembrane` does upstream
 (/root/reference/ch_shrinkwrap/recipe_modules/surface_fitting.py:46-115): a coarse start surface and a table of
@@ -19,7 +20,7 @@ from ch_shrinkwrap_amd import synth                               # noqa: E402
 from ch_shrinkwrap_amd.membrane_mesh import ShrinkwrapMembrane     # noqa: E402
 
 
-def main(scale=0.02):
+def main(scale=0.02, remesher='device'):
     cfg = synth.make_config('c4', scale=scale, seed=0)           # ERSim2 tube/sheet network with a fenestration
 
     class Surf(object):                                           # anything with .vertices / .faces works as the input surface
@@ -29,7 +30,7 @@ def main(scale=0.02):
              'error_x': cfg['sigma'][:, 0], 'error_y': cfg['sigma'][:, 1], 'error_z': cfg['sigma'][:, 2]}
     ns = {'surf': Surf, 'filtered_localizations': table}
     mod = ShrinkwrapMembrane(max_iters=39, remesh_frequency=5, curvature_weight=20.0, minimum_edge_length=max(5.0, 2.5 / np.sqrt(scale)),
-                             neck_first_iter=9)
+                             neck_first_iter=9, remesher=remesher)
     t0 = time.time()
     mesh = mod.execute(ns)
     dt = time.time() - t0
@@ -46,4 +47,4 @@ def main(scale=0.02):
 
 
 if __name__ == '__main__':
-    main(float(sys.argv[1]) if len(sys.argv) > 1 else 0.02)
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 0.02, sys.argv[2] if len(sys.argv) > 2 else 'device')

@@ -23,9 +23,9 @@ def test_library_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), 'libnanowrap_hip.so does not export %s' % n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.load().nw_abi_version() == 5
+    assert _lib.load().nw_abi_version() == 6
     assert _lib.load().nw_info(_lib.NW_INFO_POINT_SCALARS) == 14          # 13 point-side sums + the status slot that travels with them
-    assert len(names) <= 40
+    assert len(names) <= 42
 
 
 def test_log_struct_layout_matches_header():

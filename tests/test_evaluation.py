@@ -118,7 +118,7 @@ def _recipe_fit_fixed(cfg, **kw):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('name,scale,floor', [('c2', 1.0, None), ('c4', 0.02, 5.0)])
 def test_recipe_fit_left_to_converge(name, scale, floor):
-    """The recipe fit with the builtin remesher, given the iterations it needs (159 instead of the module's default 39; the start surface
+    """The recipe fit with this package's remesher (the module's default: on the device), given the iterations it needs (159 instead of the module's default 39; the start surface
     is 20 nm off, the reference's own recipes start from an isosurface of the cloud): the remesher -- the one component whose parity
     cannot be pinned (PYME's is not in the reference tree) -- must not cost the fit anything against the same fit on the FIXED start
     topology (within 1.3 x in the reference's metric), and where the fit converges it must reach sigma / 2.
@@ -139,9 +139,11 @@ def test_recipe_fit_left_to_converge(name, scale, floor):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize('remesher', ['device', 'builtin'])
 @pytest.mark.parametrize('name,scale,limit', [('c2', 1.0, 9.0), ('c4', 0.02, 13.0)])
-def test_recipe_fit_with_the_builtin_remesher(name, scale, limit):
-    """The recipe module's default fit -- 39 iterations, remeshed every 5 by this package's own remesher -- from the +20 nm start surface:
+def test_recipe_fit_with_the_builtin_remesher(name, scale, limit, remesher):
+    """The recipe module's default fit -- 39 iterations, remeshed every 5 by this package's own remesher, on the GPU (the default) or on the
+    host: the same algorithm, the same fit quality (8.07 / 8.08 nm at C2, 11.25 / 11.24 at C4 x 0.02) -- from the +20 nm start surface:
     39 iterations do not converge a fit that starts 20 nm off (C2: 8.1 nm, C4 x 0.02: 11.2 nm observed: reported, not thresholds -- see
     test_recipe_fit_left_to_converge for the statement about quality); what IS asserted: the metric falls well below the start's and the
     surface after seven remeshing passes is a clean closed mesh."""
@@ -149,9 +151,9 @@ def test_recipe_fit_with_the_builtin_remesher(name, scale, limit):
     cfg = synth.make_config(name, scale=scale, seed=0)
     truth = synth.truth_cloud(cfg)
     q0 = E.fit_quality(type('M', (), {'_vertices': {'position': cfg['vertices']}, 'faces': cfg['faces']})(), truth)
-    mesh = _recipe_fit(cfg, max_iters=39, remesh_frequency=5, curvature_weight=20.0, neck_first_iter=-1)
+    mesh = _recipe_fit(cfg, max_iters=39, remesh_frequency=5, curvature_weight=20.0, neck_first_iter=-1, remesher=remesher)
     q = E.fit_quality(mesh, truth)
-    print(name, 'start', q0, 'fitted', q, 'vertices', mesh.vertices.shape[0])
+    print(name, remesher, 'start', q0, 'fitted', q, 'vertices', mesh.vertices.shape[0])
     assert q0['mse_rms'] >= 20.0
     assert q['mse_rms'] <= 0.6 * q0['mse_rms']
     # the absolute limits of round 3 stay beside the relative statement (without them a drift of the remesher would go unnoticed --

@@ -1,0 +1,159 @@
+"""
+GPU tests of the block-boundary remesher ON THE DEVICE (include/nanowrap.h: nw_remesh_device; csrc/nw_remesh_dev.hip),
+through the C-ABI.  PYME's TriangleMesh.remesh -- what the reference calls at _membrane_mesh.pyx:1546 -- is not in the reference tree, so there
+is nothing to be bit-exact with (parity unpinned); what is asserted is what makes a remeshing step correct and useful:
+  * the result is a valid mesh of the same surface: every edge shared by exactly two faces (closed stays closed), the Euler characteristic
+    kept (genus 0 and genus 2), vertex degrees within the limit, boundaries and their vertices untouched;
+  * its statistics are the host remesher's (the same algorithm and admission tests, another order of operations): vertex count within 3 %,
+    mean edge within 2 %, longest edge within 1.25 x;
+  * the same arrays on every run (priorities are hashes, ids come from prefix sums);
+  * bad input is refused with the host remesher's errors; running out of room means starting again with more, not a wrong mesh.
+The fit-quality statement (the recipe fit in the reference's own metric, device against host remesher) is tests/test_evaluation.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ch_shrinkwrap_amd import remesh as R
+from ch_shrinkwrap_amd.trimesh import icosphere, TriMesh
+
+pytestmark = pytest.mark.gpu
+
+
+def _edges(f):
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1)
+    return np.unique(e, axis=0, return_counts=True)
+
+
+def _describe(v, f):
+    ue, cnt = _edges(f)
+    el = np.linalg.norm(v[f] - v[np.roll(f, -1, 1)], axis=2)
+    deg = np.bincount(f.ravel(), minlength=v.shape[0])
+    return dict(nv=v.shape[0], nf=f.shape[0], closed=bool((cnt == 2).all()), euler=v.shape[0] - ue.shape[0] + f.shape[0], mean=float(el.mean()),
+                mn=float(el.min()), mx=float(el.max()), deg_max=int(deg.max()), deg_min=int(deg.min()))
+
+
+def _case(name):
+    if name == 'network':
+        from ch_shrinkwrap_amd import synth
+        sdf = lambda p: 2.0 * synth.sdf_er_sim2(np.asarray(p, 'f8') * 0.5)
+        v, f = synth._c4_start_mesh(sdf, 2.96 / np.sqrt(0.06))                  # ~50 000 vertices, genus 2, thin tubes
+        return v, f, 0.85
+    if name == 'ellipsoid':
+        v, f = icosphere(6, 100.0)
+        return (v * np.array([1.0, 0.7, 1.4], 'f4')).astype('f4'), f, 0.7
+    v, f = icosphere(4, 100.0)
+    return v, f, {'sphere_finer': 0.7, 'sphere_coarser': 1.6}[name]
+
+
+@pytest.mark.parametrize('name', ['sphere_finer', 'sphere_coarser', 'ellipsoid', 'network'])
+def test_device_remesher_gives_a_valid_mesh_with_the_host_remeshers_statistics(name):
+    v, f, rel = _case(name)
+    L = float(TriMesh(v, f)._mean_edge_length) * rel
+    hv, hf = R.remesh(v, f, 5, L, 0.5, 0)
+    dv, df, st = R.remesh_device(v, f, 5, L, return_stats=True)
+    a, b, s0 = _describe(dv, df), _describe(hv, hf), _describe(v, f)
+    print(name, 'device', a, st, 'host', b)
+    assert a['closed'] and a['euler'] == s0['euler'] and a['deg_min'] >= 3 and a['deg_max'] <= 16
+    assert np.isfinite(dv).all() and df.min() == 0 and df.max() == dv.shape[0] - 1
+    assert abs(a['nv'] - b['nv']) <= 0.03 * b['nv']
+    assert abs(a['mean'] - b['mean']) <= 0.02 * b['mean']
+    assert a['mx'] <= 1.25 * b['mx'] and a['mx'] <= 2.6 * L
+    # the statistics the library reports are the result's; every split adds a vertex, every collapse takes one away
+    assert st['n_split'] - st['n_collapse'] == a['nv'] - s0['nv'] and st['max_valence'] == a['deg_max']
+    assert abs(st['mean_edge_length'] - a['mean']) <= 1e-4 * a['mean']
+    # the same arrays again
+    dv2, df2 = R.remesh_device(v, f, 5, L)
+    assert np.array_equal(dv, dv2) and np.array_equal(df, df2)
+    # what it returns is a fixed point of compaction: nothing left to do at zero iterations but to hand the mesh back
+    zv, zf = R.remesh_device(dv, df, 0, L)
+    assert np.array_equal(zv, dv) and np.array_equal(zf, df)
+
+
+def test_device_remesher_leaves_boundaries_alone():
+    """An open mesh (a sphere with a cap cut off): the vertices on the boundary loop -- and a bow-tie vertex, two fans meeting in a point --
+    are frozen: same positions, same boundary edges afterwards; the interior is remeshed."""
+    v, f = icosphere(4, 100.0)
+    keep = v[f].mean(1)[:, 2] < 60.0
+    g = f[keep]
+    used = np.unique(g)
+    remap = np.full(v.shape[0], -1, 'i4'); remap[used] = np.arange(used.size, dtype='i4')
+    v2, g2 = v[used], remap[g]
+    ue, cnt = _edges(g2)
+    bnd_edges = ue[cnt == 1]
+    assert bnd_edges.shape[0] > 20
+    bpos = v2[np.unique(bnd_edges)]
+    L = float(TriMesh(v2, g2)._mean_edge_length) * 0.7
+    dv, df, st = R.remesh_device(v2, g2, 5, L, return_stats=True)
+    ue2, cnt2 = _edges(df)
+    assert set(np.unique(cnt2)) <= {1, 2}
+    b2 = ue2[cnt2 == 1]
+    assert b2.shape[0] == bnd_edges.shape[0]
+    key = lambda p: set(map(tuple, np.round(np.sort(p.reshape(-1, 6).reshape(-1, 2, 3), axis=1).reshape(-1, 6), 3).tolist()))
+    assert key(dv[b2]) == key(v2[bnd_edges])                                       # the same boundary segments, end point for end point
+    assert st['n_split'] > 100 and dv.shape[0] > v2.shape[0]
+    assert dv.shape[0] - ue2.shape[0] + df.shape[0] == v2.shape[0] - ue.shape[0] + g2.shape[0]
+
+
+def test_device_remesher_refuses_what_the_host_remesher_refuses():
+    v, f = icosphere(4, 100.0)
+    rng = np.random.default_rng(5)
+    for kind in ('flipped', 'fin', 'doubled'):
+        for i in rng.choice(f.shape[0], 5, replace=False):
+            g = f.copy()
+            if kind == 'flipped':
+                g[i] = g[i, ::-1]
+            elif kind == 'fin':
+                g = np.vstack([g, [[g[i, 0], g[i, 1], int((g[i, 0] + v.shape[0] // 2) % v.shape[0])]]]).astype('i4')
+            else:
+                g = np.vstack([g, g[i:i + 1]]).astype('i4')
+            with pytest.raises(RuntimeError, match='2-manifold'):
+                R.remesh_device(v, g, 1, 8.0)
+    g = f.copy(); g[12, 1] = g[12, 0]
+    with pytest.raises(RuntimeError, match='bad argument'):
+        R.remesh_device(v, g, 1, 8.0)
+    g = f.copy(); g[12, 2] = v.shape[0]
+    with pytest.raises(RuntimeError, match='bad argument'):
+        R.remesh_device(v, g, 1, 8.0)
+    bad = v.copy(); bad[7, 1] = np.nan
+    with pytest.raises(RuntimeError, match='bad argument'):
+        R.remesh_device(bad, f, 1, 8.0)
+    far = v.copy(); far[7] *= 1e7                                                  # lengths that call for 10^10 faces: refused before any work
+    with pytest.raises(RuntimeError, match='bad argument'):
+        R.remesh_device(far, f, 5, 8.0)
+    with pytest.raises(ValueError):
+        R.remesh_device(v[:, :2], f, 1, 8.0)
+    # target < 0: the mean edge length of the input, as PYME's default
+    dv, df = R.remesh_device(v, f, 2, -1)
+    assert _describe(dv, df)['closed']
+
+
+def test_device_remesher_starts_again_with_more_room(monkeypatch):
+    """The arrays of a call are sized from the number of faces the edge lengths call for.  With a third of that (NW_REMESH_ROOM) the first
+    attempt runs out in the split pass: it must be abandoned as a whole and repeated with twice the room -- the result is the one of a call
+    that had room from the start."""
+    v, f = icosphere(3, 100.0)
+    L = float(TriMesh(v, f)._mean_edge_length) * 0.3
+    ref_v, ref_f = R.remesh_device(v, f, 5, L)
+    monkeypatch.setenv('NW_REMESH_ROOM', '0.3')
+    dv, df = R.remesh_device(v, f, 5, L)
+    assert dv.shape[0] > 6 * v.shape[0]
+    assert np.array_equal(dv, ref_v) and np.array_equal(df, ref_f)
+
+
+def test_driver_with_the_device_remesher():
+    """MembraneMesh(remesher='device'): three blocks with a remesh between them; every boundary hands the next block a closed mesh at the
+    scheduled target length (_membrane_mesh.pyx:1443-1455, :1544-1546)."""
+    from ch_shrinkwrap_amd import membrane_mesh as mm, synth
+    c = synth.make_config('c2', scale=0.1, seed=5)
+    m = mm.MembraneMesh(c['vertices'].copy(), c['faces'], kc=1.0, step_size=20.0, max_iter=15, remesh_frequency=5, delaunay_remesh_frequency=0, remesher='device')
+    nv0 = m.vertices.shape[0]
+    m.shrink_wrap(c['points'], c['sigma'], minimum_edge_length=float(m._mean_edge_length) / 2)
+    assert len(m.block_log) == 3 and m.vertices.shape[0] > nv0
+    for b in m.block_log:
+        assert abs(b['mean_length'] - b['target_length']) < 0.2 * b['target_length']
+    d = _describe(m.vertices, m.faces)
+    assert d['closed'] and d['euler'] == 2 and np.isfinite(m.vertices).all()
+    with pytest.raises(ValueError):
+        m.remesh(5, 3.0, 0.5, n_relax=10)                                         # relaxation is the host remesher's
