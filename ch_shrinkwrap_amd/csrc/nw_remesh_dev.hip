@@ -838,6 +838,10 @@ NW_EXPORT int nw_remesh_device(int device, const float *vertices, int64_t n_vert
     if (n_vertices < 3 || n_faces < 1 || n_vertices > (1ll << 28) || n_faces > (1ll << 28) || n_iterations < 0 || !(target_edge_length > 0.0f)) return NW_ERR_BADARG;
     *out_vertices = nullptr; *out_faces = nullptr; *out_n_vertices = 0; *out_n_faces = 0;
     std::lock_guard<std::mutex> lock(g_lock);
+    // (the calling thread's current device is the caller's business: put back on every way out)
+    int caller_device = -1;
+    if (hipGetDevice(&caller_device) != hipSuccess) return NW_ERR_HIP;
+    struct DeviceGuard { int d; ~DeviceGuard() { if (d >= 0) (void)hipSetDevice(d); } } device_guard{caller_device};
     if (hipSetDevice(device) != hipSuccess) return NW_ERR_HIP;
     if (g_session.device != device) {
         // (another device than last time: what was cached belongs to the old one)

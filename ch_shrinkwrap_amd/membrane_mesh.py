@@ -70,14 +70,14 @@ class MembraneMesh(TriMesh):
             setattr(self, key, value)
 
     # -- topology hooks ---------------------------------------------------------------------------------------
-    def _topology_changed(self, vertices, faces):
+    def _topology_changed(self, vertices, faces, all_referenced=False):
         """Rebuild the half-edge tables for a new (vertices, faces) pair; the optimiser of the old topology is dropped."""
         props, vprops = self.vertex_properties, self.vertex_vector_properties
         # (inside a fit the vertex normals of a new topology are the device's to compute: nw_set_mesh with nrm = NULL)
         # ... and the host's half-edge records and 1-rings are built when somebody asks for them (lazy_topology): the device builds its own
         # tables and the remesher works from the face array
         in_fit = getattr(self, '_in_fit', False)
-        TriMesh.__init__(self, vertices, faces, vertex_normals=not in_fit, lazy_topology=in_fit)
+        TriMesh.__init__(self, vertices, faces, vertex_normals=not in_fit, lazy_topology=in_fit, all_referenced=all_referenced)
         self.vertex_properties, self.vertex_vector_properties = props, vprops
         self._initialize_curvature_vectors()
 
@@ -262,7 +262,12 @@ class MembraneMesh(TriMesh):
         # (with this package's optimiser they stay on the device until somebody reads mesh.vertex_normals; any other optimiser object
         # offering refresh_normals() is called the plain way)
         (getattr(self.cg, 'refresh_normals_lazy', None) or self.cg.refresh_normals)()
-        self.update_geometry(vertex_normals=False)
+        # (face normals / areas / edge lengths of a mesh that this package's own remesher is about to replace, with no hook installed that
+        # could look at them first, are computed for nobody: 3.5 ms at 4 10^5 faces)
+        own_remesher = isinstance(self.remesher, str) and plan.remesh and done % self.remesh_frequency == 0
+        unobserved = own_remesher and self.hole_puncher is None and self.edge_cleaner is None and self.neck_remover is None
+        if not unobserved:
+            self.update_geometry(vertex_normals=False)
         if plan.punch and done % self.delaunay_remesh_frequency == 0 and self.hole_puncher is not None:   # :1530-1532
             self.hole_puncher(self, points, self.delaunay_eps)
             self._host_mesh_changed()

@@ -232,4 +232,7 @@ def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10, _remes
         v = pos[valid]
         f = remap[mesh.faces]
     nv, nf = (_remesh or remesh)(v, f, n, target_edge_length, l, n_relax)
-    mesh._topology_changed(nv, nf)
+    try:
+        mesh._topology_changed(nv, nf, all_referenced=True)          # (both remeshers drop the vertices no face refers to)
+    except TypeError:                                                 # (a mesh class of the caller's with the two-argument hook)
+        mesh._topology_changed(nv, nf)

@@ -194,6 +194,12 @@ class TriMesh(object):
             self._build_topology()
         return self.__dict__['_halfedge_records']
 
+    def _edge_lengths(self):
+        """Where update_geometry writes the half-edge lengths (half-edge 3f + k is edge k of face f: the faces suffice): the records' 'length'
+        field, or -- while the records of a lazy topology have not been asked for -- a packed array that is copied into them when they are."""
+        rec = self.__dict__.get('_halfedge_records')
+        return rec['length'] if rec is not None else self.__dict__['_lengths_packed']
+
     @_halfedges.setter
     def _halfedges(self, records):
         self.__dict__['_halfedge_records'] = records
@@ -213,6 +219,8 @@ class TriMesh(object):
         a slot is in use exactly when a face refers to it."""
         if not self.__dict__.get('_topology_pending'):
             return self._vertices['halfedge'] != -1
+        if self.__dict__.get('_all_referenced'):          # (a remesher's output: it drops what no face refers to)
+            return np.ones(self.__dict__['_vertex_records'].shape[0], bool)
         mask = np.zeros(self.__dict__['_vertex_records'].shape[0], bool)
         mask[self._faces_arr.ravel()] = True
         return mask
@@ -224,7 +232,7 @@ class TriMesh(object):
             pending()
         self.__dict__['_vertex_records'] = records
 
-    def __init__(self, vertices, faces, max_vertices=None, vertex_normals=True, lazy_topology=False):
+    def __init__(self, vertices, faces, max_vertices=None, vertex_normals=True, lazy_topology=False, all_referenced=False):
         vertices = np.ascontiguousarray(vertices, dtype='f4')
         faces = np.ascontiguousarray(faces, dtype='i4')
         M = vertices.shape[0] if max_vertices is None else int(max_vertices)
@@ -237,12 +245,16 @@ class TriMesh(object):
         self._ring_vertex_table = None
         self._faces = np.zeros(faces.shape[0], FACE_DTYPE)
         self._faces['halfedge'] = 3 * np.arange(faces.shape[0], dtype='i4')
-        # (the half-edge records exist from the start: update_geometry writes their 'length' field, which needs the faces only)
-        self._halfedges = np.zeros(3 * faces.shape[0], HALFEDGE_DTYPE)
         self._origin = None
+        self.__dict__['_all_referenced'] = bool(all_referenced) and M == vertices.shape[0]
         if lazy_topology and faces.shape[0] > 0 and int(faces.min()) >= 0 and int(faces.max()) < M:
+            # (no half-edge records yet -- 28 bytes a half-edge, zeroed and paged in for nothing if nobody asks: until then the lengths
+            # update_geometry computes live in a packed array)
             self.__dict__['_topology_pending'] = True
+            self.__dict__['_halfedge_records'] = None
+            self.__dict__['_lengths_packed'] = np.zeros(3 * faces.shape[0], 'f4')
         else:
+            self._halfedges = np.zeros(3 * faces.shape[0], HALFEDGE_DTYPE)
             self._build_topology()
         # vertex_normals=False (the driver's block loop): the device computes them with the next upload and hands them back after the block;
         # whoever asks before that gets them computed here, on first use (`vertex_normals`)
@@ -259,6 +271,10 @@ class TriMesh(object):
         rec = self.__dict__['_vertex_records']
         rec['halfedge'] = -1
         rec['neighbors'] = -1
+        if self.__dict__.get('_halfedge_records') is None:
+            he = np.zeros(3 * self._faces_arr.shape[0], HALFEDGE_DTYPE)
+            he['length'] = self.__dict__.pop('_lengths_packed')
+            self.__dict__['_halfedge_records'] = he
         if not self._build_topology_native(self._faces_arr):
             lengths = self.__dict__['_halfedge_records']['length'].copy()
             self._halfedges, self._origin = _build_halfedges(self._faces_arr, rec.shape[0])
@@ -334,7 +350,7 @@ class TriMesh(object):
             try:                                              # native, bit-identical to the NumPy definition below
                 from .remesh import mesh_geometry
                 # (written straight into the records' fields: no staging arrays)
-                mesh_geometry(pos, f, vertex_normals, out=(self._faces['normal'], self._faces['area'], self.__dict__['_halfedge_records']['length'],
+                mesh_geometry(pos, f, vertex_normals, out=(self._faces['normal'], self._faces['area'], self._edge_lengths(),
                                                            rec['normal'] if vertex_normals else None))
                 return
             except (RuntimeError, ValueError):                # an input the library rejects: NumPy definition below
@@ -395,8 +411,9 @@ class TriMesh(object):
         # (cached per geometry refresh: the driver asks twice per block, 2.3 ms a time at 1.2 million half-edges)
         cached = self.__dict__.get('_mean_edge_cache')
         if cached is None:
-            l = self.__dict__['_halfedge_records']['length']          # (of every face's three edges: no topology needed)
-            cached = np.mean(l[l != -1])
+            l = self._edge_lengths()                         # (of every face's three edges: no topology needed)
+            live = l != -1
+            cached = np.mean(l if live.all() else l[live])   # (the same number either way: both are one contiguous float32 array to numpy's pairwise sum)
             self.__dict__['_mean_edge_cache'] = cached
         return cached
 
