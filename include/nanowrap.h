@@ -361,7 +361,8 @@ int nw_debug(nw_ctx *ctx, int what, void *a, void *b, int cap, int *n);
  * relaxation.  A valid result of the algorithm (closed stays closed, genus kept, boundary and bow-tie vertices never touched), the same
  * arrays on every run -- not the host remesher's arrays: the order of the operations differs.
  * vertices float[3 n_vertices], faces int32[3 n_faces] in HOST memory; target_edge_length > 0; max_valence <= 0 -> 16.  Outputs are
- * allocated by the library (release with nw_host_free): vertices no face refers to are dropped, ids compacted, relative order kept.
+ * allocated by the library (release with nw_host_free): vertices no face refers to are dropped; the vertices are numbered in Morton order of
+ * their positions (what gathers by vertex id want in the next block), the faces keep their relative order.
  * NW_ERR_BADARG: sizes, an index out of range, a face that names a vertex twice, a non-finite vertex, or lengths that call for more than
  * 2^26 faces; NW_ERR_NONMANIFOLD: a directed edge occurs twice. */
 typedef struct nw_remesh_stats {
