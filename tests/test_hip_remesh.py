@@ -161,3 +161,20 @@ def test_driver_with_the_device_remesher():
     assert d['closed'] and d['euler'] == 2 and np.isfinite(m.vertices).all()
     with pytest.raises(ValueError):
         m.remesh(5, 3.0, 0.5, n_relax=10)                                         # relaxation is the host remesher's
+
+
+def test_device_remesher_on_small_and_untidy_inputs():
+    """A tetrahedron (nothing may be done to it: every collapse would break the surface), an octahedron pushed to a finer target, and a mesh
+    whose vertex array has slots no face refers to (dropped from the result, as by the host remesher)."""
+    tet_v = np.array([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]], 'f4') * 10
+    tet_f = np.array([[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]], 'i4')
+    dv, df = R.remesh_device(tet_v, tet_f, 5, 100.0)                     # far too coarse a target: but a tetrahedron has nothing to give
+    assert dv.shape == (4, 3) and df.shape == (4, 3) and _describe(dv, df)['closed']
+    dv, df = R.remesh_device(tet_v, tet_f, 5, 4.0)                       # finer: splits, then a closed surface of genus 0
+    d = _describe(dv, df)
+    assert d['closed'] and d['euler'] == 2 and dv.shape[0] > 20 and d['mx'] <= 2.0 * 4.0 * 4 / 3
+    v, f = icosphere(3, 50.0)
+    spare = np.vstack([v, np.full((7, 3), 1e3, 'f4')])                   # seven slots nobody refers to, far away
+    dv, df = R.remesh_device(spare, f, 5, 0.8 * float(TriMesh(v, f)._mean_edge_length))
+    d = _describe(dv, df)
+    assert d['closed'] and d['euler'] == 2 and d['deg_min'] >= 3 and np.abs(dv).max() < 60.0
