@@ -3,8 +3,8 @@
 // What it stands in for: PYME's TriangleMesh.remesh(5, target, 0.5, n_relax=0), which the reference calls between optimiser blocks
 // (/root/reference/ch_shrinkwrap/_membrane_mesh.pyx:1546, schedule :1443-1455) and which is not part of the reference tree (SURVEY.md 8c:
 // parity unpinned).  Same published algorithm as the host remesher (csrc/remesh.cpp; Botsch & Kobbelt 2004) and the same admission tests,
-// operation by operation: per iteration split the edges longer than 4/3 L, collapse those shorter than 4/5 L, flip towards degree six.  No
-// tangential relaxation (n_relax = 0 is what the block boundary asks for).
+// operation by operation: per iteration split the edges longer than 4/3 L, collapse those shorter than 4/5 L, flip towards degree six, then
+// n_relax steps of tangential relaxation (the block boundary asks for none).
 //
 // How a chain of local operations becomes kernels.  An operation reads and rewrites the 1-rings of a handful of vertices, its FOOTPRINT:
 //     split a-b (opposite c, d)    {a, b, c, d}
@@ -513,6 +513,41 @@ __global__ void k_rm_flip_apply(RM m, const int *__restrict__ list, unsigned rou
     atomicAdd(&m.cnt[RC_FLIP], 1);
 }
 
+// ---- tangential relaxation (HalfEdgeMesh::relax, csrc/remesh.cpp) --------------------------------------------------------------------
+// every interior vertex moves by l x (the tangential part of the vector to the centroid of its ring); all vertices at once (Jacobi: new
+// positions go to `upd`, k_rm_relax_commit copies them back).  The normal is the sum of the ring's face normals (area weights).
+__global__ void k_rm_relax(RM m, double l, D3 *__restrict__ upd)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= m.cnt[RC_NV]) return;
+    const D3 p = m.pos[v];
+    D3 out = p;
+    if (m.vhe[v] >= 0 && !m.bnd[v] && m.val[v] >= 3) {
+        D3 g{0, 0, 0}, nrm{0, 0, 0};
+        int n = 0;
+        const bool closed = rm_ring(m, v, [&](int o) {
+            const D3 x = m.pos[m.F[rm_next(o)]], y = m.pos[m.F[rm_prev(o)]];
+            g = g + x;
+            nrm = nrm + cross(x - p, y - p);
+            ++n;
+        });
+        if (closed && n > 0) {
+            const D3 d = g * (1.0 / n) - p;
+            const double nn = norm2(nrm);
+            D3 tang = d;
+            if (nn > 0) tang = d - nrm * (dot(d, nrm) / nn);
+            out = p + tang * l;
+        }
+    }
+    upd[v] = out;
+}
+
+__global__ void k_rm_relax_commit(RM m, const D3 *__restrict__ upd)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < m.cnt[RC_NV]) m.pos[v] = upd[v];
+}
+
 // ---- result ---------------------------------------------------------------------------------------------------------------------------
 __global__ void k_rm_mark_used(RM m, int nf, int *__restrict__ face_alive, int *__restrict__ vert_used)
 {
@@ -632,7 +667,7 @@ static int exclusive_scan(const int *in, int *out, int n, void *tmp, size_t tmp_
     return hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, n, s) == hipSuccess ? NW_OK : NW_ERR_HIP;
 }
 
-static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, int64_t nf_in, int n_iterations, double L, int max_valence, double room,
+static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, int64_t nf_in, int n_iterations, double L, double relax_lambda, int n_relax, int max_valence, double room,
                    std::vector<float> &ov, std::vector<int32_t> &of, nw_remesh_stats *stats, bool verbose)
 {
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -704,7 +739,8 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
 
         // sizes live on the device from here on (the splits move them); the host reads them where it needs a grid size
         int *d_list = T.get<int>(Hcap / 2 + 64), *d_list2 = T.get<int>(Hcap / 2 + 64);
-        if (!d_list || !d_list2) return NW_ERR_NOMEM;
+        D3 *d_upd = n_relax > 0 ? T.get<D3>(Vcap) : nullptr;
+        if (!d_list || !d_list2 || (n_relax > 0 && !d_upd)) return NW_ERR_NOMEM;
         {
             int init[RC_COUNT] = {0};
             init[RC_NV] = (int)nv_in; init[RC_NF] = (int)nf_in; init[RC_VCAP] = (int)Vcap; init[RC_FCAP] = (int)Fcap;
@@ -808,12 +844,16 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
             }
             if ((rc = pass(1, &n_list)) != NW_OK) return rc;
             if ((rc = pass(2, &n_list)) != NW_OK) return rc;
+            for (int k = 0; k < n_relax; ++k) {
+                hipLaunchKernelGGL(k_rm_relax, RM_GRID(nv), 0, st, m, relax_lambda, d_upd);
+                hipLaunchKernelGGL(k_rm_relax_commit, RM_GRID(nv), 0, st, m, d_upd);
+            }
             if (read_cnt(c) != NW_OK) return NW_ERR_HIP;
             if (c[RC_CORRUPT]) return NW_ERR_INTERNAL;
             if (verbose) std::fprintf(stderr, "[nw_remesh_device] iteration %d: %d / %d / %d operations so far, %d vertex slots, %d face slots; rounds so far %d / %d / %d\n", it,
                                       c[RC_SPLIT], c[RC_COLLAPSE], c[RC_FLIP], nv, nf, rounds[0], rounds[1], rounds[2]);
             // a pass that changed nothing would be repeated unchanged by every later iteration
-            if (c[RC_SPLIT] == before[RC_SPLIT] && c[RC_COLLAPSE] == before[RC_COLLAPSE] && c[RC_FLIP] == before[RC_FLIP]) break;
+            if (n_relax == 0 && c[RC_SPLIT] == before[RC_SPLIT] && c[RC_COLLAPSE] == before[RC_COLLAPSE] && c[RC_FLIP] == before[RC_FLIP]) break;      // (with relaxation every vertex moves: the next iteration sees another mesh)
         }
         const auto t2 = now();
         // compact: faces that are alive, vertices they refer to (relative order kept)
@@ -876,11 +916,11 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
 }  // namespace
 
 NW_EXPORT int nw_remesh_device(int device, const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces, int n_iterations,
-                               float target_edge_length, int max_valence, float **out_vertices, int64_t *out_n_vertices, int32_t **out_faces,
-                               int64_t *out_n_faces, nw_remesh_stats *stats)
+                               float target_edge_length, float relax_lambda, int n_relax, int max_valence, float **out_vertices, int64_t *out_n_vertices,
+                               int32_t **out_faces, int64_t *out_n_faces, nw_remesh_stats *stats)
 {
     if (!vertices || !faces || !out_vertices || !out_n_vertices || !out_faces || !out_n_faces) return NW_ERR_BADARG;
-    if (n_vertices < 3 || n_faces < 1 || n_vertices > (1ll << 28) || n_faces > (1ll << 28) || n_iterations < 0 || !(target_edge_length > 0.0f)) return NW_ERR_BADARG;
+    if (n_vertices < 3 || n_faces < 1 || n_vertices > (1ll << 28) || n_faces > (1ll << 28) || n_iterations < 0 || n_relax < 0 || n_relax > 1000 || !(target_edge_length > 0.0f)) return NW_ERR_BADARG;
     *out_vertices = nullptr; *out_faces = nullptr; *out_n_vertices = 0; *out_n_faces = 0;
     std::lock_guard<std::mutex> lock(g_lock);
     // (the calling thread's current device is the caller's business: put back on every way out)
@@ -913,7 +953,7 @@ NW_EXPORT int nw_remesh_device(int device, const float *vertices, int64_t n_vert
         // (slots of faces and vertices that die are not used again within a call: a target far below the input's lengths, where the split pass
         // overshoots and the collapses take a third back, needs several times the final size -- the attempt that runs out stops at once)
         for (int tries = 0; tries < 8 && rc == RM_RETRY; ++tries, room *= 2.0) {
-            rc = attempt(vertices, n_vertices, faces, n_faces, n_iterations, (double)target_edge_length, mv, room, ov, of, stats, verbose);
+            rc = attempt(vertices, n_vertices, faces, n_faces, n_iterations, (double)target_edge_length, (double)relax_lambda, n_relax, mv, room, ov, of, stats, verbose);
             if (rc == RM_RETRY && verbose) std::fprintf(stderr, "[nw_remesh_device] out of room at %.1f x the expected faces: again with twice that\n", room);
         }
         if (rc == RM_RETRY) return NW_ERR_NOMEM;

@@ -56,7 +56,7 @@ class MembraneMesh(TriMesh):
         self._sigma = None
         self.cg = None
         # block-boundary topology hooks (PYME's job in the reference; see module docstring)
-        self.remesher = None          # None | 'builtin' (host C++) | 'device' (GPU, n_relax = 0 only) | callable(mesh, n, target_edge_length, l, n_relax)
+        self.remesher = None          # None | 'builtin' (host C++) | 'device' (GPU) | callable(mesh, n, target_edge_length, l, n_relax)
         self.neck_remover = None      # callable(mesh, vertex_ids): delete + repair + remesh (PYME's part of remove_necks)
         self.hole_puncher = None      # callable(mesh, points, eps)
         self.edge_cleaner = None      # callable(mesh)  (remove_extra_short_edges)
@@ -84,7 +84,7 @@ class MembraneMesh(TriMesh):
     def remesh(self, n=5, target_edge_length=-1, l=0.5, n_relax=10):
         """TriangleMesh.remesh(n, target_edge_length, l, n_relax) as the reference calls it (_membrane_mesh.pyx:1546, :1219).
         `self.remesher`: None = topology held fixed; 'builtin' = this package's isotropic remesher (remesh.py, host C++); 'device' = the same
-        algorithm as kernels (include/nanowrap.h: nw_remesh_device; what the block boundary's n_relax = 0 call needs);
+        algorithm as kernels (include/nanowrap.h: nw_remesh_device);
         or any callable(mesh, n, target_edge_length, l, n_relax), e.g. one that drives PYME.  Returns True if it ran."""
         if self.remesher is None:
             if not self._warned_fixed_topology:

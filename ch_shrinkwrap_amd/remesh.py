@@ -174,9 +174,9 @@ class DeviceStats(ctypes.Structure):
                 ('max_valence', ctypes.c_int32), ('rounds_split', ctypes.c_int32), ('rounds_collapse', ctypes.c_int32), ('rounds_flip', ctypes.c_int32)]
 
 
-def remesh_device(vertices, faces, n=5, target_edge_length=-1, max_valence=16, return_stats=False, device=0):
+def remesh_device(vertices, faces, n=5, target_edge_length=-1, l=0.5, n_relax=0, max_valence=16, return_stats=False, device=0):
     """The same remeshing step on the GPU (include/nanowrap.h: nw_remesh_device; csrc/nw_remesh_dev.hip): split / collapse / flip as rounds of
-    independent operations, no relaxation.  A valid result of the algorithm and the same arrays on every run, but not the host remesher's
+    independent operations, then n_relax steps of tangential relaxation (default 0: what the block boundary asks for).  A valid result of the algorithm and the same arrays on every run, but not the host remesher's
     arrays.  Needs libnanowrap_hip.so and a GPU: there is no fallback."""
     from . import _lib as nw
     L = nw.load()
@@ -191,11 +191,11 @@ def remesh_device(vertices, faces, n=5, target_edge_length=-1, max_valence=16, r
     ov, of = ctypes.c_void_p(), ctypes.c_void_p()
     nv, nf = ctypes.c_int64(), ctypes.c_int64()
     st = DeviceStats()
-    L.nw_remesh_device.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+    L.nw_remesh_device.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.nw_host_free.argtypes = [ctypes.c_void_p]
     L.nw_host_free.restype = None
-    rc = L.nw_remesh_device(int(device), v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], int(n), target, int(max_valence),
+    rc = L.nw_remesh_device(int(device), v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], int(n), target, float(l), int(n_relax), int(max_valence),
                             ctypes.byref(ov), ctypes.byref(nv), ctypes.byref(of), ctypes.byref(nf), ctypes.byref(st))
     if rc != 0:
         names = {nw.NW_ERR_BADARG: ERRORS[-1], nw.NW_ERR_NONMANIFOLD: ERRORS[-2], nw.NW_ERR_NOMEM: ERRORS[-3], nw.NW_ERR_HIP: 'a HIP call failed (no GPU?)',
@@ -215,9 +215,7 @@ def remesh_device(vertices, faces, n=5, target_edge_length=-1, max_valence=16, r
 
 def device_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):
     """`MembraneMesh.remesher = 'device'`: the block boundary's remesh on the GPU (the reference's call has n_relax = 0: _membrane_mesh.pyx:1546)."""
-    if n_relax:
-        raise ValueError("the device remesher has no tangential relaxation (n_relax must be 0, as at the block boundary); use remesher='builtin'")
-    builtin_remesher(mesh, n, target_edge_length, l, n_relax, _remesh=lambda v, f, n, t, l, r: remesh_device(v, f, n, t, device=getattr(mesh, '_device', 0) or 0))
+    builtin_remesher(mesh, n, target_edge_length, l, n_relax, _remesh=lambda v, f, n, t, l, r: remesh_device(v, f, n, t, l, r, device=getattr(mesh, '_device', 0) or 0))
 
 
 def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10, _remesh=None):

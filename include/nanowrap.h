@@ -357,8 +357,9 @@ int nw_debug(nw_ctx *ctx, int what, void *a, void *b, int cap, int *n);
  * target_length :1443-1455, :1544), i.e. PYME's TriangleMesh.remesh -- not in the reference tree: parity unpinned, SURVEY.md 8c.  The same
  * published algorithm and the same admission tests as the host remesher (include/nw_remesh.h: nwr_remesh), operation by operation, but
  * as rounds of independent operations (csrc/nw_remesh_dev.hip): per iteration split every edge longer than 4/3 L, collapse every edge
- * shorter than 4/5 L that may be collapsed, flip where that brings the degrees closer to six, each until nothing is left to do.  No
- * relaxation.  A valid result of the algorithm (closed stays closed, genus kept, boundary and bow-tie vertices never touched), the same
+ * shorter than 4/5 L that may be collapsed, flip where that brings the degrees closer to six, each until nothing is left to do, then n_relax
+ * steps of tangential relaxation with step relax_lambda (the block boundary's call has n_relax = 0; PYME's default, which remove_necks uses at
+ * _membrane_mesh.pyx:1219, is l = 0.5, n_relax = 10).  A valid result of the algorithm (closed stays closed, genus kept, boundary and bow-tie vertices never touched), the same
  * arrays on every run -- not the host remesher's arrays: the order of the operations differs.
  * vertices float[3 n_vertices], faces int32[3 n_faces] in HOST memory; target_edge_length > 0; max_valence <= 0 -> 16.  Outputs are
  * allocated by the library (release with nw_host_free): vertices no face refers to are dropped; the vertices are numbered in Morton order of
@@ -372,8 +373,8 @@ typedef struct nw_remesh_stats {
     int32_t rounds_split, rounds_collapse, rounds_flip; /* rounds of independent operations over all iterations */
 } nw_remesh_stats;
 int nw_remesh_device(int device, const float *vertices, int64_t n_vertices, const int32_t *faces, int64_t n_faces, int n_iterations,
-                     float target_edge_length, int max_valence, float **out_vertices, int64_t *out_n_vertices, int32_t **out_faces,
-                     int64_t *out_n_faces, nw_remesh_stats *stats /* may be NULL */);
+                     float target_edge_length, float relax_lambda, int n_relax, int max_valence, float **out_vertices, int64_t *out_n_vertices,
+                     int32_t **out_faces, int64_t *out_n_faces, nw_remesh_stats *stats /* may be NULL */);
 void nw_host_free(void *p);
 
 #ifdef __cplusplus

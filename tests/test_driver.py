@@ -125,10 +125,7 @@ def test_builtin_remesher_in_the_block_schedule(recorder):
     assert m._vertices['neighbors'].shape[0] == m.vertices.shape[0] and m.cg is None
     with pytest.raises(ValueError):
         _mesh(remesher='pyme').remesh()
-    # 'device' = the same step as kernels: no relaxation there (the block boundary asks for none), and no silent fall-back to the host
-    # remesher where there is no GPU
-    with pytest.raises(ValueError):
-        _mesh(remesher='device').remesh(5, 3.0, 0.5, n_relax=10)
+    # 'device' = the same step as kernels: no silent fall-back to the host remesher where there is no GPU
     import torch
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):

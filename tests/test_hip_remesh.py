@@ -159,8 +159,9 @@ def test_driver_with_the_device_remesher():
         assert abs(b['mean_length'] - b['target_length']) < 0.2 * b['target_length']
     d = _describe(m.vertices, m.faces)
     assert d['closed'] and d['euler'] == 2 and np.isfinite(m.vertices).all()
-    with pytest.raises(ValueError):
-        m.remesh(5, 3.0, 0.5, n_relax=10)                                         # relaxation is the host remesher's
+    assert m.remesh(5, float(m._mean_edge_length), 0.5, n_relax=3)                # the reference's other call of remesh (:1219) relaxes
+    d = _describe(m.vertices, m.faces)
+    assert d['closed'] and d['euler'] == 2
 
 
 def test_device_remesher_on_small_and_untidy_inputs():
@@ -178,3 +179,24 @@ def test_device_remesher_on_small_and_untidy_inputs():
     dv, df = R.remesh_device(spare, f, 5, 0.8 * float(TriMesh(v, f)._mean_edge_length))
     d = _describe(dv, df)
     assert d['closed'] and d['euler'] == 2 and d['deg_min'] >= 3 and np.abs(dv).max() < 60.0
+
+
+def test_device_relaxation_evens_out_edge_lengths_and_keeps_the_surface():
+    """n_relax steps of tangential relaxation after every iteration (PYME's default l = 0.5, n_relax = 10): edge lengths gather closer around
+    their mean than without, as with the host remesher (tests/test_remesh.py), and the vertices stay on the sphere (tangential moves only)."""
+    v, f = icosphere(3, 100.0)
+    sd = {}
+    for where, fn in (('host', lambda r: R.remesh(v, f, 5, 12.0, 0.5, r)), ('device', lambda r: R.remesh_device(v, f, 5, 12.0, 0.5, r))):
+        for r in (0, 10):
+            xv, xf = fn(r)[:2]
+            ue, cnt = _edges(xf)
+            assert (cnt == 2).all() and xv.shape[0] - ue.shape[0] + xf.shape[0] == 2
+            L = np.linalg.norm(xv[ue[:, 0]] - xv[ue[:, 1]], axis=1)
+            sd[where, r] = L.std() / L.mean()
+            rad = np.linalg.norm(xv, axis=1)
+            assert rad.min() > 98.5 and rad.max() < 100.5
+    print(sd)
+    assert sd['device', 10] < sd['device', 0]
+    assert sd['device', 10] <= 1.15 * sd['host', 10]
+    a, b = R.remesh_device(v, f, 5, 12.0, 0.5, 10), R.remesh_device(v, f, 5, 12.0, 0.5, 10)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
