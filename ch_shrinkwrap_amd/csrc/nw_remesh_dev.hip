@@ -656,7 +656,9 @@ struct Session {
 Session g_session;
 std::mutex g_lock;
 
-#define RM_HIP(x) do { if ((x) != hipSuccess) return NW_ERR_HIP; } while (0)
+// (inside attempt(): an early exit first drains the stream -- asynchronous copies into this frame's arrays or the caller's vectors may be in flight)
+#define RM_RETURN(code) do { (void)hipStreamSynchronize(g_session.stream); return (code); } while (0)
+#define RM_HIP(x) do { if ((x) != hipSuccess) RM_RETURN(NW_ERR_HIP); } while (0)
 #define RM_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
 
 enum { RM_RETRY = 1 };        // an attempt ran out of room
@@ -682,7 +684,7 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
     int *d_cnt = B.get<int>(RC_COUNT);
     const int nblk_f = (int)((nf_in + 255) / 256);
     double *d_part0 = B.get<double>((size_t)nblk_f);
-    if (!d_vin || !d_fin || !d_cnt || !d_part0) return NW_ERR_NOMEM;
+    if (!d_vin || !d_fin || !d_cnt || !d_part0) RM_RETURN(NW_ERR_NOMEM);
     RM_HIP(hipMemcpyAsync(d_vin, vertices, sizeof(float) * 3 * (size_t)nv_in, hipMemcpyHostToDevice, st));
     RM_HIP(hipMemcpyAsync(d_fin, faces, sizeof(int) * 3 * (size_t)nf_in, hipMemcpyHostToDevice, st));
     RM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int) * RC_COUNT, st));
@@ -696,7 +698,7 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
         RM t = m;
         t.pos = T.get<D3>((size_t)nv_in); t.F = T.get<int>(3 * (size_t)nf_in); t.vhe = T.get<int>((size_t)nv_in); t.val = T.get<int>((size_t)nv_in);
         t.bnd = T.get<unsigned char>((size_t)nv_in);
-        if (!t.pos || !t.F || !t.vhe || !t.val || !t.bnd) return NW_ERR_NOMEM;
+        if (!t.pos || !t.F || !t.vhe || !t.val || !t.bnd) RM_RETURN(NW_ERR_NOMEM);
         hipLaunchKernelGGL(k_rm_load, RM_GRID(std::max(nv_in, nf_in)), 0, st, d_vin, (int)nv_in, d_fin, (int)nf_in, t);
         hipLaunchKernelGGL(k_rm_pieces, dim3(nblk_f), dim3(256), 0, st, t, (int)nf_in, high, d_part0);
         std::vector<double> part((size_t)nblk_f);
@@ -704,29 +706,29 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
         RM_HIP(hipMemcpyAsync(part.data(), d_part0, sizeof(double) * (size_t)nblk_f, hipMemcpyDeviceToHost, st));
         RM_HIP(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
         RM_HIP(hipStreamSynchronize(st));
-        if (cnt[RC_BADARG]) return NW_ERR_BADARG;
+        if (cnt[RC_BADARG]) RM_RETURN(NW_ERR_BADARG);
         double pieces = 0.0;
         for (double p : part) pieces += p;
-        if (!(pieces < 67108864.0)) return NW_ERR_BADARG;                      // (the host code's "runaway": a vertex flung far away)
+        if (!(pieces < 67108864.0)) RM_RETURN(NW_ERR_BADARG);                      // (the host code's "runaway": a vertex flung far away)
         m.high2 = high * high;
         // room for the faces: what the lengths call for (or the input, if that is more), times `room`
         const double want = std::max(pieces, (double)nf_in) * room + 8192.0;
-        if (want > 5.0e8) return NW_ERR_NOMEM;
+        if (want > 5.0e8) RM_RETURN(NW_ERR_NOMEM);
         const size_t Fcap = (size_t)want, Vcap = (size_t)nv_in + (Fcap - (size_t)nf_in) / 2 + 1024, Hcap = 3 * Fcap;
         m.pos = B.get<D3>(Vcap); m.F = B.get<int>(Hcap); m.twin = B.get<int>(Hcap); m.vhe = B.get<int>(Vcap); m.val = B.get<int>(Vcap);
         m.bnd = B.get<unsigned char>(Vcap); m.owner = B.get<u64>(Vcap); m.ckey = B.get<u64>(Hcap); m.win = B.get<int>(Hcap); m.scan = B.get<int>(Hcap);
-        if (!m.pos || !m.F || !m.twin || !m.vhe || !m.val || !m.bnd || !m.owner || !m.ckey || !m.win || !m.scan) return NW_ERR_NOMEM;
+        if (!m.pos || !m.F || !m.twin || !m.vhe || !m.val || !m.bnd || !m.owner || !m.ckey || !m.win || !m.scan) RM_RETURN(NW_ERR_NOMEM);
         size_t tmp_bytes = 0;
-        if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, m.win, m.scan, (int)Hcap, st) != hipSuccess) return NW_ERR_HIP;
+        if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, m.win, m.scan, (int)Hcap, st) != hipSuccess) RM_RETURN(NW_ERR_HIP);
         void *d_tmp = B.get<unsigned char>(tmp_bytes + 16);
-        if (!d_tmp) return NW_ERR_NOMEM;
+        if (!d_tmp) RM_RETURN(NW_ERR_NOMEM);
         hipLaunchKernelGGL(k_rm_load, RM_GRID(std::max(nv_in, nf_in)), 0, st, d_vin, (int)nv_in, d_fin, (int)nf_in, m);
         // twins through a hash table of the directed edges
         unsigned hcap = 1;
         while (hcap < 2 * 3 * (size_t)nf_in) hcap <<= 1;
         u64 *d_keys = T.get<u64>(hcap);
         int *d_vals = T.get<int>(hcap);
-        if (!d_keys || !d_vals) return NW_ERR_NOMEM;
+        if (!d_keys || !d_vals) RM_RETURN(NW_ERR_NOMEM);
         RM_HIP(hipMemsetAsync(d_keys, 0xff, sizeof(u64) * hcap, st));
         const int nh_in = (int)(3 * nf_in);
         hipLaunchKernelGGL(k_rm_hash_insert, RM_GRID(nh_in), 0, st, m, nh_in, d_keys, d_vals, hcap - 1);
@@ -734,13 +736,13 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
         hipLaunchKernelGGL(k_rm_vertex_flags, RM_GRID(nv_in), 0, st, m, (int)nv_in);
         RM_HIP(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
         RM_HIP(hipStreamSynchronize(st));
-        if (cnt[RC_NONMANIFOLD]) return NW_ERR_NONMANIFOLD;
+        if (cnt[RC_NONMANIFOLD]) RM_RETURN(NW_ERR_NONMANIFOLD);
         const auto t1 = now();
 
         // sizes live on the device from here on (the splits move them); the host reads them where it needs a grid size
         int *d_list = T.get<int>(Hcap / 2 + 64), *d_list2 = T.get<int>(Hcap / 2 + 64);
         D3 *d_upd = n_relax > 0 ? T.get<D3>(Vcap) : nullptr;
-        if (!d_list || !d_list2 || (n_relax > 0 && !d_upd)) return NW_ERR_NOMEM;
+        if (!d_list || !d_list2 || (n_relax > 0 && !d_upd)) RM_RETURN(NW_ERR_NOMEM);
         {
             int init[RC_COUNT] = {0};
             init[RC_NV] = (int)nv_in; init[RC_NF] = (int)nf_in; init[RC_VCAP] = (int)Vcap; init[RC_FCAP] = (int)Fcap;
@@ -753,14 +755,14 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
         int *h_cand = g_session.h_cand;
         for (int i = 0; i < ROUNDS_CAP; ++i) h_cand[i] = -1;
         m.host_cand = h_cand;
-        if (!m.round_cand) return NW_ERR_NOMEM;
+        if (!m.round_cand) RM_RETURN(NW_ERR_NOMEM);
         RM_HIP(hipMemsetAsync(m.round_cand, 0, sizeof(int) * ROUNDS_CAP, st));
         RM_HIP(hipMemsetAsync(m.owner, 0, sizeof(u64) * Vcap, st));
         int nv = (int)nv_in, nf = (int)nf_in;
         int rounds[3] = {0, 0, 0};
         unsigned round_id = 0, pass_seq = 0;
         auto read_cnt = [&](int *c) -> int {
-            if (hipMemcpyAsync(c, d_cnt, sizeof(int) * RC_COUNT, hipMemcpyDeviceToHost, st) != hipSuccess) return NW_ERR_HIP;
+            if (hipMemcpyAsync(c, d_cnt, sizeof(int) * RC_COUNT, hipMemcpyDeviceToHost, st) != hipSuccess) RM_RETURN(NW_ERR_HIP);
             return hipStreamSynchronize(st) == hipSuccess ? NW_OK : NW_ERR_HIP;
         };
         // one pass of one kind: the candidate list from a scan over all half-edges, then rounds over the list.  Returns the list's length.
@@ -770,14 +772,14 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
             if (kind == 0) hipLaunchKernelGGL(k_rm_candidates<0>, RM_GRID(nh), 0, st, m, m.win);
             else if (kind == 1) hipLaunchKernelGGL(k_rm_candidates<1>, RM_GRID(nh), 0, st, m, m.win);
             else hipLaunchKernelGGL(k_rm_candidates<2>, RM_GRID(nh), 0, st, m, m.win);
-            if (exclusive_scan(m.win, m.scan, nh, d_tmp, tmp_bytes, st) != NW_OK) return NW_ERR_HIP;
+            if (exclusive_scan(m.win, m.scan, nh, d_tmp, tmp_bytes, st) != NW_OK) RM_RETURN(NW_ERR_HIP);
             hipLaunchKernelGGL(k_rm_compact, RM_GRID(nh), 0, st, m, m.win, m.scan, d_list);
             int c[RC_COUNT];
-            if (read_cnt(c) != NW_OK) return NW_ERR_HIP;
+            if (read_cnt(c) != NW_OK) RM_RETURN(NW_ERR_HIP);
             const int n = c[RC_NLIST];
             *n_list_out = n;
             if (n == 0) return NW_OK;
-            if ((size_t)n > Hcap / 2 + 64) return NW_ERR_INTERNAL;
+            if ((size_t)n > Hcap / 2 + 64) RM_RETURN(NW_ERR_INTERNAL);
             const unsigned first = round_id + 1;
             const unsigned pass_no = ++pass_seq;
             const int *list = d_list;
@@ -790,7 +792,7 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
                     const volatile int *w = h_cand + (first + (unsigned)r - 2);
                     const auto t_w = now();
                     while (*w < 0 && ms(t_w, now()) < 2000.0) {}
-                    if (*w < 0) return NW_ERR_INTERNAL;
+                    if (*w < 0) RM_RETURN(NW_ERR_INTERNAL);
                 }
                 bool dry = false;
                 // (an empty round may be noticed whenever its report happens to be in -- the rounds behind it do nothing either way --, but the
@@ -805,14 +807,14 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
                 if (kind == 0) {
                     hipLaunchKernelGGL(k_rm_split_bid, RM_GRID(n), 0, st, m, list, round, seed);
                     hipLaunchKernelGGL(k_rm_split_mark, RM_GRID(n), 0, st, m, list);
-                    if (exclusive_scan(m.win, m.scan, n, d_tmp, tmp_bytes, st) != NW_OK) return NW_ERR_HIP;
+                    if (exclusive_scan(m.win, m.scan, n, d_tmp, tmp_bytes, st) != NW_OK) RM_RETURN(NW_ERR_HIP);
                     hipLaunchKernelGGL(k_rm_split_apply, RM_GRID(n), 0, st, m, list);
                     hipLaunchKernelGGL(k_rm_split_commit, dim3(1), dim3(1), 0, st, m, round);
                 } else if (kind == 1) {
                     hipLaunchKernelGGL(k_rm_collapse_bid, RM_GRID(n), 0, st, m, list, round, seed, r == 0 ? m.win : (int *)nullptr);
                     hipLaunchKernelGGL(k_rm_collapse_apply, RM_GRID(n), 0, st, m, list, round);
                     if (r == 0) {
-                        if (exclusive_scan(m.win, m.scan, n, d_tmp, tmp_bytes, st) != NW_OK) return NW_ERR_HIP;
+                        if (exclusive_scan(m.win, m.scan, n, d_tmp, tmp_bytes, st) != NW_OK) RM_RETURN(NW_ERR_HIP);
                         hipLaunchKernelGGL(k_rm_relist, RM_GRID(n), 0, st, m, list, m.win, m.scan, d_list2);
                         hipLaunchKernelGGL(k_rm_relist_commit, dim3(1), dim3(1), 0, st, m, m.win, m.scan);
                         list = d_list2;
@@ -833,23 +835,23 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
         };
         for (int it = 0; it < n_iterations; ++it) {
             int before[RC_COUNT], c[RC_COUNT], n_list = 0, rc;
-            if (read_cnt(before) != NW_OK) return NW_ERR_HIP;
+            if (read_cnt(before) != NW_OK) RM_RETURN(NW_ERR_HIP);
             // split: what a pass creates is looked at by the next one (the host code's sweeps: up to 8)
             for (int sub = 0; sub < 4; ++sub) {
-                if ((rc = pass(0, &n_list)) != NW_OK) return rc;
+                if ((rc = pass(0, &n_list)) != NW_OK) RM_RETURN(rc);
                 if (n_list == 0) break;
-                if (read_cnt(c) != NW_OK) return NW_ERR_HIP;
-                if (c[RC_OVERFLOW]) return RM_RETRY;
+                if (read_cnt(c) != NW_OK) RM_RETURN(NW_ERR_HIP);
+                if (c[RC_OVERFLOW]) RM_RETURN(RM_RETRY);
                 nv = c[RC_NV]; nf = c[RC_NF];
             }
-            if ((rc = pass(1, &n_list)) != NW_OK) return rc;
-            if ((rc = pass(2, &n_list)) != NW_OK) return rc;
+            if ((rc = pass(1, &n_list)) != NW_OK) RM_RETURN(rc);
+            if ((rc = pass(2, &n_list)) != NW_OK) RM_RETURN(rc);
             for (int k = 0; k < n_relax; ++k) {
                 hipLaunchKernelGGL(k_rm_relax, RM_GRID(nv), 0, st, m, relax_lambda, d_upd);
                 hipLaunchKernelGGL(k_rm_relax_commit, RM_GRID(nv), 0, st, m, d_upd);
             }
-            if (read_cnt(c) != NW_OK) return NW_ERR_HIP;
-            if (c[RC_CORRUPT]) return NW_ERR_INTERNAL;
+            if (read_cnt(c) != NW_OK) RM_RETURN(NW_ERR_HIP);
+            if (c[RC_CORRUPT]) RM_RETURN(NW_ERR_INTERNAL);
             if (verbose) std::fprintf(stderr, "[nw_remesh_device] iteration %d: %d / %d / %d operations so far, %d vertex slots, %d face slots; rounds so far %d / %d / %d\n", it,
                                       c[RC_SPLIT], c[RC_COLLAPSE], c[RC_FLIP], nv, nf, rounds[0], rounds[1], rounds[2]);
             // a pass that changed nothing would be repeated unchanged by every later iteration
@@ -860,12 +862,12 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
         int *d_alive = T.get<int>((size_t)nf + 1), *d_face_at = T.get<int>((size_t)nf + 1), *d_used = T.get<int>((size_t)nv + 1), *d_vert_at = T.get<int>((size_t)nv + 1);
         const int nblk = (std::max(nv, nf) + 255) / 256;
         double *d_part = T.get<double>((size_t)nblk);
-        if (!d_alive || !d_face_at || !d_used || !d_vert_at || !d_part) return NW_ERR_NOMEM;
+        if (!d_alive || !d_face_at || !d_used || !d_vert_at || !d_part) RM_RETURN(NW_ERR_NOMEM);
         RM_HIP(hipMemsetAsync(d_used, 0, sizeof(int) * ((size_t)nv + 1), st));
         RM_HIP(hipMemsetAsync(d_alive + nf, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_rm_mark_used, RM_GRID(nf), 0, st, m, nf, d_alive, d_used);
-        if (exclusive_scan(d_alive, d_face_at, nf + 1, d_tmp, tmp_bytes, st) != NW_OK) return NW_ERR_HIP;
-        if (exclusive_scan(d_used, d_vert_at, nv + 1, d_tmp, tmp_bytes, st) != NW_OK) return NW_ERR_HIP;
+        if (exclusive_scan(d_alive, d_face_at, nf + 1, d_tmp, tmp_bytes, st) != NW_OK) RM_RETURN(NW_ERR_HIP);
+        if (exclusive_scan(d_used, d_vert_at, nv + 1, d_tmp, tmp_bytes, st) != NW_OK) RM_RETURN(NW_ERR_HIP);
         int n_out[2];
         RM_HIP(hipMemcpyAsync(&n_out[0], d_face_at + nf, sizeof(int), hipMemcpyDeviceToHost, st));
         RM_HIP(hipMemcpyAsync(&n_out[1], d_vert_at + nv, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -875,7 +877,7 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
         int *d_of = T.get<int>(3 * (size_t)nf_out);
         unsigned *d_key = T.get<unsigned>((size_t)nv_out), *d_key2 = T.get<unsigned>((size_t)nv_out);
         int *d_idx = T.get<int>((size_t)nv_out), *d_order = T.get<int>((size_t)nv_out), *d_rank = T.get<int>((size_t)nv_out);
-        if (!d_ov || !d_of || !d_key || !d_key2 || !d_idx || !d_order || !d_rank) return NW_ERR_NOMEM;
+        if (!d_ov || !d_of || !d_key || !d_key2 || !d_idx || !d_order || !d_rank) RM_RETURN(NW_ERR_NOMEM);
         {
             // Morton order of the result's vertices (see k_rm_vertex_keys); the bounding cube is the input's
             double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -883,10 +885,10 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
             const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-30});
             hipLaunchKernelGGL(k_rm_vertex_keys, RM_GRID(nv), 0, st, m, nv, d_used, d_vert_at, lo[0], lo[1], lo[2], 1024.0 / ext, d_key, d_idx);
             size_t sort_bytes = 0;
-            if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_key, d_key2, d_idx, d_order, nv_out, 0, 30, st) != hipSuccess) return NW_ERR_HIP;
+            if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_key, d_key2, d_idx, d_order, nv_out, 0, 30, st) != hipSuccess) RM_RETURN(NW_ERR_HIP);
             void *d_sort = T.get<unsigned char>(sort_bytes + 16);
-            if (!d_sort) return NW_ERR_NOMEM;
-            if (hipcub::DeviceRadixSort::SortPairs(d_sort, sort_bytes, d_key, d_key2, d_idx, d_order, nv_out, 0, 30, st) != hipSuccess) return NW_ERR_HIP;
+            if (!d_sort) RM_RETURN(NW_ERR_NOMEM);
+            if (hipcub::DeviceRadixSort::SortPairs(d_sort, sort_bytes, d_key, d_key2, d_idx, d_order, nv_out, 0, 30, st) != hipSuccess) RM_RETURN(NW_ERR_HIP);
             hipLaunchKernelGGL(k_rm_rank, RM_GRID(nv_out), 0, st, d_order, nv_out, d_rank);
         }
         hipLaunchKernelGGL(k_rm_write_out, dim3(nblk), dim3(256), 0, st, m, nv, nf, d_alive, d_face_at, d_used, d_vert_at, d_rank, d_ov, d_of, d_part);
@@ -966,6 +968,7 @@ NW_EXPORT int nw_remesh_device(int device, const float *vertices, int64_t n_vert
         *out_vertices = pv; *out_n_vertices = (int64_t)(ov.size() / 3); *out_faces = pf; *out_n_faces = (int64_t)(of.size() / 3);
         return NW_OK;
     } catch (const std::exception &) {
+        (void)hipStreamSynchronize(g_session.stream);       // (as RM_RETURN: nothing of the call may still be in flight)
         return NW_ERR_NOMEM;
     }
 }
