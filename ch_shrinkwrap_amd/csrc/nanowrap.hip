@@ -246,6 +246,7 @@ struct nw_ctx {
     DevBuf<unsigned char> comm_scratch;    // staging of host buffers given to nw_comm_all_reduce
     int64_t n_staged_copy_outs = 0, n_write_backs = 0;      // nw_debug, what = 2
     std::vector<uint64_t> comm_patterns;   // communication patterns (mode, sizes, peers) that have run one block outside a capture (nw_search)
+    int comm_capture_failures = 0;         // blocks with collectives whose recording failed (RCCL calls that a stream capture does not take): after two, such blocks are launched directly
     bool direct_out = false;         // nw_search: the last update of the block writes its result into the pinned staging buffer itself
     BlockGraph graphs[8];
     int graph_next = 0;
@@ -2279,7 +2280,16 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     // pattern) -- the fall-back if RCCL's kernels as graph nodes misbehave on some node; single-GPU blocks are not affected
     static const bool graph_comm = !(getenv("NW_GRAPH_COMM") && atoi(getenv("NW_GRAPH_COMM")) == 0);
     if (!graph_comm && ctx->comm && ctx->comm_ranks > 1 && cmode) eager_first = true;
+    // ... and the same by itself if recording such a block has failed twice (a capture that RCCL's calls invalidate is not an error of the
+    // block: it runs directly; but trying again before every block would cost a failed capture each time)
+    const bool comm_block = ctx->comm && ctx->comm_ranks > 1 && cmode;
+    if (comm_block && ctx->comm_capture_failures >= 2) eager_first = true;
     nw_ctx::BlockGraph *slot = eager_first ? nullptr : block_graph(ctx, num_iters, head);
+    static const bool graphs_wanted = !(getenv("NW_GRAPH") && atoi(getenv("NW_GRAPH")) == 0);
+    if (graphs_wanted && comm_block && !eager_first && !slot && ctx->own_stream && ctx->search_done == 0 && (ctx->profiling == 0 || (head && ctx->profiling == 4)) && num_iters > (head ? 1 : 0)) {
+        if (++ctx->comm_capture_failures == 2)
+            fprintf(stderr, "[nanowrap] a block with RCCL calls could not be recorded as a hipGraph (twice): such blocks are launched directly from now on (as with NW_GRAPH_COMM=0)\n");
+    }
     {
         // (how long blocks like this one take, launch to end: the copy threads are woken shortly before -- wait_block_done)
         const uint64_t bk = ((uint64_t)num_iters << 48) ^ ((uint64_t)ctx->N << 20) ^ (uint64_t)ctx->M ^ ((uint64_t)ctx->profiling << 60);
