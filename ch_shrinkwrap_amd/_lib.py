@@ -49,6 +49,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('%s not found: build it with `python -m ch_shrinkwrap_amd.build` (hipcc, gfx950). '
                            'There is no CPU fallback for the NanoWrap hot path.' % LIB_PATH)
+    # PyTorch brings its own copy of the HIP runtime (torch/lib/libamdhip64.so), this library is linked against the system's: one process gets
+    # whichever is loaded FIRST for both.  With the system's first, torch later finds "No HIP GPUs" (seen when a test touched the library
+    # before torch.cuda); with torch's first everything works -- which is the order bench.py and the multi-GPU layer have anyway.  So:
+    # torch first, whenever it is there (it is this package's plumbing for streams and torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, f32, u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
     L.nw_abi_version.argtypes = []
