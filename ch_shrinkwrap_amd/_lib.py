@@ -52,11 +52,18 @@ def load():
     # PyTorch brings its own copy of the HIP runtime (torch/lib/libamdhip64.so), this library is linked against the system's: one process gets
     # whichever is loaded FIRST for both.  With the system's first, torch later finds "No HIP GPUs" (seen when a test touched the library
     # before torch.cuda); with torch's first everything works -- which is the order bench.py and the multi-GPU layer have anyway.  So:
-    # torch first, whenever it is there (it is this package's plumbing for streams and torch.distributed).
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # torch's copy first, whenever torch is installed (it is this package's plumbing for streams and torch.distributed) -- without importing
+    # torch, which takes a second: both copies have the SONAME libamdhip64.so.7, so loading torch's by path makes it the process's.
+    import sys
+    if 'torch' not in sys.modules:
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec('torch')
+            hip = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so') if spec and spec.origin else None
+            if hip and os.path.exists(hip):
+                ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
+        except (ImportError, OSError, ValueError):
+            pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, f32, u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
     L.nw_abi_version.argtypes = []
