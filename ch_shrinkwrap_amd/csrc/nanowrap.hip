@@ -245,8 +245,6 @@ struct nw_ctx {
     uint32_t comm_mode = 0;                // NW_FLAG_COMM_* of the current search
     DevBuf<unsigned char> comm_scratch;    // staging of host buffers given to nw_comm_all_reduce
     int64_t n_staged_copy_outs = 0, n_write_backs = 0;      // nw_debug, what = 2
-    bool graph_deferred = false;           // block_graph returned nothing because the key was new (not because recording failed)
-    std::vector<uint64_t> graph_keys_seen; // keys of blocks that have been launched directly once (block_graph: recorded when they come up again)
     std::vector<uint64_t> comm_patterns;   // communication patterns (mode, sizes, peers) that have run one block outside a capture (nw_search)
     int comm_capture_failures = 0;         // blocks with collectives whose recording failed (RCCL calls that a stream capture does not take): after two, such blocks are launched directly
     bool direct_out = false;         // nw_search: the last update of the block writes its result into the pinned staging buffer itself
@@ -2037,20 +2035,6 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head)
     if (ctx->search_done != 0) return nullptr;
     const uint64_t key = block_graph_key(ctx);
     for (auto &gph : ctx->graphs) if (gph.exec && gph.key == key) return &gph;
-    // A block is recorded when its key comes up the SECOND time: recording costs about as much host time as launching the kernels directly
-    // (1.2 ms for 42 launches) and only then starts the GPU, so a block that runs once -- every block of a fit that remeshes at its block
-    // boundaries is one: new topology, new key -- is 1.2 ms faster launched directly, and a fixed-topology loop loses one replay.
-    static const bool record_at_once = getenv("NW_GRAPH_FIRST") && atoi(getenv("NW_GRAPH_FIRST")) != 0;      // (developer knob: record a key the first time it is seen)
-    if (!record_at_once) {
-        bool seen = false;
-        for (uint64_t k : ctx->graph_keys_seen) seen = seen || k == key;
-        if (!seen) {
-            if (ctx->graph_keys_seen.size() >= 32) ctx->graph_keys_seen.erase(ctx->graph_keys_seen.begin());
-            ctx->graph_keys_seen.push_back(key);
-            ctx->graph_deferred = true;
-            return nullptr;
-        }
-    }
     if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] capturing a block of %d (%s, key %016llx, warm %d, grid generation %llu)\n", num_iters,
                                       head ? "all but its last iteration" : "one graph",
                                       (unsigned long long)key, ctx->face_warm ? 1 : 0, (unsigned long long)ctx->grid_generation);
@@ -2300,10 +2284,9 @@ NW_EXPORT int nw_search(nw_ctx *ctx, const float *lams, int n_lams, int num_iter
     // block: it runs directly; but trying again before every block would cost a failed capture each time)
     const bool comm_block = ctx->comm && ctx->comm_ranks > 1 && cmode;
     if (comm_block && ctx->comm_capture_failures >= 2) eager_first = true;
-    ctx->graph_deferred = false;
     nw_ctx::BlockGraph *slot = eager_first ? nullptr : block_graph(ctx, num_iters, head);
     static const bool graphs_wanted = !(getenv("NW_GRAPH") && atoi(getenv("NW_GRAPH")) == 0);
-    if (graphs_wanted && comm_block && !eager_first && !slot && !ctx->graph_deferred && ctx->own_stream && ctx->search_done == 0 && (ctx->profiling == 0 || (head && ctx->profiling == 4)) && num_iters > (head ? 1 : 0)) {
+    if (graphs_wanted && comm_block && !eager_first && !slot && ctx->own_stream && ctx->search_done == 0 && (ctx->profiling == 0 || (head && ctx->profiling == 4)) && num_iters > (head ? 1 : 0)) {
         if (++ctx->comm_capture_failures == 2)
             fprintf(stderr, "[nanowrap] a block with RCCL calls could not be recorded as a hipGraph (twice): such blocks are launched directly from now on (as with NW_GRAPH_COMM=0)\n");
     }
