@@ -347,15 +347,17 @@ __device__ bool rm_collapse_ok(const RM &m, int h, int *ra, int *rh, int &na)
     bool overflow = false;
     const bool closed = rm_ring(m, a, [&](int o) { if (na < RM_RING_MAX) { rh[na] = o; ra[na++] = m.F[rm_next(o)]; } else overflow = true; });
     if (!closed || overflow || na != m.val[a]) return false;
-    int common = 0;
-    const bool closed_b = rm_ring(m, b, [&](int o) { const int x = m.F[rm_next(o)]; for (int i = 0; i < na; ++i) common += (ra[i] == x); });
-    if (!closed_b || common != 2) return false;
+    // (the tests are the host code's; their order is not: "would create a long edge" turns away four in five of the short edges and needs
+    // a's ring only, so it comes before the walk round b)
     const D3 pb = m.pos[b];
     for (int i = 0; i < na; ++i) {
         const int x = ra[i];
         if (x == b) continue;
         if (norm2(m.pos[x] - pb) > m.high2) return false;
     }
+    int common = 0;
+    const bool closed_b = rm_ring(m, b, [&](int o) { const int x = m.F[rm_next(o)]; for (int i = 0; i < na; ++i) common += (ra[i] == x); });
+    if (!closed_b || common != 2) return false;
     for (int i = 0; i < na; ++i) {
         const int o = rh[i];
         const int x = m.F[rm_next(o)], y = m.F[rm_prev(o)];
