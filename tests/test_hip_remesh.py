@@ -200,3 +200,16 @@ def test_device_relaxation_evens_out_edge_lengths_and_keeps_the_surface():
     assert sd['device', 10] <= 1.15 * sd['host', 10]
     a, b = R.remesh_device(v, f, 5, 12.0, 0.5, 10), R.remesh_device(v, f, 5, 12.0, 0.5, 10)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_device_remesher_fuzz():
+    """tools/experiments/r05_remesh_fuzz.py with a fixed seed (40 random surfaces -- spheres, ellipsoids, bumpy spheres, open caps, the genus-2
+    network --, noise, targets from 0.45 to 2.2 x the mean edge, 1-6 iterations, relaxation on and off, chained calls): every result a valid
+    oriented mesh of the input's topology (Euler characteristic, boundary edges), the same arrays from a second run.  (650 cases over five
+    seeds ran clean when the kernels were written; a race between operations shows up here as a fan that does not close or a directed edge
+    that occurs twice.)"""
+    import subprocess, sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'experiments', 'r05_remesh_fuzz.py'), '40', '7'], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    assert 'all valid, all reproducible' in p.stdout
