@@ -326,9 +326,13 @@ def run_rank(args):
             scene.optimize_layout()         # (also: new shares with the margin the fit needs from here on, see HaloScene.optimize_layout)
         else:
             cg_of().optimize_layout()
-        # ... and one more untimed block after it: the set-up leaves the GPU idle for tens of milliseconds of host work (clocks drop)
-        # and re-sorts the localizations (the first block afterwards runs ~25 % slower than the following ones)
+        # ... and two more untimed blocks after it: the set-up leaves the GPU idle for tens of milliseconds of host work (clocks drop)
+        # and re-sorts the localizations (the first block afterwards runs ~25 % slower than the following ones); and a block's recording
+        # (hipGraph) is keyed by the staging half its result goes to, which alternates -- two blocks record both, so that no recording falls
+        # into the timed region (seen with NW_VERBOSE=3: the first timed block used to record the second half's graph, 0.13 ms of 5)
         run_steps(min(args.warmup, BLOCK))
+        if not halo:
+            run_steps(min(args.warmup, BLOCK))
         if halo:
             # new shares mean a new sub-mesh on the device: the block above was its first (a cold query), and the library's own set-up
             # (cell tuner, work-list order) needs a warm one -- once more, and one more untimed block behind it
@@ -452,7 +456,7 @@ def run_rank(args):
             'config': {'workload': '%s, %d localizations sigma=10 nm, %d vertices / %d faces, lams=[10], blocks of %d iterations, fixed topology%s'
                                    % (WORKLOADS[args.config], N, M, F, BLOCK, '' if args.scale == 1.0 else ' [SCALED x%.3g: debug run]' % args.scale),
                        'localizations_per_gpu': Nl, 'vertices_per_gpu': Ml, 'faces_per_gpu': Fl, 'block': BLOCK,
-                       'one_off_setup': 'nw_optimize_layout after the warm-up, before the timed region: projection re-sort of the localizations, cell-size tuner (a few timed probe queries), heavy-first order of the query work list (one timed query); then one more untimed block of min(warmup, %d) iterations: %d iterations ran before the timed region' % (BLOCK, warmup_executed),
+                       'one_off_setup': 'nw_optimize_layout after the warm-up, before the timed region: projection re-sort of the localizations, cell-size tuner (a few timed probe queries), heavy-first order of the query work list (one timed query); then two more untimed blocks of min(warmup, %d) iterations (a block\'s hipGraph is recorded per staging half of its result: both before the timed region): %d iterations ran before the timed region' % (BLOCK, warmup_executed),
                        'mode': args.mode if multi else 'single',
                        'parallelism': par},
             'roofline': {'bound': 'hbm', 'kernel': kern[dom], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
