@@ -173,12 +173,27 @@ class MembraneMesh(TriMesh):
                                      nw.ptr(self._dH), nw.ptr(self._dK), nw.ptr(self._E), nw.ptr(self._pE), nw.ptr(self._dE_neighbors), nw.ptr(dEdN)))
         return dEdN
 
+    _CURVATURE_SCALARS = ('_H', '_K', '_E', '_k_0', '_k_1', '_pE', '_dH', '_dK', '_dE_neighbors')
+    _CURVATURE_VECTORS = ('_e_0', '_e_1')
+
     def _initialize_curvature_vectors(self):
-        sz = self._position_records().shape[0]                         # _membrane_mesh.pyx:188-200
-        for name in ('_H', '_K', '_E', '_k_0', '_k_1', '_pE', '_dH', '_dK', '_dE_neighbors'):
-            setattr(self, name, np.zeros(sz, np.float32))
-        self._e_0 = np.zeros((sz, 3), np.float32)
-        self._e_1 = np.zeros((sz, 3), np.float32)
+        """_membrane_mesh.pyx:188-200 zeroes eleven per-vertex arrays; the optimiser calls this after every block (mesh_conj_grad.py:290).
+        Here the arrays are dropped and come back as zeros when somebody reads one (`__getattr__`): zeroing 7 MB per block for nobody was
+        a third of a millisecond."""
+        for name in self._CURVATURE_SCALARS + self._CURVATURE_VECTORS:
+            self.__dict__.pop(name, None)
+
+    def __getattr__(self, name):
+        # (only reached when normal lookup fails: a curvature array that has not been asked for since it was last cleared)
+        if name in MembraneMesh._CURVATURE_SCALARS or name in MembraneMesh._CURVATURE_VECTORS:
+            records = self.__dict__.get('_vertex_records')
+            if records is None:
+                raise AttributeError(name)
+            sz = records.shape[0]
+            a = np.zeros(sz if name in MembraneMesh._CURVATURE_SCALARS else (sz, 3), np.float32)
+            self.__dict__[name] = a
+            return a
+        raise AttributeError(name)
 
     def smooth_per_vertex_data(self, data):
         """PYME's TriangleMesh.smooth_per_vertex_data is not in the reference tree; this build's definition: mean over
