@@ -1024,7 +1024,7 @@ NW_EXPORT int nw_set_mesh(nw_ctx *ctx, const float *pos, const float *nrm, const
     NW_HIP(ctx->faces.ensure(3 * F));
     NW_HIP(ctx->d_small.ensure(8));
     NW_HIP(hipMemcpyAsync(ctx->pos.p, pos, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
-    NW_HIP(hipMemcpyAsync(ctx->meshpos.p, pos, 3 * M * sizeof(float), hipMemcpyDefault, ctx->stream));
+    NW_HIP(hipMemcpyAsync(ctx->meshpos.p, ctx->pos.p, 3 * M * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));      // (the same rows: one trip over PCIe is enough)
     NW_HIP(hipMemcpyAsync(ctx->faces.p, faces, 3 * F * sizeof(int), hipMemcpyDefault, ctx->stream));       // (caller's order; re-ordered below)
     ctx->face_sorted = false;
     ctx->have_valid = valid != nullptr;
