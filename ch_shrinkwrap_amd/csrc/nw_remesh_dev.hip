@@ -839,12 +839,17 @@ static int attempt(const float *vertices, int64_t nv_in, const int32_t *faces, i
             int before[RC_COUNT], c[RC_COUNT], n_list = 0, rc;
             if (read_cnt(before) != NW_OK) RM_RETURN(NW_ERR_HIP);
             // split: what a pass creates is looked at by the next one (the host code's sweeps: up to 8)
+            int first_list = 0;
             for (int sub = 0; sub < 4; ++sub) {
                 if ((rc = pass(0, &n_list)) != NW_OK) RM_RETURN(rc);
                 if (n_list == 0) break;
+                if (sub == 0) first_list = n_list;
                 if (read_cnt(c) != NW_OK) RM_RETURN(NW_ERR_HIP);
                 if (c[RC_OVERFLOW]) RM_RETURN(RM_RETRY);
                 nv = c[RC_NV]; nf = c[RC_NF];
+                // (what the splits of a sweep leave too long is the next sweep's; a sweep over a handful of edges -- a scan over all half-edges, a
+                // compaction and a few rounds for six edges of 4 10^5 -- is left to the next iteration, as the rounds' tails are)
+                if (n_list < 32 && n_list * 200 < first_list) break;
             }
             if ((rc = pass(1, &n_list)) != NW_OK) RM_RETURN(rc);
             if ((rc = pass(2, &n_list)) != NW_OK) RM_RETURN(rc);
