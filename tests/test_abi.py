@@ -74,3 +74,27 @@ def test_kernels_stay_within_their_resource_budget():
             build.check_kernel_budgets()
     finally:
         build.KERNEL_BUDGETS.clear(); build.KERNEL_BUDGETS.update(worst)
+
+
+def test_device_remesher_checks_its_arguments_before_it_touches_a_gpu():
+    """nw_remesh_device (ABI 6): sizes, NULL pointers and a non-positive target are refused with NW_ERR_BADARG before any HIP call -- also
+    where there is no GPU; with valid arguments and no GPU the call fails loudly (NW_ERR_HIP), it does not fall back to the host remesher."""
+    import numpy as np
+    from ch_shrinkwrap_amd import _lib
+    L = _lib.load()
+    v = np.zeros((4, 3), np.float32)
+    f = np.array([[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]], np.int32)
+    ov, of, nv, nf = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+    L.nw_remesh_device.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    out = (ctypes.byref(ov), ctypes.byref(nv), ctypes.byref(of), ctypes.byref(nf), None)
+    assert L.nw_remesh_device(0, None, 4, f.ctypes.data, 4, 5, 1.0, 0.5, 0, 16, *out) == _lib.NW_ERR_BADARG
+    assert L.nw_remesh_device(0, v.ctypes.data, 2, f.ctypes.data, 4, 5, 1.0, 0.5, 0, 16, *out) == _lib.NW_ERR_BADARG      # fewer than three vertices
+    assert L.nw_remesh_device(0, v.ctypes.data, 4, f.ctypes.data, 0, 5, 1.0, 0.5, 0, 16, *out) == _lib.NW_ERR_BADARG      # no face
+    assert L.nw_remesh_device(0, v.ctypes.data, 4, f.ctypes.data, 4, 5, -1.0, 0.5, 0, 16, *out) == _lib.NW_ERR_BADARG     # the C-ABI wants an explicit target
+    assert L.nw_remesh_device(0, v.ctypes.data, 4, f.ctypes.data, 4, -1, 1.0, 0.5, 0, 16, *out) == _lib.NW_ERR_BADARG
+    assert L.nw_remesh_device(0, v.ctypes.data, 4, f.ctypes.data, 4, 5, 1.0, 0.5, -3, 16, *out) == _lib.NW_ERR_BADARG
+    assert ov.value is None and of.value is None
+    import torch
+    if not torch.cuda.is_available():
+        assert L.nw_remesh_device(0, v.ctypes.data, 4, f.ctypes.data, 4, 5, 1.0, 0.5, 0, 16, *out) == _lib.NW_ERR_HIP
