@@ -10,15 +10,18 @@
 //     split a-b (opposite c, d)    {a, b, c, d}
 //     collapse a into b            {a, b} and every neighbour of a
 //     flip a-b to c-d              {a, b, c, d}
-// Two operations whose footprints share no vertex touch disjoint faces, twin links and vertex records and can run at once.  A pass is a
-// loop of ROUNDS; a round is
-//     bid    one thread per edge tests the edge exactly like the host code does (read-only: nothing is being changed), and a candidate
-//            writes its 64-bit key -- (priority, half-edge id): longest edge first for splits, shortest first for collapses, largest gain
-//            first for flips -- into every footprint vertex with atomicMax;
+// Two operations whose footprints share no vertex touch disjoint faces, twin links and vertex records and can run at once.  A pass
+// (split, collapse or flip of one iteration) first scans all half-edges with the cheap half of its test and compacts the hits into a
+// candidate LIST (a few per cent of the edges); then it is a loop of ROUNDS over that list; a round is
+//     bid    one thread per entry tests the edge exactly like the host code does (read-only: nothing is being changed), and a candidate
+//            writes its 64-bit key -- (round number, hash of the half-edge and the round, half-edge id): see rm_key for why a hash and
+//            not the edge's length -- into every footprint vertex with atomicMax;
 //     apply  a candidate that finds its own key in ALL its footprint vertices owns them and performs the operation; the others wait for
-//            the next round.  The candidate with the largest key always wins, so every round makes progress.
+//            the next round.  The candidate with the largest key always wins, so every round makes progress; the round number on top of the
+//            key makes every earlier round's keys lose, so nothing is ever cleared.
 // Nothing depends on which thread runs when: atomicMax commutes, and the ids of what a split creates come from a prefix sum over the
-// winners in half-edge order.  Two runs give the same arrays.
+// round's winners in list order.  Two runs give the same arrays.  The host launches at most two rounds ahead of the GPU's reports (every
+// round writes its number of bidders to pinned memory) and ends a pass when a round had none, or almost none.
 //
 // Layout (all in HBM for the whole call): half-edge 3f+k runs from F[3f+k] to F[3f+(k+1)%3] -- next / previous / face of a half-edge are
 // arithmetic, only the origin `F` and `twin` are stored; positions in float64 (as the host code); vhe[v] = one outgoing half-edge, val[v] =
