@@ -2035,6 +2035,14 @@ static nw_ctx::BlockGraph *block_graph(nw_ctx *ctx, int num_iters, bool head)
     if (ctx->search_done != 0) return nullptr;
     const uint64_t key = block_graph_key(ctx);
     for (auto &gph : ctx->graphs) if (gph.exec && gph.key == key) return &gph;
+    // (developer knob NW_GRAPH_DEFER=1: record a key only when it comes up the second time -- tools/experiments/r05_notes.md section 9)
+    static const bool defer_on = getenv("NW_GRAPH_DEFER") && atoi(getenv("NW_GRAPH_DEFER")) != 0;
+    if (defer_on) {
+        static std::vector<uint64_t> seen_keys;
+        bool seen = false;
+        for (uint64_t k : seen_keys) seen = seen || k == key;
+        if (!seen) { seen_keys.push_back(key); return nullptr; }
+    }
     if (getenv("NW_VERBOSE")) fprintf(stderr, "[nanowrap] capturing a block of %d (%s, key %016llx, warm %d, grid generation %llu)\n", num_iters,
                                       head ? "all but its last iteration" : "one graph",
                                       (unsigned long long)key, ctx->face_warm ? 1 : 0, (unsigned long long)ctx->grid_generation);
