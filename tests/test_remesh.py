@@ -277,3 +277,45 @@ def test_partitioned_remesher_refuses_what_the_serial_one_refuses():
     g[77, 2] = v.shape[0]
     with pytest.raises(RuntimeError, match='bad argument'):
         R.remesh(v, g, 1, 3.0, 0.5, 0)
+
+
+def test_worker_pool_survives_a_fork():
+    """The remesher's worker threads live as long as the process.  A forked child has none of them (only the forking thread survives a
+    fork): its first parallel loop must start a pool of its own instead of waiting for workers that are not there (pthread_atfork handler in
+    csrc/remesh.cpp) -- and give the parent's result."""
+    v, f = icosphere(6, 100.0)
+    v = (v * np.array([1.0, 0.7, 1.4], 'f4')).astype('f4')
+    ref_v, ref_f = R.remesh(v, f, 2, 2.5, 0.5, 0)                       # (above the partition size: the pool is running now)
+    pid = os.fork()
+    if pid == 0:
+        code = 1
+        try:
+            import signal
+            signal.alarm(120)                                            # a child that hangs is killed, the test then fails on its status
+            cv, cf = R.remesh(v, f, 2, 2.5, 0.5, 0)
+            code = 0 if (np.array_equal(cv, ref_v) and np.array_equal(cf, ref_f)) else 2
+        finally:
+            os._exit(code)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    again_v, again_f = R.remesh(v, f, 2, 2.5, 0.5, 0)                    # the parent's pool is unharmed
+    assert np.array_equal(again_v, ref_v) and np.array_equal(again_f, ref_f)
+
+
+def test_two_threads_in_the_remesher_at_once():
+    """ctypes releases the GIL: two Python threads can be inside nwr_remesh together.  The worker pool serves one caller at a time; the other
+    runs its loops on its own thread -- both get the result a lone call gets (the cuts do not depend on who runs what)."""
+    import threading
+    v, f = icosphere(6, 100.0)
+    ref = R.remesh(v, f, 2, 2.5, 0.5, 0)
+    out = [None, None, None]
+
+    def work(i):
+        out[i] = R.remesh(v, f, 2, 2.5, 0.5, 0)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    for o in out:
+        assert o is not None and np.array_equal(o[0], ref[0]) and np.array_equal(o[1], ref[1])
