@@ -213,3 +213,22 @@ def test_device_remesher_fuzz():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'experiments', 'r05_remesh_fuzz.py'), '40', '7'], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     assert 'all valid, all reproducible' in p.stdout
+
+
+def test_device_remesher_with_several_callers_at_once():
+    """Three Python threads inside nw_remesh_device together (ctypes releases the GIL): the library serialises the calls -- its cached device
+    blocks, stream and pinned words belong to one call at a time -- and each gets the result a lone call gets."""
+    import threading
+    v, f = icosphere(5, 100.0)
+    ref = R.remesh_device(v, f, 3, 5.0)
+    out = [None, None, None]
+
+    def work(i):
+        out[i] = R.remesh_device(v, f, 3, 5.0)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    for o in out:
+        assert o is not None and np.array_equal(o[0], ref[0]) and np.array_equal(o[1], ref[1])
