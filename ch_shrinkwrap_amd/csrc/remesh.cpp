@@ -1351,7 +1351,31 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
             if (input_bad) return rc;
             // safety net: an edge of (nearly) no length in the result -- never seen since the rims wait for their pass -- and the
             // serial algorithm takes over
-            if (rc != NWR_OK || !(min_edge2 > 1e-12 * (double)L * (double)L)) {
+            // ... unless the INPUT already had one (coincident vertices the optimiser produced: seen at 8 10^5 vertices, where two of a fit's
+            // seven calls then spent 4 s each in the serial algorithm, which cannot mend such an edge either -- a collapse across faces of no
+            // area is never admitted): the net is for what the partition does, not for what it was given
+            bool input_had_one = false;
+            if (rc == NWR_OK && !(min_edge2 > 1e-12 * (double)L * (double)L)) {
+                const size_t CH = 32768, nch = ((size_t)n_faces + CH - 1) / CH;
+                std::vector<double> pmin(nch, INFINITY);
+                parallel_for((int64_t)nch, 1, [&](int64_t c_lo, int64_t c_hi) {
+                    for (int64_t c = c_lo; c < c_hi; ++c) {
+                        double mn = INFINITY;
+                        for (size_t f = (size_t)c * CH; f < std::min((size_t)n_faces, (size_t)(c + 1) * CH); ++f)
+                            for (int k = 0; k < 3; ++k) {
+                                const int a = faces[3 * f + k], b = faces[3 * f + (k + 1) % 3];
+                                const double dx = (double)vertices[3 * a] - vertices[3 * b], dy = (double)vertices[3 * a + 1] - vertices[3 * b + 1], dz = (double)vertices[3 * a + 2] - vertices[3 * b + 2];
+                                mn = std::min(mn, dx * dx + dy * dy + dz * dz);
+                            }
+                        pmin[c] = mn;
+                    }
+                });
+                double mn = INFINITY;
+                for (double x : pmin) mn = std::min(mn, x);
+                input_had_one = !(mn > 1e-12 * (double)L * (double)L);
+                if (input_had_one && std::getenv("NWR_VERBOSE")) std::fprintf(stderr, "[nw_remesh] an edge of no length in the result -- and in the input: kept\n");
+            }
+            if (rc != NWR_OK || (!(min_edge2 > 1e-12 * (double)L * (double)L) && !input_had_one)) {
                 // (also when a piece failed -- out of memory in a worker, a runaway guard: the serial algorithm on the whole mesh decides)
                 if (std::getenv("NWR_VERBOSE")) std::fprintf(stderr, "[nw_remesh] the partitioned pass %s: the serial algorithm takes over\n", rc != NWR_OK ? "failed" : "left an edge of no length");
                 rc = remesh_core(vertices, n_vertices, faces, n_faces, n_iterations, target_edge_length, relax_lambda, n_relax, max_valence, nullptr, ov, of, nullptr, stats, nullptr);

@@ -319,3 +319,31 @@ def test_two_threads_in_the_remesher_at_once():
         t.join(120)
     for o in out:
         assert o is not None and np.array_equal(o[0], ref[0]) and np.array_equal(o[1], ref[1])
+
+
+def test_an_edge_of_no_length_in_the_input_does_not_send_the_partitioned_remesher_to_the_serial_one():
+    """The partitioned pass falls back to the serial algorithm if its result has an edge of (nearly) no length -- a net for what the partition
+    might do.  An input that already has such an edge (two vertices the optimiser pulled onto each other: seen in a fit at 8 10^5 vertices,
+    where the fall-back cost 4 s a call and mended nothing) must not trigger it."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from ch_shrinkwrap_amd.trimesh import icosphere
+        from ch_shrinkwrap_amd import remesh
+        v, f = icosphere(6, 100.0)
+        for face in (1234, 40000, 77777):
+            a, b, c = f[face]
+            v[b] = v[a]; v[c] = v[a]                   # a face drawn together in a point: three edges of no length, and around them
+                                                       # faces of no area, across which no collapse is admitted -- they stay
+        ov, of = remesh.remesh(v, f, 3, 3.0, 0.5, 0)
+        e = np.sort(np.concatenate([of[:, [0, 1]], of[:, [1, 2]], of[:, [2, 0]]]), 1)
+        _, cnt = np.unique(e, axis=0, return_counts=True)
+        assert (cnt == 2).all() and np.isfinite(ov).all()
+        print('OK', ov.shape[0])
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e['NWR_VERBOSE'] = '1'
+    p = subprocess.run([sys.executable, '-c', code], env=e, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and 'OK' in p.stdout, p.stderr[-2000:]
+    assert 'seam pass' in p.stderr                                   # the partitioned path ran ...
+    assert 'takes over' not in p.stderr and 'and in the input: kept' in p.stderr        # ... and stood by its result
