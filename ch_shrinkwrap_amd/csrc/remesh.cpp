@@ -1252,6 +1252,8 @@ static int remesh_partitioned(const float *vertices, int64_t n_vertices, const i
         if (rc != NWR_OK) return rc;
     }
     const auto t3 = now();
+    double shortest2 = INFINITY;
+    auto finish = [&]() {
     // compact (vertices no face refers to any more: collapsed away inside a piece), relative order kept
     {
         const size_t nv = V.size() / 3;
@@ -1292,12 +1294,34 @@ static int remesh_partitioned(const float *vertices, int64_t n_vertices, const i
         double s = 0, mn = INFINITY;
         for (size_t c = 0; c < nch; ++c) { s += psum[c]; if (!(pmin[c] >= mn)) mn = pmin[c]; }
         if (min_edge2) *min_edge2 = mn;
+        shortest2 = mn;
         if (stats) {
             *stats = tot;
             stats->mean_edge_length = nfo ? s / (3.0 * (double)nfo) : 0.0;
             stats->max_valence = nv ? *std::max_element(deg.begin(), deg.end()) : 0;
             stats->reserved = 0;
         }
+    }
+    };
+    finish();
+    // An edge of (nearly) no length in the result -- two vertices that frozen rims of both passes kept apart from a collapse; seen at
+    // 8 10^5 vertices in two of a fit's seven calls -- used to send the WHOLE mesh to the serial algorithm (4 s there).  It is mended where it
+    // is: the end points of such edges seed one more small pass (their neighbourhood as a sub-mesh of its own, in which they are interior),
+    // and only if an edge of no length survives that does the caller fall back.
+    const double none2 = 1e-12 * (double)L * (double)L;
+    if (!(shortest2 > none2)) {
+        std::vector<unsigned char> seeds2(V.size() / 3, 0);
+        size_t n_short = 0;
+        for (size_t f = 0; f < F.size() / 3; ++f)
+            for (int k = 0; k < 3; ++k) {
+                const int a = F[3 * f + k], b = F[3 * f + (k + 1) % 3];
+                const double dx = (double)V[3 * (size_t)a] - V[3 * (size_t)b], dy = (double)V[3 * (size_t)a + 1] - V[3 * (size_t)b + 1], dz = (double)V[3 * (size_t)a + 2] - V[3 * (size_t)b + 2];
+                if (!(dx * dx + dy * dy + dz * dz > none2)) { seeds2[a] = seeds2[b] = 1; ++n_short; }
+            }
+        if (verbose) std::fprintf(stderr, "[nw_remesh] %zu half-edges of no length after both passes: one more pass around them\n", n_short);
+        const int rc2 = seam_pass(V, F, seeds2, nullptr, n_iterations, L, max_valence, tot);
+        if (rc2 != NWR_OK) return rc2;
+        finish();
     }
     if (verbose) std::fprintf(stderr, "[nw_remesh] partitioned: order + runs %.1f ms, pass 1 (%d threads) %.1f ms, seam zone %.1f ms, compaction %.1f ms\n", ms(t0, t1), T, ms(t1, t2),
                               ms(t2, t3), ms(t3, now()));
@@ -1375,7 +1399,7 @@ NWR_EXPORT int nwr_remesh(const float *vertices, int64_t n_vertices, const int32
                 input_had_one = !(mn > 1e-12 * (double)L * (double)L);
                 if (input_had_one && std::getenv("NWR_VERBOSE")) std::fprintf(stderr, "[nw_remesh] an edge of no length in the result -- and in the input: kept\n");
             }
-            if (rc != NWR_OK || (!(min_edge2 > 1e-12 * (double)L * (double)L) && !input_had_one)) {
+            if (rc != NWR_OK || (!(min_edge2 > 1e-12 * (double)L * (double)L) && !input_had_one && !std::getenv("NWR_KEEP_SHORT"))) {      // (NWR_KEEP_SHORT: developer aid, the partitioned result as it is)
                 // (also when a piece failed -- out of memory in a worker, a runaway guard: the serial algorithm on the whole mesh decides)
                 if (std::getenv("NWR_VERBOSE")) std::fprintf(stderr, "[nw_remesh] the partitioned pass %s: the serial algorithm takes over\n", rc != NWR_OK ? "failed" : "left an edge of no length");
                 rc = remesh_core(vertices, n_vertices, faces, n_faces, n_iterations, target_edge_length, relax_lambda, n_relax, max_valence, nullptr, ov, of, nullptr, stats, nullptr);
