@@ -70,14 +70,15 @@ class MembraneMesh(TriMesh):
             setattr(self, key, value)
 
     # -- topology hooks ---------------------------------------------------------------------------------------
-    def _topology_changed(self, vertices, faces, all_referenced=False):
+    def _topology_changed(self, vertices, faces, all_referenced=False, mean_edge=None):
         """Rebuild the half-edge tables for a new (vertices, faces) pair; the optimiser of the old topology is dropped."""
         props, vprops = self.vertex_properties, self.vertex_vector_properties
         # (inside a fit the vertex normals of a new topology are the device's to compute: nw_set_mesh with nrm = NULL)
         # ... and the host's half-edge records and 1-rings are built when somebody asks for them (lazy_topology): the device builds its own
         # tables and the remesher works from the face array
         in_fit = getattr(self, '_in_fit', False)
-        TriMesh.__init__(self, vertices, faces, vertex_normals=not in_fit, lazy_topology=in_fit, all_referenced=all_referenced)
+        # ... as are face normals, areas and edge lengths, when the remesher has said what the block loop wants of them: the mean edge length
+        TriMesh.__init__(self, vertices, faces, vertex_normals=not in_fit, lazy_topology=in_fit, all_referenced=all_referenced, mean_edge=mean_edge if in_fit else None)
         self.vertex_properties, self.vertex_vector_properties = props, vprops
         self._initialize_curvature_vectors()
 

@@ -215,7 +215,7 @@ def remesh_device(vertices, faces, n=5, target_edge_length=-1, l=0.5, n_relax=0,
 
 def device_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10):
     """`MembraneMesh.remesher = 'device'`: the block boundary's remesh on the GPU (the reference's call has n_relax = 0: _membrane_mesh.pyx:1546)."""
-    builtin_remesher(mesh, n, target_edge_length, l, n_relax, _remesh=lambda v, f, n, t, l, r: remesh_device(v, f, n, t, l, r, device=getattr(mesh, '_device', 0) or 0))
+    builtin_remesher(mesh, n, target_edge_length, l, n_relax, _remesh=lambda v, f, n, t, l, r: remesh_device(v, f, n, t, l, r, return_stats=True, device=getattr(mesh, '_device', 0) or 0))
 
 
 def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10, _remesh=None):
@@ -236,8 +236,12 @@ def builtin_remesher(mesh, n=5, target_edge_length=-1, l=0.5, n_relax=10, _remes
         remap = np.cumsum(valid) - 1
         v = pos[valid]
         f = remap[mesh.faces]
-    nv, nf = (_remesh or remesh)(v, f, n, target_edge_length, l, n_relax)
+    if _remesh is None:
+        nv, nf, st = remesh(v, f, n, target_edge_length, l, n_relax, return_stats=True)
+    else:
+        nv, nf, st = _remesh(v, f, n, target_edge_length, l, n_relax)
     try:
-        mesh._topology_changed(nv, nf, all_referenced=True)          # (both remeshers drop the vertices no face refers to)
+        # (both remeshers drop the vertices no face refers to, and both report the mean edge length of what they return)
+        mesh._topology_changed(nv, nf, all_referenced=True, mean_edge=st.get('mean_edge_length'))
     except TypeError:                                                 # (a mesh class of the caller's with the two-argument hook)
         mesh._topology_changed(nv, nf)

@@ -194,9 +194,36 @@ class TriMesh(object):
             self._build_topology()
         return self.__dict__['_halfedge_records']
 
+    # Face normals, face areas and edge lengths may be pending too (`mean_edge` given to the constructor: the driver's block loop, which needs
+    # nothing of the geometry between two blocks but the mean edge length, and gets that from the remesher's statistics): `_faces`,
+    # `face_normals`, `area()`, the half-edge lengths compute them on first access.
+    @property
+    def _faces(self):
+        if self.__dict__.get('_geometry_pending'):
+            self._flush_geometry()
+        return self.__dict__['_face_records']
+
+    @_faces.setter
+    def _faces(self, records):
+        self.__dict__['_face_records'] = records
+
+    def _flush_geometry(self):
+        self.__dict__['_geometry_pending'] = False
+        if self.__dict__.get('_face_records') is None:
+            fr = np.zeros(self._faces_arr.shape[0], FACE_DTYPE)
+            fr['halfedge'] = 3 * np.arange(self._faces_arr.shape[0], dtype='i4')
+            self.__dict__['_face_records'] = fr
+        if self.__dict__.get('_halfedge_records') is None and self.__dict__.get('_lengths_packed') is None:
+            self.__dict__['_lengths_packed'] = np.zeros(3 * self._faces_arr.shape[0], 'f4')
+        mean = self.__dict__.get('_mean_edge_cache')
+        self.update_geometry(vertex_normals=False)
+        self.__dict__['_mean_edge_cache'] = mean          # (the value the caller has been given stays the value)
+
     def _edge_lengths(self):
         """Where update_geometry writes the half-edge lengths (half-edge 3f + k is edge k of face f: the faces suffice): the records' 'length'
         field, or -- while the records of a lazy topology have not been asked for -- a packed array that is copied into them when they are."""
+        if self.__dict__.get('_geometry_pending'):
+            self._flush_geometry()
         rec = self.__dict__.get('_halfedge_records')
         return rec['length'] if rec is not None else self.__dict__['_lengths_packed']
 
@@ -232,7 +259,7 @@ class TriMesh(object):
             pending()
         self.__dict__['_vertex_records'] = records
 
-    def __init__(self, vertices, faces, max_vertices=None, vertex_normals=True, lazy_topology=False, all_referenced=False):
+    def __init__(self, vertices, faces, max_vertices=None, vertex_normals=True, lazy_topology=False, all_referenced=False, mean_edge=None):
         vertices = np.ascontiguousarray(vertices, dtype='f4')
         faces = np.ascontiguousarray(faces, dtype='i4')
         M = vertices.shape[0] if max_vertices is None else int(max_vertices)
@@ -243,8 +270,8 @@ class TriMesh(object):
         self._nv = vertices.shape[0]
         self._faces_arr = faces
         self._ring_vertex_table = None
-        self._faces = np.zeros(faces.shape[0], FACE_DTYPE)
-        self._faces['halfedge'] = 3 * np.arange(faces.shape[0], dtype='i4')
+        self.__dict__['_geometry_pending'] = False
+        self.__dict__['_face_records'] = None
         self._origin = None
         self.__dict__['_all_referenced'] = bool(all_referenced) and M == vertices.shape[0]
         if lazy_topology and faces.shape[0] > 0 and int(faces.min()) >= 0 and int(faces.max()) < M:
@@ -252,14 +279,21 @@ class TriMesh(object):
             # update_geometry computes live in a packed array)
             self.__dict__['_topology_pending'] = True
             self.__dict__['_halfedge_records'] = None
-            self.__dict__['_lengths_packed'] = np.zeros(3 * faces.shape[0], 'f4')
+            self.__dict__['_lengths_packed'] = None
         else:
             self._halfedges = np.zeros(3 * faces.shape[0], HALFEDGE_DTYPE)
             self._build_topology()
         # vertex_normals=False (the driver's block loop): the device computes them with the next upload and hands them back after the block;
         # whoever asks before that gets them computed here, on first use (`vertex_normals`)
         self._normals_stale = not vertex_normals
-        self.update_geometry(vertex_normals=vertex_normals)
+        if self.__dict__['_topology_pending'] and not vertex_normals and mean_edge is not None and float(mean_edge) > 0:
+            # (geometry on first use; the one number the block loop asks for is the remesher's)
+            self.__dict__['_geometry_pending'] = True
+            self.__dict__['_mean_edge_cache'] = np.float32(mean_edge)
+        else:
+            self._flush_geometry()
+            if vertex_normals:
+                self.update_geometry(vertex_normals=True)
         self.cg = None
         self.vertex_properties = []
         self.vertex_vector_properties = []
@@ -272,8 +306,12 @@ class TriMesh(object):
         rec['halfedge'] = -1
         rec['neighbors'] = -1
         if self.__dict__.get('_halfedge_records') is None:
+            if self.__dict__.get('_geometry_pending'):
+                self._flush_geometry()                    # (the records are born with their 'length' field filled)
             he = np.zeros(3 * self._faces_arr.shape[0], HALFEDGE_DTYPE)
-            he['length'] = self.__dict__.pop('_lengths_packed')
+            packed = self.__dict__.pop('_lengths_packed', None)
+            if packed is not None:
+                he['length'] = packed
             self.__dict__['_halfedge_records'] = he
         if not self._build_topology_native(self._faces_arr):
             lengths = self.__dict__['_halfedge_records']['length'].copy()
@@ -343,6 +381,13 @@ class TriMesh(object):
         rec = self._position_records()
         pos = rec['position']
         f = self._faces_arr
+        if self.__dict__.get('_geometry_pending') or self.__dict__.get('_face_records') is None:
+            # (an explicit refresh of a mesh whose geometry was still pending: the records first -- _flush_geometry calls back here)
+            self.__dict__['_geometry_pending'] = False
+            self._flush_geometry()
+            if not vertex_normals:
+                self.__dict__['_mean_edge_cache'] = None
+                return
         self.__dict__['_mean_edge_cache'] = None
         if vertex_normals:
             self.__dict__['_normals_stale'] = False       # (computed here, below)

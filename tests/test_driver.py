@@ -378,3 +378,36 @@ def test_topology_records_built_on_first_use_equal_the_eager_ones(recorder):
     ref = TriMesh(m.vertices.copy(), m.faces)
     assert np.array_equal(m._vertices['neighbors'], ref._vertices['neighbors']) and np.array_equal(m._halfedges['twin'], ref._halfedges['twin'])
     assert np.array_equal(m._halfedges['length'], ref._halfedges['length'])
+
+
+def test_geometry_computed_on_first_use_equals_the_eager_one(recorder):
+    """A mesh built with `mean_edge` (what the driver gives the mesh of a new topology inside a fit: the remesher's own figure) computes face
+    normals, areas and edge lengths when somebody asks; until then `_mean_edge_length` is the given number.  Whatever is asked first --
+    `_faces`, `face_normals`, `area()`, the half-edge records, an explicit `update_geometry` --, the arrays equal an eagerly built mesh's."""
+    v, f = geodesic_sphere(6, 30.0)
+    eager = TriMesh(v, f)
+    given = float(eager._mean_edge_length) * 1.0000001
+    for first in ('_faces', 'face_normals', 'area', '_halfedges', 'update_geometry', 'update_geometry_with_normals'):
+        lazy = TriMesh(v, f, vertex_normals=False, lazy_topology=True, all_referenced=True, mean_edge=given)
+        assert lazy.__dict__['_geometry_pending'] and lazy.__dict__['_topology_pending']
+        assert lazy._mean_edge_length == np.float32(given) and lazy.__dict__['_geometry_pending']
+        if first == 'area':
+            assert lazy.area() == eager.area()
+        elif first == 'update_geometry':
+            lazy.update_geometry(vertex_normals=False)
+        elif first == 'update_geometry_with_normals':
+            lazy.update_geometry()
+        else:
+            getattr(lazy, first)
+        assert not lazy.__dict__['_geometry_pending']
+        assert np.array_equal(lazy._faces, eager._faces) and np.array_equal(lazy.face_normals, eager.face_normals)
+        assert np.array_equal(lazy._halfedges, eager._halfedges)
+        assert np.array_equal(lazy.vertex_normals, eager.vertex_normals)
+        if first.startswith('update_geometry'):
+            assert lazy._mean_edge_length == eager._mean_edge_length        # an explicit refresh recomputes it
+    # the driver: a fit with the built-in remesher hands every new topology the remesher's mean edge length
+    m = _mesh(kc=1.0, step_size=20.0, max_iter=10, remesh_frequency=5, delaunay_remesh_frequency=0, remesher='builtin')
+    m.shrink_wrap(np.zeros((5, 3), 'f4'), 10.0, minimum_edge_length=m._mean_edge_length / 2)
+    ref = TriMesh(m.vertices.copy(), m.faces)
+    assert abs(m.block_log[-1]['mean_length'] - float(ref._mean_edge_length)) < 1e-5 * float(ref._mean_edge_length)
+    assert np.array_equal(m.face_normals, ref.face_normals) and m.area() == ref.area()
