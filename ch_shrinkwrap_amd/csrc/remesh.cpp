@@ -477,6 +477,14 @@ struct HalfEdgeMesh {
                     // waits for the pass in which that vertex is interior (the collapses and flips wait anyway).  (Splitting the spokes of a
                     // rim corner -- a rim vertex with two faces in the piece -- was seen to split the same edge over and over: coincident vertices.)
                     if (boundary[from((int)h)] || boundary[vert[h]] || boundary[vert[next[h]]] || boundary[vert[next[t]]]) continue;
+                    // ... and a long edge between two faces of no area is left alone.  A needle the optimiser has drawn out -- an edge of
+                    // six target lengths whose opposite corners lie ON it -- cannot be collapsed while it touches a frozen rim, and every
+                    // split of it or of the edges "across" it puts one more vertex on the same line, at dyadic points: the midpoint of the
+                    // quarter and three-quarter points IS the midpoint (seen at 8 10^5 vertices: 1 154 positions held by up to 16 vertices
+                    // each, a few hundred edges of no length, and the whole mesh sent to the serial algorithm for it).
+                    const int a = from((int)h), b = vert[h], c = vert[next[h]], d = vert[next[t]];
+                    const double flat = 1e-8 * l2[h] * l2[h];
+                    if (norm2(face_normal(a, b, c)) < flat || norm2(face_normal(b, a, d)) < flat) continue;
                 }
                 split((int)h);
             }
