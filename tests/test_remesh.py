@@ -347,3 +347,58 @@ def test_an_edge_of_no_length_in_the_input_does_not_send_the_partitioned_remeshe
     assert p.returncode == 0 and 'OK' in p.stdout, p.stderr[-2000:]
     assert 'seam pass' in p.stderr                                   # the partitioned path ran ...
     assert 'takes over' not in p.stderr and 'and in the input: kept' in p.stderr        # ... and stood by its result
+
+
+def test_needles_do_not_breed_coincident_vertices_in_the_partitioned_remesher():
+    """Faces of no area with a long edge (a corner lying on the opposite edge: what a fit at 8 10^5 vertices produced here and there) used to be
+    split again and again inside the runs of a partitioned mesh -- a needle that touches a frozen rim cannot be collapsed there --, and on one
+    line all split points are dyadic: vertices piled up on the same positions, edges of no length appeared, and the safety net sent the whole
+    mesh to the serial algorithm (the round-4 library does on this input).  Pieces now leave such an edge alone: no position is held twice,
+    no fall-back.  The needles are put where they hurt: on faces with two RIM vertices (the 16 Morton runs of the faces are recomputed here)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from ch_shrinkwrap_amd.trimesh import icosphere
+        from ch_shrinkwrap_amd import remesh
+        v, f = icosphere(6, 100.0)
+        v = (v * np.array([1.0, 0.7, 1.4], 'f4')).astype('f4')
+        def spread(x):
+            x = x.astype(np.uint64) & 0x3ff
+            x = (x | (x << 16)) & 0x030000ff; x = (x | (x << 8)) & 0x0300f00f; x = (x | (x << 4)) & 0x030c30c3; x = (x | (x << 2)) & 0x09249249
+            return x
+        lo = v.min(0).astype('f8'); ext = float((v.max(0).astype('f8') - lo).max())
+        c = (v[f[:, 0]].astype('f8') + v[f[:, 1]] + v[f[:, 2]]) / 3.0
+        q = np.clip((c - lo) / ext * 1024.0, 0, 1023).astype(np.uint64)
+        order = np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind='stable')
+        run = np.empty(f.shape[0], int)
+        for r in range(16):
+            run[order[f.shape[0] * r // 16: f.shape[0] * (r + 1) // 16]] = r
+        lo_run = np.full(v.shape[0], 99); hi_run = np.full(v.shape[0], -1)
+        np.minimum.at(lo_run, f.ravel(), np.repeat(run, 3)); np.maximum.at(hi_run, f.ravel(), np.repeat(run, 3))
+        rim = lo_run != hi_run
+        rng = np.random.default_rng(3)
+        taken = np.zeros(v.shape[0], bool)
+        n = 0
+        for face in rng.permutation(f.shape[0]):
+            a, b, c = f[face]
+            if taken[[a, b, c]].any() or not (rim[a] and rim[b]) or rim[c]:
+                continue
+            v[c] = 0.5 * (v[a] + v[b])                 # the corner onto the middle of the opposite edge: a face of no area at a rim
+            taken[[a, b, c]] = True
+            n += 1
+            if n == 300:
+                break
+        assert n == 300
+        ov, of = remesh.remesh(v, f, 5, 1.1, 0.5, 0)   # edges are ~1.9: everything is too long, the needles' edges too
+        u, cnt = np.unique(ov, axis=0, return_counts=True)
+        e = np.sort(np.concatenate([of[:, [0, 1]], of[:, [1, 2]], of[:, [2, 0]]]), 1)
+        _, ec = np.unique(e, axis=0, return_counts=True)
+        print('RESULT', int((cnt > 1).sum()), bool((ec == 2).all()), ov.shape[0])
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e['NWR_VERBOSE'] = '1'
+    p = subprocess.run([sys.executable, '-c', code], env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = [l for l in p.stdout.splitlines() if l.startswith('RESULT')][-1].split()
+    assert 'seam pass' in p.stderr and 'takes over' not in p.stderr
+    assert res[1] == '0' and res[2] == 'True' and int(res[3]) > 100000, res          # no position held by two vertices; closed; refined
