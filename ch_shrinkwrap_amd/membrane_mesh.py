@@ -104,7 +104,13 @@ class MembraneMesh(TriMesh):
     def neck_vertices(self, neck_curvature_threshold_low=-1e-4, neck_curvature_threshold_high=1e-2):
         """The selection half of `remove_necks` (_membrane_mesh.pyx:1201-1215): curvature refreshed by the GPU kernel,
         then every vertex whose Gaussian curvature lies outside [low, high] is a neck candidate."""
-        self._populate_curvature_grad()
+        # (between two blocks only the Gaussian curvature is looked at: the kernel computes all twelve outputs, one is brought back -- 0.8 MB
+        # instead of 15 at 2 10^5 vertices; the others come with the next full refresh, which a read of any of them triggers)
+        self._curvature_outputs = ('_K',) if (getattr(self, '_in_fit', False) and not self.smooth_curvature) else None
+        try:
+            self._populate_curvature_grad()
+        finally:
+            self._curvature_outputs = None
         K = self.curvature_gaussian
         return np.flatnonzero((K < neck_curvature_threshold_low) | (K > neck_curvature_threshold_high))
 
@@ -136,7 +142,7 @@ class MembraneMesh(TriMesh):
         area[~ok] = 0
         return np.ascontiguousarray(nxt, 'i4'), np.ascontiguousarray(area, 'f4')
 
-    def curvature_grad_c(self, dN=0.1, skip_prob=0.0, jitter=None, skip_u=None):
+    def curvature_grad_c(self, dN=0.1, skip_prob=0.0, jitter=None, skip_u=None, outputs=None):
         """_membrane_mesh.pyx:323-347 -> c_curvature_grad (membrane_mesh_utils.c:915-1250) on the GPU.  Fills the
         per-vertex curvature arrays and returns dEdN (M,3).  `jitter`: optional (M,3) float64 array in [0,1) replacing the
         reference's rand() stream; None = deterministic hash.  `skip_prob` > 0 (:962, never used on the live path): a vertex whose
@@ -168,10 +174,13 @@ class MembraneMesh(TriMesh):
             nxt, area = self._neighbor_tables() if host_tables else (None, None)      # (the substrate's ring order is the library's: the tables can be built there)
         jit = None if jitter is None else np.ascontiguousarray(jitter, 'f8')
         self._initialize_curvature_vectors()
-        dEdN = np.zeros((M, 3), 'f4')
+        # outputs: names of the per-vertex arrays to bring back (None = all twelve, as the reference fills them); the C-ABI skips a NULL
+        # destination, and an array that is not fetched stays cleared (zeros on first read, and `_curv` refreshes everything then)
+        out = lambda name: getattr(self, name) if (outputs is None or name in outputs) else None
+        dEdN = np.zeros((M, 3), 'f4') if (outputs is None or 'dEdN' in outputs) else None
         nat.check(nat.L.nw_curvature(nat.h, nw.ptr(nxt), nw.ptr(area), nw.ptr(jit), float(self.kc), float(self.kg), float(self.c0), float(dN),
-                                     nw.ptr(self._k_0), nw.ptr(self._k_1), nw.ptr(self._e_0), nw.ptr(self._e_1), nw.ptr(self._H), nw.ptr(self._K),
-                                     nw.ptr(self._dH), nw.ptr(self._dK), nw.ptr(self._E), nw.ptr(self._pE), nw.ptr(self._dE_neighbors), nw.ptr(dEdN)))
+                                     nw.ptr(out('_k_0')), nw.ptr(out('_k_1')), nw.ptr(out('_e_0')), nw.ptr(out('_e_1')), nw.ptr(out('_H')), nw.ptr(out('_K')),
+                                     nw.ptr(out('_dH')), nw.ptr(out('_dK')), nw.ptr(out('_E')), nw.ptr(out('_pE')), nw.ptr(out('_dE_neighbors')), nw.ptr(dEdN)))
         return dEdN
 
     _CURVATURE_SCALARS = ('_H', '_K', '_E', '_k_0', '_k_1', '_pE', '_dH', '_dK', '_dE_neighbors')
@@ -205,7 +214,7 @@ class MembraneMesh(TriMesh):
         return (s / (1 + ok.sum(1))).astype(np.float32)
 
     def _populate_curvature_grad(self):
-        self.curvature_grad_c()                                        # :176-186
+        self.curvature_grad_c(outputs=getattr(self, '_curvature_outputs', None))       # :176-186 (neck_vertices asks for one array only)
         if self.smooth_curvature:
             self._H = self.smooth_per_vertex_data(self._H)
             self._K = self.smooth_per_vertex_data(self._K)
